@@ -1,0 +1,233 @@
+/*
+ * xv2.h — C ABI of the MI355X (gfx950) U-Net training hot path.
+ *
+ * The reference (michal2409/xView2) has no FFI layer: its hot path is the set of torch
+ * operators dispatched by model/unet.py, model/layers.py and model/loss.py.  Every entry
+ * point below therefore names the torch operator call-site it replaces (reference file:line).
+ * Conventions
+ *   - all tensors are caller-owned DEVICE buffers, fp32 unless stated, activations are NHWC
+ *     ("pixel-major, channel-minor"); `ld*` arguments are the pixel stride in floats so that a
+ *     channel slice of a wider tensor can be passed without a copy (virtual concat / groups);
+ *   - every call enqueues work on `stream` (a hipStream_t) and returns without synchronising;
+ *   - return value 0 = success, otherwise an XV2_E* code; xv2_last_error() gives the message
+ *     (thread-local), no C++ exception crosses this boundary;
+ *   - no allocation happens inside any call: workspaces are sized by the *_workspace() helpers.
+ */
+#ifndef XV2_H_
+#define XV2_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XV2_OK 0
+#define XV2_EINVAL 1   /* bad argument / unsupported shape */
+#define XV2_EHIP 2     /* a HIP runtime call failed */
+
+#define XV2_ACT_NONE 0
+#define XV2_ACT_RELU 1      /* encoders: model/unet.py:80 and the un-vendored ResNet/ResNeSt blocks */
+#define XV2_ACT_LEAKY 2     /* LeakyReLU(0.01): model/layers.py:17,37,94 */
+#define XV2_ACT_SIGMOID 3   /* attention gate: model/layers.py:147,165 */
+
+const char* xv2_last_error(void);
+int xv2_version(void);
+
+/* ---- convolution ------------------------------------------------------------------------
+ * Geometry of one nn.Conv2d (model/layers.py:35,71,92,139,180; torchvision/resnest blocks),
+ * groups handled by the caller through channel-offset views.  The input may be the virtual
+ * concatenation of two tensors (torch.cat at model/layers.py:114,167): channels [0,C0) come
+ * from x0, [C0,C0+C1) from x1.  C0 and C1 must be multiples of 32, except the RGB stems which
+ * are passed as a single 4-channel (zero padded) source (C0=4, C1=0).
+ */
+typedef struct xv2_conv_desc {
+    int32_t N, IH, IW;          /* input batch / height / width */
+    int32_t C0, C1;             /* input channels taken from source 0 / source 1 */
+    int32_t Cout;               /* output channels, multiple of 32 */
+    int32_t KH, KW, stride, pad, dil;
+    int32_t OH, OW;             /* output height / width */
+} xv2_conv_desc;
+
+/* weight repacking: w_oihw[Cout][Cin][KH][KW] (the reference's state_dict layout)
+ *   -> w_ohwi[Cout][KH*KW][CinP]  (forward operand; CinP = Cin padded to `cin_pad`)
+ *   -> w_ihwo[CinP][KH*KW][Cout]  (backward-data operand)                                  */
+int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad,
+                    float* w_ohwi, float* w_ihwo, void* stream);
+
+/* y = conv2d(cat(x0,x1), w) [+ bias]; replaces F.conv2d.  If `stats` != NULL the kernel also
+ * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]
+ * (tile count = xv2_conv2d_forward_stats_tiles(d)), consumed by xv2_bn_reduce_stats. */
+int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
+int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
+                       int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
+                       float* stats, void* stream);
+/* dx = conv2d_backward_input(dy, w); dx0/dx1 receive the channel ranges of the two sources */
+int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
+                             const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
+                             void* stream);
+/* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
+size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
+int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,
+                               const float* x1, int ldx1, const float* dy, int lddy,
+                               float* dw_oihw, int cin_real, float* workspace, void* stream);
+
+/* nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83).  `d` describes the
+ * EQUIVALENT convolution (input = the large 2H x 2W tensor with C0 = conv-transpose output
+ * channels, Cout = conv-transpose input channels): forward of the transposed conv is the
+ * backward-data of `d`, and vice versa; weights are the torch tensor [Cin_T][Cout_T][2][2]
+ * viewed as OIHW of `d`. */
+int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,
+                                 const float* w_ihwo, float* y, int ldy, void* stream);
+int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
+                                       const float* w_ohwi, float* dx, int lddx, void* stream);
+int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const float* x, int ldx,
+                                         const float* dy, int lddy, float* dw, float* workspace,
+                                         void* stream);
+
+/* 1x1 convolution with a handful of output channels (segmentation heads n_class<=4,
+ * model/layers.py:177,180; attention psi conv model/layers.py:145).  NHWC in; output either
+ * NHWC (nchw_out=0) or NCHW (nchw_out=1, the layout model/unet.py:191-197 returns). */
+int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
+                          const float* w, const float* bias, float* y, int nchw_out, void* stream);
+int xv2_head_conv_backward(const float* x, int ldx, const float* dy, int64_t npix, int64_t hw,
+                           int Cin, int Cout, const float* w, int nchw_dy, float* dx, int lddx,
+                           float* dw, float* dbias, float* workspace, void* stream);
+size_t xv2_head_conv_backward_workspace(int64_t npix, int Cin, int Cout);
+
+/* ---- batch norm + activation (nn.BatchNorm2d + ReLU/LeakyReLU, everywhere) -------------- */
+/* partial sums [tiles][C][2] -> sums[C][2] (double), fixed-order (deterministic) reduction;
+ * scratch: XV2_BN_SCRATCH_ROWS*C*2 doubles */
+#define XV2_BN_SCRATCH_ROWS 64
+int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
+                        void* stream);
+/* direct statistics of an NHWC tensor (when no conv epilogue produced them):
+ * workspace = xv2_bn_tensor_stats_workspace() bytes (partials followed by the double scratch) */
+int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums,
+                        float* workspace, void* stream);
+size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C);
+/* sums (+count, possibly all-reduced across ranks) -> mean, invstd, scale, shift; updates the
+ * running statistics exactly like torch (momentum, unbiased running_var). */
+int xv2_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, int C, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, int C,
+                       void* stream);
+/* z = act(y*scale[c] + shift[c] (+ residual)) */
+int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
+                       const float* residual, int ldr, int act, float* z, int ldz,
+                       int64_t npix, int C, void* stream);
+/* backward: pass 1 -> sums2[C][2] = (sum g, sum g*xhat), g = dz*act'(z) */
+int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz,
+                               const float* y, int ldy, const float* mean, const float* invstd,
+                               int act, int64_t npix, int C, double* sums2, float* workspace,
+                               void* stream);
+size_t xv2_bn_backward_workspace(int64_t npix, int C);
+/* pass 2 -> dy (and dresidual = g if requested).  dgamma = sums2[:,1], dbeta = sums2[:,0] of
+ * the LOCAL rank (torch SyncBatchNorm semantics); sums2 passed here may be all-reduced.
+ * `count` is the (global) number of elements per channel; eval-mode BN passes train=0. */
+int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y,
+                              int ldy, const float* mean, const float* invstd,
+                              const float* gamma, const double* sums2, double count, int act,
+                              int train, float* dy, int lddy, float* dres, int lddres,
+                              int64_t npix, int C, void* stream);
+
+/* ---- pooling / resampling ----------------------------------------------------------------- */
+/* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order) */
+int xv2_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, float* y, uint8_t* idx,
+                             void* stream);
+int xv2_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int N, int H, int W, int C,
+                              float* dx, void* stream);
+/* nn.AvgPool2d(k, s, pad, count_include_pad) (ResNeSt avd / avg_down shortcuts) */
+int xv2_avgpool_forward(const float* x, int N, int H, int W, int C, int k, int s, int pad,
+                        int count_include_pad, int OH, int OW, float* y, void* stream);
+int xv2_avgpool_backward(const float* dy, int N, int H, int W, int C, int k, int s, int pad,
+                         int count_include_pad, int OH, int OW, float* dx, void* stream);
+/* F.adaptive_avg_pool2d(x, bins) (model/layers.py:14; bins=1 is the split-attention GAP) */
+int xv2_adaptive_avgpool_forward(const float* x, int ldx, int N, int H, int W, int C, int bins,
+                                 float* y, void* stream);
+int xv2_adaptive_avgpool_backward(const float* dy, int N, int H, int W, int C, int bins,
+                                  float* dx, int lddx, int accumulate, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=True) (model/layers.py:27,154,188) */
+int xv2_bilinear_forward(const float* x, int N, int IH, int IW, int C, int OH, int OW, float* y,
+                         int ldy, void* stream);
+int xv2_bilinear_backward(const float* dy, int lddy, int N, int IH, int IW, int C, int OH, int OW,
+                          float* dx, void* stream);
+
+/* ---- split attention (ResNeSt SplAtConv2d, radix 2) --------------------------------------- */
+/* gap[n][c] = mean_{hw}(x[n,hw,c] + x[n,hw,C+c]) for x NHWC with 2C channels */
+int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, float* gap, float* workspace,
+                          void* stream);
+size_t xv2_splat_gap_workspace(int N, int64_t hw, int C);
+/* small dense layers on [N][Cin] vectors (fc1/fc2 are 1x1 convs on 1x1 maps) */
+int xv2_linear_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin,
+                       int Cout, void* stream);
+int xv2_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                        float* db, int N, int Cin, int Cout, void* stream);
+/* rSoftMax over the radix axis: logits[n][r*C + c] -> att[n][r*C + c] */
+int xv2_rsoftmax_forward(const float* logits, float* att, int N, int C, void* stream);
+int xv2_rsoftmax_backward(const float* att, const float* datt, float* dlogits, int N, int C,
+                          void* stream);
+/* out[n,hw,c] = att[n][c]*x[n,hw,c] + att[n][C+c]*x[n,hw,C+c] */
+int xv2_splat_apply_forward(const float* x, const float* att, int N, int64_t hw, int C,
+                            float* out, void* stream);
+/* dx (2C channels) += / = ; datt[n][2C] (reduction over hw); dgap adds the GAP branch */
+int xv2_splat_apply_backward(const float* x, const float* att, const float* dout,
+                             const float* dgap, int N, int64_t hw, int C, float* dx, float* datt,
+                             float* workspace, void* stream);
+
+/* ---- attention gate glue (model/layers.py:161-166) ---------------------------------------- */
+/* r = relu(a + b) */
+int xv2_add_relu_forward(const float* a, const float* b, float* r, int64_t n, void* stream);
+int xv2_add_relu_backward(const float* r, const float* dr, float* dab, int64_t n, void* stream);
+/* out[p][c] = skip[p][c] * gate[p] */
+int xv2_gate_mul_forward(const float* skip, int lds, const float* gate, float* out, int64_t npix,
+                         int C, void* stream);
+int xv2_gate_mul_backward(const float* skip, int lds, const float* gate, const float* dout,
+                          float* dskip, float* dgate, int64_t npix, int C, void* stream);
+/* generic elementwise helpers */
+int xv2_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int xv2_axpby(float alpha, const float* a, float beta, const float* b, float* out, int64_t n,
+              void* stream);
+
+/* ---- layout --------------------------------------------------------------------------------- */
+/* NCHW image [N][C][H][W] (model/plt.py:51 batch["image"]) -> NHWC with Cp >= C (zero padded) */
+int xv2_nchw_to_nhwc(const float* x, int64_t x_batch_stride, int N, int C, int H, int W,
+                     float* y, int Cp, void* stream);
+int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, int W, float* y, void* stream);
+/* strided channel copy: dst[p][doff + c] = src[p][soff + c] (materialised concat) */
+int xv2_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t npix, int C,
+                      void* stream);
+
+/* ---- losses (model/loss.py:78-101 + monai 0.4.0 DiceLoss/FocalLoss, Ohem == mean CE) ------- */
+#define XV2_LOSS_DICE 1
+#define XV2_LOSS_FOCAL 2
+#define XV2_LOSS_CE 4      /* "ce" and "ohem" (model/loss.py:24-51 is numerically mean CE) */
+/* logits NCHW [N][C][H][W]; labels uint8 [N][LH][LW] sampled with stride `lstride`
+ * (deep supervision nearest down-sampling, model/plt.py:73).  post != 0 applies the building
+ * mask of model/loss.py:86-90 (pixels with label 0 are dropped, label-1 is the class).
+ * `terms` is a bit-or of XV2_LOSS_*.  acc[XV2_LOSS_ACC_DOUBLES] doubles of device scratch.    */
+#define XV2_LOSS_ACC_DOUBLES 32
+int xv2_loss_forward(const float* logits, const uint8_t* labels, int N, int C, int H, int W,
+                     int lstride, int post, int terms, double* acc, float* loss, float* workspace,
+                     void* stream);
+size_t xv2_loss_workspace(int N, int C, int H, int W);
+/* dlogits = gscale[0] * weight * dLoss/dlogits, uses acc[] written by the forward call */
+int xv2_loss_backward(const float* logits, const uint8_t* labels, int N, int C, int H, int W,
+                      int lstride, int post, int terms, const double* acc, const float* gscale,
+                      float weight, float* dlogits, void* stream);
+/* argmax over channels of NCHW logits (utils/f1.py:14,36): first maximum wins (torch.argmax) */
+int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint8_t* labels,
+                    void* stream);
+
+/* ---- optimizer (model/plt.py:154 torch.optim.AdamW) ---------------------------------------- */
+int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XV2_H_ */

@@ -1,0 +1,305 @@
+// Loss kernels (model/loss.py:78-101 with monai 0.4.0 DiceLoss / FocalLoss restated, Ohem == mean CE
+// because of the tuple-slice at model/loss.py:45), argmax label maps (utils/f1.py:14,36), weight
+// repacking and the AdamW step (model/plt.py:154).
+//
+// Forward: one streaming pass over the NCHW logits computes every sum the composed loss needs
+//   per class c: I_c = sum p_c*[y==c], G_c = sum [y==c], P_c = sum p_c      (Dice, batch=True)
+//   F = sum -(1-p_t)^2 log p_t,  E = sum -log p_t,  n = number of (masked-in) pixels
+// fp32 inside a thread, fp64 across threads/blocks, fixed order -> acc[] -> scalar loss.
+// Backward: a second streaming pass forms dL/dlogits analytically from acc[] (no autograd graph).
+#include "xv2_common.h"
+#include <algorithm>
+
+namespace xv2 {
+
+constexpr int LOSS_BLOCKS = 1024;
+// acc layout (doubles): [0..3] I_c, [4..7] G_c, [8..11] P_c, [12] F, [13] E, [14] n
+constexpr int NACC = 15;
+
+template <int C>
+__device__ __forceinline__ void softmax_px(const float* __restrict__ logits, int64_t base, int64_t hw, float* p,
+                                           float& lse) {
+    float l[C];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        l[c] = logits[base + c * hw];
+        m = fmaxf(m, l[c]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        p[c] = expf(l[c] - m);
+        s += p[c];
+    }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+    lse = m + logf(s);
+}
+
+__device__ __forceinline__ int label_at(const uint8_t* __restrict__ labels, int64_t n, int h, int w, int H, int W,
+                                        int ls) {
+    return labels[(n * (int64_t)H * ls + (int64_t)h * ls) * ((int64_t)W * ls) + (int64_t)w * ls];
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) loss_fwd_kernel(const float* __restrict__ logits,
+                                                        const uint8_t* __restrict__ labels, int N, int H, int W,
+                                                        int ls, int post, double* __restrict__ part) {
+    __shared__ double sh[4][NACC];
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    float a[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) a[k] = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        const int h = (int)(q / W), w = (int)(q - (int64_t)h * W);
+        int y = label_at(labels, n, h, w, H, W, ls);
+        if (post) {
+            if (y == 0) continue;
+            y -= 1;
+        }
+        float p[C], lse;
+        softmax_px<C>(logits, n * C * hw + q, hw, p, lse);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float t = (y == c) ? 1.f : 0.f;
+            a[c] += p[c] * t;
+            a[4 + c] += t;
+            a[8 + c] += p[c];
+        }
+        const float lt = logits[n * C * hw + q + (int64_t)(y < C ? y : 0) * hw] - lse;  // log p_t
+        const float pt = expf(lt);
+        a[12] += -(1.f - pt) * (1.f - pt) * lt;
+        a[13] += -lt;
+        a[14] += 1.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const double v = wave_sum((double)a[k]);
+        if (lane == 0) sh[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC)
+        part[(size_t)blockIdx.x * NACC + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ part, int nblocks, int C, int terms,
+                                   double* __restrict__ acc, float* __restrict__ loss) {
+    __shared__ double tot[NACC];
+    if (threadIdx.x < NACC) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * NACC + threadIdx.x];
+        tot[threadIdx.x] = s;
+        acc[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double L = 0.0;
+        const double n = tot[14];
+        if (terms & XV2_LOSS_DICE) {
+            // monai DiceLoss(softmax, to_onehot_y, batch): include_background=False iff C == 2
+            // (model/loss.py:18-19)
+            const int c0 = (C == 2) ? 1 : 0;
+            double f = 0.0;
+            for (int c = c0; c < C; ++c) f += 1.0 - (2.0 * tot[c] + 1e-5) / (tot[4 + c] + tot[8 + c] + 1e-5);
+            L += f / (double)(C - c0);
+        }
+        if (terms & XV2_LOSS_FOCAL) L += tot[12] / n;
+        if (terms & XV2_LOSS_CE) L += tot[13] / n;
+        loss[0] = (float)L;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__ logits,
+                                                        const uint8_t* __restrict__ labels, int N, int H, int W,
+                                                        int ls, int post, int terms, const double* __restrict__ acc,
+                                                        const float* __restrict__ gscale, float weight,
+                                                        float* __restrict__ dlogits) {
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    const float gs = gscale[0] * weight;
+    const int c0 = (C == 2) ? 1 : 0;
+    // dice: dL/dI_c = -2/(den_c)/K ; dL/dP_c = (2I_c+eps)/den_c^2/K  with den = G+P+eps
+    float dI[C], dP[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        dI[c] = 0.f;
+        dP[c] = 0.f;
+        if ((terms & XV2_LOSS_DICE) && c >= c0) {
+            const double den = acc[4 + c] + acc[8 + c] + 1e-5;
+            dI[c] = (float)(-2.0 / den / (double)(C - c0));
+            dP[c] = (float)((2.0 * acc[c] + 1e-5) / (den * den) / (double)(C - c0));
+        }
+    }
+    const float inv_n = (float)(1.0 / acc[14]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        const int h = (int)(q / W), w = (int)(q - (int64_t)h * W);
+        int y = label_at(labels, n, h, w, H, W, ls);
+        const int64_t base = n * C * hw + q;
+        bool drop = false;
+        if (post) {
+            if (y == 0) drop = true;
+            y -= 1;
+        }
+        if (drop) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) dlogits[base + c * hw] = 0.f;
+            continue;
+        }
+        float p[C], lse;
+        softmax_px<C>(logits, base, hw, p, lse);
+        // dL/dp_c from dice
+        float dp[C];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            dp[c] = dI[c] * ((y == c) ? 1.f : 0.f) + dP[c];
+            dot += dp[c] * p[c];
+        }
+        // focal / ce act through log p_t: d(log p_t)/dl_c = [c==t] - p_c
+        float dlt = 0.f;
+        const float pt = p[y < C ? y : 0];
+        const float lt = logf(fmaxf(pt, 1e-45f));
+        if (terms & XV2_LOSS_FOCAL) dlt += (2.f * (1.f - pt) * pt * lt - (1.f - pt) * (1.f - pt)) * inv_n;
+        if (terms & XV2_LOSS_CE) dlt += -inv_n;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float g = p[c] * (dp[c] - dot) + dlt * (((y == c) ? 1.f : 0.f) - p[c]);
+            dlogits[base + c * hw] = gs * g;
+        }
+    }
+}
+
+template <int C>
+__global__ void argmax_kernel(const float* __restrict__ logits, int64_t total, int64_t hw, int add,
+                              uint8_t* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        float best = logits[n * C * hw + q];
+        int bi = 0;
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            const float v = logits[(n * C + c) * hw + q];
+            if (v > best) {  // first maximum wins, like torch.argmax
+                best = v;
+                bi = c;
+            }
+        }
+        out[i] = (uint8_t)(bi + add);
+    }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int T, int CinP,
+                                   float* __restrict__ ohwi, float* __restrict__ ihwo) {
+    const size_t total = (size_t)Cout * T * CinP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinP);
+        const size_t q = i / CinP;
+        const int t = (int)(q % T);
+        const int co = (int)(q / T);
+        const float v = ci < Cin ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+        if (ohwi) ohwi[i] = v;
+        if (ihwo) ihwo[((size_t)ci * T + t) * Cout + co] = v;
+    }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        float pi = p[i];
+        pi *= 1.f - lr * wd;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace xv2
+
+using namespace xv2;
+
+extern "C" size_t xv2_loss_workspace(int N, int C, int H, int W) {
+    (void)N; (void)C; (void)H; (void)W;
+    return (size_t)LOSS_BLOCKS * NACC * sizeof(double);
+}
+
+extern "C" int xv2_loss_forward(const float* logits, const uint8_t* labels, int N, int C, int H, int W, int lstride,
+                                int post, int terms, double* acc, float* loss, float* workspace, void* stream) {
+    XV2_CHECK_ARG(C == 2 || C == 4, "loss: C=%d unsupported (2 or 4)", C);
+    XV2_CHECK_ARG(terms != 0 && (terms & ~7) == 0, "loss: bad terms mask %d", terms);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * H * W;
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), LOSS_BLOCKS);
+    double* part = reinterpret_cast<double*>(workspace);
+    if (C == 2)
+        hipLaunchKernelGGL(loss_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
+    else
+        hipLaunchKernelGGL(loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, part, grid, C, terms, acc, loss);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_loss_backward(const float* logits, const uint8_t* labels, int N, int C, int H, int W, int lstride,
+                                 int post, int terms, const double* acc, const float* gscale, float weight,
+                                 float* dlogits, void* stream) {
+    XV2_CHECK_ARG(C == 2 || C == 4, "loss: C=%d unsupported (2 or 4)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)N * H * W;
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 4096);
+    if (C == 2)
+        hipLaunchKernelGGL(loss_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post,
+                           terms, acc, gscale, weight, dlogits);
+    else
+        hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post,
+                           terms, acc, gscale, weight, dlogits);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint8_t* labels,
+                               void* stream) {
+    XV2_CHECK_ARG(C == 2 || C == 4, "argmax: C=%d unsupported (2 or 4)", C);
+    const int64_t total = (int64_t)N * hw;
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 4096);
+    if (C == 2)
+        hipLaunchKernelGGL(argmax_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, total, hw, add, labels);
+    else
+        hipLaunchKernelGGL(argmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, total, hw, add, labels);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad, float* w_ohwi,
+                               float* w_ihwo, void* stream) {
+    XV2_CHECK_ARG(cin_pad >= Cin, "pack_weight: cin_pad < Cin");
+    const size_t total = (size_t)Cout * KH * KW * cin_pad;
+    const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH * KW,
+                       cin_pad, w_ohwi, w_ihwo);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream) {
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    const int grid = (int)std::min<int64_t>(cdiv(n, 256), 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}

@@ -1,0 +1,418 @@
+// BatchNorm2d (training and eval) fused with ReLU / LeakyReLU(0.01) / sigmoid and the residual add,
+// NHWC.  HBM-bound streaming kernels: 16-byte accesses, channel = fastest index, deterministic
+// two-level reductions (fp32 inside a row chunk, fp64 across chunks).
+// Reference sites: nn.BatchNorm2d + activation at model/layers.py:16-17,36-37,72,93-94 and in the
+// un-vendored ResNet/ResNeSt blocks; torch semantics (biased batch variance for normalisation,
+// unbiased for running_var, momentum 0.1, eps 1e-5).
+#include "xv2_common.h"
+#include <algorithm>
+
+namespace xv2 {
+
+// ---------------------------------------------------------------------------------------------
+// column partials: for every chunk of `rpb` rows, part[chunk][C][2] = (sum f0, sum f1) per channel.
+// F(row, c4 or c, vec) returns the two quantities to accumulate.
+struct ChunkGeom {
+    int rpb;        // rows per block
+    int64_t chunks;
+};
+
+static ChunkGeom chunk_geom(int64_t npix, int C) {
+    ChunkGeom g;
+    int64_t rows_per_pass = (C % 4 == 0 && C / 4 <= 256 && (256 % (C / 4)) == 0) ? 256 / (C / 4) : 4;
+    int64_t rpb = cdiv(npix, 2048);
+    rpb = cdiv(rpb, rows_per_pass) * rows_per_pass;
+    if (rpb < rows_per_pass * 4) rpb = rows_per_pass * 4;
+    g.rpb = (int)rpb;
+    g.chunks = cdiv(npix, rpb);
+    return g;
+}
+
+// MODE 0: tensor stats (x, x*x).  MODE 1: BN backward (g, g*xhat).
+template <int MODE>
+struct ColOp {
+    const float* a;   // MODE0: x          MODE1: dz
+    const float* z;   // MODE1
+    const float* y;   // MODE1
+    const float* mean;
+    const float* invstd;
+    int lda, ldz, ldy, act;
+    __device__ __forceinline__ void apply(int64_t row, int c, float& f0, float& f1) const {
+        if constexpr (MODE == 0) {
+            const float v = a[row * lda + c];
+            f0 += v;
+            f1 += v * v;
+        } else {
+            const float g = a[row * lda + c] * act_grad_from_output(z[row * ldz + c], act);
+            const float xh = (y[row * ldy + c] - mean[c]) * invstd[c];
+            f0 += g;
+            f1 += g * xh;
+        }
+    }
+    __device__ __forceinline__ void apply4(int64_t row, int c, float4& f0, float4& f1, const float4& mu,
+                                           const float4& is) const {
+        if constexpr (MODE == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(a + row * lda + c);
+            f0.x += v.x; f0.y += v.y; f0.z += v.z; f0.w += v.w;
+            f1.x += v.x * v.x; f1.y += v.y * v.y; f1.z += v.z * v.z; f1.w += v.w * v.w;
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(a + row * lda + c);
+            const float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
+            const float4 yy = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            const float gx = d.x * act_grad_from_output(zz.x, act), gy = d.y * act_grad_from_output(zz.y, act);
+            const float gz = d.z * act_grad_from_output(zz.z, act), gw = d.w * act_grad_from_output(zz.w, act);
+            f0.x += gx; f0.y += gy; f0.z += gz; f0.w += gw;
+            f1.x += gx * ((yy.x - mu.x) * is.x); f1.y += gy * ((yy.y - mu.y) * is.y);
+            f1.z += gz * ((yy.z - mu.z) * is.z); f1.w += gw * ((yy.w - mu.w) * is.w);
+        }
+    }
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, int64_t npix, int C, int rpb,
+                                                              float* __restrict__ part) {
+    __shared__ float sh[256 * 8];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = min(r0 + (int64_t)rpb, npix);
+    float* out = part + (size_t)blockIdx.x * C * 2;
+    const int C4 = C / 4;
+    if (C % 4 == 0 && C4 <= 256 && (256 % C4) == 0) {
+        const int rpp = 256 / C4;
+        const int tx = tid % C4, ty = tid / C4;
+        float4 f0 = make_float4(0, 0, 0, 0), f1 = make_float4(0, 0, 0, 0);
+        float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
+        if constexpr (MODE == 1) {
+            mu = *reinterpret_cast<const float4*>(op.mean + tx * 4);
+            is = *reinterpret_cast<const float4*>(op.invstd + tx * 4);
+        }
+        for (int64_t r = r0 + ty; r < r1; r += rpp) op.apply4(r, tx * 4, f0, f1, mu, is);
+        float* s = sh + tid * 8;
+        s[0] = f0.x; s[1] = f0.y; s[2] = f0.z; s[3] = f0.w;
+        s[4] = f1.x; s[5] = f1.y; s[6] = f1.z; s[7] = f1.w;
+        __syncthreads();
+        if (tid < C4) {
+            float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+            for (int q = 0; q < rpp; ++q) {
+                const float* t = sh + (q * C4 + tid) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0[k] += t[k];
+                    a1[k] += t[4 + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                out[(tid * 4 + k) * 2 + 0] = a0[k];
+                out[(tid * 4 + k) * 2 + 1] = a1[k];
+            }
+        }
+    } else {
+        // generic fallback: 64 channel lanes x 4 row lanes
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int cb = 0; cb < C; cb += 64) {
+            const int c = cb + tx;
+            float f0 = 0.f, f1 = 0.f;
+            if (c < C)
+                for (int64_t r = r0 + ty; r < r1; r += 4) op.apply(r, c, f0, f1);
+            sh[tid * 2] = f0;
+            sh[tid * 2 + 1] = f1;
+            __syncthreads();
+            if (ty == 0 && c < C) {
+                float a0 = 0.f, a1 = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    a0 += sh[(q * 64 + tx) * 2];
+                    a1 += sh[(q * 64 + tx) * 2 + 1];
+                }
+                out[c * 2] = a0;
+                out[c * 2 + 1] = a1;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// stage 1: grid (ceil(C/32), S): scratch[s][C][2] = sum over tiles t == s (mod S)... contiguous ranges
+__global__ void __launch_bounds__(256) reduce_stats_stage1(const float* __restrict__ part, int64_t tiles, int C,
+                                                           int S, double* __restrict__ scratch) {
+    __shared__ double sh[256 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 channels x 8 row lanes
+    const int c = blockIdx.x * 32 + tx;
+    const int64_t per = cdiv(tiles, S);
+    const int64_t t0 = (int64_t)blockIdx.y * per, t1 = min(t0 + per, tiles);
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int64_t t = t0 + ty; t < t1; t += 8) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)t * C + c) * 2);
+            a0 += v.x;
+            a1 += v.y;
+        }
+    sh[threadIdx.x * 2] = a0;
+    sh[threadIdx.x * 2 + 1] = a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double b0 = 0.0, b1 = 0.0;
+        for (int q = 0; q < 8; ++q) {
+            b0 += sh[(q * 32 + tx) * 2];
+            b1 += sh[(q * 32 + tx) * 2 + 1];
+        }
+        scratch[((size_t)blockIdx.y * C + c) * 2] = b0;
+        scratch[((size_t)blockIdx.y * C + c) * 2 + 1] = b1;
+    }
+}
+__global__ void reduce_stats_stage2(const double* __restrict__ scratch, int C, int S, double* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over C*2
+    if (i >= C * 2) return;
+    double a = 0.0;
+    for (int s = 0; s < S; ++s) a += scratch[(size_t)s * C * 2 + i];
+    sums[i] = a;
+}
+
+static int reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st) {
+    int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));
+    if (S < 1) S = 1;
+    hipLaunchKernelGGL(reduce_stats_stage1, dim3((unsigned)cdiv(C, 32), S), dim3(256), 0, st, partial, tiles, C, S,
+                       scratch);
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_stats_stage2, dim3((unsigned)cdiv(C * 2, 256)), dim3(256), 0, st, scratch, C, S, sums);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c * 2] / count;
+    double var = sums[c * 2 + 1] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * (float)is;
+    scale[c] = sc;
+    shift[c] = b - (float)m * sc;
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ res, int ldr, int act,
+                                                          float* __restrict__ z, int ldz, int64_t npix, int C) {
+    if constexpr (VEC) {
+        const int C4 = C >> 2;
+        const int64_t total = npix * C4;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / C4;
+            const int c = (int)(i - row * C4) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+            const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+            float4 o;
+            o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(res + row * ldr + c);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
+            *reinterpret_cast<float4*>(z + row * ldz + c) = o;
+        }
+    } else {
+        const int64_t total = npix * C;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / C;
+            const int c = (int)(i - row * C);
+            float o = y[row * ldy + c] * scale[c] + shift[c];
+            if (res) o += res[row * ldr + c];
+            z[row * ldz + c] = apply_act(o, act);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict__ dz, int lddz,
+                                                          const float* __restrict__ z, int ldz,
+                                                          const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma,
+                                                          const double* __restrict__ sums2, double count, int act,
+                                                          int train, float* __restrict__ dy, int lddy,
+                                                          float* __restrict__ dres, int lddres, int64_t npix, int C) {
+    const float inv_count = (float)(1.0 / count);
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = npix * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / CV;
+        const int c = (int)(i - row * CV) * V;
+        float d[V], zz[V], yy[V], o[V], g[V];
+        if constexpr (VEC) {
+            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + row * lddz + c);
+            *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
+            if (train) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + row * ldy + c);
+        } else {
+            d[0] = dz[row * lddz + c];
+            zz[0] = z[row * ldz + c];
+            if (train) yy[0] = y[row * ldy + c];
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            g[k] = d[k] * act_grad_from_output(zz[k], act);
+            const float gi = (gamma ? gamma[c + k] : 1.f) * invstd[c + k];
+            if (train) {
+                const float xh = (yy[k] - mean[c + k]) * invstd[c + k];
+                const float sg = (float)sums2[(c + k) * 2] * inv_count;
+                const float sgx = (float)sums2[(c + k) * 2 + 1] * inv_count;
+                o[k] = gi * (g[k] - sg - xh * sgx);
+            } else {
+                o[k] = gi * g[k];
+            }
+        }
+        if constexpr (VEC) {
+            *reinterpret_cast<float4*>(dy + row * lddy + c) = *reinterpret_cast<float4*>(o);
+            if (dres) *reinterpret_cast<float4*>(dres + row * lddres + c) = *reinterpret_cast<float4*>(g);
+        } else {
+            dy[row * lddy + c] = o[0];
+            if (dres) dres[row * lddres + c] = g[0];
+        }
+    }
+}
+
+static inline int ew_grid(int64_t total) {
+    int64_t b = cdiv(total, 256);
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace xv2
+
+using namespace xv2;
+
+extern "C" int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
+                                   void* stream) {
+    XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_reduce_stats: empty");
+    return reduce_stats(partial, tiles, C, sums, scratch, (hipStream_t)stream);
+}
+
+extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
+    const ChunkGeom g = chunk_geom(npix, C);
+    size_t part = (size_t)g.chunks * C * 2 * sizeof(float);
+    part = (part + 15) & ~(size_t)15;
+    return part + (size_t)XV2_BN_SCRATCH_ROWS * C * 2 * sizeof(double);
+}
+extern "C" size_t xv2_bn_backward_workspace(int64_t npix, int C) { return xv2_bn_tensor_stats_workspace(npix, C); }
+
+template <int MODE>
+static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st) {
+    const ChunkGeom g = chunk_geom(npix, C);
+    size_t part = (size_t)g.chunks * C * 2 * sizeof(float);
+    part = (part + 15) & ~(size_t)15;
+    double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
+    hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks), dim3(256), 0, st, op, npix, C, g.rpb,
+                       workspace);
+    XV2_CHECK_LAUNCH();
+    return reduce_stats(workspace, g.chunks, C, sums, scratch, st);
+}
+
+extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums, float* workspace,
+                                   void* stream) {
+    XV2_CHECK_ARG(npix > 0 && C > 0, "bn_tensor_stats: empty");
+    ColOp<0> op;
+    op.a = x; op.lda = ldx; op.z = nullptr; op.y = nullptr; op.mean = nullptr; op.invstd = nullptr;
+    op.ldz = op.ldy = 0; op.act = 0;
+    return column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
+}
+
+extern "C" int xv2_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, int C, void* stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums,
+                       count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, int C,
+                                  void* stream) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma,
+                       beta, running_mean, running_var, eps, scale, shift, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+static inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 4) return false;
+    for (int l : lds)
+        if (l % 4) return false;
+    for (const void* p : ptrs)
+        if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+    return true;
+}
+
+extern "C" int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
+                                  const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
+                                  void* stream) {
+    XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_forward: empty");
+    const bool vec = vec_ok(C, {ldy, ldz, residual ? ldr : 0}, {y, z, residual, scale, shift});
+    const int grid = ew_grid(npix * (vec ? C / 4 : C));
+    if (vec)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
+                           shift, residual, ldr, act, z, ldz, npix, C);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
+                           shift, residual, ldr, act, z, ldz, npix, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                          const float* mean, const float* invstd, int act, int64_t npix, int C,
+                                          double* sums2, float* workspace, void* stream) {
+    XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_reduce: empty");
+    XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
+    ColOp<1> op;
+    op.a = dz; op.lda = lddz; op.z = z; op.ldz = ldz; op.y = y; op.ldy = ldy; op.mean = mean; op.invstd = invstd;
+    op.act = act;
+    return column_sums<1>(op, npix, C, sums2, workspace, (hipStream_t)stream);
+}
+
+extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                         const float* mean, const float* invstd, const float* gamma,
+                                         const double* sums2, double count, int act, int train, float* dy, int lddy,
+                                         float* dres, int lddres, int64_t npix, int C, void* stream) {
+    XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
+    const bool vec = vec_ok(C, {lddz, ldz, ldy, lddy, dres ? lddres : 0}, {dz, z, y, dy, dres});
+    const int grid = ew_grid(npix * (vec ? C / 4 : C));
+    if (vec)
+        hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+                           y, ldy, mean, invstd, gamma, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+                           y, ldy, mean, invstd, gamma, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}

@@ -1,0 +1,624 @@
+// Narrow / pointwise pieces of the U-Net hot path that are HBM- or latency-bound, not MFMA-shaped:
+//   * 1x1 "head" convolutions with <= 4 output channels (model/layers.py:177,180; psi conv :145)
+//   * attention-gate glue (model/layers.py:161-166)
+//   * split-attention glue of the ResNeSt block (radix-2 sum + GAP, tiny fc layers, rSoftMax,
+//     attention-weighted recombination)
+//   * NCHW <-> NHWC conversion at the model boundary (model/plt.py:51 hands NCHW images)
+// All reductions are two-level with a fixed order (deterministic), no atomics.
+#include "xv2_common.h"
+#include <algorithm>
+
+namespace xv2 {
+
+static inline int grid_for(int64_t total, int cap = 8192) {
+    int64_t b = cdiv(total, 256);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ----------------------------------------------------------------------------------- head conv
+// L lanes cooperate on one pixel (L = min(64, Cin/4), power of two); each lane owns 4 channels
+// of every 4*L chunk.  COUT <= 4.
+constexpr int HEAD_BLOCKS = 1024;
+
+template <int COUT>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, int ldx, int64_t npix,
+                                                        int64_t hw, int Cin, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int nchw, int L) {
+    const int tid = threadIdx.x;
+    const int lane_in = tid % L;
+    const int gpb = 256 / L;
+    const int64_t g0 = (int64_t)blockIdx.x * gpb + tid / L;
+    const int64_t gstride = (int64_t)gridDim.x * gpb;
+    for (int64_t p = g0; p < npix; p += gstride) {
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int c = lane_in * 4; c < Cin; c += 4 * L) {
+            const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float4 ww = *reinterpret_cast<const float4*>(w + o * Cin + c);
+                acc[o] += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+            for (int s = L >> 1; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+        if (lane_in == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float r = acc[o] + (bias ? bias[o] : 0.f);
+                if (nchw) {
+                    const int64_t n = p / hw, q = p - n * hw;
+                    y[(n * COUT + o) * hw + q] = r;
+                } else {
+                    y[p * COUT + o] = r;
+                }
+            }
+        }
+    }
+}
+
+// dx[p][c] = sum_o dy[p][o] w[o][c];  per-block partial dw[o][c] = sum_p dy[p][o] x[p][c], db[o]
+template <int COUT>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ dy, int64_t npix, int64_t hw,
+                                                        int Cin, const float* __restrict__ w, int nchw,
+                                                        float* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                        int L) {
+    extern __shared__ float sh[];  // [gpb][COUT][4*L chunk] reduced per chunk
+    const int tid = threadIdx.x;
+    const int lane_in = tid % L;
+    const int grp = tid / L;
+    const int gpb = 256 / L;
+    const int64_t g0 = (int64_t)blockIdx.x * gpb + grp;
+    const int64_t gstride = (int64_t)gridDim.x * gpb;
+    float* mypart = part + (size_t)blockIdx.x * COUT * (Cin + 1);
+    float dbacc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) dbacc[o] = 0.f;
+    for (int cb = 0; cb < Cin; cb += 4 * L) {
+        const int c = cb + lane_in * 4;
+        float4 ww[COUT];
+        float4 dwacc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            ww[o] = *reinterpret_cast<const float4*>(w + o * Cin + c);
+            dwacc[o] = make_float4(0, 0, 0, 0);
+        }
+        for (int64_t p = g0; p < npix; p += gstride) {
+            float g[COUT];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                if (nchw) {
+                    const int64_t n = p / hw, q = p - n * hw;
+                    g[o] = dy[(n * COUT + o) * hw + q];
+                } else {
+                    g[o] = dy[p * COUT + o];
+                }
+            }
+            const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+            float4 d = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                d.x += g[o] * ww[o].x; d.y += g[o] * ww[o].y; d.z += g[o] * ww[o].z; d.w += g[o] * ww[o].w;
+                dwacc[o].x += g[o] * v.x; dwacc[o].y += g[o] * v.y; dwacc[o].z += g[o] * v.z; dwacc[o].w += g[o] * v.w;
+                if (cb == 0 && lane_in == 0) dbacc[o] += g[o];
+            }
+            if (dx) *reinterpret_cast<float4*>(dx + p * lddx + c) = d;
+        }
+        // reduce dwacc over the groups of this block (fixed order)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+            *reinterpret_cast<float4*>(sh + ((grp * COUT + o) * L + lane_in) * 4) = dwacc[o];
+        __syncthreads();
+        for (int i = tid; i < COUT * L * 4; i += 256) {
+            const int o = i / (L * 4), k = i % (L * 4);
+            float s = 0.f;
+            for (int q = 0; q < gpb; ++q) s += sh[((q * COUT + o) * L) * 4 + k];
+            mypart[o * (Cin + 1) + cb + k] = s;
+        }
+        __syncthreads();
+    }
+    // bias partial
+    if (lane_in == 0) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) sh[grp * COUT + o] = dbacc[o];
+    }
+    __syncthreads();
+    if (tid < COUT) {
+        float s = 0.f;
+        for (int q = 0; q < gpb; ++q) s += sh[q * COUT + tid];
+        mypart[tid * (Cin + 1) + Cin] = s;
+    }
+}
+
+__global__ void head_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout, int Cin,
+                                       float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = Cin + 1;
+    if (i >= Cout * row) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * Cout * row + i];
+    const int o = i / row, c = i % row;
+    if (c < Cin) dw[o * Cin + c] = s;
+    else if (db) db[o] = s;
+}
+
+// ------------------------------------------------------------------------------- elementwise
+__global__ void add_relu_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                    float4* __restrict__ r, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = a[i], y = b[i];
+        r[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+    }
+}
+__global__ void add_relu_bwd_kernel(const float4* __restrict__ r, const float4* __restrict__ dr,
+                                    float4* __restrict__ d, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = r[i], g = dr[i];
+        d[i] = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
+    }
+}
+__global__ void axpby_kernel(float alpha, const float4* __restrict__ a, float beta, const float4* __restrict__ b,
+                             float4* __restrict__ o, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 x = a[i];
+        float4 y = make_float4(0, 0, 0, 0);
+        if (b) y = b[i];
+        o[i] = make_float4(alpha * x.x + beta * y.x, alpha * x.y + beta * y.y, alpha * x.z + beta * y.z,
+                           alpha * x.w + beta * y.w);
+    }
+}
+
+__global__ void gate_mul_fwd_kernel(const float* __restrict__ skip, int lds, const float* __restrict__ gate,
+                                    float* __restrict__ out, int64_t npix, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = npix * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        const float g = gate[p];
+        const float4 v = *reinterpret_cast<const float4*>(skip + p * lds + c);
+        *reinterpret_cast<float4*>(out + p * C + c) = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
+    }
+}
+// one wave per pixel group: dskip = dout*gate ; dgate[p] = sum_c dout*skip
+__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const float* __restrict__ skip, int lds,
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ dout,
+                                                            float* __restrict__ dskip, float* __restrict__ dgate,
+                                                            int64_t npix, int C, int L) {
+    const int tid = threadIdx.x, lane_in = tid % L, gpb = 256 / L;
+    for (int64_t p = (int64_t)blockIdx.x * gpb + tid / L; p < npix; p += (int64_t)gridDim.x * gpb) {
+        const float g = gate[p];
+        float acc = 0.f;
+        for (int c = lane_in * 4; c < C; c += 4 * L) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + p * C + c);
+            const float4 s = *reinterpret_cast<const float4*>(skip + p * lds + c);
+            acc += d.x * s.x + d.y * s.y + d.z * s.z + d.w * s.w;
+            *reinterpret_cast<float4*>(dskip + p * C + c) = make_float4(d.x * g, d.y * g, d.z * g, d.w * g);
+        }
+        for (int s = L >> 1; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+        if (lane_in == 0) dgate[p] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int64_t bstride, int N, int C, int64_t hw,
+                                    float* __restrict__ y, int Cp) {
+    const int64_t total = (int64_t)N * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        for (int c = 0; c < Cp; ++c) y[i * Cp + c] = c < C ? x[n * bstride + c * hw + q] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, int N, int C, int64_t hw,
+                                    float* __restrict__ y) {
+    const int64_t total = (int64_t)N * C * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i % hw;
+        const int64_t t = i / hw;
+        const int c = (int)(t % C);
+        const int64_t n = t / C;
+        y[i] = x[(n * hw + q) * ldx + c];
+    }
+}
+__global__ void copy_channels_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                     int64_t npix, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = npix * C4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        *reinterpret_cast<float4*>(dst + p * ldd + c) = *reinterpret_cast<const float4*>(src + p * lds + c);
+    }
+}
+
+// -------------------------------------------------------------------------- split attention
+constexpr int SPLAT_CHUNKS = 64;
+// part[n][chunk][C2] = column sums of x[n, rows of chunk, :]
+__global__ void __launch_bounds__(256) splat_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            int64_t hw, int C2, int rows_per_chunk,
+                                                            float* __restrict__ part) {
+    // a: tensor [N][hw][C2]; if b != null the summed quantity is a*b (same layout for the first C2/..)
+    __shared__ float sh[256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cb = 0; cb < C2; cb += 64) {
+        const int c = cb + tx;
+        float s = 0.f;
+        if (c < C2)
+            for (int64_t r = r0 + ty; r < r1; r += 4) {
+                const size_t o = ((size_t)n * hw + r) * C2 + c;
+                s += b ? a[o] * b[o] : a[o];
+            }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (ty == 0 && c < C2)
+            part[((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c] = sh[tx] + sh[64 + tx] + sh[128 + tx] + sh[192 + tx];
+        __syncthreads();
+    }
+}
+__global__ void splat_gap_finish_kernel(const float* __restrict__ part, int N, int C, int chunks, float inv_hw,
+                                        float* __restrict__ gap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        const float* p = part + ((size_t)n * SPLAT_CHUNKS + k) * 2 * C;
+        s += p[c] + p[C + c];
+    }
+    gap[i] = s * inv_hw;
+}
+// datt[n][r*C+c] = sum_hw dout[n,hw,c] * x[n,hw,r*C+c]
+__global__ void __launch_bounds__(256) splat_datt_partial_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ dout, int64_t hw, int C,
+                                                                  int rows_per_chunk, float* __restrict__ part) {
+    __shared__ float sh[256];
+    const int n = blockIdx.y, chunk = blockIdx.x, C2 = 2 * C;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cb = 0; cb < C2; cb += 64) {
+        const int c = cb + tx;
+        float s = 0.f;
+        if (c < C2) {
+            const int cc = c < C ? c : c - C;
+            for (int64_t r = r0 + ty; r < r1; r += 4)
+                s += x[((size_t)n * hw + r) * C2 + c] * dout[((size_t)n * hw + r) * C + cc];
+        }
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (ty == 0 && c < C2)
+            part[((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c] = sh[tx] + sh[64 + tx] + sh[128 + tx] + sh[192 + tx];
+        __syncthreads();
+    }
+}
+__global__ void splat_datt_finish_kernel(const float* __restrict__ part, int N, int C2, int chunks,
+                                         float* __restrict__ datt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C2) return;
+    const int n = i / C2, c = i % C2;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
+    datt[i] = s;
+}
+__global__ void splat_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ att, int64_t hw,
+                                       int C, float* __restrict__ out, int64_t total4) {
+    const int C4 = C >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        const int64_t n = p / hw;
+        const float4 a0 = *reinterpret_cast<const float4*>(att + n * 2 * C + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(att + n * 2 * C + C + c);
+        const float4 x0 = *reinterpret_cast<const float4*>(x + p * 2 * C + c);
+        const float4 x1 = *reinterpret_cast<const float4*>(x + p * 2 * C + C + c);
+        *reinterpret_cast<float4*>(out + p * C + c) =
+            make_float4(a0.x * x0.x + a1.x * x1.x, a0.y * x0.y + a1.y * x1.y, a0.z * x0.z + a1.z * x1.z,
+                        a0.w * x0.w + a1.w * x1.w);
+    }
+}
+__global__ void splat_apply_bwd_kernel(const float* __restrict__ att, const float* __restrict__ dout,
+                                       const float* __restrict__ dgap, int64_t hw, int C, float inv_hw,
+                                       float* __restrict__ dx, int64_t total4) {
+    const int C4 = C >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        const int64_t n = p / hw;
+        const float4 a0 = *reinterpret_cast<const float4*>(att + n * 2 * C + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(att + n * 2 * C + C + c);
+        const float4 d = *reinterpret_cast<const float4*>(dout + p * C + c);
+        float4 g = make_float4(0, 0, 0, 0);
+        if (dgap) {
+            g = *reinterpret_cast<const float4*>(dgap + n * C + c);
+            g.x *= inv_hw; g.y *= inv_hw; g.z *= inv_hw; g.w *= inv_hw;
+        }
+        *reinterpret_cast<float4*>(dx + p * 2 * C + c) =
+            make_float4(d.x * a0.x + g.x, d.y * a0.y + g.y, d.z * a0.z + g.z, d.w * a0.w + g.w);
+        *reinterpret_cast<float4*>(dx + p * 2 * C + C + c) =
+            make_float4(d.x * a1.x + g.x, d.y * a1.y + g.y, d.z * a1.z + g.z, d.w * a1.w + g.w);
+    }
+}
+
+// tiny dense layers: one wave per output element
+__global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y, int N,
+                                                          int Cin, int Cout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    if (wid >= (int64_t)N * Cout) return;
+    const int n = (int)(wid / Cout), o = (int)(wid % Cout);
+    float s = 0.f;
+    for (int c = lane; c < Cin; c += 64) s += x[n * Cin + c] * w[(size_t)o * Cin + c];
+    s = wave_sum(s);
+    if (lane == 0) y[wid] = s + (b ? b[o] : 0.f);
+}
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                     float* __restrict__ dx, int N, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Cin) return;
+    const int n = i / Cin, c = i % Cin;
+    float s = 0.f;
+    for (int o = 0; o < Cout; ++o) s += dy[n * Cout + o] * w[(size_t)o * Cin + c];
+    dx[i] = s;
+}
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                     float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * (Cin + 1)) return;
+    const int o = i / (Cin + 1), c = i % (Cin + 1);
+    float s = 0.f;
+    if (c < Cin) {
+        for (int n = 0; n < N; ++n) s += dy[n * Cout + o] * x[n * Cin + c];
+        dw[(size_t)o * Cin + c] = s;
+    } else if (db) {
+        for (int n = 0; n < N; ++n) s += dy[n * Cout + o];
+        db[o] = s;
+    }
+}
+__global__ void rsoftmax_fwd_kernel(const float* __restrict__ l, float* __restrict__ a, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    const float l0 = l[n * 2 * C + c], l1 = l[n * 2 * C + C + c];
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.f / (e0 + e1);
+    a[n * 2 * C + c] = e0 * inv;
+    a[n * 2 * C + C + c] = e1 * inv;
+}
+__global__ void rsoftmax_bwd_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                    float* __restrict__ dl, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    const float a0 = a[n * 2 * C + c], a1 = a[n * 2 * C + C + c];
+    const float d0 = da[n * 2 * C + c], d1 = da[n * 2 * C + C + c];
+    const float dot = a0 * d0 + a1 * d1;
+    dl[n * 2 * C + c] = a0 * (d0 - dot);
+    dl[n * 2 * C + C + c] = a1 * (d1 - dot);
+}
+
+static int pick_L(int Cin) {
+    int L = 1;
+    while (L * 2 <= 64 && L * 2 * 4 <= Cin) L *= 2;
+    return L;
+}
+
+}  // namespace xv2
+
+using namespace xv2;
+
+extern "C" int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
+                                     const float* w, const float* bias, float* y, int nchw_out, void* stream) {
+    XV2_CHECK_ARG(Cout >= 1 && Cout <= 4, "head_conv: Cout=%d must be in 1..4", Cout);
+    XV2_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0, "head_conv: Cin=%d must be a multiple of 4", Cin);
+    const int L = pick_L(Cin);
+    XV2_CHECK_ARG(Cin % (4 * L) == 0, "head_conv: Cin=%d unsupported", Cin);
+    const int grid = (int)std::min<int64_t>(cdiv(npix, 256 / L), 16384);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_HF(CO) \
+    hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, st, x, ldx, npix, hw, Cin, w, bias, y, nchw_out, L)
+    switch (Cout) {
+        case 1: LAUNCH_HF(1); break;
+        case 2: LAUNCH_HF(2); break;
+        case 3: LAUNCH_HF(3); break;
+        default: LAUNCH_HF(4); break;
+    }
+#undef LAUNCH_HF
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" size_t xv2_head_conv_backward_workspace(int64_t npix, int Cin, int Cout) {
+    (void)npix;
+    return (size_t)HEAD_BLOCKS * Cout * (Cin + 1) * sizeof(float);
+}
+
+extern "C" int xv2_head_conv_backward(const float* x, int ldx, const float* dy, int64_t npix, int64_t hw, int Cin,
+                                      int Cout, const float* w, int nchw_dy, float* dx, int lddx, float* dw,
+                                      float* dbias, float* workspace, void* stream) {
+    XV2_CHECK_ARG(Cout >= 1 && Cout <= 4, "head_conv: Cout=%d must be in 1..4", Cout);
+    XV2_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (!dx || lddx % 4 == 0), "head_conv: Cin=%d must be a multiple of 4", Cin);
+    const int L = pick_L(Cin);
+    XV2_CHECK_ARG(Cin % (4 * L) == 0, "head_conv: Cin=%d unsupported", Cin);
+    int grid = (int)std::min<int64_t>(cdiv(npix, 256 / L), HEAD_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t smem = (size_t)(256 / L) * Cout * L * 4 * sizeof(float);
+#define LAUNCH_HB(CO)                                                                                        \
+    hipLaunchKernelGGL(head_bwd_kernel<CO>, dim3(grid), dim3(256), smem, st, x, ldx, dy, npix, hw, Cin, w, \
+                       nchw_dy, dx, lddx, workspace, L)
+    switch (Cout) {
+        case 1: LAUNCH_HB(1); break;
+        case 2: LAUNCH_HB(2); break;
+        case 3: LAUNCH_HB(3); break;
+        default: LAUNCH_HB(4); break;
+    }
+#undef LAUNCH_HB
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, st,
+                       workspace, grid, Cout, Cin, dw, dbias);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_add_relu_forward(const float* a, const float* b, float* r, int64_t n, void* stream) {
+    XV2_CHECK_ARG(n % 4 == 0, "add_relu: n must be a multiple of 4");
+    hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)a, (const float4*)b, (float4*)r, n / 4);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_add_relu_backward(const float* r, const float* dr, float* dab, int64_t n, void* stream) {
+    XV2_CHECK_ARG(n % 4 == 0, "add_relu: n must be a multiple of 4");
+    hipLaunchKernelGGL(add_relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)r, (const float4*)dr, (float4*)dab, n / 4);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_axpby(float alpha, const float* a, float beta, const float* b, float* out, int64_t n,
+                         void* stream) {
+    XV2_CHECK_ARG(n % 4 == 0, "axpby: n must be a multiple of 4");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, alpha,
+                       (const float4*)a, beta, (const float4*)b, (float4*)out, n / 4);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    return xv2_axpby(1.f, a, 1.f, b, out, n, stream);
+}
+extern "C" int xv2_gate_mul_forward(const float* skip, int lds, const float* gate, float* out, int64_t npix, int C,
+                                    void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0, "gate_mul: C must be a multiple of 4");
+    hipLaunchKernelGGL(gate_mul_fwd_kernel, dim3(grid_for(npix * C / 4)), dim3(256), 0, (hipStream_t)stream, skip,
+                       lds, gate, out, npix, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_gate_mul_backward(const float* skip, int lds, const float* gate, const float* dout, float* dskip,
+                                     float* dgate, int64_t npix, int C, void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0, "gate_mul: C must be a multiple of 4");
+    const int L = pick_L(C);
+    hipLaunchKernelGGL(gate_mul_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(npix, 256 / L), 16384)), dim3(256),
+                       0, (hipStream_t)stream, skip, lds, gate, dout, dskip, dgate, npix, C, L);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_nchw_to_nhwc(const float* x, int64_t x_batch_stride, int N, int C, int H, int W, float* y, int Cp,
+                                void* stream) {
+    XV2_CHECK_ARG(Cp >= C, "nchw_to_nhwc: Cp < C");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_batch_stride, N, C, (int64_t)H * W, y, Cp);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, int W, float* y, void* stream) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * C * H * W)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, N, C, (int64_t)H * W, y);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t npix, int C, void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "copy_channels: multiples of 4 required");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * C / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                       lds, dst, ldd, npix, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" size_t xv2_splat_gap_workspace(int N, int64_t hw, int C) {
+    (void)hw;
+    return (size_t)N * SPLAT_CHUNKS * 2 * C * sizeof(float);
+}
+static inline int splat_rows(int64_t hw, int& chunks) {
+    int rpc = (int)cdiv(hw, SPLAT_CHUNKS);
+    if (rpc < 4) rpc = 4;
+    chunks = (int)cdiv(hw, rpc);
+    return rpc;
+}
+extern "C" int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, float* gap, float* workspace,
+                                     void* stream) {
+    int chunks;
+    const int rpc = splat_rows(hw, chunks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, N), dim3(256), 0, st, x, (const float*)nullptr, hw, 2 * C,
+                       rpc, workspace);
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, st, workspace, N, C,
+                       chunks, 1.f / (float)hw, gap);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_splat_apply_forward(const float* x, const float* att, int N, int64_t hw, int C, float* out,
+                                       void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0, "splat_apply: C must be a multiple of 4");
+    const int64_t total4 = (int64_t)N * hw * C / 4;
+    hipLaunchKernelGGL(splat_apply_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, att, hw,
+                       C, out, total4);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_splat_apply_backward(const float* x, const float* att, const float* dout, const float* dgap,
+                                        int N, int64_t hw, int C, float* dx, float* datt, float* workspace,
+                                        void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0, "splat_apply: C must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    if (datt) {
+        int chunks;
+        const int rpc = splat_rows(hw, chunks);
+        hipLaunchKernelGGL(splat_datt_partial_kernel, dim3(chunks, N), dim3(256), 0, st, x, dout, hw, C, rpc,
+                           workspace);
+        XV2_CHECK_LAUNCH();
+        hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(N * 2 * C, 256)), dim3(256), 0, st,
+                           workspace, N, 2 * C, chunks, datt);
+        XV2_CHECK_LAUNCH();
+    }
+    if (dx) {
+        const int64_t total4 = (int64_t)N * hw * C / 4;
+        hipLaunchKernelGGL(splat_apply_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, st, att, dout, dgap, hw, C,
+                           1.f / (float)hw, dx, total4);
+        XV2_CHECK_LAUNCH();
+    }
+    return XV2_OK;
+}
+extern "C" int xv2_linear_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout,
+                                  void* stream) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)cdiv((int64_t)N * Cout * 64, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, b, y, N, Cin, Cout);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                                   int N, int Cin, int Cout, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(N * Cin, 256)), dim3(256), 0, st, w, dy, dx, N,
+                           Cin, Cout);
+        XV2_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, st, x, dy, dw,
+                       db, N, Cin, Cout);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_rsoftmax_forward(const float* logits, float* att, int N, int C, void* stream) {
+    hipLaunchKernelGGL(rsoftmax_fwd_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, att, N, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_rsoftmax_backward(const float* att, const float* datt, float* dlogits, int N, int C,
+                                     void* stream) {
+    hipLaunchKernelGGL(rsoftmax_bwd_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, att,
+                       datt, dlogits, N, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}

@@ -1,0 +1,318 @@
+// Weight gradient of a convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   dW[co][t][c] = sum_{m} dY[m][co] * X[pix(m, t)][c]        (m over N*OH*OW output pixels)
+//
+// Both operands are NHWC, i.e. contiguous along the NON-reduced dimension, so the LDS tiles are
+// kept exactly as loaded ([32 pixels][channels]) and the MFMA fragments are gathered with
+// conflict-free ds_read_b32 (lane = channel).  The reduction over pixels is split across
+// gridDim.y (and, for narrow tiles, across the waves of a block); every split writes its own
+// slab part[split][Cout][T][Ctot] and a second kernel sums the slabs in a fixed order
+// (deterministic, no atomics) while transposing into the reference's OIHW parameter layout.
+// Replaces the weight-gradient half of autograd for every nn.Conv2d / nn.ConvTranspose2d of
+// model/layers.py and of the encoder blocks.
+#include "xv2_common.h"
+#include <algorithm>
+
+namespace xv2 {
+
+struct WTap {
+    short dh, dw;
+};
+
+struct WgradParams {
+    const float* X0;
+    const float* X1;
+    const float* DY;
+    float* part;
+    int C0, C1, Ctot, ldX0, ldX1, ldDY, Cout;
+    int IH, IW, OH, OW, stride;
+    int M;
+    int T;
+    int ktiles, kt_per_split;
+    int tiles_n;  // column tiles per tap (Ctot / BN), or column tiles overall for SMALLC
+    WTap taps[52];
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+    constexpr int MR = BM / WGM / 32, NR = BN / WGN / 32;
+    static_assert(WGM * WGN * WK == 4, "4 waves");
+    constexpr int AF4 = BM / 4, ARPP = 256 / AF4, APASS = 32 / ARPP;  // float4 per row, rows per pass
+    constexpr int BF4 = BN / 4, BRPP = 256 / BF4, BPASS = 32 / BRPP;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][32][BM]   dY tile
+    float* Bs = smem + 2 * 32 * BM;   // [2][32][BN]   X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wk = wave % WK;
+    const int wmn = wave / WK;
+    const int wm = wmn / WGN, wn = wmn % WGN;
+
+    // block -> (row tile, tap, column tile)
+    int b = blockIdx.x;
+    const int tn = b % p.tiles_n;
+    b /= p.tiles_n;
+    int tap = 0;
+    if constexpr (!SMALLC) {
+        tap = b % p.T;
+        b /= p.T;
+    }
+    const int tmr = b;
+    const int co0 = tmr * BM;
+    const int cn0 = tn * BN;  // column offset (channel within tap, or tap*4+c for SMALLC)
+
+    const float* xsrc;
+    int ldx, xch;
+    if (cn0 < p.C0) {
+        xsrc = p.X0; ldx = p.ldX0; xch = cn0;
+    } else {
+        xsrc = p.X1; ldx = p.ldX1; xch = cn0 - p.C0;
+    }
+
+    const int a_c4 = tid % AF4, a_r = tid / AF4;
+    const int b_c4 = tid % BF4, b_r = tid / BF4;
+    int dh = 0, dw = 0;
+    bool tapok = true;
+    if constexpr (SMALLC) {
+        const int t = (cn0 >> 2) + b_c4;
+        tapok = t < p.T;
+        dh = p.taps[tapok ? t : 0].dh;
+        dw = p.taps[tapok ? t : 0].dw;
+    } else {
+        dh = p.taps[tap].dh;
+        dw = p.taps[tap].dw;
+    }
+    const int ohw = p.OH * p.OW;
+
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+
+    float4 ra[APASS], rb[BPASS];
+    auto gload = [&](int kt) {
+        const int mb = kt * 32;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int m = mb + a_r + j * ARPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M) v = *reinterpret_cast<const float4*>(p.DY + (size_t)m * p.ldDY + co0 + a_c4 * 4);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int m = mb + b_r + j * BRPP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M && tapok) {
+                const int n = m / ohw;
+                const int rem = m - n * ohw;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) {
+                    const size_t pix = ((size_t)n * p.IH + ih) * p.IW + iw;
+                    if constexpr (SMALLC)
+                        v = *reinterpret_cast<const float4*>(p.X0 + pix * p.ldX0);
+                    else
+                        v = *reinterpret_cast<const float4*>(xsrc + pix * ldx + xch + b_c4 * 4);
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * 32 * BM;
+        float* bb = Bs + buf * 32 * BN;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            *reinterpret_cast<float4*>(a + (a_r + j * ARPP) * BM + a_c4 * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j)
+            *reinterpret_cast<float4*>(bb + (b_r + j * BRPP) * BN + b_c4 * 4) = rb[j];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) gload(kt + 1);
+        const float* a = As + buf * 32 * BM + wm * (MR * 32) + l31;
+        const float* bb = Bs + buf * 32 * BN + wn * (NR * 32) + l31;
+#pragma unroll
+        for (int s0 = 0; s0 < 16 / WK; ++s0) {
+            const int s = s0 * WK + wk;
+            float af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) af[i] = a[(2 * s + h) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bf[j] = bb[(2 * s + h) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // store the slab: part[split*WK + wk][co][T][Ctot]   (SMALLC: [co][T*4])
+    const size_t rowlen = (size_t)p.T * p.Ctot;
+    float* slab = p.part + (size_t)(blockIdx.y * WK + wk) * p.Cout * rowlen;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int col = cn0 + wn * (NR * 32) + j * 32 + l31;
+        size_t coloff;
+        bool cok = true;
+        if constexpr (SMALLC) {
+            cok = col < p.T * 4;
+            coloff = col;
+        } else {
+            coloff = (size_t)tap * p.Ctot + col;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm * (MR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (cok) slab[(size_t)row * rowlen + coloff] = acc[i][j][r];
+            }
+    }
+}
+
+// out_oihw[co][ci][t] = sum_z part[z][co][t][ci]   (ci < cin_real)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int Cout, int T, int Ctot,
+                                    int cin_real, float* __restrict__ out) {
+    const size_t total = (size_t)Cout * T * Ctot;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ctot);
+        const size_t q = i / Ctot;
+        const int t = (int)(q % T);
+        const int co = (int)(q / T);
+        float s = 0.f;
+        for (int z = 0; z < nslab; ++z) s += part[(size_t)z * total + i];
+        if (ci < cin_real) out[((size_t)co * cin_real + ci) * T + t] = s;
+    }
+}
+
+struct WgradPlan {
+    int bm, bn, wk, splitk, kt_per, ktiles, tiles;
+    bool smallc;
+};
+
+static WgradPlan make_plan(const xv2_conv_desc* d) {
+    WgradPlan pl;
+    const int Ctot = d->C0 + d->C1;
+    pl.smallc = (d->C0 == 4 && d->C1 == 0);
+    const int T = d->KH * d->KW;
+    int bm = (d->Cout % 128 == 0) ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
+    int bn;
+    if (pl.smallc) {
+        bn = 64;
+        if (bm == 128) bm = 64;
+        pl.tiles = (d->Cout / bm) * (int)cdiv(T * 4, bn);
+    } else {
+        auto fit = [&](int v) { return d->C0 % v == 0 && d->C1 % v == 0; };
+        bn = fit(128) ? 128 : (fit(64) ? 64 : 32);
+        if (bm == 128 && bn != 128) bm = 64;
+        if (bn == 128 && bm != 128) bn = 64;
+        pl.tiles = (d->Cout / bm) * (Ctot / bn) * T;
+    }
+    pl.bm = bm;
+    pl.bn = bn;
+    pl.wk = 4 / ((bm / 32 > 2 ? 2 : bm / 32) * (bn / 32 > 2 ? 2 : bn / 32));
+    const int64_t M = (int64_t)d->N * d->OH * d->OW;
+    pl.ktiles = (int)cdiv(M, 32);
+    int want = (int)cdiv(1536, pl.tiles);
+    int maxsplit = pl.ktiles / 4 > 0 ? pl.ktiles / 4 : 1;
+    int splitk = want < 1 ? 1 : want;
+    if (splitk > maxsplit) splitk = maxsplit;
+    pl.kt_per = (int)cdiv(pl.ktiles, splitk);
+    pl.splitk = (int)cdiv(pl.ktiles, pl.kt_per);
+    return pl;
+}
+
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC>
+static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
+    constexpr size_t smem = (size_t)2 * 32 * (BM + BN) * 4;
+    auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC>;
+    hipLaunchKernelGGL(kern, dim3(pl.tiles, pl.splitk), dim3(256), smem, stream, p);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
+                      const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
+                      hipStream_t stream) {
+    XV2_CHECK_ARG(d->KH * d->KW <= 52, "too many taps");
+    XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
+    const WgradPlan pl = make_plan(d);
+    XV2_CHECK_ARG(pl.smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
+                  "backward_weight: C0=%d C1=%d must be multiples of 32", d->C0, d->C1);
+    WgradParams p;
+    p.X0 = x0; p.X1 = x1; p.DY = dy; p.part = workspace;
+    p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1; p.ldX0 = ldx0; p.ldX1 = ldx1; p.ldDY = lddy;
+    p.Cout = d->Cout;
+    p.IH = d->IH; p.IW = d->IW; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride;
+    p.M = d->N * d->OH * d->OW;
+    p.T = d->KH * d->KW;
+    p.ktiles = pl.ktiles; p.kt_per_split = pl.kt_per;
+    p.tiles_n = pl.smallc ? (int)cdiv(p.T * 4, pl.bn) : p.Ctot / pl.bn;
+    for (int kh = 0; kh < d->KH; ++kh)
+        for (int kw = 0; kw < d->KW; ++kw) {
+            p.taps[kh * d->KW + kw].dh = (short)(kh * d->dil - d->pad);
+            p.taps[kh * d->KW + kw].dw = (short)(kw * d->dil - d->pad);
+        }
+    int rc;
+    if (pl.smallc) {
+        if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
+        else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
+    } else if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false>(p, pl, stream);
+    else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false>(p, pl, stream);
+    else if (pl.bm == 64 && pl.bn == 32) rc = launch_wgrad<64, 32, 2, 1, 2, false>(p, pl, stream);
+    else if (pl.bm == 32 && pl.bn == 64) rc = launch_wgrad<32, 64, 1, 2, 2, false>(p, pl, stream);
+    else rc = launch_wgrad<32, 32, 1, 1, 4, false>(p, pl, stream);
+    if (rc) return rc;
+    const size_t total = (size_t)d->Cout * p.T * p.Ctot;
+    const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, pl.splitk * pl.wk,
+                       d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+}  // namespace xv2
+
+using namespace xv2;
+
+extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d) {
+    const WgradPlan pl = make_plan(d);
+    return (size_t)pl.splitk * pl.wk * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
+}
+
+extern "C" int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,
+                                          const float* x1, int ldx1, const float* dy, int lddy,
+                                          float* dw_oihw, int cin_real, float* workspace, void* stream) {
+    return wgrad_impl(d, x0, ldx0, x1, ldx1, dy, lddy, dw_oihw, cin_real, workspace, (hipStream_t)stream);
+}
+
+// conv_transpose: the equivalent conv `d` has input = the transposed conv's OUTPUT gradient (large
+// tensor, C0 channels) and output-gradient = the transposed conv's INPUT x (Cout channels).
+extern "C" int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const float* x, int ldx,
+                                                    const float* dy, int lddy, float* dw, float* workspace,
+                                                    void* stream) {
+    return wgrad_impl(d, dy, lddy, nullptr, 0, x, ldx, dw, d->C0, workspace, (hipStream_t)stream);
+}
