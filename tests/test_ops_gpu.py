@@ -1,0 +1,312 @@
+"""Op-level numerics of the HIP kernels (through the C ABI) against plain PyTorch fp32 on CPU.
+Tolerances: fp32 MFMA is an exact-fp32 fmaf chain, so only summation order differs: 2e-4 relative to the
+tensor's max magnitude for convolutions with K up to ~14k, 1e-5-class for streaming kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def nhwc(t):  # CPU NCHW -> GPU NHWC
+    return t.permute(0, 2, 3, 1).contiguous().to(dev())
+
+
+def nchw(t):  # GPU NHWC -> CPU NCHW
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, "%s: rel-to-max error %.3e > %.1e" % (what, err, tol)
+
+
+CONV_CASES = [
+    # N, H, W, C0, C1, Cout, k, stride, pad, dil, groups
+    (2, 16, 16, 32, 0, 32, 3, 1, 1, 1, 1),
+    (2, 20, 12, 64, 0, 64, 3, 1, 1, 1, 1),
+    (1, 17, 19, 64, 0, 128, 3, 2, 1, 1, 1),
+    (2, 16, 16, 128, 0, 256, 1, 1, 0, 1, 1),
+    (2, 16, 16, 256, 0, 64, 1, 2, 0, 1, 1),
+    (2, 12, 12, 64, 32, 64, 3, 1, 1, 1, 1),
+    (1, 12, 12, 128, 256, 128, 3, 1, 1, 1, 1),
+    (2, 16, 16, 64, 0, 64, 3, 1, 2, 2, 1),
+    (2, 16, 16, 64, 0, 128, 3, 1, 1, 1, 2),
+    (1, 40, 40, 32, 0, 32, 3, 1, 1, 1, 1),
+    (2, 8, 8, 512, 0, 512, 3, 1, 1, 1, 1),
+    (1, 64, 64, 64, 0, 64, 3, 1, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bn_act_forward_backward(case):
+    from xview2_amd import ops
+    N, H, W, C0, C1, Cout, k, s, p, d, G = case
+    torch.manual_seed(sum(case))
+    x0 = torch.randn(N, C0, H, W)
+    x1 = torch.randn(N, C1, H, W) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, k, k) * (2.0 / (k * k * (C0 + C1) / G)) ** 0.5
+    gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    # reference (CPU, torch autograd)
+    xr = xin.clone().requires_grad_(True)
+    wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    yr = F.conv2d(xr, wr, None, s, p, d, G)
+    zr = F.leaky_relu(F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5), 0.01)
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    # HIP
+    bnm = torch.nn.BatchNorm2d(Cout).to(dev())
+    with torch.no_grad():
+        bnm.weight.copy_(gamma)
+        bnm.bias.copy_(beta)
+    wg = w.to(dev()).requires_grad_(True)
+    a0 = nhwc(x0).requires_grad_(True)
+    a1 = nhwc(x1).requires_grad_(True) if C1 else None
+    cfg = ops.conv_cfg(k, k, s, p, d, G)
+    z = ops.ConvBnActFn.apply(a0, a1, wg, bnm.weight, bnm.bias, None, cfg, ops.BnState(bnm), ops.ACT_LEAKY, True)
+    z.backward(nhwc(dz))
+    close(nchw(z), zr, 2e-4, "z")
+    close(bnm.running_mean, rm, 2e-4, "running_mean")
+    close(bnm.running_var, rv, 2e-4, "running_var")
+    dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
+    close(dx, xr.grad, 5e-4, "dx")
+    close(wg.grad, wr.grad, 5e-4, "dw")
+    close(bnm.weight.grad, gr.grad, 5e-4, "dgamma")
+    close(bnm.bias.grad, br.grad, 5e-4, "dbeta")
+
+
+def test_conv_plain_bias_and_residual_relu():
+    from xview2_amd import ops
+    torch.manual_seed(3)
+    N, H, W, C, Co = 2, 12, 12, 64, 64
+    x = torch.randn(N, C, H, W)
+    w = torch.randn(Co, C, 3, 3) * 0.05
+    b = torch.randn(Co)
+    xr, wr, br_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br_, 1, 1)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    a = nhwc(x).requires_grad_(True)
+    wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.ConvFn.apply(a, None, wg, bg, ops.conv_cfg(3, 3, 1, 1))
+    y.backward(nhwc(dy))
+    close(nchw(y), yr, 2e-4, "y")
+    close(nchw(a.grad), xr.grad, 5e-4, "dx")
+    close(wg.grad, wr.grad, 5e-4, "dw")
+    close(bg.grad, br_.grad, 5e-4, "db")
+    # residual + relu (bottleneck tail), eval-mode BN as well
+    res = torch.randn(N, Co, H, W)
+    for training in (True, False):
+        bnr = torch.nn.BatchNorm2d(Co)
+        bnr.running_mean.normal_()
+        bnr.running_var.uniform_(0.5, 2)
+        bnr.train(training)
+        bng = torch.nn.BatchNorm2d(Co).to(dev())
+        bng.load_state_dict(bnr.state_dict())
+        xr2, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        wr2 = w.clone().requires_grad_(True)
+        zr = F.relu(bnr(F.conv2d(xr2, wr2, None, 1, 1)) + rr)
+        zr.backward(dy)
+        a2, r2 = nhwc(x).requires_grad_(True), nhwc(res).requires_grad_(True)
+        wg2 = w.to(dev()).requires_grad_(True)
+        z = ops.ConvBnActFn.apply(a2, None, wg2, bng.weight, bng.bias, r2, ops.conv_cfg(3, 3, 1, 1),
+                                  ops.BnState(bng), ops.ACT_RELU, training)
+        z.backward(nhwc(dy))
+        close(nchw(z), zr, 2e-4, "z res")
+        close(nchw(a2.grad), xr2.grad, 5e-4, "dx res")
+        close(nchw(r2.grad), rr.grad, 1e-6, "dres")
+        close(wg2.grad, wr2.grad, 5e-4, "dw res")
+        close(bng.weight.grad, bnr.weight.grad, 5e-4, "dgamma res")
+        close(bng.running_var, bnr.running_var, 2e-4, "rv")
+
+
+@pytest.mark.parametrize("cout", [64, 32])
+def test_stem_conv_rgb(cout):
+    from xview2_amd import ops
+    torch.manual_seed(5)
+    k, s, p = (7, 2, 3) if cout == 64 else (3, 2, 1)
+    x = torch.randn(2, 3, 40, 36)
+    w = torch.randn(cout, 3, k, k) * 0.1
+    wr = w.clone().requires_grad_(True)
+    bnr = torch.nn.BatchNorm2d(cout)
+    zr = F.relu(bnr(F.conv2d(x, wr, None, s, p)))
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    bng = torch.nn.BatchNorm2d(cout).to(dev())
+    a = ops.nchw_to_nhwc(x.to(dev()), 4)
+    wg = w.to(dev()).requires_grad_(True)
+    z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, None, ops.conv_cfg(k, k, s, p), ops.BnState(bng),
+                              ops.ACT_RELU, True)
+    z.backward(nhwc(dz))
+    close(nchw(z), zr, 2e-4, "stem z")
+    close(wg.grad, wr.grad, 5e-4, "stem dw")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 32), (1, 6, 10, 128, 64), (2, 4, 4, 2048, 512)])
+def test_conv_transpose(shape):
+    from xview2_amd import ops
+    N, H, W, Cin, Cout = shape
+    torch.manual_seed(7)
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cin, Cout, 2, 2) * (1.0 / Cin) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    a, wg = nhwc(x).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    y = ops.ConvTranspose2x2Fn.apply(a, wg)
+    y.backward(nhwc(dy))
+    close(nchw(y), yr, 2e-4, "convT y")
+    close(nchw(a.grad), xr.grad, 5e-4, "convT dx")
+    close(wg.grad, wr.grad, 5e-4, "convT dw")
+
+
+@pytest.mark.parametrize("cin,cout,nchw_out", [(32, 2, True), (64, 4, True), (128, 1, False), (512, 4, True)])
+def test_head_conv(cin, cout, nchw_out):
+    from xview2_amd import ops
+    torch.manual_seed(11)
+    x = torch.randn(2, cin, 24, 20)
+    w, b = torch.randn(cout, cin, 1, 1) * 0.1, torch.randn(cout)
+    xr, wr, br_ = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br_)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    a, wg, bg = nhwc(x).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.HeadConvFn.apply(a, wg, bg, nchw_out)
+    y.backward(dy.to(dev()) if nchw_out else nhwc(dy))
+    close(y.cpu() if nchw_out else nchw(y), yr, 1e-5, "head y")
+    close(nchw(a.grad), xr.grad, 1e-5, "head dx")
+    close(wg.grad, wr.grad, 1e-4, "head dw")
+    close(bg.grad, br_.grad, 1e-4, "head db")
+
+
+def test_pools_and_bilinear():
+    from xview2_amd import ops
+    torch.manual_seed(13)
+    x = torch.randn(2, 32, 18, 22)
+    x[0, :, :4, :4] = 0.0  # ties (post-ReLU zeros)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    a = nhwc(x).requires_grad_(True)
+    y = ops.MaxPool3x3s2Fn.apply(a)
+    y.backward(nhwc(dy))
+    close(nchw(y), yr, 0, "maxpool")
+    close(nchw(a.grad), xr.grad, 1e-6, "maxpool dx")
+    for (k, s, p, ceil, incl) in [(3, 2, 1, False, True), (2, 2, 0, True, False), (3, 1, 1, False, True),
+                                  (1, 1, 0, True, False)]:
+        xr = x.clone().requires_grad_(True)
+        yr = F.avg_pool2d(xr, k, s, p, ceil, incl)
+        dy = torch.randn_like(yr)
+        yr.backward(dy)
+        a = nhwc(x).requires_grad_(True)
+        y = ops.AvgPoolFn.apply(a, k, s, p, ceil, incl)
+        y.backward(nhwc(dy))
+        close(nchw(y), yr, 1e-6, "avgpool")
+        close(nchw(a.grad), xr.grad, 1e-6, "avgpool dx")
+    for bins in (1, 2, 3, 6):
+        xr = x.clone().requires_grad_(True)
+        yr = F.adaptive_avg_pool2d(xr, bins)
+        dy = torch.randn_like(yr)
+        yr.backward(dy)
+        a = nhwc(x).requires_grad_(True)
+        y = ops.AdaptiveAvgPoolFn.apply(a, bins)
+        y.backward(nhwc(dy))
+        close(nchw(y), yr, 1e-6, "adaptive")
+        close(nchw(a.grad), xr.grad, 1e-6, "adaptive dx")
+    for (ih, iw, oh, ow) in [(9, 11, 18, 22), (1, 1, 8, 8), (3, 3, 16, 16), (6, 6, 16, 16), (16, 16, 8, 8)]:
+        xs = torch.randn(2, 32, ih, iw)
+        xr = xs.clone().requires_grad_(True)
+        yr = F.interpolate(xr, (oh, ow), mode="bilinear", align_corners=True)
+        dy = torch.randn_like(yr)
+        yr.backward(dy)
+        a = nhwc(xs).requires_grad_(True)
+        y = ops.BilinearFn.apply(a, oh, ow)
+        y.backward(nhwc(dy))
+        close(nchw(y), yr, 1e-5, "bilinear")
+        close(nchw(a.grad), xr.grad, 1e-5, "bilinear dx")
+
+
+def test_gate_and_split_attention():
+    from xview2_amd import ops
+    torch.manual_seed(17)
+    skip, gate = torch.randn(2, 64, 10, 12), torch.rand(2, 1, 10, 12)
+    sr, gr = skip.clone().requires_grad_(True), gate.clone().requires_grad_(True)
+    outr = sr * gr
+    do = torch.randn_like(outr)
+    outr.backward(do)
+    s, g = nhwc(skip).requires_grad_(True), nhwc(gate).requires_grad_(True)
+    out = ops.GateMulFn.apply(s, g)
+    out.backward(nhwc(do))
+    close(nchw(out), outr, 1e-6, "gate")
+    close(nchw(s.grad), sr.grad, 1e-6, "gate dskip")
+    close(nchw(g.grad), gr.grad, 1e-5, "gate dgate")
+    a, b = torch.randn(2, 32, 8, 8), torch.randn(2, 32, 8, 8)
+    ar, br_ = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = F.relu(ar + br_)
+    rr.backward(do[:, :32, :8, :8])
+    ag, bg = nhwc(a).requires_grad_(True), nhwc(b).requires_grad_(True)
+    r = ops.AddReluFn.apply(ag, bg)
+    r.backward(nhwc(do[:, :32, :8, :8]))
+    close(nchw(r), rr, 1e-6, "addrelu")
+    close(nchw(ag.grad), ar.grad, 1e-6, "addrelu d")
+    # split attention (radix 2, cardinality 1) vs a literal torch transcription of SplAtConv2d.forward tail
+    N, C, H, W, inter = 4, 64, 12, 10, 32
+    x = torch.relu(torch.randn(N, 2 * C, H, W))
+    fc1 = torch.nn.Conv2d(C, inter, 1)
+    bn1 = torch.nn.BatchNorm2d(inter)
+    fc2 = torch.nn.Conv2d(inter, 2 * C, 1)
+    xr = x.clone().requires_grad_(True)
+    sp = torch.split(xr, C, dim=1)
+    gap = F.adaptive_avg_pool2d(sp[0] + sp[1], 1)
+    att = fc2(F.relu(bn1(fc1(gap))))
+    att = F.softmax(att.view(N, 1, 2, -1).transpose(1, 2), dim=1).reshape(N, -1).view(N, -1, 1, 1)
+    at = torch.split(att, C, dim=1)
+    outr = at[0] * sp[0] + at[1] * sp[1]
+    do = torch.randn_like(outr)
+    outr.backward(do)
+    bng = torch.nn.BatchNorm2d(inter).to(dev())
+    p = [t.detach().clone().to(dev()).requires_grad_(True) for t in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    xg = nhwc(x).requires_grad_(True)
+    out = ops.SplitAttentionFn.apply(xg, p[0], p[1], bng.weight, bng.bias, p[2], p[3], ops.BnState(bng), True)
+    out.backward(nhwc(do))
+    close(nchw(out), outr, 2e-5, "splat out")
+    close(nchw(xg.grad), xr.grad, 2e-4, "splat dx")
+    close(p[0].grad, fc1.weight.grad, 1e-3, "splat dw1")
+    close(p[2].grad, fc2.weight.grad, 1e-3, "splat dw2")
+    close(p[3].grad, fc2.bias.grad, 1e-3, "splat db2")
+    close(bng.weight.grad, bn1.weight.grad, 1e-3, "splat dg1")
+
+
+def test_layout_and_argmax_and_adamw():
+    from xview2_amd import ops
+    torch.manual_seed(19)
+    x6 = torch.randn(2, 6, 10, 14).to(dev())
+    a = ops.nchw_to_nhwc(x6[:, 3:], 4)
+    assert torch.equal(a[..., :3].cpu(), x6[:, 3:].permute(0, 2, 3, 1).cpu()) and float(a[..., 3].abs().max()) == 0.0
+    b = ops.nhwc_to_nchw(ops.nchw_to_nhwc(x6))
+    assert torch.equal(b, x6)
+    logits = torch.randn(2, 4, 9, 9)
+    logits[0, 1] = logits[0, 2]  # ties: first maximum must win
+    lab = ops.argmax_labels(logits.to(dev()), 1).cpu().long()
+    assert torch.equal(lab, torch.argmax(logits, 1) + 1)
+    p = torch.randn(1000)
+    g = torch.randn(1000)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=3e-4, weight_decay=0.01)
+    pg, m, v = p.to(dev()), torch.zeros(1000, device=dev()), torch.zeros(1000, device=dev())
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step(pg, (g * step).to(dev()), m, v, 3e-4, 0.9, 0.999, 1e-8, 0.01, step)
+    close(pg, pr, 1e-6, "adamw")

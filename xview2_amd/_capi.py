@@ -1,0 +1,106 @@
+"""ctypes binding of include/xv2.h: argtypes are generated from the header so the Python side can
+never drift from the C ABI.  `call("xv2_...", *args)` accepts torch tensors (-> device pointer),
+`Ptr` (tensor + element offset), None (-> NULL), ints and floats; a non-zero status raises."""
+import ctypes
+import os
+import re
+
+import torch
+
+from . import _lib
+
+_CT = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+    "float": ctypes.c_float, "double": ctypes.c_double,
+}
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of xv2_conv_desc."""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "IH", "IW", "C0", "C1", "Cout", "KH", "KW", "stride", "pad", "dil", "OH", "OW")]
+
+    def key(self):
+        return tuple(getattr(self, f[0]) for f in self._fields_)
+
+
+class Ptr:
+    """Device pointer into `tensor` advanced by `offset` elements (channel-offset views)."""
+    __slots__ = ("tensor", "offset")
+
+    def __init__(self, tensor, offset=0):
+        self.tensor = tensor
+        self.offset = offset
+
+    def addr(self):
+        return self.tensor.data_ptr() + self.offset * self.tensor.element_size()
+
+
+def _parse_header():
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "xv2.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^\s*([a-z_0-9 ]+?\**)\s*\b(xv2_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3)
+        argt = []
+        for a in args.split(","):
+            a = a.strip()
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                argt.append(ctypes.c_void_p)
+            else:
+                ty = a.replace("const", "").split()[0]
+                argt.append(_CT[ty])
+        if "char" in ret:
+            rt = ctypes.c_char_p
+        else:
+            rt = _CT[ret.replace("const", "").strip()]
+        protos[name] = (rt, argt)
+    return protos
+
+
+_protos = None
+_funcs = {}
+
+
+def _func(name):
+    global _protos
+    f = _funcs.get(name)
+    if f is None:
+        if _protos is None:
+            _protos = _parse_header()
+        L = _lib.lib()
+        f = getattr(L, name)
+        f.restype, f.argtypes = _protos[name]
+        _funcs[name] = f
+    return f
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    if isinstance(a, Ptr):
+        return a.addr()
+    if isinstance(a, ConvDesc):
+        return ctypes.addressof(a)
+    return a
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Status-returning entry point on the current torch stream (stream argument appended)."""
+    f = _func(name)
+    rc = f(*[_conv(a) for a in args], stream_handle())
+    if rc != 0:
+        raise RuntimeError("%s: %s" % (name, _lib.lib().xv2_last_error().decode()))
+
+
+def query(name, *args):
+    """Value-returning helper (workspace sizes, tile counts): no stream argument."""
+    return _func(name)(*[_conv(a) for a in args])

@@ -301,30 +301,28 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     return XV2_OK;
 }
 
-static int pick_bm(const IgemmParams& p, int bn) {
-    const int64_t blocks128 = cdiv(p.M, 128) * (p.Nout / bn);
-    return (blocks128 >= 384 || bn == 32) ? 128 : 64;
+static void pick_tile(int64_t M, int Nout, bool smallc, int& bm, int& bn) {
+    bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
+    const int64_t blocks128 = cdiv(M, 128) * (Nout / bn);
+    bm = (smallc || blocks128 >= 384 || bn == 32) ? 128 : 64;
 }
 
-int64_t igemm_stats_tiles(int64_t M, int Nout) {
-    IgemmParams p;
-    p.M = (int)M;
-    p.Nout = Nout;
-    const int bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
-    return cdiv(M, pick_bm(p, bn));
+int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc) {
+    int bm, bn;
+    pick_tile(M, Nout, smallc, bm, bn);
+    return cdiv(M, bm);
 }
 
 int igemm_launch(const IgemmParams& p, bool smallc, hipStream_t stream) {
     XV2_CHECK_ARG(p.Nout % 32 == 0, "igemm: Nout=%d must be a multiple of 32", p.Nout);
     XV2_CHECK_ARG(p.M > 0, "igemm: empty problem");
-    const int bn = (p.Nout % 128 == 0) ? 128 : (p.Nout % 64 == 0 ? 64 : 32);
+    int bm, bn;
+    pick_tile(p.M, p.Nout, smallc, bm, bn);
     if (smallc) {
-        XV2_CHECK_ARG(bn <= 64 || true, "unreachable");
         if (bn == 128) return launch_one<128, 128, 2, 2, true>(p, stream);
         if (bn == 64) return launch_one<128, 64, 2, 2, true>(p, stream);
         return launch_one<128, 32, 4, 1, true>(p, stream);
     }
-    const int bm = pick_bm(p, bn);
     if (bn == 128) {
         if (bm == 128) return launch_one<128, 128, 2, 2, false>(p, stream);
         return launch_one<64, 128, 2, 2, false>(p, stream);
@@ -357,7 +355,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
 using namespace xv2;
 
 extern "C" int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d) {
-    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout);
+    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, d->C0 == 4 && d->C1 == 0);
 }
 
 extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,

@@ -1,0 +1,653 @@
+"""torch.autograd bindings of the HIP hot path (include/xv2.h).
+
+Every Function here owns its backward analytically (no torch op is differentiated): forward and
+backward both go through the C ABI.  Activations are NHWC tensors ``[N, H, W, C]`` (contiguous).
+PyTorch is used for device memory, streams and autograd bookkeeping only.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+from ._capi import ConvDesc, Ptr, call, query
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+ACTS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
+LOSS_DICE, LOSS_FOCAL, LOSS_CE = 1, 2, 4
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("xview2_amd ops run on the MI355X only (got a %s tensor); there is no CPU fallback"
+                           % t.device)
+
+
+def _f32(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _ws(nbytes, like):
+    return torch.empty(((int(nbytes) + 3) // 4 + 4,), dtype=torch.float32, device=like.device)
+
+
+def conv_cfg(kh, kw=None, stride=1, pad=0, dil=1, groups=1):
+    return SimpleNamespace(kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, dil=dil, groups=groups)
+
+
+def _out_hw(IH, IW, g):
+    OH = (IH + 2 * g.pad - g.dil * (g.kh - 1) - 1) // g.stride + 1
+    OW = (IW + 2 * g.pad - g.dil * (g.kw - 1) - 1) // g.stride + 1
+    return OH, OW
+
+
+def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW):
+    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw (non-autograd) convolution pieces; groups are channel-offset views over the same tensors
+def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
+    Cout, Cin, KH, KW = w_oihw.shape
+    ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw) if want_ohwi else None
+    ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw) if want_ihwo else None
+    call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, ohwi, ihwo)
+    return ohwi, ihwo
+
+
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False):
+    """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None"""
+    N, IH, IW, C0t = x0.shape
+    C1t = x1.shape[3] if x1 is not None else 0
+    Cout_t = weight.shape[0]
+    G = g.groups
+    OH, OW = _out_hw(IH, IW, g)
+    y = _f32((N, OH, OW, Cout_t), x0)
+    sums = torch.empty((Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
+    w = weight.contiguous()
+    if G > 1 and x1 is not None:
+        raise RuntimeError("grouped convolution over a virtual concat is not supported")
+    C0g, Coutg = C0t // G, Cout_t // G
+    cin_w = w.shape[1]
+    for gi in range(G):
+        wg = w[gi * Coutg:(gi + 1) * Coutg]
+        ohwi, _ = _pack(wg, C0g + C1t, True, False)
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+        part = None
+        if want_stats:
+            tiles = query("xv2_conv2d_forward_stats_tiles", d)
+            part = _f32((tiles, Coutg, 2), x0)
+        call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
+             None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part)
+        if want_stats:
+            scratch = torch.empty((64 * Coutg * 2,), dtype=torch.float64, device=x0.device)
+            call("xv2_bn_reduce_stats", part, tiles, Coutg, Ptr(sums, gi * Coutg * 2), scratch)
+    assert cin_w <= C0g + C1t
+    return y, sums
+
+
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t):
+    N, IH, IW = in_shape
+    _, OH, OW, Cout_t = dy.shape
+    G = g.groups
+    w = weight.contiguous()
+    C0g, Coutg = C0t // G, Cout_t // G
+    dx0 = _f32((N, IH, IW, C0t), dy)
+    dx1 = _f32((N, IH, IW, C1t), dy) if C1t else None
+    for gi in range(G):
+        wg = w[gi * Coutg:(gi + 1) * Coutg]
+        _, ihwo = _pack(wg, C0g + C1t, False, True)
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+        call("xv2_conv2d_backward_data", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t)
+    return dx0, dx1
+
+
+def _conv_backward_weight(x0, x1, dy, weight, g):
+    N, IH, IW, C0t = x0.shape
+    C1t = x1.shape[3] if x1 is not None else 0
+    _, OH, OW, Cout_t = dy.shape
+    G = g.groups
+    C0g, Coutg = C0t // G, Cout_t // G
+    cin_real = weight.shape[1]
+    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    for gi in range(G):
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+        ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+        call("xv2_conv2d_backward_weight", d, Ptr(x0, gi * C0g), C0t, x1, C1t, Ptr(dy, gi * Coutg), Cout_t,
+             Ptr(dw, gi * Coutg * cin_real * g.kh * g.kw), cin_real, ws)
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# batch-norm pieces
+def _sync_group(bn):
+    return bn.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _bn_train_coeffs(sums, count, bn, like):
+    """sums: double [C,2] local; returns mean, invstd, scale, shift, global count"""
+    C = sums.shape[0]
+    if _sync_group(bn):
+        buf = torch.cat([sums.reshape(-1), torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
+        dist.all_reduce(buf)
+        sums = buf[:-1].reshape(C, 2)
+        count = float(buf[-1].item()) if bn.exact_count else float(count) * dist.get_world_size()
+    mean, invstd, scale, shift = (_f32((C,), like) for _ in range(4))
+    call("xv2_bn_finalize", sums, float(count), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
+         bn.running_mean, bn.running_var, mean, invstd, scale, shift, C)
+    return mean, invstd, scale, shift, float(count)
+
+
+def _bn_eval_coeffs(bn, like):
+    C = bn.running_mean.shape[0]
+    scale, shift = _f32((C,), like), _f32((C,), like)
+    call("xv2_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C)
+    invstd = _f32((C,), like)
+    one = torch.ones((C,), dtype=torch.float32, device=like.device)
+    call("xv2_bn_eval_coeffs", one, None, bn.running_mean, bn.running_var, float(bn.eps), invstd, _f32((C,), like), C)
+    return bn.running_mean, invstd, scale, shift
+
+
+def _bn_forward(y, residual, act, bn, sums, training):
+    """y raw [.., C]; returns z and the context needed by _bn_backward"""
+    C = y.shape[-1]
+    npix = y.numel() // C
+    if training:
+        if sums is None:
+            sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+            ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), y)
+            call("xv2_bn_tensor_stats", y, C, npix, C, sums, ws)
+        mean, invstd, scale, shift, count = _bn_train_coeffs(sums, npix, bn, y)
+    else:
+        mean, invstd, scale, shift = _bn_eval_coeffs(bn, y)
+        count = float(npix)
+    z = torch.empty_like(y)
+    call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
+    return z, (mean, invstd, count)
+
+
+def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
+    mean, invstd, count = stats
+    C = y.shape[-1]
+    npix = y.numel() // C
+    dz = dz.contiguous()
+    sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+    ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
+    call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, act, npix, C, sums2, ws)
+    dgamma = sums2[:, 1].to(torch.float32)
+    dbeta = sums2[:, 0].to(torch.float32)
+    if training and _sync_group(bn):
+        dist.all_reduce(sums2)
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_res else None
+    call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, sums2, float(count), act,
+         1 if training else 0, dy, C, dres, C, npix, C)
+    return dy, dres, dgamma, dbeta
+
+
+class BnState:
+    """The pieces of an nn.BatchNorm2d the kernels touch (buffers are updated in place)."""
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "eps", "momentum", "sync", "exact_count")
+
+    def __init__(self, m, sync=False):
+        self.weight, self.bias = m.weight, m.bias
+        self.running_mean, self.running_var = m.running_mean, m.running_var
+        self.eps, self.momentum = m.eps, m.momentum
+        self.sync = sync
+        self.exact_count = False
+
+
+# ------------------------------------------------------------------------------------------------
+class ConvBnActFn(torch.autograd.Function):
+    """z = act(BN(conv(cat(x0, x1), W)) [+ residual])  (one autograd node per conv layer)"""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training):
+        _need_cuda(x0)
+        x0 = x0.contiguous()
+        x1 = x1.contiguous() if x1 is not None else None
+        residual = residual.contiguous() if residual is not None else None
+        y, sums = _conv_forward(x0, x1, weight, g, None, want_stats=training)
+        z, stats = _bn_forward(y, residual, act, bn, sums, training)
+        ctx.save_for_backward(x0, x1, weight, gamma, y, z, stats[0], stats[1])
+        ctx.count = stats[2]
+        ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
+        ctx.has_res = residual is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, x1, weight, gamma, y, z, mean, invstd = ctx.saved_tensors
+        g = ctx.g
+        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count), gamma, ctx.act, ctx.bn,
+                                               ctx.training, ctx.has_res and ctx.needs_input_grad[5])
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
+                                           x1.shape[3] if x1 is not None else 0)
+        dw = _conv_backward_weight(x0, x1, dy, weight, g) if ctx.needs_input_grad[2] else None
+        return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
+                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None)
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(cat(x0, x1), W) + bias (no normalisation)"""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, g):
+        _need_cuda(x0)
+        x0 = x0.contiguous()
+        x1 = x1.contiguous() if x1 is not None else None
+        y, _ = _conv_forward(x0, x1, weight, g, bias, want_stats=False)
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.g, ctx.has_bias = g, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = ctx.g
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
+                                           x1.shape[3] if x1 is not None else 0)
+        dw = _conv_backward_weight(x0, x1, dy, weight, g) if ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            C = dy.shape[-1]
+            npix = dy.numel() // C
+            sums = torch.empty((C, 2), dtype=torch.float64, device=dy.device)
+            ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), dy)
+            call("xv2_bn_tensor_stats", dy, C, npix, C, sums, ws)
+            db = sums[:, 0].to(torch.float32)
+        return dx0, dx1, dw, db, None
+
+
+class ConvTranspose2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, Cin = x.shape
+        Cout = weight.shape[1]
+        g = conv_cfg(2, 2, stride=2, pad=0)
+        d = _desc(N, 2 * H, 2 * W, Cout, 0, Cin, g, H, W)  # the equivalent 2x2/s2 convolution
+        _, ihwo = _pack(weight.contiguous(), Cout, False, True)
+        y = _f32((N, 2 * H, 2 * W, Cout), x)
+        call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
+        ctx.save_for_backward(x, weight)
+        ctx.d = d
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        d = ctx.d
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            ohwi, _ = _pack(weight.contiguous(), Cout, True, False)
+            dx = torch.empty_like(x)
+            call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+            call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
+        return dx, dw
+
+
+class HeadConvFn(torch.autograd.Function):
+    """1x1 conv to <= 4 channels; NHWC in, NCHW (default) or NHWC out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nchw_out):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        y = _f32((N, Cout, H, W) if nchw_out else (N, H, W, Cout), x)
+        w2 = weight.reshape(Cout, Cin).contiguous()
+        call("xv2_head_conv_forward", x, Cin, N * H * W, H * W, Cin, Cout, w2, bias, y, 1 if nchw_out else 0)
+        ctx.save_for_backward(x, w2)
+        ctx.nchw, ctx.has_bias, ctx.wshape = nchw_out, bias is not None, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, H, W, Cin = x.shape
+        Cout = w2.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2)
+        db = _f32((Cout,), x) if ctx.has_bias else None
+        ws = _ws(query("xv2_head_conv_backward_workspace", N * H * W, Cin, Cout), x)
+        call("xv2_head_conv_backward", x, Cin, dy, N * H * W, H * W, Cin, Cout, w2, 1 if ctx.nchw else 0, dx, Cin,
+             dw, db, ws)
+        return dx, dw.reshape(ctx.wshape), db, None
+
+
+class BnActFn(torch.autograd.Function):
+    """z = act(BN(y) [+ residual]) for tensors that did not come out of the MFMA conv kernel."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, bn, act, training):
+        _need_cuda(y)
+        y = y.contiguous()
+        z, stats = _bn_forward(y, residual, act, bn, None, training)
+        ctx.save_for_backward(y, z, gamma, stats[0], stats[1])
+        ctx.count, ctx.bn, ctx.act, ctx.training = stats[2], bn, act, training
+        ctx.has_res = residual is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, z, gamma, mean, invstd = ctx.saved_tensors
+        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count), gamma, ctx.act, ctx.bn,
+                                               ctx.training, ctx.has_res)
+        return dy, dgamma, dbeta, dres, None, None, None
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = _f32((N, OH, OW, C), x)
+        idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        call("xv2_maxpool3x3s2_forward", x, N, H, W, C, y, idx)
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C = ctx.shape
+        dx = _f32(ctx.shape, dy)
+        call("xv2_maxpool3x3s2_backward", dy.contiguous(), idx, N, H, W, C, dx)
+        return dx
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, pad, ceil_mode, count_include_pad):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+
+        def osz(L):
+            num = L + 2 * pad - k
+            o = (-(-num // s) if ceil_mode else num // s) + 1
+            if ceil_mode and (o - 1) * s >= L + pad:
+                o -= 1
+            return o
+        OH, OW = osz(H), osz(W)
+        y = _f32((N, OH, OW, C), x)
+        call("xv2_avgpool_forward", x, N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW, y)
+        ctx.cfg = (N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, k, s, pad, inc, OH, OW = ctx.cfg
+        dx = _f32((N, H, W, C), dy)
+        call("xv2_avgpool_backward", dy.contiguous(), N, H, W, C, k, s, pad, inc, OH, OW, dx)
+        return dx, None, None, None, None, None
+
+
+class AdaptiveAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bins):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        y = _f32((N, bins, bins, C), x)
+        call("xv2_adaptive_avgpool_forward", x, C, N, H, W, C, bins, y)
+        ctx.cfg = (N, H, W, C, bins)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, bins = ctx.cfg
+        dx = _f32((N, H, W, C), dy)
+        call("xv2_adaptive_avgpool_backward", dy.contiguous(), N, H, W, C, bins, dx, C, 0)
+        return dx, None
+
+
+class BilinearFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) to (OH, OW)."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, IH, IW, C = x.shape
+        y = _f32((N, OH, OW, C), x)
+        call("xv2_bilinear_forward", x, N, IH, IW, C, OH, OW, y, C)
+        ctx.cfg = (N, IH, IW, C, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, IH, IW, C, OH, OW = ctx.cfg
+        dx = _f32((N, IH, IW, C), dy)
+        call("xv2_bilinear_backward", dy.contiguous(), C, N, IH, IW, C, OH, OW, dx)
+        return dx, None, None
+
+
+class AddReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a)
+        a, b = a.contiguous(), b.contiguous()
+        r = torch.empty_like(a)
+        call("xv2_add_relu_forward", a, b, r, a.numel())
+        ctx.save_for_backward(r)
+        return r
+
+    @staticmethod
+    def backward(ctx, dr):
+        (r,) = ctx.saved_tensors
+        d = torch.empty_like(r)
+        call("xv2_add_relu_backward", r, dr.contiguous(), d, r.numel())
+        return d, d
+
+
+class GateMulFn(torch.autograd.Function):
+    """skip * gate, gate broadcast over channels (model/layers.py:166)."""
+
+    @staticmethod
+    def forward(ctx, skip, gate):
+        _need_cuda(skip)
+        skip, gate = skip.contiguous(), gate.contiguous()
+        C = skip.shape[-1]
+        out = torch.empty_like(skip)
+        call("xv2_gate_mul_forward", skip, C, gate, out, skip.numel() // C, C)
+        ctx.save_for_backward(skip, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        skip, gate = ctx.saved_tensors
+        C = skip.shape[-1]
+        dskip = torch.empty_like(skip)
+        dgate = torch.empty_like(gate)
+        call("xv2_gate_mul_backward", skip, C, gate, dout.contiguous(), dskip, dgate, skip.numel() // C, C)
+        return dskip, dgate
+
+
+class SplitAttentionFn(torch.autograd.Function):
+    """ResNeSt radix-2 split attention on top of the (already BN+ReLU'd) grouped-conv output x
+    [N,H,W,2C]: gap -> fc1 -> BN1 -> ReLU -> fc2 -> rSoftMax -> sum_r att_r * x_r."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, bn1, training):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, C2 = x.shape
+        C, hw = C2 // 2, H * W
+        inter = w1.shape[0]
+        gap = _f32((N, C), x)
+        call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x))
+        w1m, w2m = w1.reshape(inter, C).contiguous(), w2.reshape(C2, inter).contiguous()
+        h1 = _f32((N, inter), x)
+        call("xv2_linear_forward", gap, w1m, b1, h1, N, C, inter)
+        a1, st = _bn_forward(h1, None, ACT_RELU, bn1, None, training)
+        logits = _f32((N, C2), x)
+        call("xv2_linear_forward", a1, w2m, b2, logits, N, inter, C2)
+        att = _f32((N, C2), x)
+        call("xv2_rsoftmax_forward", logits, att, N, C)
+        out = _f32((N, H, W, C), x)
+        call("xv2_splat_apply_forward", x, att, N, hw, C, out)
+        ctx.save_for_backward(x, gap, w1m, h1, a1, g1, st[0], st[1], w2m, att)
+        ctx.count, ctx.bn1, ctx.training = st[2], bn1, training
+        ctx.shapes = (w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, H, W, C2 = x.shape
+        C, hw = C2 // 2, H * W
+        inter = w1m.shape[0]
+        datt = _f32((N, C2), x)
+        ws = _ws(query("xv2_splat_gap_workspace", N, hw, C), x)
+        call("xv2_splat_apply_backward", x, att, dout, None, N, hw, C, None, datt, ws)
+        dlogits = _f32((N, C2), x)
+        call("xv2_rsoftmax_backward", att, datt, dlogits, N, C)
+        da1, dw2, db2 = _f32((N, inter), x), torch.empty_like(w2m), _f32((C2,), x)
+        call("xv2_linear_backward", a1, w2m, dlogits, da1, dw2, db2, N, inter, C2)
+        dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count), g1, ACT_RELU, ctx.bn1,
+                                         ctx.training, False)
+        dgap, dw1, db1 = _f32((N, C), x), torch.empty_like(w1m), _f32((inter,), x)
+        call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
+        dx = torch.empty_like(x)
+        call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws)
+        s1, s2 = ctx.shapes
+        return dx, dw1.reshape(s1), db1, dg1, dbe1, dw2.reshape(s2), db2, None, None
+
+
+class LossFn(torch.autograd.Function):
+    """Composed Dice/Focal/CE loss on NCHW logits (model/loss.py:85-101)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, terms, post, lstride):
+        _need_cuda(logits)
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        if labels.dtype != torch.uint8:
+            labels = labels.to(torch.uint8)
+        N, C, H, W = logits.shape
+        acc = torch.empty((32,), dtype=torch.float64, device=logits.device)
+        loss = _f32((1,), logits)
+        ws = _ws(query("xv2_loss_workspace", N, C, H, W), logits)
+        call("xv2_loss_forward", logits, labels, N, C, H, W, lstride, 1 if post else 0, terms, acc, loss, ws)
+        ctx.save_for_backward(logits, labels, acc)
+        ctx.cfg = (terms, post, lstride)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, acc = ctx.saved_tensors
+        terms, post, lstride = ctx.cfg
+        N, C, H, W = logits.shape
+        d = torch.empty_like(logits)
+        gs = gout.reshape(1).to(torch.float32).contiguous()
+        call("xv2_loss_backward", logits, labels, N, C, H, W, lstride, 1 if post else 0, terms, acc, gs, 1.0, d)
+        return d, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers (no gradient: images do not require grad; outputs of nhwc_to_nchw are for tests / eval)
+def nchw_to_nhwc(x, c_pad=None):
+    """x: NCHW (possibly a channel slice of a wider NCHW tensor) -> NHWC with channels padded to c_pad."""
+    _need_cuda(x)
+    N, C, H, W = x.shape
+    if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
+        x = x.contiguous()
+    Cp = C if c_pad is None else c_pad
+    y = _f32((N, H, W, Cp), x)
+    call("xv2_nchw_to_nhwc", x, x.stride(0), N, C, H, W, y, Cp)
+    return y
+
+
+def nhwc_to_nchw(x):
+    _need_cuda(x)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    y = _f32((N, C, H, W), x)
+    call("xv2_nhwc_to_nchw", x, C, N, C, H, W, y)
+    return y
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nchw_to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        return nhwc_to_nchw(d)
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        return nchw_to_nhwc(d)
+
+
+class CatChannelsFn(torch.autograd.Function):
+    """Materialised channel concat (only where a virtual concat cannot be used)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        _need_cuda(xs[0])
+        xs = [t.contiguous() for t in xs]
+        cs = [t.shape[-1] for t in xs]
+        out = _f32(tuple(xs[0].shape[:-1]) + (sum(cs),), xs[0])
+        npix = xs[0].numel() // cs[0]
+        off = 0
+        for t, c in zip(xs, cs):
+            call("xv2_copy_channels", t, c, Ptr(out, off), sum(cs), npix, c)
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        cs = ctx.cs
+        npix = d.numel() // sum(cs)
+        outs, off = [], 0
+        for c in cs:
+            o = _f32(tuple(d.shape[:-1]) + (c,), d)
+            call("xv2_copy_channels", Ptr(d, off), sum(cs), o, c, npix, c)
+            outs.append(o)
+            off += c
+        return tuple(outs)
+
+
+def argmax_labels(logits, add=0):
+    """bit-exact torch.argmax(logits, 1) (+add) as uint8 (utils/f1.py:14,36)."""
+    _need_cuda(logits)
+    logits = logits.contiguous()
+    N, C, H, W = logits.shape
+    out = torch.empty((N, H, W), dtype=torch.uint8, device=logits.device)
+    call("xv2_argmax_nchw", logits, N, C, H * W, add, out)
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("xv2_adamw_step", p, g, m, v, p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd),
+         int(step), float(grad_scale))
