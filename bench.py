@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of the U-Net hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched once per rank by torchrun)
+
+N=1 workload = BASELINE.json configs[1]: --type pre --encoder resnet50 --loss_str dice, 1024x1024, batch 2 per GPU,
+fp32, synthetic tiles (seeded uniform-uint8 RGB normalised with ImageNet mean/std, rectangle masks), key-seeded
+random weights.  One step = forward + loss + backward (+ RCCL gradient all-reduce overlapped with backward when
+N>1) + fused AdamW step, everything through the HIP C ABI.  Weak scaling: per-GPU batch fixed.
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline:     dominant kernel's algorithmic conv FLOPs / its HIP-event time, against the fp32 MFMA peak
+  cpu_baseline: the CPU oracle (PyTorch fp32 restatement of the reference path) timed on the host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
+
+
+def synthetic_batch(args_ns, batch, size, seed, device):
+    """uint8 RGB uniform[0,255] -> A.Normalize() (data_loading/pytorch_loader.py:63), masks with
+    guaranteed building pixels (seeded rectangles covering ~5-10 %)."""
+    g = torch.Generator().manual_seed(seed)
+    c = 3 if args_ns.type == "pre" else 6
+    img = torch.randint(0, 256, (batch, c, size, size), generator=g, dtype=torch.uint8).float() / 255.0
+    mean = torch.tensor([0.485, 0.456, 0.406] * (c // 3)).view(1, c, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225] * (c // 3)).view(1, c, 1, 1)
+    img = (img - mean) / std
+    mask = torch.zeros(batch, size, size, dtype=torch.uint8)
+    hi = 2 if args_ns.type == "pre" else 5
+    for b in range(batch):
+        for _ in range(12):
+            h, w = [int(v) for v in torch.randint(size // 16, size // 5, (2,), generator=g)]
+            y0 = int(torch.randint(0, size - h, (1,), generator=g))
+            x0 = int(torch.randint(0, size - w, (1,), generator=g))
+            mask[b, y0:y0 + h, x0:x0 + w] = int(torch.randint(1, hi, (1,), generator=g))
+    return img.to(device), mask.to(device)
+
+
+def make_args(encoder="resnet50", ttype="pre", loss_str="dice", dmg_model="siamese", **kw):
+    from types import SimpleNamespace
+    d = dict(encoder=encoder, dilation=1, ppm=False, aspp=False, no_skip=False, interpolate=False, attention=False,
+             dec_interp=False, deep_supervision=False, loss_str=loss_str, dmg_model=dmg_model, type=ttype)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def cpu_baseline(a, size, batch, seed):
+    """one fwd+loss+bwd+AdamW step of the CPU oracle at the SAME shape (bounded sample: a single step)"""
+    from oracle import torch_ref
+    from xview2_amd.weights import deterministic_init_
+    torch.manual_seed(0)
+    m = torch_ref.build_model(a)
+    deterministic_init_(m, 1)
+    m.train()
+    x, y = synthetic_batch(a, batch, size, seed, "cpu")
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-4)
+    loss_fn = torch_ref.Loss(a)
+    t0 = time.time()
+    loss = torch_ref.compute_loss(loss_fn, m(x), y, a.deep_supervision)
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 training step (fwd+loss+bwd+AdamW) of the PyTorch-CPU oracle, %s %dx%dx%d fp32, no warm-up"
+                      % (a.encoder, batch, size, size), "seconds": dt, "loss": float(loss)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--encoder", default="resnet50")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
+    ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
+    opt = ap.parse_args()
+
+    from xview2_amd import _capi, criterion, dist as xdist, networks
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+
+    rank, local, world = xdist.init_from_env()
+    if opt.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (opt.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    a = make_args(opt.encoder)
+    torch.manual_seed(0)
+    model = networks.UNetLoc(a)
+    deterministic_init_(model, 1)
+    model.to(dev).train()
+    loss_fn = criterion.Loss(a)
+    optim = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.0)
+    reducer = xdist.GradReducer(optim)
+    x, y = synthetic_batch(a, opt.batch, opt.size, 1 + rank, dev)
+
+    def step():
+        optim.zero_grad()
+        reducer.prepare()
+        loss = criterion.compute_loss(loss_fn, model(x), y, a.deep_supervision)
+        loss.backward()
+        optim.step(reducer.finish())
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opt.warmup):
+        step()
+    prof = not opt.no_prof
+    barrier()
+    if prof:
+        _capi.query("xv2_prof_enable", 1)
+    t0 = time.time()
+    for _ in range(opt.steps):
+        loss = step()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / opt.steps * 1e3
+    value = world * opt.batch * opt.steps / dt
+
+    roof = None
+    if prof:
+        rows = []
+        nk = _capi.query("xv2_prof_num_kernels")
+        for kid in range(nk):
+            tms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(n))
+            if n.value:
+                rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
+                             "gflop": fl.value / 1e9, "launches": n.value})
+        _capi.query("xv2_prof_enable", 0)
+        rows.sort(key=lambda r: -r["ms"])
+        if rows:
+            top = rows[0]
+            ach = top["gflop"] / top["ms"]            # GFLOP/ms == TFLOP/s
+            tot_ms, tot_gf = sum(r["ms"] for r in rows), sum(r["gflop"] for r in rows)
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": top["kernel"],
+                    "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
+                    "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
+                    "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / opt.steps, 3),
+                                         "gflop_per_step": round(tot_gf / opt.steps, 1)},
+                    "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
+                                    "ms_per_step": round(r["ms"] / opt.steps, 3), "launches_per_step": r["launches"] / opt.steps}
+                                   for r in rows]}
+    out = {
+        "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
+        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "--type pre --encoder %s --loss_str dice, %dx%d, batch %d per GPU, fp32 train step "
+                               "(fwd+loss+bwd+allreduce+AdamW)" % (opt.encoder, opt.size, opt.size, opt.batch),
+                   "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
+        "loss": float(loss),
+        "model_tflops": round(value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3, 2),
+        "roofline": roof,
+    }
+    if rank == 0 and not opt.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+"""Whole-model parity of the HIP path against the CPU oracle (oracle.torch_ref, itself pinned to the
+reference by tests/golden): identical key-seeded weights and inputs, training mode (batch-statistics BN).
+Gates (north_star): fp32 logits within 1e-3 relative (max-abs error / max-abs reference), loss within 1e-3,
+argmax label maps bit-exact away from numerical ties.  Parameter gradients of these tiny (64x64, batch 2)
+training-mode-BN problems are ill-conditioned - the fp32 CPU oracle itself is ~5e-2 away from an fp64 run of the
+same oracle - so the gradient gate is relative to that: per tensor, ||g_hip - g_f64|| must be within 3x of
+||g_cpu32 - g_f64|| (+1e-3 floor), i.e. the HIP path is as accurate as the reference's own fp32 arithmetic.
+(Single-layer gradients are checked tightly, 5e-4, in tests/test_ops_gpu.py.)  The same conditioning probe
+guards the logits: ResNeSt's split attention normalises a batch of TWO values per channel (SplAt bn1 on the
+[B=2, C] GAP vector), which makes its training-mode forward chaotic in fp32 (the CPU oracle is ~5e-2 from its
+own fp64 run); there the gate is 3x that fp32 self-error, elsewhere the plain 1e-3 applies."""
+import copy
+
+import pytest
+import torch
+
+from tests.golden.cases import ARGS, MODEL_CASES, labels, model_input
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = ["pre_resnet50", "pre_resnet50_ds_attn", "pre_resnet50_ppm", "pre_resnet50_aspp_dil2",
+         "pre_resnet50_dil4_noskip", "pre_resnet50_decinterp", "pre_resnest50", "pre_resnest50_dil2",
+         "pre_resnest101_attn", "post_siamese_resnest50_ds", "post_siameseEnc_resnet50",
+         "post_fused_resnest50_attn_ds", "post_fused_resnet50_decinterp", "post_fusedEnc_resnet50",
+         "post_parallel_resnet50", "post_parallelEnc_resnet50_aspp", "post_diff_resnet50"]
+
+
+def case_batch(name):
+    # ResNeSt's SplAt bn1 normalises one value per image: batch 2 is chaotic in fp32 (see module docstring),
+    # batch 8 is well conditioned and gets the plain 1e-3 gate
+    return 8 if "resnest" in name else 2
+
+
+def build_pair(a, seed=1):
+    from oracle import torch_ref
+    from xview2_amd import networks
+    from xview2_amd.weights import deterministic_init_
+    torch.manual_seed(0)
+    ora = torch_ref.build_model(a)
+    deterministic_init_(ora, seed)
+    hip = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
+    hip.load_state_dict(ora.state_dict())
+    return ora, hip.to(DEV)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+
+
+def argmax_mismatch(lh, lo, margin=1e-3):
+    """#pixels whose argmax differs although the oracle's top-2 logits are separated by more than `margin`
+    (relative to the logit range): exact ties / near-ties may legitimately flip under 1e-3 noise"""
+    from xview2_amd import ops
+    ah = ops.argmax_labels(lh).cpu().long()
+    ao = torch.argmax(lo, 1)
+    top2 = torch.topk(lo, 2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]) / max(float(lo.abs().max()), 1e-12)
+    bad = (ah != ao) & (gap > margin)
+    # and the HIP argmax kernel itself must be bit-exact with torch.argmax on the SAME logits
+    assert torch.equal(ah, torch.argmax(lh.cpu(), 1))
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_parity(name):
+    from oracle import torch_ref
+    from xview2_amd import criterion
+    a = ARGS(**MODEL_CASES[name])
+    if a.loss_str == "coral":
+        pytest.skip("coral loss has no HIP kernel yet")
+    ora, hip = build_pair(a)
+    ora64 = copy.deepcopy(ora).double()
+    ora.train()
+    hip.train()
+    x, y = model_input(a, batch=case_batch(name)), labels(a, batch=case_batch(name))
+    lo_fn, lh_fn = torch_ref.Loss(a), criterion.Loss(a)
+    po = ora(x)
+    loss_o = torch_ref.compute_loss(lo_fn, po, y, a.deep_supervision)
+    loss_o.backward()
+    ph = hip(x.to(DEV))
+    loss_h = criterion.compute_loss(lh_fn, ph, y.to(DEV), a.deep_supervision)
+    loss_h.backward()
+    po = po if isinstance(po, list) else [po]
+    ph = ph if isinstance(ph, list) else [ph]
+    assert len(po) == len(ph)
+    # fp64 run of the same oracle: measures how well-conditioned this configuration is in fp32 at all
+    ora64.train()
+    p64 = ora64(x.double())
+    loss64 = torch_ref.compute_loss(lo_fn, p64, y, a.deep_supervision)
+    loss64.backward()
+    p64 = p64 if isinstance(p64, list) else [p64]
+    cond = max(rel(o, q) for o, q in zip(po, p64))      # fp32-CPU-oracle vs fp64-oracle logit error
+    gate = max(1e-3, 3.0 * cond)
+    for i, (o, h, q) in enumerate(zip(po, ph, p64)):
+        assert o.shape == h.shape
+        assert rel(h, q) <= gate, "%s logits[%d]: hip-vs-f64 %.3e > gate %.3e (cpu32-vs-f64 %.3e)" % (
+            name, i, rel(h, q), gate, cond)
+    if cond <= 3e-4:   # well-conditioned: the plain 1e-3 gate against the fp32 oracle and exact label maps
+        assert rel(ph[0], po[0]) <= 1e-3
+        assert argmax_mismatch(ph[0], po[0]) == 0
+    assert abs(float(loss_h) - float(loss64)) <= max(1e-3, 3.0 * abs(float(loss_o) - float(loss64))) * max(
+        1.0, abs(float(loss64)))
+    # gradients (aliased FusedUNet entries share storage: named_parameters de-duplicates them)
+    g64 = {k: p.grad for k, p in ora64.named_parameters() if p.grad is not None}
+    go = {k: p.grad for k, p in ora.named_parameters() if p.grad is not None}
+    ratios = []
+    gmax = max(float(g.norm()) for g in g64.values())
+    for k, p in hip.named_parameters():
+        if k not in go:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        ref = g64[k]
+        if float(ref.norm()) < 1e-7 * gmax:
+            continue      # mathematically zero gradients (e.g. a conv bias in front of a train-mode BN)
+        nrm = max(float(ref.norm()), 1e-30)
+        e_hip = float((p.grad.detach().cpu().double() - ref).norm()) / nrm
+        e_cpu = float((go[k].double() - ref).norm()) / nrm
+        ratios.append((e_hip / max(e_cpu, 1e-12), e_hip, e_cpu, k, ref.numel()))
+    ratios.sort()
+    med = ratios[len(ratios) // 2][0]
+    # LeakyReLU/ReLU masks are discontinuous: one pre-activation within rounding distance of 0 flips its
+    # derivative (x100 for LeakyReLU) in one implementation and not the other, which shows up as an isolated
+    # ~1e-3..1e-2 jump on the few tensors directly upstream (both the CPU oracle and the HIP path exhibit such
+    # jumps against fp64, at different layers).  Hence: a small share of tensors may exceed the tight bound,
+    # none may be grossly off, and the median accuracy must match the CPU's.
+    loose = [r for r in ratios if r[1] > 10.0 * r[2] + 2e-3]
+    # (single-element tensors - the 1-channel psi BatchNorm - are sums with near-total cancellation: loose only)
+    bad = [r for r in ratios if r[1] > 10.0 * r[2] + 3e-2 and r[4] > 1]
+    assert not bad and len(loose) <= max(3, len(ratios) // 20) and med <= 2.0, "%s: median hip/cpu32 error ratio %.2f; offenders (ratio, hip, cpu32, key): %s" % (
+        name, med, bad[-5:])
+    # BN running statistics after one training step
+    so, sh = ora.state_dict(), hip.state_dict()
+    for k in so:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            assert rel(sh[k], so[k]) <= 1e-3, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sh[k]) == int(so[k]), k
+
+
+@pytest.mark.parametrize("name", ["pre_resnet50", "pre_resnest50", "post_siamese_resnest50_ds",
+                                  "post_fused_resnest50_attn_ds", "pre_resnet50_interpolate"])
+def test_eval_forward_parity(name):
+    a = ARGS(**MODEL_CASES[name])
+    ora, hip = build_pair(a)
+    ora64 = copy.deepcopy(ora).double().eval()
+    ora.eval()
+    hip.eval()
+    x = model_input(a, batch=case_batch(name))
+    with torch.no_grad():
+        o, h, q = ora(x), hip(x.to(DEV)), ora64(x.double())
+    assert torch.is_tensor(h) and o.shape == h.shape      # eval returns a Tensor even with deep supervision
+    cond = rel(o, q)
+    assert rel(h, q) <= max(1e-3, 3.0 * cond), "hip-vs-f64 %.3e, cpu32-vs-f64 %.3e" % (rel(h, q), cond)
+    if cond <= 3e-4:
+        assert rel(h, o) <= 1e-3
+        assert argmax_mismatch(h, o) == 0
+
+
+def test_cfg1_shape_512_resnet50_dice():
+    """BASELINE configs[0]: --type pre --encoder resnet50 --loss_str dice, 1x512x512 tile"""
+    from oracle import torch_ref
+    from xview2_amd import criterion
+    a = ARGS(encoder="resnet50", loss_str="dice", type="pre")
+    ora, hip = build_pair(a)
+    ora.train()
+    hip.train()
+    x, y = model_input(a, batch=1, size=512), labels(a, batch=1, size=512)
+    po = ora(x)
+    lo = torch_ref.Loss(a)(po, y)
+    ph = hip(x.to(DEV))
+    lh = criterion.Loss(a)(ph, y.to(DEV))
+    lh.backward()
+    assert rel(ph, po) <= 1e-3
+    assert abs(float(lh) - float(lo)) <= 1e-3
+    assert argmax_mismatch(ph, po) == 0

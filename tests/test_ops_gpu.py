@@ -310,3 +310,41 @@ def test_layout_and_argmax_and_adamw():
         opt.step()
         ops.adamw_step(pg, (g * step).to(dev()), m, v, 3e-4, 0.9, 0.999, 1e-8, 0.01, step)
     close(pg, pr, 1e-6, "adamw")
+
+
+@pytest.mark.parametrize("name", ["pre_dice", "pre_focal+dice", "pre_ce", "pre_ohem+dice", "post_focal+dice",
+                                  "post_dice", "post_ce+focal", "post_ohem"])
+def test_loss_forward_backward_vs_oracle(name):
+    """fused loss kernels against the CPU oracle's Loss (itself bit-equal to model/loss.py, tests/golden)"""
+    from oracle import torch_ref
+    from tests.golden.cases import ARGS, LOSS_CASES, loss_inputs
+    from xview2_amd import criterion
+    a = ARGS(**LOSS_CASES[name])
+    yp, yt = loss_inputs(a, batch=2, size=48)
+    ypr = yp.clone().double().requires_grad_(True)
+    lo = torch_ref.Loss(a)(ypr, yt)
+    lo.backward()
+    ypg = yp.to(dev()).requires_grad_(True)
+    lh = criterion.Loss(a)(ypg, yt.to(dev()))
+    (lh * 0.5).backward()
+    assert abs(float(lh) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+    close(ypg.grad * 2.0, ypr.grad, 2e-5, "dlogits " + name)
+
+
+def test_loss_deep_supervision_label_stride():
+    from oracle import torch_ref
+    from tests.golden.cases import ARGS, labels
+    from xview2_amd import criterion
+    a = ARGS(type="post", loss_str="focal+dice", deep_supervision=True)
+    torch.manual_seed(23)
+    preds = [torch.randn(2, 4, 32, 32), torch.randn(2, 4, 16, 16), torch.randn(2, 4, 8, 8)]
+    y = labels(a, 2, 32)
+    pr = [p.clone().double().requires_grad_(True) for p in preds]
+    lo = torch_ref.compute_loss(torch_ref.Loss(a), pr, y, True)
+    lo.backward()
+    pg = [p.to(dev()).requires_grad_(True) for p in preds]
+    lh = criterion.compute_loss(criterion.Loss(a), pg, y.to(dev()), True)
+    lh.backward()
+    assert abs(float(lh) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+    for g, r in zip(pg, pr):
+        close(g.grad, r.grad, 2e-5, "ds dlogits")

@@ -1,0 +1,60 @@
+"""Loss composition on the fused HIP loss kernels: drop-in for the reference's model/loss.py ``Loss``.
+
+``--loss_str`` is a '+'-separated sum of dice, focal, ce, ohem (model/loss.py:68-83).  dice/focal are the
+monai 0.4.0 losses with the constructor arguments of model/loss.py:11-13; ``ohem`` is numerically the mean
+cross-entropy (the reference slices the (values, indices) tuple of ``sort`` at model/loss.py:45, so no
+negative is ever dropped).  All terms of one call share a single softmax pass; for ``--type post`` the
+building mask of model/loss.py:86-90 is applied inside the kernels (no compaction, order-independent sums).
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+_TERM_BITS = {"dice": ops.LOSS_DICE, "focal": ops.LOSS_FOCAL, "ce": ops.LOSS_CE, "ohem": ops.LOSS_CE}
+
+
+class Loss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.loss_str = args.loss_str
+        self.post = args.type == "post"
+        self.names = self.loss_str.split("+")
+        for n in self.names:
+            if n not in ("dice", "focal", "ce", "ohem", "mse", "coral"):
+                raise KeyError(n)
+        self.unsupported = [n for n in self.names if n in ("mse", "coral")]
+
+    def forward(self, y_pred, y_true, label_stride=1):
+        """y_pred NCHW logits; y_true [N, H*label_stride, W*label_stride] uint8/long labels."""
+        if self.unsupported:
+            raise NotImplementedError(
+                "loss term(s) %s have no HIP kernel yet (not used by any benchmark configuration)" % self.unsupported)
+        # the reference sums the terms one by one; duplicated names count twice
+        total = None
+        counts = {}
+        for n in self.names:
+            counts[_TERM_BITS[n]] = counts.get(_TERM_BITS[n], 0) + 1
+        while counts:
+            bits = 0
+            for b in list(counts):
+                bits |= b
+                counts[b] -= 1
+                if counts[b] == 0:
+                    del counts[b]
+            part = ops.LossFn.apply(y_pred, y_true, bits, self.post, label_stride)
+            total = part if total is None else total + part
+        return total
+
+
+def compute_loss(loss_fn, preds, label, deep_supervision):
+    """model/plt.py:69-77: L(out) + 1/2 L(out_dec4, lbl[::2, ::2]) + 1/4 L(out_dec3, lbl[::4, ::4]), times
+    1/(2 - 2^-3); the nearest-neighbour label down-sampling is index arithmetic inside the loss kernel."""
+    if not deep_supervision:
+        return loss_fn(preds, label)
+    loss = loss_fn(preds[0], label)
+    for i, pred in enumerate(preds[1:]):
+        stride = label.shape[-1] // pred.shape[-1]
+        loss = loss + 0.5 ** (i + 1) * loss_fn(pred, label, label_stride=stride)
+    c_norm = 1 / (2 - 2 ** (-len(preds)))
+    return c_norm * loss

@@ -1,6 +1,9 @@
 // Thread-local error string of the C ABI (include/xv2.h: xv2_last_error).
 #include <stdarg.h>
 #include <stdio.h>
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
 #include "../../include/xv2.h"
 namespace xv2 {
 static thread_local char g_err[512] = "";
@@ -13,3 +16,64 @@ void set_error(const char* fmt, ...) {
 }  // namespace xv2
 extern "C" const char* xv2_last_error(void) { return xv2::g_err; }
 extern "C" int xv2_version(void) { return 1; }
+
+// ---- profiler -------------------------------------------------------------------------------
+namespace xv2 {
+struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<std::string> g_prof_names;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static size_t g_prof_pool_next = 0;
+static hipEvent_t prof_event() {
+    if (g_prof_pool_next == g_prof_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_prof_pool.push_back(e);
+    }
+    return g_prof_pool[g_prof_pool_next++];
+}
+int prof_register(const char* name) {
+    g_prof_names.emplace_back(name);
+    return (int)g_prof_names.size() - 1;
+}
+void prof_begin(int kid, double flops, hipStream_t stream) {
+    if (!g_prof_on) return;
+    ProfRec r{kid, flops, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, stream);
+    g_prof_recs.push_back(r);
+}
+void prof_end(hipStream_t stream) {
+    if (!g_prof_on || g_prof_recs.empty()) return;
+    (void)hipEventRecord(g_prof_recs.back().b, stream);
+}
+}  // namespace xv2
+extern "C" int xv2_prof_enable(int on) {
+    xv2::g_prof_on = on != 0;
+    if (on) {
+        xv2::g_prof_recs.clear();
+        xv2::g_prof_pool_next = 0;
+    }
+    return XV2_OK;
+}
+extern "C" int xv2_prof_num_kernels(void) { return (int)xv2::g_prof_names.size(); }
+extern "C" const char* xv2_prof_kernel_name(int kid) {
+    return (kid >= 0 && kid < (int)xv2::g_prof_names.size()) ? xv2::g_prof_names[kid].c_str() : "";
+}
+extern "C" int xv2_prof_summary(int kid, double* total_ms, double* total_flops, int64_t* launches) {
+    double ms = 0.0, fl = 0.0;
+    int64_t n = 0;
+    for (auto& r : xv2::g_prof_recs) {
+        if (r.kid != kid) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+        ms += t;
+        fl += r.flops;
+        ++n;
+    }
+    *total_ms = ms;
+    *total_flops = fl;
+    *launches = n;
+    return XV2_OK;
+}

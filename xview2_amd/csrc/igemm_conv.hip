@@ -50,6 +50,7 @@ struct IgemmParams {
     int cpt;           // 32-channel chunks per tap (Ctot/32)
     int nkt;           // K tiles
     int stats_row0;    // first stats row of this launch
+    int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
     Tap taps[52];
 };
 
@@ -295,8 +296,17 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    static int kid = -1;
+    if (kid < 0) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, SMALLC ? "rgb" : "c32");
+        kid = prof_register(nm);
+    }
     const int grid = (int)(cdiv(p.M, BM) * (p.Nout / BN));
+    const double kreal = SMALLC ? (double)p.ntaps * p.cin_real : (double)p.ntaps * p.Ctot;
+    prof_begin(kid, 2.0 * (double)p.M * p.Nout * kreal, stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+    prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -345,6 +355,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bias = nullptr;
     p.stats = nullptr;
     p.stats_row0 = 0;
+    p.cin_real = 3;
     p.A1 = nullptr;
     p.Out1 = nullptr;
     return XV2_OK;

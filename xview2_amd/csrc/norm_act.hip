@@ -39,7 +39,9 @@ struct ColOp {
     int lda, ldz, ldy, act;
     __device__ __forceinline__ void apply(int64_t row, int c, float& f0, float& f1) const {
         if constexpr (MODE == 0) {
-            const float v = a[row * lda + c];
+            // shifted sums (shift = the tensor's first row): avoids the E[x^2]-E[x]^2 cancellation when
+            // |mean| >> std (e.g. split-attention bn1 over a handful of near-equal GAP values)
+            const float v = a[row * lda + c] - a[c];
             f0 += v;
             f1 += v * v;
         } else {
@@ -52,7 +54,8 @@ struct ColOp {
     __device__ __forceinline__ void apply4(int64_t row, int c, float4& f0, float4& f1, const float4& mu,
                                            const float4& is) const {
         if constexpr (MODE == 0) {
-            const float4 v = *reinterpret_cast<const float4*>(a + row * lda + c);
+            float4 v = *reinterpret_cast<const float4*>(a + row * lda + c);
+            v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;   // mu = first row (shift)
             f0.x += v.x; f0.y += v.y; f0.z += v.z; f0.w += v.w;
             f1.x += v.x * v.x; f1.y += v.y * v.y; f1.z += v.z * v.z; f1.w += v.w * v.w;
         } else {
@@ -70,12 +73,12 @@ struct ColOp {
 
 template <int MODE>
 __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, int64_t npix, int C, int rpb,
-                                                              float* __restrict__ part) {
+                                                              double* __restrict__ part) {
     __shared__ float sh[256 * 8];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = min(r0 + (int64_t)rpb, npix);
-    float* out = part + (size_t)blockIdx.x * C * 2;
+    double* out = part + (size_t)blockIdx.x * C * 2;
     const int C4 = C / 4;
     if (C % 4 == 0 && C4 <= 256 && (256 % C4) == 0) {
         const int rpp = 256 / C4;
@@ -85,6 +88,8 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
         if constexpr (MODE == 1) {
             mu = *reinterpret_cast<const float4*>(op.mean + tx * 4);
             is = *reinterpret_cast<const float4*>(op.invstd + tx * 4);
+        } else {
+            mu = *reinterpret_cast<const float4*>(op.a + tx * 4);
         }
         for (int64_t r = r0 + ty; r < r1; r += rpp) op.apply4(r, tx * 4, f0, f1, mu, is);
         float* s = sh + tid * 8;
@@ -92,7 +97,7 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
         s[4] = f1.x; s[5] = f1.y; s[6] = f1.z; s[7] = f1.w;
         __syncthreads();
         if (tid < C4) {
-            float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
             for (int q = 0; q < rpp; ++q) {
                 const float* t = sh + (q * C4 + tid) * 8;
 #pragma unroll
@@ -112,17 +117,31 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
         const int tx = tid & 63, ty = tid >> 6;
         for (int cb = 0; cb < C; cb += 64) {
             const int c = cb + tx;
-            float f0 = 0.f, f1 = 0.f;
-            if (c < C)
-                for (int64_t r = r0 + ty; r < r1; r += 4) op.apply(r, c, f0, f1);
-            sh[tid * 2] = f0;
-            sh[tid * 2 + 1] = f1;
+            // narrow / odd channel counts (e.g. the 1-channel psi BN): few lanes, long columns -> fp64 running
+            // sums, flushed from fp32 every 16 rows
+            double d0 = 0.0, d1 = 0.0;
+            if (c < C) {
+                float f0 = 0.f, f1 = 0.f;
+                int k = 0;
+                for (int64_t r = r0 + ty; r < r1; r += 4) {
+                    op.apply(r, c, f0, f1);
+                    if (++k == 16) {
+                        d0 += f0; d1 += f1;
+                        f0 = f1 = 0.f;
+                        k = 0;
+                    }
+                }
+                d0 += f0; d1 += f1;
+            }
+            double* shd = reinterpret_cast<double*>(sh);
+            shd[tid * 2] = d0;
+            shd[tid * 2 + 1] = d1;
             __syncthreads();
             if (ty == 0 && c < C) {
-                float a0 = 0.f, a1 = 0.f;
+                double a0 = 0.0, a1 = 0.0;
                 for (int q = 0; q < 4; ++q) {
-                    a0 += sh[(q * 64 + tx) * 2];
-                    a1 += sh[(q * 64 + tx) * 2 + 1];
+                    a0 += shd[(q * 64 + tx) * 2];
+                    a1 += shd[(q * 64 + tx) * 2 + 1];
                 }
                 out[c * 2] = a0;
                 out[c * 2 + 1] = a1;
@@ -133,7 +152,8 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
 }
 
 // stage 1: grid (ceil(C/32), S): scratch[s][C][2] = sum over tiles t == s (mod S)... contiguous ranges
-__global__ void __launch_bounds__(256) reduce_stats_stage1(const float* __restrict__ part, int64_t tiles, int C,
+template <typename T>
+__global__ void __launch_bounds__(256) reduce_stats_stage1(const T* __restrict__ part, int64_t tiles, int C,
                                                            int S, double* __restrict__ scratch) {
     __shared__ double sh[256 * 2];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 channels x 8 row lanes
@@ -143,9 +163,8 @@ __global__ void __launch_bounds__(256) reduce_stats_stage1(const float* __restri
     double a0 = 0.0, a1 = 0.0;
     if (c < C)
         for (int64_t t = t0 + ty; t < t1; t += 8) {
-            const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)t * C + c) * 2);
-            a0 += v.x;
-            a1 += v.y;
+            a0 += (double)part[((size_t)t * C + c) * 2];
+            a1 += (double)part[((size_t)t * C + c) * 2 + 1];
         }
     sh[threadIdx.x * 2] = a0;
     sh[threadIdx.x * 2 + 1] = a1;
@@ -168,10 +187,20 @@ __global__ void reduce_stats_stage2(const double* __restrict__ scratch, int C, i
     sums[i] = a;
 }
 
-static int reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st) {
+// sums of (x - s) and (x - s)^2  ->  sums of x and x^2, in fp64 (no cancellation at this precision)
+__global__ void unshift_stats_kernel(double* __restrict__ sums, const float* __restrict__ x, double n, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double sh = (double)x[c], s1 = sums[c * 2], s2 = sums[c * 2 + 1];
+    sums[c * 2] = s1 + n * sh;
+    sums[c * 2 + 1] = s2 + 2.0 * sh * s1 + n * sh * sh;
+}
+
+template <typename T>
+static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st) {
     int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));
     if (S < 1) S = 1;
-    hipLaunchKernelGGL(reduce_stats_stage1, dim3((unsigned)cdiv(C, 32), S), dim3(256), 0, st, partial, tiles, C, S,
+    hipLaunchKernelGGL(reduce_stats_stage1<T>, dim3((unsigned)cdiv(C, 32), S), dim3(256), 0, st, partial, tiles, C, S,
                        scratch);
     XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_stats_stage2, dim3((unsigned)cdiv(C * 2, 256)), dim3(256), 0, st, scratch, C, S, sums);
@@ -314,12 +343,12 @@ using namespace xv2;
 extern "C" int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
                                    void* stream) {
     XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_reduce_stats: empty");
-    return reduce_stats(partial, tiles, C, sums, scratch, (hipStream_t)stream);
+    return reduce_stats<float>(partial, tiles, C, sums, scratch, (hipStream_t)stream);
 }
 
 extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
     const ChunkGeom g = chunk_geom(npix, C);
-    size_t part = (size_t)g.chunks * C * 2 * sizeof(float);
+    size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
     return part + (size_t)XV2_BN_SCRATCH_ROWS * C * 2 * sizeof(double);
 }
@@ -328,13 +357,14 @@ extern "C" size_t xv2_bn_backward_workspace(int64_t npix, int C) { return xv2_bn
 template <int MODE>
 static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st) {
     const ChunkGeom g = chunk_geom(npix, C);
-    size_t part = (size_t)g.chunks * C * 2 * sizeof(float);
+    size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
+    double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
     hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks), dim3(256), 0, st, op, npix, C, g.rpb,
-                       workspace);
+                       dpart);
     XV2_CHECK_LAUNCH();
-    return reduce_stats(workspace, g.chunks, C, sums, scratch, st);
+    return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st);
 }
 
 extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums, float* workspace,
@@ -343,7 +373,12 @@ extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C,
     ColOp<0> op;
     op.a = x; op.lda = ldx; op.z = nullptr; op.y = nullptr; op.mean = nullptr; op.invstd = nullptr;
     op.ldz = op.ldy = 0; op.act = 0;
-    return column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
+    int rc = column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(unshift_stats_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, x,
+                       (double)npix, C);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
 }
 
 extern "C" int xv2_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,

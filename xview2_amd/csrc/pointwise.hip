@@ -141,11 +141,11 @@ __global__ void head_bwd_reduce_kernel(const float* __restrict__ part, int nbloc
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = Cin + 1;
     if (i >= Cout * row) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * Cout * row + i];
+    double s = 0.0;  // the per-class bias gradients cancel almost exactly (softmax): sum the partials in fp64
+    for (int b = 0; b < nblocks; ++b) s += (double)part[(size_t)b * Cout * row + i];
     const int o = i / row, c = i % row;
-    if (c < Cin) dw[o * Cin + c] = s;
-    else if (db) db[o] = s;
+    if (c < Cin) dw[o * Cin + c] = (float)s;
+    else if (db) db[o] = (float)s;
 }
 
 // ------------------------------------------------------------------------------- elementwise

@@ -249,7 +249,15 @@ template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 32 * (BM + BN) * 4;
     auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC>;
+    static int kid = -1;
+    if (kid < 0) {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, WK, SMALLC ? "rgb" : "c32");
+        kid = prof_register(nm);
+    }
+    prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * (SMALLC ? 3.0 : (double)p.Ctot), stream);
     hipLaunchKernelGGL(kern, dim3(pl.tiles, pl.splitk), dim3(256), smem, stream, p);
+    prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

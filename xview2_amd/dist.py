@@ -1,0 +1,111 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU (reference: Trainer(accelerator="ddp",
+sync_batchnorm=gpus > 1), main.py:106-107).
+
+* Gradients live in the flat buffer of ``FlatAdamW``; it is cut into buckets in REVERSE parameter order (the
+  order backward produces them).  A per-parameter post-accumulate hook counts a bucket down; when its last
+  gradient has been written, the bucket slice is all-reduced (SUM) on a side HIP stream, fenced by events, so
+  the collective overlaps with the rest of backward.  The 1/world averaging is folded into the optimizer
+  kernel (grad_scale), no extra pass.
+* xGMI is point-to-point (7 links per GPU): buckets are large (default 64 MiB) so each RCCL call is
+  bandwidth- not latency-bound; there is no per-parameter collective.
+* SyncBatchNorm: xview2_amd.nn.SYNC_BN makes every BN all-reduce its (sum, sum-of-squares) in forward and
+  (sum g, sum g*xhat) in backward - same statistics as torch.nn.SyncBatchNorm.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import nn as xnn
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradReducer:
+    def __init__(self, optimizer, bucket_bytes=64 << 20, sync_bn=True, overlap=True):
+        self.opt = optimizer
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.overlap = overlap
+        self.on_gpu = optimizer.flat_g.is_cuda
+        if sync_bn and self.enabled:
+            xnn.SYNC_BN = True
+        self.buckets = []       # (start, end, [param indices])
+        self.pending = []
+        if not self.enabled:
+            return
+        cap = max(1, bucket_bytes // 4)
+        n = len(optimizer.params)
+        cur_end = optimizer.total
+        members, cur_start = [], optimizer.total
+        for i in range(n - 1, -1, -1):
+            members.append(i)
+            cur_start = optimizer.offsets[i]
+            if cur_end - cur_start >= cap or i == 0:
+                self.buckets.append((cur_start, cur_end, members))
+                members, cur_end = [], cur_start
+        self.bucket_of = {}
+        for b, (_, _, mem) in enumerate(self.buckets):
+            for i in mem:
+                self.bucket_of[i] = b
+        self.remaining = [len(m) for _, _, m in self.buckets]
+        self.side = torch.cuda.Stream() if self.on_gpu else None
+        self.handles = []
+        for i, p in enumerate(optimizer.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.bucket_of[i]
+            self.remaining[b] -= 1
+            if self.remaining[b] == 0 and self.overlap:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        sl = self.opt.flat_g[s:e]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()                                    # bucket's gradients are complete on the compute stream
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.handles.append(dist.all_reduce(sl, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(sl, async_op=True))
+
+    def prepare(self):
+        """call before backward"""
+        if self.enabled:
+            self.remaining = [len(m) for _, _, m in self.buckets]
+            self.handles = []
+
+    def finish(self):
+        """call after backward: launches whatever did not fire (unused parameters keep zero grads) and makes
+        the compute stream wait for the collectives.  Returns the grad_scale for the optimizer."""
+        if not self.enabled:
+            return 1.0
+        for b, r in enumerate(self.remaining):
+            if r != 0 or not self.overlap:
+                self._launch(b)
+                self.remaining[b] = 0
+        for h in self.handles:
+            h.wait()
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.handles = []
+        return 1.0 / self.world

@@ -1,0 +1,81 @@
+"""Glue between parameter containers and the HIP ops.
+
+``torch.nn.Conv2d`` / ``BatchNorm2d`` / ``ConvTranspose2d`` objects are used purely as PARAMETER CONTAINERS
+(same constructor arguments, default init and ``state_dict`` keys as the reference's modules); their
+``forward`` is never called - the functions below route them through the fused HIP autograd nodes.
+Activations are NHWC.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+# set by xview2_amd.dist when training data-parallel (reference: Trainer(sync_batchnorm=gpus > 1), main.py:106)
+SYNC_BN = False
+
+
+def _cfg(conv):
+    g = getattr(conv, "_xv2_cfg", None)
+    if g is None:
+        kh, kw = conv.kernel_size
+        assert conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+        assert conv.dilation[0] == conv.dilation[1]
+        g = ops.conv_cfg(kh, kw, conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups)
+        conv._xv2_cfg = g
+    return g
+
+
+def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None):
+    """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
+                                 ops.BnState(bn, SYNC_BN), act, bn.training)
+
+
+def conv(conv_m, x0, x1=None):
+    return ops.ConvFn.apply(x0, x1, conv_m.weight, conv_m.bias, _cfg(conv_m))
+
+
+def bn_act(bn, y, act=ops.ACT_NONE, residual=None):
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return ops.BnActFn.apply(y, bn.weight, bn.bias, residual, ops.BnState(bn, SYNC_BN), act, bn.training)
+
+
+def head_conv(conv_m, x, nchw_out=True):
+    return ops.HeadConvFn.apply(x, conv_m.weight, conv_m.bias, nchw_out)
+
+
+def cat_channels(*xs):
+    return ops.CatChannelsFn.apply(*xs)
+
+
+class Numbered(nn.Module):
+    """Container whose children are registered under '0', '1', ... like nn.Sequential (so checkpoints keep the
+    reference's keys), but with an explicit forward supplied by subclasses."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m if m is not None else nn.Identity())
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def __len__(self):
+        return len(self._modules)
+
+
+class Chain(Numbered):
+    """nn.Sequential equivalent for NHWC HIP blocks."""
+
+    def forward(self, x):
+        for m in self._modules.values():
+            x = m(x)
+        return x
+
+
+def to_nhwc_image(x_nchw):
+    """[N,3,H,W] image (possibly a channel slice of the 6-channel pre/post pair) -> NHWC padded to 4 channels."""
+    return ops.nchw_to_nhwc(x_nchw, 4)

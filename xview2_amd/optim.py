@@ -1,0 +1,62 @@
+"""AdamW on one flat parameter/gradient buffer: one HIP launch per step (model/plt.py:154 uses
+torch.optim.AdamW as the default --optimizer; same update rule, decoupled weight decay).
+
+All parameters are re-pointed at views of a single fp32 buffer and their ``.grad`` at views of a second one,
+so (a) the optimizer step is a single streaming kernel over 4 arrays, (b) the data-parallel reducer
+(xview2_amd.dist) all-reduces contiguous slices without packing copies.
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdamW:
+    def __init__(self, params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        seen, plist = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:      # FusedUNet registers every stage twice
+                seen.add(id(p))
+                plist.append(p)
+        self.params = plist
+        dev = plist[0].device
+        sizes = [p.numel() for p in plist]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4                      # keep every view 16-byte aligned
+        self.offsets, self.total = offs, total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(plist, offs):
+                view = self.flat_p[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "params": plist}]  # what utils/scheduler.py NoamLR touches
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):        # autograd may have replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
+                       self.eps, self.weight_decay, self.step_count, grad_scale)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd["lr"]

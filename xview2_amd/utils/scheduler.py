@@ -1,0 +1,35 @@
+"""Noam learning-rate schedule (linear warm-up, exponential decay), stepped once per optimizer step.
+Host-side scalar arithmetic with the constructor contract of the reference's utils/scheduler.py:6-59
+(warmup_epochs, total_epochs, steps_per_epoch, init_lr, max_lr, final_lr); works with any optimizer object
+exposing ``param_groups`` (torch.optim.* or xview2_amd.optim.FlatAdamW)."""
+
+
+class NoamLR:
+    def __init__(self, optimizer, warmup_epochs, total_epochs, steps_per_epoch, init_lr, max_lr, final_lr):
+        self.optimizer = optimizer
+        self.n = len(optimizer.param_groups)
+        self.init_lr, self.max_lr, self.final_lr = init_lr, max_lr, final_lr
+        self.warmup_steps = int(warmup_epochs * steps_per_epoch)
+        self.total_steps = total_epochs * steps_per_epoch
+        self.linear_increment = (max_lr - init_lr) / self.warmup_steps
+        self.exponential_gamma = (final_lr / max_lr) ** (1 / (self.total_steps - self.warmup_steps))
+        self.current_step = 0
+        self.lr = [init_lr] * self.n
+        for g in optimizer.param_groups:
+            g["lr"] = init_lr
+
+    def get_lr(self):
+        return list(self.lr)
+
+    def step(self, current_step=None):
+        self.current_step = current_step if current_step is not None else self.current_step + 1
+        s = self.current_step
+        if s <= self.warmup_steps:
+            lr = self.init_lr + s * self.linear_increment
+        elif s <= self.total_steps:
+            lr = self.max_lr * (self.exponential_gamma ** (s - self.warmup_steps))
+        else:
+            lr = self.final_lr
+        for i, g in enumerate(self.optimizer.param_groups):
+            self.lr[i] = lr
+            g["lr"] = lr
