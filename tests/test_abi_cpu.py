@@ -1,0 +1,108 @@
+"""CPU-side checks of the C-ABI boundary and of the host logic (no compute: there is no GPU here)."""
+import ctypes
+
+import pytest
+import torch
+
+from tests.golden.cases import ARGS, MODEL_CASES
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from xview2_amd import _lib
+    path = _lib.build()
+    lib = ctypes.CDLL(path)
+    names = _lib.declared_symbols()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.xv2_last_error.restype = ctypes.c_char_p
+    assert lib.xv2_version() >= 1 and isinstance(lib.xv2_last_error(), bytes)
+
+
+def test_header_prototypes_parse_and_bind():
+    from xview2_amd import _capi
+    protos = _capi._parse_header()
+    from xview2_amd import _lib
+    assert set(protos) == set(_lib.declared_symbols())
+    rt, argt = protos["xv2_conv2d_forward"]
+    assert rt is ctypes.c_int and len(argt) == 11
+    assert protos["xv2_conv2d_backward_weight_workspace"][0] is ctypes.c_size_t
+    # argument validation is reachable without a GPU: a bad descriptor must come back as XV2_EINVAL + message
+    d = _capi.ConvDesc(1, 8, 8, 33, 0, 32, 3, 3, 1, 1, 1, 8, 8)
+    f = _capi._func("xv2_conv2d_forward")
+    rc = f(ctypes.addressof(d), None, 33, None, 0, None, None, None, 32, None, None)
+    assert rc == 1 and b"multiples of 32" in _lib.lib().xv2_last_error()
+    assert _capi.query("xv2_conv2d_backward_weight_workspace", _capi.ConvDesc(2, 64, 64, 64, 0, 64, 3, 3, 1, 1, 1, 64, 64)) > 0
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from xview2_amd import networks
+    m = networks.UNetLoc(ARGS())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 64, 64))
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xview2_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_state_dict_surface_matches_reference_keys(name):
+    """same keys and shapes as the reference modules (pinned through the oracle + golden key digests)"""
+    import hashlib
+    import json
+    import os
+    from xview2_amd import networks
+    a = ARGS(**MODEL_CASES[name])
+    m = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
+    sd = m.state_dict()
+    txt = "\n".join("%s:%s" % (k, tuple(v.shape)) for k, v in sorted(sd.items()))
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+    assert [hashlib.sha1(txt.encode()).hexdigest(), len(sd)] == gold["keys"][name]
+
+
+def test_reference_construction_errors_are_kept():
+    from xview2_amd import networks
+    with pytest.raises(TypeError):
+        networks.get_dmg_unet(ARGS(type="post", dmg_model="cat", loss_str="ce"))
+    with pytest.raises(ValueError):
+        networks.get_decoder([64, 256, 512, 1024, 2048], 3, False)
+    m = networks.get_dmg_unet(ARGS(type="post", dmg_model="fused", ppm=True, dec_interp=True, loss_str="ce"))
+    assert not any("ppm" in k for k in m.state_dict()) and m.dec_l1_pre.skip_channels == 0
+
+
+def test_cli_flags_match_reference_defaults():
+    from argparse import ArgumentParser
+    from xview2_amd.model.plt import Model
+    a = Model.add_model_specific_args(ArgumentParser()).parse_args([])
+    assert (a.optimizer, a.dmg_model, a.encoder, a.loss_str) == ("adamw", "siamese", "resnest200", "focal+dice")
+    assert (a.lr, a.init_lr, a.final_lr, a.weight_decay, a.momentum, a.warmup, a.dilation) == (
+        3e-4, 1e-4, 1e-4, 0, 0.9, 1, 1)
+    for flag in ("tta", "ppm", "aspp", "no_skip", "deep_supervision", "attention", "autoaugment", "interpolate",
+                 "dec_interp", "use_scheduler"):
+        assert getattr(a, flag) is False
+
+
+def test_noam_schedule_matches_reference_golden():
+    import json
+    import os
+    from xview2_amd.utils.scheduler import NoamLR
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))["noam"]
+
+    class Opt:
+        param_groups = [{"lr": 1.0}]
+    s = NoamLR(Opt(), warmup_epochs=1, total_epochs=4, steps_per_epoch=5, init_lr=1e-4, max_lr=3e-4, final_lr=1e-5)
+    got = []
+    for _ in range(25):
+        s.step()
+        got.append(s.get_lr()[0])
+    assert max(abs(a - b) for a, b in zip(got, gold)) < 1e-12

@@ -9,6 +9,11 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so): it MUST be loaded before libxv2.so so that
+# both share one runtime (and one device context); loading libxv2.so first would pull in /opt/rocm's copy
+# and every launch would fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libxv2.so")

@@ -15,8 +15,9 @@ class NoamLR:
         self.exponential_gamma = (final_lr / max_lr) ** (1 / (self.total_steps - self.warmup_steps))
         self.current_step = 0
         self.lr = [init_lr] * self.n
-        for g in optimizer.param_groups:
-            g["lr"] = init_lr
+        # torch's _LRScheduler.__init__ (the reference's base class, utils/scheduler.py:43) performs one
+        # step() at construction: the schedule starts at current_step == 1
+        self.step()
 
     def get_lr(self):
         return list(self.lr)
