@@ -59,13 +59,17 @@ int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int 
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]
  * (tile count = xv2_conv2d_forward_stats_tiles(d)), consumed by xv2_bn_reduce_stats. */
 int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
+/* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
+ * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
+size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
                        int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
-                       float* stats, void* stream);
+                       float* stats, float* workspace, void* stream);
 /* dx = conv2d_backward_input(dy, w); dx0/dx1 receive the channel ranges of the two sources */
+size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
                              const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
-                             void* stream);
+                             float* workspace, void* stream);
 /* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
 size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,

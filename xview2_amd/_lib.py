@@ -16,7 +16,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libxv2.so")
+LIB_PATH = os.environ.get("XV2_LIB", os.path.join(_HERE, "libxv2.so"))
 SOURCES = ["errors.cpp", "igemm_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
            "loss_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -73,7 +73,8 @@ def lib():
                 "(hipcc, gfx950). There is no CPU fallback for the HIP hot path." % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.xv2_last_error.restype = ctypes.c_char_p
-        for name in ("xv2_conv2d_backward_weight_workspace", "xv2_head_conv_backward_workspace",
+        for name in ("xv2_conv2d_backward_weight_workspace", "xv2_conv2d_forward_workspace",
+                     "xv2_conv2d_backward_data_workspace", "xv2_head_conv_backward_workspace",
                      "xv2_bn_tensor_stats_workspace", "xv2_bn_backward_workspace", "xv2_splat_gap_workspace",
                      "xv2_loss_workspace"):
             getattr(_lib, name).restype = ctypes.c_size_t

@@ -20,12 +20,28 @@
 // Epilogue: optional bias, scattered NHWC store through a per-row pixel-offset table, and
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
 #include "xv2_common.h"
+#include <stdlib.h>
+#include <algorithm>
+
+#ifndef XV2_ABL
+#define XV2_ABL 0   // debug ablations (scripts/ablate.sh): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
+#endif
 
 namespace xv2 {
 
 struct Tap {
     short dh, dw;
     int slot;
+};
+
+// one output-parity class of a strided backward-data (a plain convolution has exactly one class)
+struct ClassInfo {
+    int tap0, ntaps;   // slice of taps[]
+    int OHl, OWl;      // logical output grid of the class
+    int M;             // N * OHl * OWl
+    int os0;           // pixel offset of the class inside the output image
+    int nkt;           // K tiles
+    int mtiles;        // ceil(M / BM)
 };
 
 struct IgemmParams {
@@ -36,21 +52,21 @@ struct IgemmParams {
     float* Out0;
     float* Out1;
     float* stats;
+    float* part;       // split-K slabs [ksplit][M][Nout] (ksplit > 1 only)
+    unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
     int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
     int ldA0, ldA1;
     int IH, IW;        // spatial size of A
     int s_in;
-    int OHl, OWl;      // logical output grid
-    int M;             // N * OHl * OWl
-    int osN, osH, osW, os0;  // output pixel index = n*osN + a*osH + b*osW + os0
+    int osN, osH, osW; // output pixel index = n*osN + a*osH + b*osW + os0
     int Nout, N0;      // GEMM N; columns < N0 go to Out0 (ld ldo0), others to Out1 (ldo1)
     int ldo0, ldo1;
     int T;             // tap slots per B row
-    int ntaps;
     int cpt;           // 32-channel chunks per tap (Ctot/32)
-    int nkt;           // K tiles
-    int stats_row0;    // first stats row of this launch
+    int ksplit, kt_per_split;
     int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
+    int ncls;
+    ClassInfo cls[4];
     Tap taps[52];
 };
 
@@ -85,22 +101,27 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    const ClassInfo ci = p.cls[blockIdx.y];
     const int ntn = p.Nout / BN;
     const int tn = bid % ntn, tm = bid / ntn;
+    if (tm >= ci.mtiles) return;   // classes of one launch may differ by a tile (uniform per block)
     const int m0 = tm * BM, n0 = tn * BN;
+    const Tap* taps = p.taps + ci.tap0;
+    const int kt_begin = blockIdx.z * p.kt_per_split;
+    const int kt_end = min(kt_begin + p.kt_per_split, ci.nkt);
 
     const int c4 = tid & 7, r0 = tid >> 3;
-    const int ohw = p.OHl * p.OWl;
+    const int ohw = ci.OHl * ci.OWl;
 
     int a_n[AROWS], a_h[AROWS], a_w[AROWS];
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
         const int m = m0 + r0 + 32 * j;
-        if (m < p.M) {
+        if (m < ci.M) {
             const int n = m / ohw;
             const int rem = m - n * ohw;
-            const int a = rem / p.OWl;
-            const int b = rem - a * p.OWl;
+            const int a = rem / ci.OWl;
+            const int b = rem - a * ci.OWl;
             a_n[j] = n * p.IH;
             a_h[j] = a * p.s_in;
             a_w[j] = b * p.s_in;
@@ -110,15 +131,44 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             a_w[j] = 0;
         }
     }
+    // fast loader state (32-channel path): per-row pixel index + per-tap validity bits, buffer descriptors.
+    // A K-tile load is then  offset = (pix + dpix(tap)) * ld + channel  ->  one buffer_load_dwordx4 whose
+    // out-of-image rows are redirected past num_records (the hardware returns zeros: conv padding for free).
+    int a_pix[AROWS];
+    unsigned a_msk[AROWS];
+    int b_off[BROWS];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsA0, rsA1, rsB;
+    if constexpr (!SMALLC) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            a_pix[j] = (a_n[j] + a_h[j]) * p.IW + a_w[j];
+            unsigned mk = 0;
+            for (int t = 0; t < ci.ntaps; ++t) {
+                const int ih = a_h[j] + taps[t].dh, iw = a_w[j] + taps[t].dw;
+                if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) mk |= 1u << t;
+            }
+            a_msk[j] = mk;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) b_off[j] = (n0 + r0 + 32 * j) * (p.T * p.Ctot) + c4 * 4;
+        rsA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
+        rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1 ? p.A1 : p.A0), 0, p.A1 ? p.bytesA1 : p.bytesA0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
+    }
     if (tid < BM) {
         const int m = m0 + tid;
         int off = -1;
-        if (m < p.M) {
-            const int n = m / ohw;
-            const int rem = m - n * ohw;
-            const int a = rem / p.OWl;
-            const int b = rem - a * p.OWl;
-            off = n * p.osN + a * p.osH + b * p.osW + p.os0;
+        if (m < ci.M) {
+            if (p.ksplit > 1) {
+                off = m;   // slab rows are plain GEMM rows
+            } else {
+                const int n = m / ohw;
+                const int rem = m - n * ohw;
+                const int a = rem / ci.OWl;
+                const int b = rem - a * ci.OWl;
+                off = n * p.osN + a * p.osH + b * p.osW + ci.os0;
+            }
         }
         rowoff[tid] = off;
     }
@@ -126,40 +176,36 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     float4 ra[AROWS], rb[BROWS];
 
     auto gload = [&](int kt) {
+#if XV2_ABL & 1
+        return;
+#endif
         if constexpr (!SMALLC) {
             const int tap = kt / p.cpt;
             const int cc = (kt - tap * p.cpt) * BK;
-            const Tap t = p.taps[tap];
-            const float* src;
-            int ld, ch;
-            if (cc < p.C0) {
-                src = p.A0; ld = p.ldA0; ch = cc;
-            } else {
-                src = p.A1; ld = p.ldA1; ch = cc - p.C0;
-            }
-            ch += c4 * 4;
+            const Tap t = taps[tap];
+            const int dpix = t.dh * p.IW + t.dw;
+            const bool first = cc < p.C0;
+            const int ld = first ? p.ldA0 : p.ldA1;
+            const int ch = (first ? cc : cc - p.C0) + c4 * 4;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
-                const int ih = a_h[j] + t.dh, iw = a_w[j] + t.dw;
-                const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const size_t pix = (size_t)(a_n[j] + ih) * p.IW + iw;
-                    v = *reinterpret_cast<const float4*>(src + pix * ld + ch);
-                }
-                ra[j] = v;
+                const bool ok = (a_msk[j] >> tap) & 1u;
+                const int off = ok ? (((a_pix[j] + dpix) * ld + ch) << 2) : (int)0x80000000;
+                const i32x4 v = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 0, 0)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0);
+                ra[j] = __builtin_bit_cast(float4, v);
             }
-            const size_t kb = (size_t)t.slot * p.Ctot + cc + c4 * 4;
-            const size_t rowstride = (size_t)p.T * p.Ctot;
+            const int kb = t.slot * p.Ctot + cc;
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
-                rb[j] = *reinterpret_cast<const float4*>(p.B + (size_t)(n0 + r0 + 32 * j) * rowstride + kb);
+                const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << 2, 0, 0);
+                rb[j] = __builtin_bit_cast(float4, v);
             }
         } else {
             // 4-channel source: every float4 is one tap
             const int tap = kt * 8 + c4;
-            const bool tok = tap < p.ntaps;
-            const Tap t = p.taps[tok ? tap : 0];
+            const bool tok = tap < ci.ntaps;
+            const Tap t = taps[tok ? tap : 0];
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
                 const int ih = a_h[j] + t.dh, iw = a_w[j] + t.dw;
@@ -180,6 +226,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         }
     };
     auto lstore = [&](int buf) {
+#if XV2_ABL & 2
+        return;
+#endif
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -198,13 +247,20 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
+    // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
+    // (tile kt).  The LDS store of the next tile sits at the START of an iteration, so nothing but the MFMA
+    // tail stands between the last fragment read and the barrier.
+    gload(kt_begin);
     lstore(0);
+    if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
     __syncthreads();
 
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < p.nkt) gload(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
+            lstore(buf ^ 1);
+            if (kt + 2 < kt_end) gload(kt + 2);
+        }
         const float* a = As + buf * BM * LDS_LD + (wm * WTM + l31) * LDS_LD + 4 * h;
         const float* b = Bs + buf * BN * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * h;
 #pragma unroll
@@ -216,6 +272,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < NR; ++j)
                 bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * LDS_LD + kk * 8);
+#if XV2_ABL & 4
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) acc[i][j][0] += af[i].x * bf[j].x + af[i].y * bf[j].y + af[i].z * bf[j].z + af[i].w * bf[j].w;
+#else
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -225,19 +287,25 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
+#endif
         }
-        if (kt + 1 < p.nkt) lstore(buf ^ 1);
         __syncthreads();
     }
 
+#if XV2_ABL & 8
+    if (acc[0][0][0] == 123.456f) p.Out0[0] = 1.f;
+    return;
+#endif
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int col = n0 + wn * WTN + j * 32 + l31;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float bv = (p.bias && p.ksplit == 1) ? p.bias[col] : 0.f;
         float* outp;
         int ldo, ocol;
-        if (col < p.N0) {
+        if (p.ksplit > 1) {
+            outp = p.part + (size_t)blockIdx.z * ci.M * p.Nout; ldo = p.Nout; ocol = col;
+        } else if (col < p.N0) {
             outp = p.Out0; ldo = p.ldo0; ocol = col;
         } else {
             outp = p.Out1; ldo = p.ldo1; ocol = col - p.N0;
@@ -255,7 +323,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 s2 += acc[i][j][r] * acc[i][j][r];
             }
         }
-        if (p.stats) {
+        if (p.stats && p.ksplit == 1) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
@@ -265,7 +333,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             }
         }
     }
-    if (p.stats) {
+    if (p.stats && p.ksplit == 1) {
         __syncthreads();
         if (tid < BN) {
             float s1 = 0.f, s2 = 0.f;
@@ -274,9 +342,60 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 s1 += red[(w * BN + tid) * 2 + 0];
                 s2 += red[(w * BN + tid) * 2 + 1];
             }
-            float* st = p.stats + ((size_t)(p.stats_row0 + tm) * p.Nout + n0 + tid) * 2;
+            float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
             st[0] = s1;
             st[1] = s2;
+        }
+    }
+}
+
+// Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
+// for 64-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.
+constexpr int SPLITK_ROWS = 64;
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M,
+                                                             int Nout, const float* __restrict__ bias,
+                                                             float* __restrict__ out0, int ldo0, int N0,
+                                                             float* __restrict__ out1, int ldo1,
+                                                             float* __restrict__ stats) {
+    __shared__ float sh[256 * 8];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * SPLITK_ROWS;
+    const size_t slab = (size_t)M * Nout;
+    for (int cb = 0; cb < Nout; cb += 256) {
+        const int c = cb + tx * 4;
+        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        if (c < Nout) {
+            float4 bv = make_float4(0, 0, 0, 0);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
+            for (int r = r0 + ty; r < min(r0 + SPLITK_ROWS, M); r += 4) {
+                float4 a = make_float4(0, 0, 0, 0);
+                for (int z = 0; z < ksplit; ++z) {
+                    const float4 v = *reinterpret_cast<const float4*>(part + z * slab + (size_t)r * Nout + c);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+                s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+                s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
+                a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+                if (c < N0) *reinterpret_cast<float4*>(out0 + (size_t)r * ldo0 + c) = a;
+                else *reinterpret_cast<float4*>(out1 + (size_t)r * ldo1 + (c - N0)) = a;
+            }
+        }
+        if (stats) {
+            float* q = sh + threadIdx.x * 8;
+            q[0] = s1.x; q[1] = s1.y; q[2] = s1.z; q[3] = s1.w; q[4] = s2.x; q[5] = s2.y; q[6] = s2.z; q[7] = s2.w;
+            __syncthreads();
+            if (ty == 0 && c < Nout) {
+                for (int k = 0; k < 4; ++k) {
+                    float a1 = 0.f, a2 = 0.f;
+                    for (int w = 0; w < 4; ++w) {
+                        a1 += sh[(w * 64 + tx) * 8 + k];
+                        a2 += sh[(w * 64 + tx) * 8 + 4 + k];
+                    }
+                    stats[((size_t)blockIdx.x * Nout + c + k) * 2] = a1;
+                    stats[((size_t)blockIdx.x * Nout + c + k) * 2 + 1] = a2;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -302,32 +421,78 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, SMALLC ? "rgb" : "c32");
         kid = prof_register(nm);
     }
-    const int grid = (int)(cdiv(p.M, BM) * (p.Nout / BN));
-    const double kreal = SMALLC ? (double)p.ntaps * p.cin_real : (double)p.ntaps * p.Ctot;
-    prof_begin(kid, 2.0 * (double)p.M * p.Nout * kreal, stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+    IgemmParams q = p;
+    int maxtiles = 0;
+    double flops = 0.0;
+    for (int c = 0; c < q.ncls; ++c) {
+        q.cls[c].mtiles = (int)cdiv(q.cls[c].M, BM);
+        maxtiles = std::max(maxtiles, q.cls[c].mtiles);
+        const double kreal = SMALLC ? (double)q.cls[c].ntaps * q.cin_real : (double)q.cls[c].ntaps * q.Ctot;
+        flops += 2.0 * (double)q.cls[c].M * q.Nout * kreal;
+    }
+    const int grid = maxtiles * (q.Nout / BN);
+    prof_begin(kid, flops, stream);
+    hipLaunchKernelGGL(kern, dim3(grid, q.ncls, q.ksplit), dim3(256), smem, stream, q);
     prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 
-static void pick_tile(int64_t M, int Nout, bool smallc, int& bm, int& bn) {
+// tile shape and split-K factor; `nkt` = K tiles of the (single-class) problem, 0 disables split-K
+static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& bn, int& ksplit) {
     bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
     const int64_t blocks128 = cdiv(M, 128) * (Nout / bn);
+    ksplit = 1;
+    if (!smallc && bn == 128 && nkt >= 16 && blocks128 < 256) {
+        // small pixel count, deep reduction (encoder stages 3-4, decoder level 1): keep the 128-row tile for
+        // arithmetic intensity and fill the chip by splitting K instead of shrinking the tile
+        int want = (int)cdiv(512, blocks128);
+        int cap = nkt / 8;
+        ksplit = std::max(1, std::min(std::min(want, cap), 8));
+    }
+    if (ksplit > 1) {
+        bm = 128;
+        return;
+    }
     bm = (smallc || blocks128 >= 384 || bn == 32) ? 128 : 64;
 }
 
-int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc) {
-    int bm, bn;
-    pick_tile(M, Nout, smallc, bm, bn);
-    return cdiv(M, bm);
+int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt) {
+    int bm, bn, ks;
+    pick_tile(M, Nout, smallc, nkt, bm, bn, ks);
+    return ks > 1 ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
 }
 
-int igemm_launch(const IgemmParams& p, bool smallc, hipStream_t stream) {
+size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt) {
+    int bm, bn, ks;
+    pick_tile(M, Nout, smallc, nkt, bm, bn, ks);
+    return ks > 1 ? (size_t)ks * M * Nout * sizeof(float) : 0;
+}
+
+int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stream) {
     XV2_CHECK_ARG(p.Nout % 32 == 0, "igemm: Nout=%d must be a multiple of 32", p.Nout);
-    XV2_CHECK_ARG(p.M > 0, "igemm: empty problem");
-    int bm, bn;
-    pick_tile(p.M, p.Nout, smallc, bm, bn);
+    XV2_CHECK_ARG(p.ncls >= 1 && p.cls[0].M > 0, "igemm: empty problem");
+    int bm, bn, ks;
+    int64_t maxM = 0;
+    for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, p.cls[c].M);
+    pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
+    p.ksplit = ks;
+    p.part = splitk_ws;
+    p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);
+    if (ks == 1) {
+        int mk = 0;
+        for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
+        p.kt_per_split = mk;
+    } else {
+        p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
+        int rc = launch_one<128, 128, 2, 2, false>(p, stream);
+        if (rc) return rc;
+        const int M = p.cls[0].M;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS)), dim3(256), 0, stream,
+                           splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats);
+        XV2_CHECK_LAUNCH();
+        return XV2_OK;
+    }
     if (smallc) {
         if (bn == 128) return launch_one<128, 128, 2, 2, true>(p, stream);
         if (bn == 64) return launch_one<128, 64, 2, 2, true>(p, stream);
@@ -344,7 +509,7 @@ int igemm_launch(const IgemmParams& p, bool smallc, hipStream_t stream) {
     return launch_one<128, 32, 4, 1, false>(p, stream);
 }
 
-// python-style floor division / modulo helpers for the parity decomposition
+// python-style floor division for the parity decomposition
 static inline int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
@@ -354,11 +519,18 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
                   "tensor too large for 32-bit pixel indices");
     p.bias = nullptr;
     p.stats = nullptr;
-    p.stats_row0 = 0;
+    p.part = nullptr;
+    p.ksplit = 1;
     p.cin_real = 3;
     p.A1 = nullptr;
     p.Out1 = nullptr;
+    p.ncls = 1;
     return XV2_OK;
+}
+
+static inline bool is_rgb(const xv2_conv_desc* d) { return d->C0 == 4 && d->C1 == 0; }
+static inline int fwd_nkt(const xv2_conv_desc* d) {
+    return is_rgb(d) ? (int)cdiv(d->KH * d->KW * 4, BK) : d->KH * d->KW * ((d->C0 + d->C1) / BK);
 }
 
 }  // namespace xv2
@@ -366,27 +538,37 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
 using namespace xv2;
 
 extern "C" int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d) {
-    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, d->C0 == 4 && d->C1 == 0);
+    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d));
+}
+extern "C" size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d) {
+    return igemm_splitk_bytes((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d));
+}
+extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {
+    if (d->stride != 1) return 0;
+    return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK));
 }
 
 extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
                                   int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
-                                  float* stats, void* stream) {
+                                  float* stats, float* workspace, void* stream) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
-    const bool smallc = (d->C0 == 4 && d->C1 == 0);
+    const bool smallc = is_rgb(d);
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
+    XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
+                  "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
     p.ldA0 = ldx0; p.ldA1 = ldx1;
     p.IH = d->IH; p.IW = d->IW; p.s_in = d->stride;
-    p.OHl = d->OH; p.OWl = d->OW; p.M = d->N * d->OH * d->OW;
-    p.osN = d->OH * d->OW; p.osH = d->OW; p.osW = 1; p.os0 = 0;
+    p.osN = d->OH * d->OW; p.osH = d->OW; p.osW = 1;
     p.Nout = d->Cout; p.N0 = d->Cout; p.ldo0 = ldy; p.ldo1 = 0;
-    p.T = d->KH * d->KW; p.ntaps = p.T;
+    p.T = d->KH * d->KW;
+    ClassInfo& c = p.cls[0];
+    c.tap0 = 0; c.ntaps = p.T; c.OHl = d->OH; c.OWl = d->OW; c.M = d->N * d->OH * d->OW; c.os0 = 0;
     for (int kh = 0; kh < d->KH; ++kh)
         for (int kw = 0; kw < d->KW; ++kw) {
             Tap& t = p.taps[kh * d->KW + kw];
@@ -394,25 +576,29 @@ extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int l
             t.dw = (short)(kw * d->dil - d->pad);
             t.slot = kh * d->KW + kw;
         }
-    if (smallc) {
-        p.cpt = 1;
-        p.nkt = (int)cdiv(p.ntaps * 4, BK);
-    } else {
-        p.cpt = p.Ctot / BK;
-        p.nkt = p.ntaps * p.cpt;
+    p.cpt = smallc ? 1 : p.Ctot / BK;
+    c.nkt = fwd_nkt(d);
+    {
+        const long long pixels = (long long)d->N * d->IH * d->IW;
+        const long long b0 = pixels * ldx0 * 4, b1 = x1 ? pixels * ldx1 * 4 : 0;
+        const long long bw = (long long)d->Cout * p.T * p.Ctot * 4;
+        XV2_CHECK_ARG(b0 < (1ll << 31) && b1 < (1ll << 31) && bw < (1ll << 31) && p.T <= 32 || smallc,
+                      "conv2d_forward: operands of 2 GiB or more (or more than 32 taps) are not supported");
+        p.bytesA0 = (unsigned)b0; p.bytesA1 = (unsigned)b1; p.bytesB = (unsigned)bw;
     }
-    return igemm_launch(p, smallc, (hipStream_t)stream);
+    return igemm_launch(p, smallc, workspace, (hipStream_t)stream);
 }
 
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]
 static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
-                      float* dx0, int lddx0, float* dx1, int lddx1, hipStream_t stream) {
+                      float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_data: Cout=%d must be a multiple of 32", d->Cout);
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
+    XV2_CHECK_ARG(s <= 2, "backward_data: stride %d unsupported (1 or 2)", s);
     p.A0 = dy; p.A1 = nullptr; p.B = w_ihwo;
     p.C0 = d->Cout; p.C1 = 0; p.Ctot = d->Cout; p.ldA0 = lddy; p.ldA1 = 0;
     p.IH = d->OH; p.IW = d->OW; p.s_in = 1;
@@ -420,27 +606,42 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     p.Out0 = dx0; p.ldo0 = lddx0; p.Out1 = dx1; p.ldo1 = lddx1;
     p.T = d->KH * d->KW;
     p.cpt = p.Ctot / BK;
+    p.osN = d->IH * d->IW; p.osH = s * d->IW; p.osW = s;
+    {
+        const long long b0 = (long long)d->N * d->OH * d->OW * lddy * 4;
+        const long long bw = (long long)(d->C0 + d->C1) * p.T * d->Cout * 4;
+        XV2_CHECK_ARG(b0 < (1ll << 31) && bw < (1ll << 31) && p.T <= 32,
+                      "backward_data: operands of 2 GiB or more (or more than 32 taps) are not supported");
+        p.bytesA0 = (unsigned)b0; p.bytesA1 = 0; p.bytesB = (unsigned)bw;
+    }
     bool need_zero = false;
-    struct Cls { int pi, pj, ntaps; Tap taps[52]; };
-    static thread_local Cls cls[16];
-    XV2_CHECK_ARG(s * s <= 16, "stride %d unsupported", s);
+    int ncls = 0, ntap = 0;
     for (int pi = 0; pi < s; ++pi)
         for (int pj = 0; pj < s; ++pj) {
-            Cls& c = cls[pi * s + pj];
-            c.pi = pi; c.pj = pj; c.ntaps = 0;
+            const int OHl = (d->IH - pi + s - 1) / s, OWl = (d->IW - pj + s - 1) / s;
+            if (OHl <= 0 || OWl <= 0) continue;
+            ClassInfo c;
+            c.tap0 = ntap; c.ntaps = 0; c.OHl = OHl; c.OWl = OWl; c.M = d->N * OHl * OWl;
+            c.os0 = pi * d->IW + pj;
             for (int kh = 0; kh < d->KH; ++kh) {
                 const int nh = pi + d->pad - kh * d->dil;
                 if (((nh % s) + s) % s != 0) continue;
                 for (int kw = 0; kw < d->KW; ++kw) {
                     const int nw = pj + d->pad - kw * d->dil;
                     if (((nw % s) + s) % s != 0) continue;
-                    Tap& t = c.taps[c.ntaps++];
+                    Tap& t = p.taps[ntap++];
                     t.dh = (short)fdiv(nh, s);
                     t.dw = (short)fdiv(nw, s);
                     t.slot = kh * d->KW + kw;
+                    ++c.ntaps;
                 }
             }
-            if (c.ntaps == 0 && pi < d->IH && pj < d->IW) need_zero = true;
+            if (c.ntaps == 0) {
+                need_zero = true;
+                continue;
+            }
+            c.nkt = c.ntaps * p.cpt;
+            p.cls[ncls++] = c;
         }
     if (need_zero) {
         XV2_CHECK_ARG(lddx0 == d->C0 && (d->C1 == 0 || lddx1 == d->C1),
@@ -448,36 +649,24 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
         XV2_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)d->N * d->IH * d->IW * d->C0 * 4, stream));
         if (d->C1) XV2_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)d->N * d->IH * d->IW * d->C1 * 4, stream));
     }
-    for (int ci = 0; ci < s * s; ++ci) {
-        const Cls& c = cls[ci];
-        if (c.ntaps == 0) continue;
-        p.OHl = (d->IH - c.pi + s - 1) / s;
-        p.OWl = (d->IW - c.pj + s - 1) / s;
-        if (p.OHl <= 0 || p.OWl <= 0) continue;
-        p.M = d->N * p.OHl * p.OWl;
-        p.osN = d->IH * d->IW; p.osH = s * d->IW; p.osW = s; p.os0 = c.pi * d->IW + c.pj;
-        p.ntaps = c.ntaps;
-        for (int i = 0; i < c.ntaps; ++i) p.taps[i] = c.taps[i];
-        p.nkt = p.ntaps * p.cpt;
-        rc = igemm_launch(p, false, stream);
-        if (rc) return rc;
-    }
-    return XV2_OK;
+    if (ncls == 0) return XV2_OK;
+    p.ncls = ncls;
+    return igemm_launch(p, false, (s == 1) ? workspace : nullptr, stream);
 }
 
 extern "C" int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
                                         const float* w_ihwo, float* dx0, int lddx0, float* dx1,
-                                        int lddx1, void* stream) {
-    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, (hipStream_t)stream);
+                                        int lddx1, float* workspace, void* stream) {
+    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream);
 }
 
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,
                                             const float* w_ihwo, float* y, int ldy, void* stream) {
     XV2_CHECK_ARG(d->C1 == 0, "conv_transpose2d: single output tensor expected");
-    return dgrad_impl(d, x, ldx, w_ihwo, y, ldy, nullptr, 0, (hipStream_t)stream);
+    return dgrad_impl(d, x, ldx, w_ihwo, y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
                                                   const float* w_ohwi, float* dx, int lddx, void* stream) {
-    return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, stream);
+    return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
 }

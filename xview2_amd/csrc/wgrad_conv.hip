@@ -30,6 +30,8 @@ struct WgradParams {
     int T;
     int ktiles, kt_per_split;
     int tiles_n;  // column tiles per tap (Ctot / BN), or column tiles overall for SMALLC
+    int fast;     // OW % 32 == 0 and operands < 2 GiB: scalar pixel decode + buffer loads
+    unsigned bytesX0, bytesX1, bytesDY;
     WTap taps[52];
 };
 
@@ -92,7 +94,47 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
 
     float4 ra[APASS], rb[BPASS];
+    // fast path: a 32-pixel reduction tile never crosses an output row (OW % 32 == 0), so its (n, oh, ow0) is
+    // wave-uniform and each lane only adds a constant: one VALU add + one select per 16-byte buffer load.
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(cn0 < p.C0 || SMALLC ? p.X0 : p.X1), 0, (cn0 < p.C0 || SMALLC) ? p.bytesX0 : p.bytesX1, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.bytesDY, 0x00020000);
+    int a_const[APASS], b_const[BPASS], b_k[BPASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) a_const[j] = (a_r + j * ARPP) * p.ldDY + co0 + a_c4 * 4;
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        b_k[j] = (b_r + j * BRPP) * p.stride + dw;
+        b_const[j] = b_k[j] * ldx + xch + b_c4 * 4;
+    }
+    auto gload_fast = [&](int kt) {
+        const int mb = kt * 32;             // uniform
+        const int n = mb / ohw;
+        const int rem = mb - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow0 = rem - oh * p.OW;
+        const int ih = oh * p.stride + dh;
+        const bool rowok = (unsigned)ih < (unsigned)p.IH;
+        const int ubase = ((n * p.IH + ih) * p.IW + ow0 * p.stride) * ldx;
+        const int iw0 = ow0 * p.stride;
+        const int dbase = mb * p.ldDY;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (dbase + a_const[j]) << 2, 0, 0));
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const bool ok = rowok && (unsigned)(iw0 + b_k[j]) < (unsigned)p.IW;
+            const int off = ok ? ((ubase + b_const[j]) << 2) : (int)0x80000000;
+            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+        }
+    };
     auto gload = [&](int kt) {
+        if constexpr (!SMALLC) {
+            if (p.fast) {
+                gload_fast(kt);
+                return;
+            }
+        }
         const int mb = kt * 32;
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
@@ -144,11 +186,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     if (kt0 < kt1) {
         gload(kt0);
         lstore(0);
+        if (kt0 + 1 < kt1) gload(kt0 + 1);
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        if (kt + 1 < kt1) gload(kt + 1);
+        if (kt + 1 < kt1) {
+            lstore(buf ^ 1);
+            if (kt + 2 < kt1) gload(kt + 2);
+        }
         const float* a = As + buf * 32 * BM + wm * (MR * 32) + l31;
         const float* bb = Bs + buf * 32 * BN + wn * (NR * 32) + l31;
 #pragma unroll
@@ -165,7 +211,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
                 for (int j = 0; j < NR; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < kt1) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -279,6 +324,15 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     p.T = d->KH * d->KW;
     p.ktiles = pl.ktiles; p.kt_per_split = pl.kt_per;
     p.tiles_n = pl.smallc ? (int)cdiv(p.T * 4, pl.bn) : p.Ctot / pl.bn;
+    {
+        const long long bx0 = (long long)d->N * d->IH * d->IW * ldx0 * 4;
+        const long long bx1 = x1 ? (long long)d->N * d->IH * d->IW * ldx1 * 4 : 0;
+        const long long bdy = (long long)p.M * lddy * 4;
+        p.fast = (d->OW % 32 == 0 && bx0 < (1ll << 31) && bx1 < (1ll << 31) && bdy < (1ll << 31)) ? 1 : 0;
+        p.bytesX0 = (unsigned)std::min<long long>(bx0, 0x7fffffffll);
+        p.bytesX1 = (unsigned)std::min<long long>(bx1, 0x7fffffffll);
+        p.bytesDY = (unsigned)std::min<long long>(bdy, 0x7fffffffll);
+    }
     for (int kh = 0; kh < d->KH; ++kh)
         for (int kw = 0; kw < d->KW; ++kw) {
             p.taps[kh * d->KW + kw].dh = (short)(kh * d->dil - d->pad);

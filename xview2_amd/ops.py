@@ -76,8 +76,10 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False):
         if want_stats:
             tiles = query("xv2_conv2d_forward_stats_tiles", d)
             part = _f32((tiles, Coutg, 2), x0)
+        wsb = query("xv2_conv2d_forward_workspace", d)
         call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
-             None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part)
+             None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part,
+             _ws(wsb, x0) if wsb else None)
         if want_stats:
             scratch = torch.empty((64 * Coutg * 2,), dtype=torch.float64, device=x0.device)
             call("xv2_bn_reduce_stats", part, tiles, Coutg, Ptr(sums, gi * Coutg * 2), scratch)
@@ -97,7 +99,9 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t):
         wg = w[gi * Coutg:(gi + 1) * Coutg]
         _, ihwo = _pack(wg, C0g + C1t, False, True)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
-        call("xv2_conv2d_backward_data", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t)
+        wsb = query("xv2_conv2d_backward_data_workspace", d)
+        call("xv2_conv2d_backward_data", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
+             _ws(wsb, dy) if wsb else None)
     return dx0, dx1
 
 
