@@ -123,10 +123,13 @@ int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
                        const float* residual, int ldr, int act, float* z, int ldz,
                        int64_t npix, int C, void* stream);
-/* backward: pass 1 -> sums2[C][2] = (sum g, sum g*xhat), g = dz*act'(z) */
+/* backward: pass 1 -> sums2[C][2] = (sum g, sum g*xhat), g = dz*act'; the activation mask comes from the saved
+ * output z, or - when z is NULL (no residual) - is recomputed from y*scale+shift, which saves a third of the
+ * HBM traffic.  dgamma/dbeta (optional) receive the fp32 copies of the LOCAL sums. */
 int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz,
                                const float* y, int ldy, const float* mean, const float* invstd,
-                               int act, int64_t npix, int C, double* sums2, float* workspace,
+                               const float* scale, const float* shift, int act, int64_t npix, int C,
+                               double* sums2, float* dgamma, float* dbeta, float* workspace,
                                void* stream);
 size_t xv2_bn_backward_workspace(int64_t npix, int C);
 /* pass 2 -> dy (and dresidual = g if requested).  dgamma = sums2[:,1], dbeta = sums2[:,0] of
@@ -134,7 +137,8 @@ size_t xv2_bn_backward_workspace(int64_t npix, int C);
  * `count` is the (global) number of elements per channel; eval-mode BN passes train=0. */
 int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y,
                               int ldy, const float* mean, const float* invstd,
-                              const float* gamma, const double* sums2, double count, int act,
+                              const float* gamma, const float* scale, const float* shift,
+                              const double* sums2, double count, int act,
                               int train, float* dy, int lddy, float* dres, int lddres,
                               int64_t npix, int C, void* stream);
 

@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
     const size_t slab = (size_t)M * Nout;
-    for (int cb = 0; cb < Nout; cb += 256) {
+    for (int cb = blockIdx.y * 256; cb < Nout; cb += gridDim.y * 256) {
         const int c = cb + tx * 4;
         float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
         if (c < Nout) {
@@ -488,7 +488,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         int rc = launch_one<128, 128, 2, 2, false>(p, stream);
         if (rc) return rc;
         const int M = p.cls[0].M;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256)),
+                           dim3(256), 0, stream,
                            splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats);
         XV2_CHECK_LAUNCH();
         return XV2_OK;

@@ -36,6 +36,8 @@ struct ColOp {
     const float* y;   // MODE1
     const float* mean;
     const float* invstd;
+    const float* scale;   // MODE1 with z == nullptr: the activation mask is recomputed from y*scale+shift
+    const float* shift;
     int lda, ldz, ldy, act;
     __device__ __forceinline__ void apply(int64_t row, int c, float& f0, float& f1) const {
         if constexpr (MODE == 0) {
@@ -45,8 +47,11 @@ struct ColOp {
             f0 += v;
             f1 += v * v;
         } else {
-            const float g = a[row * lda + c] * act_grad_from_output(z[row * ldz + c], act);
-            const float xh = (y[row * ldy + c] - mean[c]) * invstd[c];
+            const float yv = y[row * ldy + c];
+            const float ag = z ? act_grad_from_output(z[row * ldz + c], act)
+                               : act_grad_from_pre(__fmaf_rn(yv, scale[c], shift[c]), act);
+            const float g = a[row * lda + c] * ag;
+            const float xh = (yv - mean[c]) * invstd[c];
             f0 += g;
             f1 += g * xh;
         }
@@ -60,10 +65,20 @@ struct ColOp {
             f1.x += v.x * v.x; f1.y += v.y * v.y; f1.z += v.z * v.z; f1.w += v.w * v.w;
         } else {
             const float4 d = *reinterpret_cast<const float4*>(a + row * lda + c);
-            const float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
             const float4 yy = *reinterpret_cast<const float4*>(y + row * ldy + c);
-            const float gx = d.x * act_grad_from_output(zz.x, act), gy = d.y * act_grad_from_output(zz.y, act);
-            const float gz = d.z * act_grad_from_output(zz.z, act), gw = d.w * act_grad_from_output(zz.w, act);
+            float gx, gy, gz, gw;
+            if (z) {
+                const float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
+                gx = d.x * act_grad_from_output(zz.x, act); gy = d.y * act_grad_from_output(zz.y, act);
+                gz = d.z * act_grad_from_output(zz.z, act); gw = d.w * act_grad_from_output(zz.w, act);
+            } else {
+                const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+                const float4 sf = *reinterpret_cast<const float4*>(shift + c);
+                gx = d.x * act_grad_from_pre(__fmaf_rn(yy.x, sc.x, sf.x), act);
+                gy = d.y * act_grad_from_pre(__fmaf_rn(yy.y, sc.y, sf.y), act);
+                gz = d.z * act_grad_from_pre(__fmaf_rn(yy.z, sc.z, sf.z), act);
+                gw = d.w * act_grad_from_pre(__fmaf_rn(yy.w, sc.w, sf.w), act);
+            }
             f0.x += gx; f0.y += gy; f0.z += gz; f0.w += gw;
             f1.x += gx * ((yy.x - mu.x) * is.x); f1.y += gy * ((yy.y - mu.y) * is.y);
             f1.z += gz * ((yy.z - mu.z) * is.z); f1.w += gw * ((yy.w - mu.w) * is.w);
@@ -179,12 +194,23 @@ __global__ void __launch_bounds__(256) reduce_stats_stage1(const T* __restrict__
         scratch[((size_t)blockIdx.y * C + c) * 2 + 1] = b1;
     }
 }
-__global__ void reduce_stats_stage2(const double* __restrict__ scratch, int C, int S, double* __restrict__ sums) {
+__global__ void reduce_stats_stage2(const double* __restrict__ scratch, int C, int S, double* __restrict__ sums,
+                                    float* __restrict__ f0, float* __restrict__ f1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over C*2
     if (i >= C * 2) return;
-    double a = 0.0;
-    for (int s = 0; s < S; ++s) a += scratch[(size_t)s * C * 2 + i];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        a0 += scratch[(size_t)s * C * 2 + i];
+        a1 += scratch[(size_t)(s + 1) * C * 2 + i];
+        a2 += scratch[(size_t)(s + 2) * C * 2 + i];
+        a3 += scratch[(size_t)(s + 3) * C * 2 + i];
+    }
+    for (; s < S; ++s) a0 += scratch[(size_t)s * C * 2 + i];
+    const double a = (a0 + a1) + (a2 + a3);
     sums[i] = a;
+    if (f0 && !(i & 1)) f0[i >> 1] = (float)a;   // BN backward: dbeta = sum g
+    if (f1 && (i & 1)) f1[i >> 1] = (float)a;    //              dgamma = sum g*xhat
 }
 
 // sums of (x - s) and (x - s)^2  ->  sums of x and x^2, in fp64 (no cancellation at this precision)
@@ -197,13 +223,15 @@ __global__ void unshift_stats_kernel(double* __restrict__ sums, const float* __r
 }
 
 template <typename T>
-static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st) {
+static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st,
+                        float* f0 = nullptr, float* f1 = nullptr) {
     int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));
     if (S < 1) S = 1;
     hipLaunchKernelGGL(reduce_stats_stage1<T>, dim3((unsigned)cdiv(C, 32), S), dim3(256), 0, st, partial, tiles, C, S,
                        scratch);
     XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_stats_stage2, dim3((unsigned)cdiv(C * 2, 256)), dim3(256), 0, st, scratch, C, S, sums);
+    hipLaunchKernelGGL(reduce_stats_stage2, dim3((unsigned)cdiv(C * 2, 256)), dim3(256), 0, st, scratch, C, S, sums, f0,
+                       f1);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -259,7 +287,8 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
             const float4 sc = *reinterpret_cast<const float4*>(scale + c);
             const float4 sh = *reinterpret_cast<const float4*>(shift + c);
             float4 o;
-            o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+            o.x = __fmaf_rn(v.x, sc.x, sh.x); o.y = __fmaf_rn(v.y, sc.y, sh.y);
+            o.z = __fmaf_rn(v.z, sc.z, sh.z); o.w = __fmaf_rn(v.w, sc.w, sh.w);
             if (res) {
                 const float4 r = *reinterpret_cast<const float4*>(res + row * ldr + c);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -272,7 +301,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / C;
             const int c = (int)(i - row * C);
-            float o = y[row * ldy + c] * scale[c] + shift[c];
+            float o = __fmaf_rn(y[row * ldy + c], scale[c], shift[c]);
             if (res) o += res[row * ldr + c];
             z[row * ldz + c] = apply_act(o, act);
         }
@@ -286,6 +315,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
                                                           const double* __restrict__ sums2, double count, int act,
                                                           int train, float* __restrict__ dy, int lddy,
                                                           float* __restrict__ dres, int lddres, int64_t npix, int C) {
@@ -297,18 +328,20 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
         const int64_t row = i / CV;
         const int c = (int)(i - row * CV) * V;
         float d[V], zz[V], yy[V], o[V], g[V];
+        const bool need_y = train || !z;
         if constexpr (VEC) {
             *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + row * lddz + c);
-            *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
-            if (train) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            if (z) *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
+            if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + row * ldy + c);
         } else {
             d[0] = dz[row * lddz + c];
-            zz[0] = z[row * ldz + c];
-            if (train) yy[0] = y[row * ldy + c];
+            if (z) zz[0] = z[row * ldz + c];
+            if (need_y) yy[0] = y[row * ldy + c];
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            g[k] = d[k] * act_grad_from_output(zz[k], act);
+            g[k] = d[k] * (z ? act_grad_from_output(zz[k], act)
+                             : act_grad_from_pre(__fmaf_rn(yy[k], scale[c + k], shift[c + k]), act));
             const float gi = (gamma ? gamma[c + k] : 1.f) * invstd[c + k];
             if (train) {
                 const float xh = (yy[k] - mean[c + k]) * invstd[c + k];
@@ -326,6 +359,59 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
             dy[row * lddy + c] = o[0];
             if (dres) dres[row * lddres + c] = g[0];
         }
+    }
+}
+
+// Streaming form for C % 4 == 0 with C/4 dividing 256 (every conv layer of the U-Net): a thread owns ONE group of
+// 4 channels for its whole life, so the seven per-channel coefficient vectors are loaded once into registers and
+// the loop body is 2-3 16-byte loads + one 16-byte store per element vector (HBM-bound).
+__global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __restrict__ dz, int lddz,
+                                                               const float* __restrict__ z, int ldz,
+                                                               const float* __restrict__ y, int ldy,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const double* __restrict__ sums2, double count, int act,
+                                                               int train, float* __restrict__ dy, int lddy,
+                                                               float* __restrict__ dres, int lddres, int64_t npix, int C,
+                                                               int rows_per_block) {
+    const int C4 = C >> 2, rpp = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    const int c = tx * 4;
+    const float inv_count = (float)(1.0 / count);
+    float gi[4], mu[4], is[4], sg[4], sgx[4], sc[4], sf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        is[k] = invstd[c + k];
+        mu[k] = mean[c + k];
+        gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
+        sg[k] = train ? (float)sums2[(c + k) * 2] * inv_count : 0.f;
+        sgx[k] = train ? (float)sums2[(c + k) * 2 + 1] * inv_count : 0.f;
+        sc[k] = z ? 0.f : scale[c + k];
+        sf[k] = z ? 0.f : shift[c + k];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + (int64_t)rows_per_block, npix);
+    const bool need_y = train || !z;
+    for (int64_t r = r0 + ty; r < r1; r += rpp) {
+        float d[4], zz[4], yy[4], o[4], g[4];
+        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + r * lddz + c);
+        if (z) *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + r * ldz + c);
+        if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + r * ldy + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[k] = d[k] * (z ? act_grad_from_output(zz[k], act) : act_grad_from_pre(__fmaf_rn(yy[k], sc[k], sf[k]), act));
+            if (train) {
+                const float xh = (yy[k] - mu[k]) * is[k];
+                o[k] = gi[k] * (g[k] - sg[k] - xh * sgx[k]);
+            } else {
+                o[k] = gi[k] * g[k];
+            }
+        }
+        *reinterpret_cast<float4*>(dy + r * lddy + c) = *reinterpret_cast<float4*>(o);
+        if (dres) *reinterpret_cast<float4*>(dres + r * lddres + c) = *reinterpret_cast<float4*>(g);
     }
 }
 
@@ -355,7 +441,8 @@ extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
 extern "C" size_t xv2_bn_backward_workspace(int64_t npix, int C) { return xv2_bn_tensor_stats_workspace(npix, C); }
 
 template <int MODE>
-static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st) {
+static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st,
+                       float* f0 = nullptr, float* f1 = nullptr) {
     const ChunkGeom g = chunk_geom(npix, C);
     size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
@@ -364,7 +451,7 @@ static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums,
     hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks), dim3(256), 0, st, op, npix, C, g.rpb,
                        dpart);
     XV2_CHECK_LAUNCH();
-    return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st);
+    return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
 
 extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums, float* workspace,
@@ -372,6 +459,7 @@ extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C,
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_tensor_stats: empty");
     ColOp<0> op;
     op.a = x; op.lda = ldx; op.z = nullptr; op.y = nullptr; op.mean = nullptr; op.invstd = nullptr;
+    op.scale = op.shift = nullptr;
     op.ldz = op.ldy = 0; op.act = 0;
     int rc = column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
     if (rc) return rc;
@@ -425,29 +513,44 @@ extern "C" int xv2_bn_act_forward(const float* y, int ldy, const float* scale, c
 }
 
 extern "C" int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                                          const float* mean, const float* invstd, int act, int64_t npix, int C,
-                                          double* sums2, float* workspace, void* stream) {
+                                          const float* mean, const float* invstd, const float* scale,
+                                          const float* shift, int act, int64_t npix, int C, double* sums2,
+                                          float* dgamma, float* dbeta, float* workspace, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_reduce: empty");
-    XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
+    XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && (!z || ldz % 4 == 0) && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
+    XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
     ColOp<1> op;
     op.a = dz; op.lda = lddz; op.z = z; op.ldz = ldz; op.y = y; op.ldy = ldy; op.mean = mean; op.invstd = invstd;
+    op.scale = scale; op.shift = shift;
     op.act = act;
-    return column_sums<1>(op, npix, C, sums2, workspace, (hipStream_t)stream);
+    return column_sums<1>(op, npix, C, sums2, workspace, (hipStream_t)stream, dbeta, dgamma);
 }
 
 extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                                          const float* mean, const float* invstd, const float* gamma,
-                                         const double* sums2, double count, int act, int train, float* dy, int lddy,
-                                         float* dres, int lddres, int64_t npix, int C, void* stream) {
+                                         const float* scale, const float* shift, const double* sums2, double count,
+                                         int act, int train, float* dy, int lddy, float* dres, int lddres,
+                                         int64_t npix, int C, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
-    const bool vec = vec_ok(C, {lddz, ldz, ldy, lddy, dres ? lddres : 0}, {dz, z, y, dy, dres});
+    XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
+    const bool vec = vec_ok(C, {lddz, z ? ldz : 0, ldy, lddy, dres ? lddres : 0}, {dz, z, y, dy, dres});
+    if (vec && C / 4 <= 256 && 256 % (C / 4) == 0) {
+        const int rpp = 256 / (C / 4);
+        int64_t rpb = cdiv(npix, 4096);
+        rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
+        hipLaunchKernelGGL(bn_act_bwd_rows_kernel, dim3((unsigned)cdiv(npix, rpb)), dim3(256), 0, (hipStream_t)stream,
+                           dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy,
+                           lddy, dres, lddres, npix, C, (int)rpb);
+        XV2_CHECK_LAUNCH();
+        return XV2_OK;
+    }
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
-                           y, ldy, mean, invstd, gamma, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
-                           y, ldy, mean, invstd, gamma, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

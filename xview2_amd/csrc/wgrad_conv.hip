@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 }
 
 // out_oihw[co][ci][t] = sum_z part[z][co][t][ci]   (ci < cin_real)
+// T == 1: input and output orders coincide -> plain streaming sum.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int Cout, int T, int Ctot,
                                     int cin_real, float* __restrict__ out) {
     const size_t total = (size_t)Cout * T * Ctot;
@@ -247,10 +248,47 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, i
         const size_t q = i / Ctot;
         const int t = (int)(q % T);
         const int co = (int)(q / T);
-        float s = 0.f;
-        for (int z = 0; z < nslab; ++z) s += part[(size_t)z * total + i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains: the slab loads overlap
+        int z = 0;
+        for (; z + 4 <= nslab; z += 4) {
+            s0 += part[(size_t)z * total + i];
+            s1 += part[(size_t)(z + 1) * total + i];
+            s2 += part[(size_t)(z + 2) * total + i];
+            s3 += part[(size_t)(z + 3) * total + i];
+        }
+        for (; z < nslab; ++z) s0 += part[(size_t)z * total + i];
+        const float s = (s0 + s1) + (s2 + s3);
         if (ci < cin_real) out[((size_t)co * cin_real + ci) * T + t] = s;
     }
+}
+// T > 1: one block per (co, 64-channel chunk): coalesced 256-byte slab reads, LDS transpose to [ci][t], then one
+// contiguous 64*T-float store into the OIHW row.
+__global__ void __launch_bounds__(256) wgrad_reduce_t_kernel(const float* __restrict__ part, int nslab, int Cout, int T,
+                                                              int Ctot, int cin_real, float* __restrict__ out) {
+    __shared__ float sh[64 * 52];
+    const int chunks = Ctot / 64;
+    const int co = blockIdx.x / chunks, ci0 = (blockIdx.x % chunks) * 64;
+    const size_t total = (size_t)Cout * T * Ctot;
+    const size_t base = ((size_t)co * T) * Ctot + ci0;
+    const int n = T * 64;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int t = e >> 6, c = e & 63;
+        const float* p = part + base + (size_t)t * Ctot + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 4 <= nslab; z += 4) {
+            s0 += p[(size_t)z * total];
+            s1 += p[(size_t)(z + 1) * total];
+            s2 += p[(size_t)(z + 2) * total];
+            s3 += p[(size_t)(z + 3) * total];
+        }
+        for (; z < nslab; ++z) s0 += p[(size_t)z * total];
+        sh[c * T + t] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    const int valid = min(64, cin_real - ci0);
+    float* o = out + ((size_t)co * cin_real + ci0) * T;
+    for (int e = threadIdx.x; e < valid * T; e += 256) o[e] = sh[e];
 }
 
 struct WgradPlan {
@@ -281,7 +319,7 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     pl.wk = 4 / ((bm / 32 > 2 ? 2 : bm / 32) * (bn / 32 > 2 ? 2 : bn / 32));
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     pl.ktiles = (int)cdiv(M, 32);
-    int want = (int)cdiv(1536, pl.tiles);
+    int want = (int)cdiv(640, pl.tiles);
     int maxsplit = pl.ktiles / 4 > 0 ? pl.ktiles / 4 : 1;
     int splitk = want < 1 ? 1 : want;
     if (splitk > maxsplit) splitk = maxsplit;
@@ -349,9 +387,14 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     else rc = launch_wgrad<32, 32, 1, 1, 4, false>(p, pl, stream);
     if (rc) return rc;
     const size_t total = (size_t)d->Cout * p.T * p.Ctot;
-    const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, pl.splitk * pl.wk,
-                       d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
+    if (p.T > 1 && p.Ctot % 64 == 0) {
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(d->Cout * (p.Ctot / 64)), dim3(256), 0, stream, workspace,
+                           pl.splitk * pl.wk, d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
+    } else {
+        const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, pl.splitk * pl.wk,
+                           d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
+    }
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

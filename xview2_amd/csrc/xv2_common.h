@@ -38,7 +38,7 @@ __host__ __device__ static inline int64_t cdiv(int64_t a, int64_t b) { return (a
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == XV2_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == XV2_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;
-    if (act == XV2_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    if (act == XV2_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
     return v;
 }
 
@@ -47,6 +47,17 @@ __device__ __forceinline__ float act_grad_from_output(float z, int act) {
     if (act == XV2_ACT_RELU) return z > 0.f ? 1.f : 0.f;
     if (act == XV2_ACT_LEAKY) return z > 0.f ? 1.f : 0.01f;
     if (act == XV2_ACT_SIGMOID) return z * (1.f - z);
+    return 1.f;
+}
+
+// derivative of the activation expressed through its INPUT u (pre-activation)
+__device__ __forceinline__ float act_grad_from_pre(float u, int act) {
+    if (act == XV2_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    if (act == XV2_ACT_LEAKY) return u > 0.f ? 1.f : 0.01f;
+    if (act == XV2_ACT_SIGMOID) {
+        const float z = 1.f / (1.f + expf(-u));
+        return z * (1.f - z);
+    }
     return 1.f;
 }
 

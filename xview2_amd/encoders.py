@@ -92,8 +92,7 @@ class SplAtConv2d(nn.Module):
 
     def forward(self, x):
         x = xnn.conv_bn_act(self.conv, self.bn0, x, act=ops.ACT_RELU)
-        if self.bn1.training:
-            self.bn1.num_batches_tracked.add_(1)
+        xnn.bump_bn_counter(self.bn1)
         return ops.SplitAttentionFn.apply(x, self.fc1.weight, self.fc1.bias, self.bn1.weight, self.bn1.bias,
                                           self.fc2.weight, self.fc2.bias, ops.BnState(self.bn1, xnn.SYNC_BN),
                                           self.bn1.training)

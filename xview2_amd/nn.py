@@ -25,10 +25,27 @@ def _cfg(conv):
     return g
 
 
+def _flush_bn_counter(bn, *_):
+    n = getattr(bn, "_xv2_pending", 0)
+    if n and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(n)
+        bn._xv2_pending = 0
+
+
+def bump_bn_counter(bn):
+    """num_batches_tracked += 1 without a device launch per layer per step: counted on the host and written
+    back whenever the module's state_dict is taken (checkpoint surface stays exact)."""
+    if not (bn.training and bn.num_batches_tracked is not None):
+        return
+    if not hasattr(bn, "_xv2_pending"):
+        bn._xv2_pending = 0
+        bn.register_state_dict_pre_hook(_flush_bn_counter)
+    bn._xv2_pending += 1
+
+
 def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None):
     """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node."""
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_bn_counter(bn)
     return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
                                  ops.BnState(bn, SYNC_BN), act, bn.training)
 
@@ -38,8 +55,7 @@ def conv(conv_m, x0, x1=None):
 
 
 def bn_act(bn, y, act=ops.ACT_NONE, residual=None):
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_bn_counter(bn)
     return ops.BnActFn.apply(y, bn.weight, bn.bias, residual, ops.BnState(bn, SYNC_BN), act, bn.training)
 
 

@@ -54,8 +54,9 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
     return ohwi, ihwo
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False):
-    """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None"""
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None):
+    """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.  If `ihwo_out` is a list, the backward-data weight
+    packs are produced by the same repack launch and appended to it (one per group)."""
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     Cout_t = weight.shape[0]
@@ -70,7 +71,9 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False):
     cin_w = w.shape[1]
     for gi in range(G):
         wg = w[gi * Coutg:(gi + 1) * Coutg]
-        ohwi, _ = _pack(wg, C0g + C1t, True, False)
+        ohwi, ihwo = _pack(wg, C0g + C1t, True, ihwo_out is not None)
+        if ihwo_out is not None:
+            ihwo_out.append(ihwo)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         part = None
         if want_stats:
@@ -87,7 +90,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False):
     return y, sums
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
     N, IH, IW = in_shape
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
@@ -96,8 +99,10 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t):
     dx0 = _f32((N, IH, IW, C0t), dy)
     dx1 = _f32((N, IH, IW, C1t), dy) if C1t else None
     for gi in range(G):
-        wg = w[gi * Coutg:(gi + 1) * Coutg]
-        _, ihwo = _pack(wg, C0g + C1t, False, True)
+        if ihwo_packs:
+            ihwo = ihwo_packs[gi]
+        else:
+            _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
         call("xv2_conv2d_backward_data", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
@@ -166,24 +171,25 @@ def _bn_forward(y, residual, act, bn, sums, training):
         count = float(npix)
     z = torch.empty_like(y)
     call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
-    return z, (mean, invstd, count)
+    return z, (mean, invstd, count, scale, shift)
 
 
 def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
-    mean, invstd, count = stats
+    """z may be None (layers without a residual input): the activation mask is then recomputed from y"""
+    mean, invstd, count, scale, shift = stats
     C = y.shape[-1]
     npix = y.numel() // C
     dz = dz.contiguous()
     sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+    dgamma, dbeta = _f32((C,), y), _f32((C,), y)
     ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
-    call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, act, npix, C, sums2, ws)
-    dgamma = sums2[:, 1].to(torch.float32)
-    dbeta = sums2[:, 0].to(torch.float32)
+    call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
+         dbeta, ws)
     if training and _sync_group(bn):
         dist.all_reduce(sums2)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, sums2, float(count), act,
+    call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, scale, shift, sums2, float(count), act,
          1 if training else 0, dy, C, dres, C, npix, C)
     return dy, dres, dgamma, dbeta
 
@@ -210,24 +216,29 @@ class ConvBnActFn(torch.autograd.Function):
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         residual = residual.contiguous() if residual is not None else None
-        y, sums = _conv_forward(x0, x1, weight, g, None, want_stats=training)
+        need_dx = x0.requires_grad or (x1 is not None and x1.requires_grad)
+        ctx.ihwo = [] if need_dx else None
+        y, sums = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo)
         z, stats = _bn_forward(y, residual, act, bn, sums, training)
-        ctx.save_for_backward(x0, x1, weight, gamma, y, z, stats[0], stats[1])
+        ctx.has_res = residual is not None
+        # the activation mask of the backward pass is recomputed from y unless a residual entered before it
+        ctx.save_for_backward(x0, x1, weight, gamma, y, z if ctx.has_res else None, stats[0], stats[1], stats[3],
+                              stats[4])
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
-        ctx.has_res = residual is not None
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x0, x1, weight, gamma, y, z, mean, invstd = ctx.saved_tensors
+        x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
         g = ctx.g
-        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count), gamma, ctx.act, ctx.bn,
-                                               ctx.training, ctx.has_res and ctx.needs_input_grad[5])
+        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
+                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5])
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0)
+                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo)
+        ctx.ihwo = None
         dw = _conv_backward_weight(x0, x1, dy, weight, g) if ctx.needs_input_grad[2] else None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
                 dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None)
@@ -342,16 +353,16 @@ class BnActFn(torch.autograd.Function):
         _need_cuda(y)
         y = y.contiguous()
         z, stats = _bn_forward(y, residual, act, bn, None, training)
-        ctx.save_for_backward(y, z, gamma, stats[0], stats[1])
-        ctx.count, ctx.bn, ctx.act, ctx.training = stats[2], bn, act, training
         ctx.has_res = residual is not None
+        ctx.save_for_backward(y, z if ctx.has_res else None, gamma, stats[0], stats[1], stats[3], stats[4])
+        ctx.count, ctx.bn, ctx.act, ctx.training = stats[2], bn, act, training
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        y, z, gamma, mean, invstd = ctx.saved_tensors
-        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count), gamma, ctx.act, ctx.bn,
-                                               ctx.training, ctx.has_res)
+        y, z, gamma, mean, invstd, scale, shift = ctx.saved_tensors
+        dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
+                                               ctx.bn, ctx.training, ctx.has_res)
         return dy, dgamma, dbeta, dres, None, None, None
 
 
@@ -509,14 +520,14 @@ class SplitAttentionFn(torch.autograd.Function):
         call("xv2_rsoftmax_forward", logits, att, N, C)
         out = _f32((N, H, W, C), x)
         call("xv2_splat_apply_forward", x, att, N, hw, C, out)
-        ctx.save_for_backward(x, gap, w1m, h1, a1, g1, st[0], st[1], w2m, att)
+        ctx.save_for_backward(x, gap, w1m, h1, a1, g1, st[0], st[1], w2m, att, st[3], st[4])
         ctx.count, ctx.bn1, ctx.training = st[2], bn1, training
         ctx.shapes = (w1.shape, w2.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
+        x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att, scale1, shift1 = ctx.saved_tensors
         dout = dout.contiguous()
         N, H, W, C2 = x.shape
         C, hw = C2 // 2, H * W
@@ -528,8 +539,8 @@ class SplitAttentionFn(torch.autograd.Function):
         call("xv2_rsoftmax_backward", att, datt, dlogits, N, C)
         da1, dw2, db2 = _f32((N, inter), x), torch.empty_like(w2m), _f32((C2,), x)
         call("xv2_linear_backward", a1, w2m, dlogits, da1, dw2, db2, N, inter, C2)
-        dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count), g1, ACT_RELU, ctx.bn1,
-                                         ctx.training, False)
+        dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count, scale1, shift1), g1, ACT_RELU,
+                                         ctx.bn1, ctx.training, False)
         dgap, dw1, db1 = _f32((N, C), x), torch.empty_like(w1m), _f32((inter,), x)
         call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
         dx = torch.empty_like(x)
