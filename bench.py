@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="debug: run the RCCL gradient/SyncBN collectives even with one rank (overhead probe)")
     opt = ap.parse_args()
 
     from xview2_amd import _capi, criterion, dist as xdist, networks
@@ -94,6 +96,13 @@ def main():
     from xview2_amd.weights import deterministic_init_
 
     rank, local, world = xdist.init_from_env()
+    if opt.force_collectives and world == 1:
+        from xview2_amd import ops as _ops
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        _ops.FORCE_COLLECTIVES = True
     if opt.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (opt.gpus, world))
     if not torch.cuda.is_available():
@@ -182,7 +191,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

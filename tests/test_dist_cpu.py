@@ -55,7 +55,7 @@ def _worker(rank, world, port, q):
     sums = torch.tensor([[1.0 + rank, 2.0], [3.0, 4.0 * (rank + 1)]], dtype=torch.float64)
 
     class BN:
-        sync, exact_count = True, True
+        sync = True
     assert ops._sync_group(BN)
     buf = torch.cat([sums.reshape(-1), torch.tensor([10.0 + rank], dtype=torch.float64)])
     dist.all_reduce(buf)

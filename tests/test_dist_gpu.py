@@ -1,0 +1,62 @@
+"""The RCCL code paths (bucketed gradient all-reduce on the side stream, SyncBatchNorm statistics exchange) on a real
+GPU with a single-rank NCCL process group: with one rank the collectives are identities, so a training step must
+reproduce the non-distributed step bit for bit.  (Multi-rank logic is covered on CPU/gloo in test_dist_cpu.py;
+8-GPU runs are the driver's.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from tests.golden.cases import ARGS, labels, model_input
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(model, opt, red, a, x, y):
+    from xview2_amd import criterion
+    opt.zero_grad()
+    red.prepare()
+    loss = criterion.compute_loss(criterion.Loss(a), model(x), y, a.deep_supervision)
+    loss.backward()
+    opt.step(red.finish())
+    return float(loss)
+
+
+def test_single_rank_nccl_step_equals_plain_step():
+    from xview2_amd import dist as xdist
+    from xview2_amd import networks, nn as xnn, ops
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        a = ARGS(encoder="resnest50", deep_supervision=True, attention=True)
+        x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
+        out = {}
+        for mode in ("plain", "dist"):
+            ops.FORCE_COLLECTIVES = mode == "dist"
+            xnn.SYNC_BN = False
+            torch.manual_seed(0)
+            m = networks.UNetLoc(a)
+            deterministic_init_(m, 1)
+            m.cuda().train()
+            opt = FlatAdamW(m.parameters(), lr=1e-3)
+            red = xdist.GradReducer(opt, bucket_bytes=8 << 20)
+            assert red.enabled == (mode == "dist") and xnn.SYNC_BN == (mode == "dist")
+            losses = [_step(m, opt, red, a, x, y) for _ in range(2)]
+            torch.cuda.synchronize()
+            out[mode] = (losses, opt.flat_p.clone(), m.state_dict()["unet.enc_l2.1.0.bn1.running_var"].clone())
+        assert out["plain"][0] == out["dist"][0]
+        assert torch.equal(out["plain"][1], out["dist"][1])
+        assert torch.equal(out["plain"][2], out["dist"][2])
+    finally:
+        ops.FORCE_COLLECTIVES = False
+        xnn.SYNC_BN = False
+        dist.destroy_process_group()

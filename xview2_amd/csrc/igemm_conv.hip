@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         return;
 #endif
         if constexpr (!SMALLC) {
-            const int tap = kt / p.cpt;
-            const int cc = (kt - tap * p.cpt) * BK;
+            // K order = (32-channel chunk, tap): consecutive K-tiles re-read the same channel slice of
+            // neighbouring pixels, which the per-CU L1 can serve (tap-major order re-streamed it from L2)
+            const int chunk = kt / ci.ntaps;
+            const int tap = kt - chunk * ci.ntaps;
+            const int cc = chunk * BK;
             const Tap t = taps[tap];
             const int dpix = t.dh * p.IW + t.dw;
             const bool first = cc < p.C0;
@@ -296,56 +299,69 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     if (acc[0][0][0] == 123.456f) p.Out0[0] = 1.f;
     return;
 #endif
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The tile is staged through LDS (the A/B buffers are free now) so that global stores are 16 bytes per lane
+    // and cover whole 128..512-byte output rows: for the K<=256 1x1 convolutions the dword-store epilogue was
+    // two thirds of the kernel.  BatchNorm partial sums are taken from the registers on the way.
+    constexpr int CLD = BN + 4;
+    float* Cs = smem;
+    const bool do_stats = p.stats && p.ksplit == 1;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int col = n0 + wn * WTN + j * 32 + l31;
-        const float bv = (p.bias && p.ksplit == 1) ? p.bias[col] : 0.f;
-        float* outp;
-        int ldo, ocol;
-        if (p.ksplit > 1) {
-            outp = p.part + (size_t)blockIdx.z * ci.M * p.Nout; ldo = p.Nout; ocol = col;
-        } else if (col < p.N0) {
-            outp = p.Out0; ldo = p.ldo0; ocol = col;
-        } else {
-            outp = p.Out1; ldo = p.ldo1; ocol = col - p.N0;
-        }
+        const int cl = wn * WTN + j * 32 + l31;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int off = rowoff[row];
-                const float v = acc[i][j][r] + bv;
-                if (off >= 0) outp[(size_t)off * ldo + ocol] = v;
+                Cs[row * CLD + cl] = acc[i][j][r];
                 s1 += acc[i][j][r];
                 s2 += acc[i][j][r] * acc[i][j][r];
             }
         }
-        if (p.stats && p.ksplit == 1) {
+        if (do_stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
-                const int cl = wn * WTN + j * 32 + l31;
                 red[(wm * BN + cl) * 2 + 0] = s1;
                 red[(wm * BN + cl) * 2 + 1] = s2;
             }
         }
     }
-    if (p.stats && p.ksplit == 1) {
-        __syncthreads();
-        if (tid < BN) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) {
-                s1 += red[(w * BN + tid) * 2 + 0];
-                s2 += red[(w * BN + tid) * 2 + 1];
+    __syncthreads();
+    {
+        constexpr int F4R = BN / 4;
+        float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
+#pragma unroll 4
+        for (int e = tid; e < BM * F4R; e += 256) {
+            const int row = e / F4R, c = (e % F4R) * 4;
+            const int off = rowoff[row];
+            if (off < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + c);
+            const int col = n0 + c;
+            if (slab) {
+                *reinterpret_cast<float4*>(slab + (size_t)off * p.Nout + col) = v;
+                continue;
             }
-            float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-            st[0] = s1;
-            st[1] = s2;
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (col < p.N0) *reinterpret_cast<float4*>(p.Out0 + (size_t)off * p.ldo0 + col) = v;
+            else *reinterpret_cast<float4*>(p.Out1 + (size_t)off * p.ldo1 + (col - p.N0)) = v;
         }
+    }
+    if (do_stats && tid < BN) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) {
+            s1 += red[(w * BN + tid) * 2 + 0];
+            s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
+        st[0] = s1;
+        st[1] = s2;
     }
 }
 
@@ -559,6 +575,7 @@ extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int l
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
+    XV2_CHECK_ARG(ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "conv2d_forward: output must be 16-byte aligned");
     XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
                   "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
@@ -600,6 +617,9 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
     XV2_CHECK_ARG(s <= 2, "backward_data: stride %d unsupported (1 or 2)", s);
+    XV2_CHECK_ARG(lddx0 % 4 == 0 && (reinterpret_cast<uintptr_t>(dx0) & 15) == 0 &&
+                      (!dx1 || (lddx1 % 4 == 0 && (reinterpret_cast<uintptr_t>(dx1) & 15) == 0)),
+                  "backward_data: outputs must be 16-byte aligned");
     p.A0 = dy; p.A1 = nullptr; p.B = w_ihwo;
     p.C0 = d->Cout; p.C1 = 0; p.Ctot = d->Cout; p.ldA0 = lddy; p.ldA1 = 0;
     p.IH = d->OH; p.IW = d->OW; p.s_in = 1;

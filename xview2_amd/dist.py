@@ -38,8 +38,9 @@ def init_from_env(backend=None):
 class GradReducer:
     def __init__(self, optimizer, bucket_bytes=64 << 20, sync_bn=True, overlap=True):
         self.opt = optimizer
+        from . import ops
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or (ops.FORCE_COLLECTIVES and dist.is_initialized())
         self.overlap = overlap
         self.on_gpu = optimizer.flat_g.is_cuda
         if sync_bn and self.enabled:

@@ -128,18 +128,22 @@ def _conv_backward_weight(x0, x1, dy, weight, g):
 
 # ------------------------------------------------------------------------------------------------
 # batch-norm pieces
+FORCE_COLLECTIVES = False   # tests: exercise the collective code paths on a single-rank process group
+
+
 def _sync_group(bn):
-    return bn.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return bn.sync and dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def _bn_train_coeffs(sums, count, bn, like):
     """sums: double [C,2] local; returns mean, invstd, scale, shift, global count"""
     C = sums.shape[0]
     if _sync_group(bn):
-        buf = torch.cat([sums.reshape(-1), torch.tensor([float(count)], dtype=torch.float64, device=sums.device)])
-        dist.all_reduce(buf)
-        sums = buf[:-1].reshape(C, 2)
-        count = float(buf[-1].item()) if bn.exact_count else float(count) * dist.get_world_size()
+        # every rank holds the same per-GPU batch (weak scaling), so the global count is local*world and the
+        # exchange is ONE in-place all-reduce of the fp64 (sum, sum-of-squares) vector - no host round trip
+        dist.all_reduce(sums)
+        count = float(count) * dist.get_world_size()
     mean, invstd, scale, shift = (_f32((C,), like) for _ in range(4))
     call("xv2_bn_finalize", sums, float(count), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
          bn.running_mean, bn.running_var, mean, invstd, scale, shift, C)
@@ -196,14 +200,13 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
 
 class BnState:
     """The pieces of an nn.BatchNorm2d the kernels touch (buffers are updated in place)."""
-    __slots__ = ("weight", "bias", "running_mean", "running_var", "eps", "momentum", "sync", "exact_count")
+    __slots__ = ("weight", "bias", "running_mean", "running_var", "eps", "momentum", "sync")
 
     def __init__(self, m, sync=False):
         self.weight, self.bias = m.weight, m.bias
         self.running_mean, self.running_var = m.running_mean, m.running_var
         self.eps, self.momentum = m.eps, m.momentum
         self.sync = sync
-        self.exact_count = False
 
 
 # ------------------------------------------------------------------------------------------------
