@@ -156,19 +156,25 @@ def main():
         rows = []
         nk = _capi.query("xv2_prof_num_kernels")
         for kid in range(nk):
-            tms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(n))
+            tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
+                        ctypes.addressof(n))
             if n.value:
                 rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
-                             "gflop": fl.value / 1e9, "launches": n.value})
+                             "gflop": fl.value / 1e9, "mbytes": by.value / 1e6, "launches": n.value})
         _capi.query("xv2_prof_enable", 0)
         rows.sort(key=lambda r: -r["ms"])
         if rows:
             top = rows[0]
             ach = top["gflop"] / top["ms"]            # GFLOP/ms == TFLOP/s
             tot_ms, tot_gf = sum(r["ms"] for r in rows), sum(r["gflop"] for r in rows)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
+                traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": top["kernel"],
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": top["kernel"],
+                    "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
                     "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                     "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                     "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / opt.steps, 3),

@@ -238,12 +238,14 @@ int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------------
  * When enabled, every launch of an MFMA kernel (implicit-GEMM conv / weight-gradient) is bracketed
  * by hipEvents on its own stream and tagged with its algorithmic FLOP count (2*M*N*K of the
- * convolution it computes, real channel counts).  xv2_prof_summary synchronises the recorded
+ * convolution it computes, real channel counts) and its algorithmic byte count (each operand read
+ * once, the result written once).  xv2_prof_summary synchronises the recorded
  * events and returns the totals per kernel id. */
 int xv2_prof_enable(int on);
 int xv2_prof_num_kernels(void);
 const char* xv2_prof_kernel_name(int kid);
-int xv2_prof_summary(int kid, double* total_ms, double* total_flops, int64_t* launches);
+int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* total_algorithmic_bytes,
+                     int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,9 @@ def prof_time(fn, iters=10):
     torch.cuda.synchronize()
     tot = 0.0
     for kid in range(_capi.query("xv2_prof_num_kernels")):
-        a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        _capi.query("xv2_prof_summary", kid, ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(n))
+        a, b, c, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _capi.query("xv2_prof_summary", kid, ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c),
+                    ctypes.addressof(n))
         tot += a.value
     _capi.query("xv2_prof_enable", 0)
     return tot / iters

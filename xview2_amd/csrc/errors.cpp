@@ -19,7 +19,7 @@ extern "C" int xv2_version(void) { return 1; }
 
 // ---- profiler -------------------------------------------------------------------------------
 namespace xv2 {
-struct ProfRec { int kid; double flops; hipEvent_t a, b; };
+struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<std::string> g_prof_names;
 static std::vector<ProfRec> g_prof_recs;
@@ -37,9 +37,9 @@ int prof_register(const char* name) {
     g_prof_names.emplace_back(name);
     return (int)g_prof_names.size() - 1;
 }
-void prof_begin(int kid, double flops, hipStream_t stream) {
+void prof_begin(int kid, double flops, double bytes, hipStream_t stream) {
     if (!g_prof_on) return;
-    ProfRec r{kid, flops, prof_event(), prof_event()};
+    ProfRec r{kid, flops, bytes, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, stream);
     g_prof_recs.push_back(r);
 }
@@ -60,8 +60,9 @@ extern "C" int xv2_prof_num_kernels(void) { return (int)xv2::g_prof_names.size()
 extern "C" const char* xv2_prof_kernel_name(int kid) {
     return (kid >= 0 && kid < (int)xv2::g_prof_names.size()) ? xv2::g_prof_names[kid].c_str() : "";
 }
-extern "C" int xv2_prof_summary(int kid, double* total_ms, double* total_flops, int64_t* launches) {
-    double ms = 0.0, fl = 0.0;
+extern "C" int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* total_bytes,
+                                int64_t* launches) {
+    double ms = 0.0, fl = 0.0, by = 0.0;
     int64_t n = 0;
     for (auto& r : xv2::g_prof_recs) {
         if (r.kid != kid) continue;
@@ -70,10 +71,12 @@ extern "C" int xv2_prof_summary(int kid, double* total_ms, double* total_flops, 
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
         ms += t;
         fl += r.flops;
+        by += r.bytes;
         ++n;
     }
     *total_ms = ms;
     *total_flops = fl;
+    *total_bytes = by;
     *launches = n;
     return XV2_OK;
 }

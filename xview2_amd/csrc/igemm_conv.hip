@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#ifndef XV2_SCHED
+#define XV2_SCHED 0
+#endif
 #ifndef XV2_ABL
 #define XV2_ABL 0   // debug ablations (scripts/ablate.sh): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 #endif
@@ -292,6 +295,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 }
 #endif
         }
+#if XV2_SCHED
+        // spread the next tile's buffer loads between the MFMAs instead of issuing them as one burst
+        {
+            constexpr int NM = MR * NR * 16, NL = AROWS + BROWS;
+#pragma unroll
+            for (int g = 0; g < NL; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+#endif
         __syncthreads();
     }
 
@@ -447,7 +462,11 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
         flops += 2.0 * (double)q.cls[c].M * q.Nout * kreal;
     }
     const int grid = maxtiles * (q.Nout / BN);
-    prof_begin(kid, flops, stream);
+    // algorithmic bytes: input pixels x channels + weights + output, each once
+    double abytes = 4.0 * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
+                               (SMALLC ? q.cin_real : q.Ctot) + (double)q.Nout * q.T * (SMALLC ? q.cin_real : q.Ctot));
+    for (int c = 0; c < q.ncls; ++c) abytes += 4.0 * (double)q.cls[c].M * q.Nout;
+    prof_begin(kid, flops, abytes, stream);
     hipLaunchKernelGGL(kern, dim3(grid, q.ncls, q.ksplit), dim3(256), smem, stream, q);
     prof_end(stream);
     XV2_CHECK_LAUNCH();

@@ -319,11 +319,26 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     pl.wk = 4 / ((bm / 32 > 2 ? 2 : bm / 32) * (bn / 32 > 2 ? 2 : bn / 32));
     const int64_t M = (int64_t)d->N * d->OH * d->OW;
     pl.ktiles = (int)cdiv(M, 32);
-    int want = (int)cdiv(640, pl.tiles);
-    int maxsplit = pl.ktiles / 4 > 0 ? pl.ktiles / 4 : 1;
-    int splitk = want < 1 ? 1 : want;
-    if (splitk > maxsplit) splitk = maxsplit;
-    pl.kt_per = (int)cdiv(pl.ktiles, splitk);
+    // split the pixel reduction so that the grid fills the chip in whole "rounds": capacity = resident blocks
+    // (LDS-limited: 2 per CU for the 128x128 tile, 4 otherwise); among the split factors that keep >= 8 K-tiles
+    // per block take the smallest one whose last round is >= 90 % full (fewer slabs = less reduce traffic).
+    const int cap = 256 * ((bm == 128) ? 2 : 4);
+    const int maxsplit = std::max(1, pl.ktiles / 8);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sk = 1; sk <= maxsplit && sk <= 256; ++sk) {
+        const int64_t blocks = (int64_t)pl.tiles * sk;
+        const double eff = (double)blocks / (double)(cdiv(blocks, cap) * cap);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = sk;
+        }
+        if (eff >= 0.9) {
+            best = sk;
+            break;
+        }
+    }
+    pl.kt_per = (int)cdiv(pl.ktiles, best);
     pl.splitk = (int)cdiv(pl.ktiles, pl.kt_per);
     return pl;
 }
@@ -338,7 +353,10 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t s
         snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, WK, SMALLC ? "rgb" : "c32");
         kid = prof_register(nm);
     }
-    prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * (SMALLC ? 3.0 : (double)p.Ctot), stream);
+    const double creal = SMALLC ? 3.0 : (double)p.Ctot;
+    prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * creal,
+               4.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * creal + (double)p.M * p.Cout + (double)p.Cout * p.T * creal),
+               stream);
     hipLaunchKernelGGL(kern, dim3(pl.tiles, pl.splitk), dim3(256), smem, stream, p);
     prof_end(stream);
     XV2_CHECK_LAUNCH();

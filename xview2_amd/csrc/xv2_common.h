@@ -10,7 +10,7 @@ namespace xv2 {
 void set_error(const char* fmt, ...);
 // bench-time profiler (errors.cpp): no-ops unless xv2_prof_enable(1) was called
 int prof_register(const char* name);
-void prof_begin(int kid, double flops, hipStream_t stream);
+void prof_begin(int kid, double flops, double algorithmic_bytes, hipStream_t stream);
 void prof_end(hipStream_t stream);
 
 #define XV2_CHECK_ARG(cond, ...)                 \
