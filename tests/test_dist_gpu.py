@@ -60,3 +60,32 @@ def test_single_rank_nccl_step_equals_plain_step():
         ops.FORCE_COLLECTIVES = False
         xnn.SYNC_BN = False
         dist.destroy_process_group()
+
+
+def test_flat_optimizer_direct_gradient_slots_match_autograd_accumulation():
+    """FlatAdamW hands every parameter's slice of the flat gradient buffer to the HIP backward kernels; the result
+    must equal plain autograd accumulation, including the shared-weight case (SiameseUNet runs its U-Net twice)."""
+    from xview2_amd import criterion, networks
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    a = ARGS(type="post", dmg_model="siamese", loss_str="focal+dice", deep_supervision=True)
+    x, y = model_input(a).cuda(), labels(a).cuda()
+    grads = {}
+    for mode in ("autograd", "flat"):
+        torch.manual_seed(0)
+        m = networks.get_dmg_unet(a)
+        deterministic_init_(m, 1)
+        m.cuda().train()
+        opt = FlatAdamW(m.parameters()) if mode == "flat" else None
+        if opt:
+            opt.zero_grad()
+        loss = criterion.compute_loss(criterion.Loss(a), m(x), y, True)
+        loss.backward()
+        if opt:
+            opt._gather_foreign_grads()
+            base = opt.flat_g.data_ptr()
+            assert all(p.grad is None or p.grad.data_ptr() == base + 4 * o for p, o in zip(opt.params, opt.offsets))
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert grads["autograd"].keys() == grads["flat"].keys()
+    for k in grads["flat"]:
+        assert torch.equal(grads["autograd"][k], grads["flat"][k]), k

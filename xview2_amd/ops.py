@@ -30,6 +30,26 @@ def _ws(nbytes, like):
     return torch.empty(((int(nbytes) + 3) // 4 + 4,), dtype=torch.float32, device=like.device)
 
 
+def grad_slot(param):
+    """Fresh view of the parameter's slice in the optimizer's flat gradient buffer, or None (no flat optimizer, or
+    the slice was already handed out this step - shared weights accumulate through autograd instead)."""
+    slot = getattr(param, "_xv2_slot", None)
+    if slot is None:
+        return None
+    opt, off = slot
+    if param._xv2_epoch == opt.epoch:
+        return None
+    param._xv2_epoch = opt.epoch
+    return opt.flat_g[off:off + param.numel()].view(param.shape)
+
+
+def _grad_like(param, like=None):
+    g = grad_slot(param)
+    if g is None:
+        g = torch.empty_like(param if like is None else like, memory_format=torch.contiguous_format)
+    return g
+
+
 def conv_cfg(kh, kw=None, stride=1, pad=0, dil=1, groups=1):
     return SimpleNamespace(kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, dil=dil, groups=groups)
 
@@ -110,14 +130,14 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
     return dx0, dx1
 
 
-def _conv_backward_weight(x0, x1, dy, weight, g):
+def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
     C0g, Coutg = C0t // G, Cout_t // G
     cin_real = weight.shape[1]
-    dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    dw = _grad_like(weight if wparam is None else wparam)
     for gi in range(G):
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
@@ -185,7 +205,7 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
     npix = y.numel() // C
     dz = dz.contiguous()
     sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
-    dgamma, dbeta = _f32((C,), y), _f32((C,), y)
+    dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
     ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
     call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
          dbeta, ws)
@@ -229,6 +249,7 @@ class ConvBnActFn(torch.autograd.Function):
                               stats[4])
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
+        ctx.wparam = weight
         return z
 
     @staticmethod
@@ -242,7 +263,8 @@ class ConvBnActFn(torch.autograd.Function):
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0, ctx.ihwo)
         ctx.ihwo = None
-        dw = _conv_backward_weight(x0, x1, dy, weight, g) if ctx.needs_input_grad[2] else None
+        dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
+        ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
                 dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None)
 
@@ -258,6 +280,7 @@ class ConvFn(torch.autograd.Function):
         y, _ = _conv_forward(x0, x1, weight, g, bias, want_stats=False)
         ctx.save_for_backward(x0, x1, weight)
         ctx.g, ctx.has_bias = g, bias is not None
+        ctx.wparam = weight
         return y
 
     @staticmethod
@@ -269,7 +292,8 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0)
-        dw = _conv_backward_weight(x0, x1, dy, weight, g) if ctx.needs_input_grad[2] else None
+        dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
+        ctx.wparam = None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             C = dy.shape[-1]
@@ -297,6 +321,7 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
         ctx.save_for_backward(x, weight)
         ctx.d = d
+        ctx.wparam = weight
         return y
 
     @staticmethod
@@ -311,7 +336,7 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
             dx = torch.empty_like(x)
             call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            dw = _grad_like(ctx.wparam)
             ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
             call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
         return dx, dw

@@ -34,18 +34,33 @@ class FlatAdamW:
                 view = self.flat_p[o:o + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+                p.grad = None
+                # the HIP backward kernels write a parameter's gradient straight into its slice of flat_g
+                # (ops.grad_slot): autograd then adopts that view as .grad without an accumulation kernel
+                p._xv2_slot = (self, o)
+                p._xv2_epoch = -1
+        self.epoch = 0
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": plist}]  # what utils/scheduler.py NoamLR touches
 
     def zero_grad(self):
-        self.flat_g.zero_()
-        for p, o in zip(self.params, self.offsets):        # autograd may have replaced .grad
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+        self.flat_g.zero_()            # one memset; parameters that get no gradient this step stay at zero
+        self.epoch += 1
+        for p in self.params:
+            p.grad = None
+
+    def _gather_foreign_grads(self):
+        """gradients that did not come from a HIP backward kernel (torch-side ops) are copied into their slice"""
+        base = self.flat_g.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() != base + 4 * o:
+                self.flat_g[o:o + p.numel()].view_as(p).copy_(g)
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
 
     def step(self, grad_scale=1.0):
+        self._gather_foreign_grads()
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
