@@ -82,11 +82,20 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--encoder", default="resnet50")
+    ap.add_argument("--type", default="pre", choices=["pre", "post"])
+    ap.add_argument("--dmg_model", default="siamese")
+    ap.add_argument("--loss_str", default=None)
+    ap.add_argument("--deep_supervision", action="store_true")
+    ap.add_argument("--attention", action="store_true")
+    ap.add_argument("--ppm", action="store_true")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step from a captured hipGraph (measured equal to eager launches on 1 GPU: "
+                         "the step is GPU-bound; default is eager)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="debug: run the RCCL gradient/SyncBN collectives even with one rank (overhead probe)")
     opt = ap.parse_args()
@@ -110,9 +119,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    a = make_args(opt.encoder)
+    a = make_args(opt.encoder, opt.type, opt.loss_str or ("dice" if opt.type == "pre" else "focal+dice"),
+                  opt.dmg_model, deep_supervision=opt.deep_supervision, attention=opt.attention, ppm=opt.ppm)
     torch.manual_seed(0)
-    model = networks.UNetLoc(a)
+    model = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
     deterministic_init_(model, 1)
     model.to(dev).train()
     loss_fn = criterion.Loss(a)
@@ -133,17 +143,32 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # whole-step hipGraph (falls back to eager launches if capture is not possible); the HIP-event bracketing of
+    # individual MFMA launches needs eager launches, so the roofline leg runs as a separate eager pass below
+    graphed = None
+    if opt.graph and world == 1:
+        try:
+            from xview2_amd.graph import GraphedStep
+            graphed = GraphedStep(lambda: step(), optim, [], warmup=max(1, opt.warmup))
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("hipGraph capture failed (%s: %s); running eagerly\n" % (type(e).__name__, e))
+            graphed = None
+    run = graphed if graphed is not None else step
     for _ in range(opt.warmup):
-        step()
+        run()
     prof = not opt.no_prof
     barrier()
-    if prof:
-        _capi.query("xv2_prof_enable", 1)
     t0 = time.time()
     for _ in range(opt.steps):
-        loss = step()
+        loss = run()
     barrier()
     dt = time.time() - t0
+    if prof:   # roofline leg: the same steps launched eagerly with HIP events around every MFMA launch
+        psteps = min(opt.steps, 5)
+        _capi.query("xv2_prof_enable", 1)
+        for _ in range(psteps):
+            step()
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -177,19 +202,22 @@ def main():
                     "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
                     "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                     "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
-                    "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / opt.steps, 3),
-                                         "gflop_per_step": round(tot_gf / opt.steps, 1)},
+                    "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
+                                         "gflop_per_step": round(tot_gf / psteps, 1)},
                     "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
-                                    "ms_per_step": round(r["ms"] / opt.steps, 3), "launches_per_step": r["launches"] / opt.steps}
+                                    "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
                                    for r in rows]}
     out = {
         "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "--type pre --encoder %s --loss_str dice, %dx%d, batch %d per GPU, fp32 train step "
-                               "(fwd+loss+bwd+allreduce+AdamW)" % (opt.encoder, opt.size, opt.size, opt.batch),
+        "config": {"workload": "--type %s%s --encoder %s --loss_str %s%s%s, %dx%d, batch %d per GPU, fp32 train step "
+                               "(fwd+loss+bwd+allreduce+AdamW)" % (
+                                   a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
+                                   a.loss_str, " --deep_supervision" if a.deep_supervision else "",
+                                   " --attention" if a.attention else "", opt.size, opt.size, opt.batch),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
-        "loss": float(loss),
+        "loss": float(loss), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3, 2),
         "roofline": roof,
     }

@@ -235,6 +235,12 @@ int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, void* stream);
 
+/* hipGraph-capturable variant: learning rate and step counter are read from device memory (the step counter is
+ * incremented by the call), so a captured training step can be replayed while the schedule advances */
+int xv2_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                       int* step_dev, float grad_scale, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) --------------------------------------
  * When enabled, every launch of an MFMA kernel (implicit-GEMM conv / weight-gradient) is bracketed
  * by hipEvents on its own stream and tagged with its algorithmic FLOP count (2*M*N*K of the

@@ -87,6 +87,7 @@ def test_single_process_reducer_is_a_noop():
     red.prepare()
     lin(torch.randn(2, 4)).sum().backward()
     assert red.finish() == 1.0 and not red.enabled
+    opt._gather_foreign_grads()      # torch-side gradients are adopted into the flat buffer at step time
     # parameters and gradients live in the flat buffers (views, 16-byte aligned slices)
     assert lin.weight.data_ptr() == opt.flat_p.data_ptr() and lin.weight.grad.data_ptr() == opt.flat_g.data_ptr()
     assert float(opt.flat_g.abs().sum()) > 0

@@ -89,3 +89,38 @@ def test_flat_optimizer_direct_gradient_slots_match_autograd_accumulation():
     assert grads["autograd"].keys() == grads["flat"].keys()
     for k in grads["flat"]:
         assert torch.equal(grads["autograd"][k], grads["flat"][k]), k
+
+
+def test_hipgraph_replay_matches_eager_steps():
+    """whole-step hipGraph capture (forward + loss + backward + AdamW with device-side step/lr) == eager steps"""
+    from xview2_amd import criterion, networks
+    from xview2_amd.graph import GraphedStep
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    a = ARGS(encoder="resnet50", deep_supervision=True)
+    x, y = model_input(a).cuda(), labels(a).cuda()
+    res = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        m = networks.UNetLoc(a)
+        deterministic_init_(m, 1)
+        m.cuda().train()
+        opt = FlatAdamW(m.parameters(), lr=1e-3)
+        lf = criterion.Loss(a)
+
+        def step():
+            opt.zero_grad()
+            loss = criterion.compute_loss(lf, m(x), y, True)
+            loss.backward()
+            opt.step()
+            return loss
+        if mode == "eager":
+            losses = [float(step()) for _ in range(5)]
+        else:
+            g = GraphedStep(step, opt, [], warmup=2)          # 2 eager warm-up steps ran; capture executes nothing
+            losses = [None, None] + [float(g()) for _ in range(3)]
+        torch.cuda.synchronize()
+        res[mode] = (losses, opt.flat_p.clone(), int(m.state_dict()["unet.enc_l1.1.num_batches_tracked"]))
+    assert res["eager"][0][2:] == res["graph"][0][2:]
+    assert torch.equal(res["eager"][1], res["graph"][1])
+    assert res["eager"][2] == res["graph"][2] == 5

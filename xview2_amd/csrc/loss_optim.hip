@@ -87,14 +87,23 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(const float* __restrict__
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-__global__ void loss_finish_kernel(const double* __restrict__ part, int nblocks, int C, int terms,
-                                   double* __restrict__ acc, float* __restrict__ loss) {
+__global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restrict__ part, int nblocks, int C,
+                                                           int terms, double* __restrict__ acc,
+                                                           float* __restrict__ loss) {
+    __shared__ double sh[16][16];
     __shared__ double tot[NACC];
+    // 16 lanes per accumulator, each summing every 16th block partial (fixed order), then a 16-term tail
+    const int k = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    double s = 0.0;
+    if (k < NACC)
+        for (int b = lane; b < nblocks; b += 16) s += part[(size_t)b * NACC + k];
+    sh[lane][k] = s;
+    __syncthreads();
     if (threadIdx.x < NACC) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * NACC + threadIdx.x];
-        tot[threadIdx.x] = s;
-        acc[threadIdx.x] = s;
+        double t = 0.0;
+        for (int l = 0; l < 16; ++l) t += sh[l][threadIdx.x];
+        tot[threadIdx.x] = t;
+        acc[threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -224,9 +233,44 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// graph-capturable form: learning rate and step counter live in device memory, so a captured launch stays valid
+// while the host-side schedule / step count advance
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev, float b1,
+                                 float b2, float eps, float wd, const int* __restrict__ step_dev, float gscale) {
+    const float lr = lr_dev[0];
+    const float step = (float)(step_dev[0] + 1);
+    const float bc1 = 1.f - powf(b1, step);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, step));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        float pi = p[i];
+        pi *= 1.f - lr * wd;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+__global__ void inc_i32_kernel(int* p) { p[0] += 1; }
+
 }  // namespace xv2
 
 using namespace xv2;
+
+extern "C" int xv2_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                                  int* step_dev, float grad_scale, void* stream) {
+    const int grid = (int)std::min<int64_t>(cdiv(n, 256), 4096);
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(inc_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
 
 extern "C" size_t xv2_loss_workspace(int N, int C, int H, int W) {
     (void)N; (void)C; (void)H; (void)W;
@@ -246,7 +290,7 @@ extern "C" int xv2_loss_forward(const float* logits, const uint8_t* labels, int 
     else
         hipLaunchKernelGGL(loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
     XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, part, grid, C, terms, acc, loss);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, part, grid, C, terms, acc, loss);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

@@ -136,13 +136,17 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ void head_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout, int Cin,
-                                       float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: 64 lanes stride over the block partials (fp64), fixed-order shuffle tree
+__global__ void __launch_bounds__(256) head_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int Cout,
+                                                               int Cin, float* __restrict__ dw,
+                                                               float* __restrict__ db) {
     const int row = Cin + 1;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= Cout * row) return;
     double s = 0.0;  // the per-class bias gradients cancel almost exactly (softmax): sum the partials in fp64
-    for (int b = 0; b < nblocks; ++b) s += (double)part[(size_t)b * Cout * row + i];
+    for (int b = lane; b < nblocks; b += 64) s += (double)part[(size_t)b * Cout * row + i];
+    s = wave_sum(s);
+    if (lane != 0) return;
     const int o = i / row, c = i % row;
     if (c < Cin) dw[o * Cin + c] = (float)s;
     else if (db) db[o] = (float)s;
@@ -463,7 +467,7 @@ extern "C" int xv2_head_conv_backward(const float* x, int ldx, const float* dy, 
     }
 #undef LAUNCH_HB
     XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)cdiv((int64_t)Cout * (Cin + 1) * 64, 256)), dim3(256), 0, st,
                        workspace, grid, Cout, Cin, dw, dbias);
     XV2_CHECK_LAUNCH();
     return XV2_OK;

@@ -70,7 +70,13 @@ class GradReducer:
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _make_hook(self, i):
-        def hook(_p):
+        def hook(p):
+            # gradients produced outside the HIP kernels (torch-side ops) are not views of the flat buffer yet
+            o = self.opt.offsets[i]
+            if p.grad is not None and p.grad.data_ptr() != self.opt.flat_g.data_ptr() + 4 * o:
+                view = self.opt.flat_g[o:o + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
             b = self.bucket_of[i]
             self.remaining[b] -= 1
             if self.remaining[b] == 0 and self.overlap:

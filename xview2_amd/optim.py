@@ -43,6 +43,11 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.param_groups = [{"lr": lr, "params": plist}]  # what utils/scheduler.py NoamLR touches
+        # device-resident copies for hipGraph capture (see xview2_amd.graph.GraphedStep)
+        self.capturable = dev.type == "cuda"   # always the device-state kernel on the GPU: one code path, graph-safe
+        self.lr_dev = torch.tensor([lr], dtype=torch.float32, device=dev) if dev.type == "cuda" else None
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        self._lr_on_dev = lr
 
     def zero_grad(self):
         self.flat_g.zero_()            # one memset; parameters that get no gradient this step stay at zero
@@ -59,10 +64,24 @@ class FlatAdamW:
                 self.flat_g[o:o + p.numel()].view_as(p).copy_(g)
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
 
+    def sync_lr(self):
+        """push the host-side learning rate to the device copy (call OUTSIDE a captured region)"""
+        lr = self.param_groups[0]["lr"]
+        if self.lr_dev is not None and lr != self._lr_on_dev:
+            self.lr_dev.fill_(lr)
+            self._lr_on_dev = lr
+
     def step(self, grad_scale=1.0):
         self._gather_foreign_grads()
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
+        if self.capturable:
+            from ._capi import call
+            self.sync_lr()
+            call("xv2_adamw_step_dev", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_p.numel(),
+                 self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                 self.step_dev, float(grad_scale))
+            return
         ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                        self.eps, self.weight_decay, self.step_count, grad_scale)
 
