@@ -252,6 +252,8 @@ int xv2_prof_num_kernels(void);
 const char* xv2_prof_kernel_name(int kid);
 int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* total_algorithmic_bytes,
                      int64_t* launches);
+int xv2_prof_num_records(void);
+int xv2_prof_record(int i, int* kid, double* ms, double* flops, double* algorithmic_bytes);
 
 #ifdef __cplusplus
 }

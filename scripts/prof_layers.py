@@ -1,0 +1,40 @@
+"""Per-launch MFMA kernel times of one cfg2 training step (in-library HIP-event profiler), sorted by time."""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from xview2_amd import _capi, criterion, networks
+from xview2_amd.optim import FlatAdamW
+from xview2_amd.weights import deterministic_init_
+a = bench.make_args(sys.argv[1] if len(sys.argv) > 1 else "resnet50")
+m = networks.UNetLoc(a); deterministic_init_(m, 1); m.cuda().train()
+opt = FlatAdamW(m.parameters()); lf = criterion.Loss(a)
+x, y = bench.synthetic_batch(a, 2, 1024, 1, "cuda")
+def step():
+    opt.zero_grad(); l = lf(m(x), y); l.backward(); opt.step()
+for _ in range(2): step()
+torch.cuda.synchronize()
+_capi.query("xv2_prof_enable", 1)
+step(); torch.cuda.synchronize()
+n = _capi.query("xv2_prof_num_records")
+rows = []
+for i in range(n):
+    kid, ms, fl, by = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _capi._func("xv2_prof_record")(i, ctypes.addressof(kid), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(by))
+    rows.append((ms.value, fl.value / 1e9, by.value / 1e6, _capi.query("xv2_prof_kernel_name", kid.value).decode(), i))
+_capi.query("xv2_prof_enable", 0)
+tot = sum(r[0] for r in rows)
+print("launches %d total %.2f ms" % (n, tot))
+rows.sort(reverse=True)
+acc = 0
+for ms, gf, mb, name, i in rows[:45]:
+    acc += ms
+    print("#%3d %-34s %7.3f ms %8.2f GF %7.1f TF  %7.1f MB(alg) cum %.1f%%" % (i, name, ms, gf, gf / ms, mb, 100 * acc / tot))
+# efficiency buckets
+import collections
+b = collections.defaultdict(lambda: [0.0, 0.0])
+for ms, gf, mb, name, i in rows:
+    tf = gf / ms
+    k = "<60" if tf < 60 else "<80" if tf < 80 else "<100" if tf < 100 else "<120" if tf < 120 else ">=120"
+    b[k][0] += ms; b[k][1] += gf
+for k in ("<60", "<80", "<100", "<120", ">=120"):
+    print("TF %-6s time %.2f ms  %.0f GF" % (k, b[k][0], b[k][1]))

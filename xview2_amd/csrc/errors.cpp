@@ -80,3 +80,15 @@ extern "C" int xv2_prof_summary(int kid, double* total_ms, double* total_flops, 
     *launches = n;
     return XV2_OK;
 }
+extern "C" int xv2_prof_num_records(void) { return (int)xv2::g_prof_recs.size(); }
+extern "C" int xv2_prof_record(int i, int* kid, double* ms, double* flops, double* bytes) {
+    if (i < 0 || i >= (int)xv2::g_prof_recs.size()) return XV2_EINVAL;
+    auto& r = xv2::g_prof_recs[i];
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return XV2_EHIP;
+    *kid = r.kid;
+    *ms = t;
+    *flops = r.flops;
+    *bytes = r.bytes;
+    return XV2_OK;
+}

@@ -476,20 +476,39 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
 // tile shape and split-K factor; `nkt` = K tiles of the (single-class) problem, 0 disables split-K
 static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& bn, int& ksplit) {
     bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
-    const int64_t blocks128 = cdiv(M, 128) * (Nout / bn);
     ksplit = 1;
-    if (!smallc && bn == 128 && nkt >= 16 && blocks128 < 256) {
-        // small pixel count, deep reduction (encoder stages 3-4, decoder level 1): keep the 128-row tile for
-        // arithmetic intensity and fill the chip by splitting K instead of shrinking the tile
-        int want = (int)cdiv(512, blocks128);
-        int cap = nkt / 8;
-        ksplit = std::max(1, std::min(std::min(want, cap), 8));
-    }
-    if (ksplit > 1) {
+    if (smallc || bn == 32) {
         bm = 128;
         return;
     }
-    bm = (smallc || blocks128 >= 384 || bn == 32) ? 128 : 64;
+    // Cost model in "rounds": the chip holds `cap` blocks at once (LDS-limited: 2 per CU for the 128x128, 64x128 and
+    // 128x64 tiles, 4 per CU for 64x64); a launch takes ceil(blocks / cap) rounds of (tile rows x K share) work.
+    // Candidates: 128-row tile, 64-row tile (measured ~8 % less efficient per FLOP), and for bn == 128 the 128-row
+    // tile with K split 2..8 ways (partials reduced by splitk_reduce_kernel, charged as extra traffic).
+    const int ntn = Nout / bn;
+    auto rounds = [&](int64_t blocks, int cap) { return (double)cdiv(blocks, cap); };
+    const int cap128 = 512, cap64 = (bn == 64) ? 1024 : 512;
+    const double k = (double)std::max(nkt, 1);
+    double best = rounds(cdiv(M, 128) * ntn, cap128) * 128.0 * k;
+    bm = 128;
+    const double c64 = rounds(cdiv(M, 64) * ntn, cap64) * 64.0 * k / 0.92;
+    if (c64 < best * 0.97) {
+        best = c64;
+        bm = 64;
+    }
+    if (bn == 128 && nkt >= 16) {
+        const int64_t blocks128 = cdiv(M, 128) * ntn;
+        for (int ks = 2; ks <= 8 && nkt / ks >= 8; ++ks) {
+            const double per = (double)cdiv(nkt, ks);
+            // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab
+            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + 6.0);
+            if (c < best * 0.95) {
+                best = c;
+                bm = 128;
+                ksplit = ks;
+            }
+        }
+    }
 }
 
 int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt) {
