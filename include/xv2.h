@@ -213,6 +213,8 @@ int xv2_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t np
 #define XV2_LOSS_DICE 1
 #define XV2_LOSS_FOCAL 2
 #define XV2_LOSS_CE 4      /* "ce" and "ohem" (model/loss.py:24-51 is numerically mean CE) */
+#define XV2_LOSS_MSE 8     /* "mse" (model/loss.py:92-94), C = 1, exclusive */
+#define XV2_LOSS_CORAL 16  /* "coral" (model/loss.py:54-65), C = 3, exclusive */
 /* logits NCHW [N][C][H][W]; labels uint8 [N][LH][LW] sampled with stride `lstride`
  * (deep supervision nearest down-sampling, model/plt.py:73).  post != 0 applies the building
  * mask of model/loss.py:86-90 (pixels with label 0 are dropped, label-1 is the class).

@@ -23,7 +23,7 @@ CASES = ["pre_resnet50", "pre_resnet50_ds_attn", "pre_resnet50_ppm", "pre_resnet
          "pre_resnet50_dil4_noskip", "pre_resnet50_decinterp", "pre_resnest50", "pre_resnest50_dil2",
          "pre_resnest101_attn", "post_siamese_resnest50_ds", "post_siameseEnc_resnet50",
          "post_fused_resnest50_attn_ds", "post_fused_resnet50_decinterp", "post_fusedEnc_resnet50",
-         "post_parallel_resnet50", "post_parallelEnc_resnet50_aspp", "post_diff_resnet50"]
+         "post_parallel_resnet50", "post_parallelEnc_resnet50_aspp", "post_diff_resnet50", "post_siamese_coral"]
 
 
 def case_batch(name):
@@ -68,8 +68,6 @@ def test_train_step_parity(name):
     from oracle import torch_ref
     from xview2_amd import criterion
     a = ARGS(**MODEL_CASES[name])
-    if a.loss_str == "coral":
-        pytest.skip("coral loss has no HIP kernel yet")
     ora, hip = build_pair(a)
     ora64 = copy.deepcopy(ora).double()
     ora.train()

@@ -313,7 +313,7 @@ def test_layout_and_argmax_and_adamw():
 
 
 @pytest.mark.parametrize("name", ["pre_dice", "pre_focal+dice", "pre_ce", "pre_ohem+dice", "post_focal+dice",
-                                  "post_dice", "post_ce+focal", "post_ohem"])
+                                  "post_dice", "post_ce+focal", "post_ohem", "post_mse", "post_coral"])
 def test_loss_forward_backward_vs_oracle(name):
     """fused loss kernels against the CPU oracle's Loss (itself bit-equal to model/loss.py, tests/golden)"""
     from oracle import torch_ref
@@ -321,7 +321,7 @@ def test_loss_forward_backward_vs_oracle(name):
     from xview2_amd import criterion
     a = ARGS(**LOSS_CASES[name])
     yp, yt = loss_inputs(a, batch=2, size=48)
-    ypr = yp.clone().double().requires_grad_(True)
+    ypr = yp.clone().requires_grad_(True) if a.loss_str == "mse" else yp.clone().double().requires_grad_(True)
     lo = torch_ref.Loss(a)(ypr, yt)
     lo.backward()
     ypg = yp.to(dev()).requires_grad_(True)

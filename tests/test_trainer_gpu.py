@@ -1,0 +1,32 @@
+"""End-to-end CLI run on tiny synthetic tiles: train (with Noam schedule, deep supervision), checkpoint, resume-free
+eval from the checkpoint with TTA, --ckpt_pre encoder transplant into a damage model."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_train_eval_and_transplant(tmp_path):
+    import main as cli
+    res = str(tmp_path / "pre")
+    common = ["--data", "synthetic", "--encoder", "resnet50", "--precision", "32", "--batch_size", "2",
+              "--val_batch_size", "2", "--train_size", "64", "--eval_size", "64", "--steps_per_epoch", "3"]
+    m = cli.main(["--exec_mode", "train", "--type", "pre", "--loss_str", "dice", "--epochs", "2", "--results", res,
+                  "--deep_supervision", "--use_scheduler", "--warmup", "1"] + common)
+    ck = os.path.join(res, "checkpoints", "last.ckpt")
+    assert os.path.exists(ck) and os.path.exists(os.path.join(res, "checkpoints", "best.ckpt"))
+    sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+    assert "model.unet.enc_l1.0.weight" in sd and "model.unet.dec_l1.conv_tranpose.conv.weight" in sd
+    assert int(sd["model.unet.enc_l1.1.num_batches_tracked"]) == 6          # 2 epochs x 3 steps
+    # eval from the checkpoint with TTA flips; writes the .npy probabilities the reference's post-processing reads
+    res2 = str(tmp_path / "eval")
+    cli.main(["--exec_mode", "eval", "--type", "pre", "--ckpt", ck, "--results", res2, "--tta"] + common)
+    assert len(os.listdir(os.path.join(res2, "probs"))) == 4
+    # damage model initialised from the localization checkpoint
+    res3 = str(tmp_path / "post")
+    mp = cli.main(["--exec_mode", "train", "--type", "post", "--dmg_model", "siamese", "--loss_str", "focal+dice",
+                   "--epochs", "1", "--results", res3, "--ckpt_pre", ck] + common)
+    assert os.path.exists(os.path.join(res3, "checkpoints", "last.ckpt"))
+    assert mp.model.unet.enc_l1[0].weight.shape == m.model.unet.enc_l1[0].weight.shape

@@ -1,7 +1,7 @@
 """Loss composition on the fused HIP loss kernels: drop-in for the reference's model/loss.py ``Loss``.
 
 ``--loss_str`` is a '+'-separated sum of dice, focal, ce, ohem (model/loss.py:68-83).  dice/focal are the
-monai 0.4.0 losses with the constructor arguments of model/loss.py:11-13; ``ohem`` is numerically the mean
+monai 0.4.0 losses with the constructor arguments of model/loss.py:11-13; ``mse`` / ``coral`` (model/loss.py:54-65,92-94) have their own kernels; ``ohem`` is numerically the mean
 cross-entropy (the reference slices the (values, indices) tuple of ``sort`` at model/loss.py:45, so no
 negative is ever dropped).  All terms of one call share a single softmax pass; for ``--type post`` the
 building mask of model/loss.py:86-90 is applied inside the kernels (no compaction, order-independent sums).
@@ -23,13 +23,16 @@ class Loss(nn.Module):
         for n in self.names:
             if n not in ("dice", "focal", "ce", "ohem", "mse", "coral"):
                 raise KeyError(n)
-        self.unsupported = [n for n in self.names if n in ("mse", "coral")]
+        if ("mse" in self.names or "coral" in self.names) and len(self.names) > 1:
+            # the reference special-cases loss_str == "mse" (float targets) and its coral head has 3 logits:
+            # neither composes with the softmax-based terms
+            raise ValueError("mse / coral cannot be combined with other loss terms")
 
     def forward(self, y_pred, y_true, label_stride=1):
         """y_pred NCHW logits; y_true [N, H*label_stride, W*label_stride] uint8/long labels."""
-        if self.unsupported:
-            raise NotImplementedError(
-                "loss term(s) %s have no HIP kernel yet (not used by any benchmark configuration)" % self.unsupported)
+        if self.names[0] in ("mse", "coral"):
+            bits = ops.LOSS_MSE if self.names[0] == "mse" else ops.LOSS_CORAL
+            return ops.LossFn.apply(y_pred, y_true, bits, self.post, label_stride)
         # the reference sums the terms one by one; duplicated names count twice
         total = None
         counts = {}

@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restri
         }
         if (terms & XV2_LOSS_FOCAL) L += tot[12] / n;
         if (terms & XV2_LOSS_CE) L += tot[13] / n;
+        if (terms & (XV2_LOSS_MSE | XV2_LOSS_CORAL)) L = tot[12] / n;
         loss[0] = (float)L;
     }
 }
@@ -180,6 +181,85 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const float* __restrict__
         for (int c = 0; c < C; ++c) {
             const float g = p[c] * (dp[c] - dot) + dlt * (((y == c) ? 1.f : 0.f) - p[c]);
             dlogits[base + c * hw] = gs * g;
+        }
+    }
+}
+
+// "mse" (model/loss.py:92-94: relu(y_pred[:,0]) vs label-1 on building pixels) and "coral" (model/loss.py:54-65:
+// ordinal levels [1]*k+[0]*(3-k), sum_k logsig(x_k)*lv_k + (logsig(x_k)-x_k)*(1-lv_k)); --type post only.
+// MODE 0 = mse (C = 1), MODE 1 = coral (C = 3).  acc[12] = sum of per-pixel losses, acc[14] = pixel count.
+template <int MODE>
+__global__ void __launch_bounds__(256) loss_aux_fwd_kernel(const float* __restrict__ logits,
+                                                            const uint8_t* __restrict__ labels, int N, int H, int W,
+                                                            int ls, int post, double* __restrict__ part) {
+    __shared__ double sh[4][2];
+    constexpr int C = MODE == 0 ? 1 : 3;
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    float a = 0.f, cnt = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        const int h = (int)(q / W), w = (int)(q - (int64_t)h * W);
+        int y = label_at(labels, n, h, w, H, W, ls);
+        if (post) {
+            if (y == 0) continue;
+            y -= 1;
+        }
+        const int64_t base = n * C * hw + q;
+        if (MODE == 0) {
+            const float p = fmaxf(logits[base], 0.f);
+            const float d = p - (float)y;
+            a += d * d;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float x = logits[base + k * hw];
+                const float ls_ = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));   // logsigmoid(x)
+                a -= (k < y) ? ls_ : (ls_ - x);
+            }
+        }
+        cnt += 1.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double va = wave_sum((double)a), vc = wave_sum((double)cnt);
+    if (lane == 0) {
+        sh[wave][0] = va;
+        sh[wave][1] = vc;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = 0.0;
+        if (threadIdx.x == 12) v = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+        if (threadIdx.x == 14) v = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+        part[(size_t)blockIdx.x * NACC + threadIdx.x] = v;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) loss_aux_bwd_kernel(const float* __restrict__ logits,
+                                                            const uint8_t* __restrict__ labels, int N, int H, int W,
+                                                            int ls, int post, const double* __restrict__ acc,
+                                                            const float* __restrict__ gscale, float weight,
+                                                            float* __restrict__ dlogits) {
+    constexpr int C = MODE == 0 ? 1 : 3;
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    const float gs = gscale[0] * weight * (float)(1.0 / acc[14]);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        const int h = (int)(q / W), w = (int)(q - (int64_t)h * W);
+        int y = label_at(labels, n, h, w, H, W, ls);
+        const int64_t base = n * C * hw + q;
+        const bool drop = post && y == 0;
+        y -= post ? 1 : 0;
+        if (MODE == 0) {
+            const float x = logits[base];
+            dlogits[base] = (drop || x <= 0.f) ? 0.f : gs * 2.f * (x - (float)y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float x = logits[base + k * hw];
+                const float sg = 1.f / (1.f + expf(-x));
+                dlogits[base + k * hw] = drop ? 0.f : gs * (sg - ((k < y) ? 1.f : 0.f));
+            }
         }
     }
 }
@@ -279,13 +359,19 @@ extern "C" size_t xv2_loss_workspace(int N, int C, int H, int W) {
 
 extern "C" int xv2_loss_forward(const float* logits, const uint8_t* labels, int N, int C, int H, int W, int lstride,
                                 int post, int terms, double* acc, float* loss, float* workspace, void* stream) {
-    XV2_CHECK_ARG(C == 2 || C == 4, "loss: C=%d unsupported (2 or 4)", C);
-    XV2_CHECK_ARG(terms != 0 && (terms & ~7) == 0, "loss: bad terms mask %d", terms);
+    const bool aux = terms == XV2_LOSS_MSE || terms == XV2_LOSS_CORAL;
+    XV2_CHECK_ARG(terms != 0 && (aux || (terms & ~7) == 0), "loss: bad terms mask %d", terms);
+    XV2_CHECK_ARG(aux ? (C == (terms == XV2_LOSS_MSE ? 1 : 3)) : (C == 2 || C == 4),
+                  "loss: C=%d does not fit the requested terms (dice/focal/ce: 2 or 4, mse: 1, coral: 3)", C);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * H * W;
     const int grid = (int)std::min<int64_t>(cdiv(total, 256), LOSS_BLOCKS);
     double* part = reinterpret_cast<double*>(workspace);
-    if (C == 2)
+    if (terms == XV2_LOSS_MSE)
+        hipLaunchKernelGGL(loss_aux_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
+    else if (terms == XV2_LOSS_CORAL)
+        hipLaunchKernelGGL(loss_aux_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
+    else if (C == 2)
         hipLaunchKernelGGL(loss_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
     else
         hipLaunchKernelGGL(loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post, part);
@@ -298,11 +384,17 @@ extern "C" int xv2_loss_forward(const float* logits, const uint8_t* labels, int 
 extern "C" int xv2_loss_backward(const float* logits, const uint8_t* labels, int N, int C, int H, int W, int lstride,
                                  int post, int terms, const double* acc, const float* gscale, float weight,
                                  float* dlogits, void* stream) {
-    XV2_CHECK_ARG(C == 2 || C == 4, "loss: C=%d unsupported (2 or 4)", C);
+    XV2_CHECK_ARG(C >= 1 && C <= 4, "loss: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)N * H * W;
     const int grid = (int)std::min<int64_t>(cdiv(total, 256), 4096);
-    if (C == 2)
+    if (terms == XV2_LOSS_MSE)
+        hipLaunchKernelGGL(loss_aux_bwd_kernel<0>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post,
+                           acc, gscale, weight, dlogits);
+    else if (terms == XV2_LOSS_CORAL)
+        hipLaunchKernelGGL(loss_aux_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post,
+                           acc, gscale, weight, dlogits);
+    else if (C == 2)
         hipLaunchKernelGGL(loss_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, N, H, W, lstride, post,
                            terms, acc, gscale, weight, dlogits);
     else
@@ -314,11 +406,13 @@ extern "C" int xv2_loss_backward(const float* logits, const uint8_t* labels, int
 
 extern "C" int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint8_t* labels,
                                void* stream) {
-    XV2_CHECK_ARG(C == 2 || C == 4, "argmax: C=%d unsupported (2 or 4)", C);
+    XV2_CHECK_ARG(C >= 2 && C <= 4, "argmax: C=%d unsupported (2..4)", C);
     const int64_t total = (int64_t)N * hw;
     const int grid = (int)std::min<int64_t>(cdiv(total, 256), 4096);
     if (C == 2)
         hipLaunchKernelGGL(argmax_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, total, hw, add, labels);
+    else if (C == 3)
+        hipLaunchKernelGGL(argmax_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, total, hw, add, labels);
     else
         hipLaunchKernelGGL(argmax_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, total, hw, add, labels);
     XV2_CHECK_LAUNCH();

@@ -71,6 +71,15 @@ class Model(_Base):
         results = getattr(args, "results", ".")
         self.dllogger = _JsonLogger(os.path.join(results, "%s.json" % getattr(args, "logname", "logs")))
 
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu"):
+        """PL-style: hyper-parameters (the argparse Namespace) travel inside the checkpoint (model/plt.py:23)"""
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        hp = ckpt["hyper_parameters"]
+        model = cls(hp["args"] if isinstance(hp, dict) and "args" in hp else hp)
+        model.load_state_dict(ckpt["state_dict"])
+        return model
+
     def forward(self, img):  # model/plt.py:42-48
         pred = self.model(img)
         if getattr(self.args, "tta", False):

@@ -13,7 +13,7 @@ from ._capi import ConvDesc, Ptr, call, query
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACTS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
-LOSS_DICE, LOSS_FOCAL, LOSS_CE = 1, 2, 4
+LOSS_DICE, LOSS_FOCAL, LOSS_CE, LOSS_MSE, LOSS_CORAL = 1, 2, 4, 8, 16
 
 
 def _need_cuda(t):
