@@ -87,6 +87,8 @@ class GradReducer:
         s, e, _ = self.buckets[b]
         sl = self.opt.flat_g[s:e]
         if self.on_gpu:
+            from . import ops
+            ops.join_wgrad_stream()                        # weight gradients are produced on ops' side stream
             ev = torch.cuda.Event()
             ev.record()                                    # bucket's gradients are complete on the compute stream
             with torch.cuda.stream(self.side):

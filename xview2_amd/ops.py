@@ -130,14 +130,63 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
     return dx0, dx1
 
 
+# Weight gradients are needed only at the optimizer step (or by the gradient all-reduce), so their kernels can run
+# on a side stream concurrently with the backward-data / BatchNorm chain: the tails of the many ~100 us encoder
+# launches overlap instead of serialising.  join_wgrad_stream() is called before anything consumes the gradients.
+ASYNC_WGRAD = True
+_wgrad_stream = None
+
+
+def _side_stream():
+    global _wgrad_stream
+    if _wgrad_stream is None:
+        _wgrad_stream = torch.cuda.Stream()
+    return _wgrad_stream
+
+
+_join_queued = False
+
+
+def join_wgrad_stream():
+    global _join_queued
+    _join_queued = False
+    if _wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(_wgrad_stream)
+
+
 def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
+    global _join_queued
+    # Asynchronous only for the first gradient a parameter receives in a step AND when it goes straight into the
+    # flat buffer: autograd then merely adopts the tensor.  Any other case (plain autograd accumulation, shared
+    # weights' second contribution) involves an accumulation kernel on the compute stream and stays in order.
+    out = grad_slot(weight if wparam is None else wparam) if ASYNC_WGRAD else None
+    if out is None:
+        return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam)
+    if not _join_queued:
+        # the compute stream re-joins the side stream when this backward pass ends, whoever consumes the gradients
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+            _join_queued = True
+        except RuntimeError:      # not inside a backward pass (direct call): stay synchronous
+            return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())          # dy (and x) are ready on the compute stream
+    with torch.cuda.stream(side):
+        dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
+    for t in (x0, x1, dy):                                 # keep the caching allocator from recycling them early
+        if t is not None:
+            t.record_stream(side)
+    return dw
+
+
+def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
     C0g, Coutg = C0t // G, Cout_t // G
     cin_real = weight.shape[1]
-    dw = _grad_like(weight if wparam is None else wparam)
+    dw = out if out is not None else _grad_like(weight if wparam is None else wparam)
     for gi in range(G):
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)

@@ -72,6 +72,7 @@ class FlatAdamW:
             self._lr_on_dev = lr
 
     def step(self, grad_scale=1.0):
+        ops.join_wgrad_stream()      # weight-gradient kernels run on a side stream (ops.ASYNC_WGRAD)
         self._gather_foreign_grads()
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
