@@ -157,18 +157,48 @@ def main():
     for _ in range(opt.warmup):
         run()
     prof = not opt.no_prof
+    from xview2_amd import ops as _xops
+
+    def collect():
+        rows = []
+        for kid in range(_capi.query("xv2_prof_num_kernels")):
+            tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
+                        ctypes.addressof(n))
+            if n.value:
+                rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
+                             "gflop": fl.value / 1e9, "mbytes": by.value / 1e6, "launches": n.value})
+        rows.sort(key=lambda r: -r["ms"])
+        return rows
+
     barrier()
+    if prof and graphed is None:
+        _capi.query("xv2_prof_enable", 1)     # HIP events around every MFMA launch, inside the timed region
     t0 = time.time()
     for _ in range(opt.steps):
         loss = run()
     barrier()
     dt = time.time() - t0
-    if prof:   # roofline leg: the same steps launched eagerly with HIP events around every MFMA launch
-        psteps = min(opt.steps, 5)
+    rows, iso = [], []
+    psteps = opt.steps
+    if prof:
+        if graphed is None:
+            rows = collect()
+        # second leg: the same step with the weight-gradient kernels serialised on the compute stream (no
+        # co-scheduling), i.e. every kernel alone on the chip - the per-kernel roofline without contention
+        _xops.ASYNC_WGRAD = False
+        isteps = min(opt.steps, 4)
+        step()
+        torch.cuda.synchronize()
         _capi.query("xv2_prof_enable", 1)
-        for _ in range(psteps):
+        for _ in range(isteps):
             step()
         torch.cuda.synchronize()
+        iso = collect()
+        _capi.query("xv2_prof_enable", 0)
+        _xops.ASYNC_WGRAD = True
+        if not rows:
+            rows, psteps = iso, isteps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -177,36 +207,31 @@ def main():
     value = world * opt.batch * opt.steps / dt
 
     roof = None
-    if prof:
-        rows = []
-        nk = _capi.query("xv2_prof_num_kernels")
-        for kid in range(nk):
-            tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
-                        ctypes.addressof(n))
-            if n.value:
-                rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
-                             "gflop": fl.value / 1e9, "mbytes": by.value / 1e6, "launches": n.value})
-        _capi.query("xv2_prof_enable", 0)
-        rows.sort(key=lambda r: -r["ms"])
-        if rows:
-            top = rows[0]
-            ach = top["gflop"] / top["ms"]            # GFLOP/ms == TFLOP/s
-            tot_ms, tot_gf = sum(r["ms"] for r in rows), sum(r["gflop"] for r in rows)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
-                traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": top["kernel"],
-                    "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
-                    "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
-                    "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
-                    "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
-                                         "gflop_per_step": round(tot_gf / psteps, 1)},
-                    "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
-                                    "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
-                                   for r in rows]}
+    if prof and rows:
+        top = rows[0]
+        ach = top["gflop"] / top["ms"]            # GFLOP/ms == TFLOP/s
+        tot_ms, tot_gf = sum(r["ms"] for r in rows), sum(r["gflop"] for r in rows)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
+            traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
+        iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": top["kernel"],
+                "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
+                "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
+                "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
+                "note": "timed region co-schedules weight-gradient kernels on a side stream; 'isolated' = same "
+                        "kernel with every launch alone on the chip",
+                "isolated": None if iso_top is None else {
+                    "achieved": round(iso_top["gflop"] / iso_top["ms"], 2),
+                    "frac": round(iso_top["gflop"] / iso_top["ms"] / PEAK_F32_MFMA_TFLOPS, 4),
+                    "avg_launch_us": round(iso_top["ms"] / iso_top["launches"] * 1e3, 2)},
+                "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
+                                     "gflop_per_step": round(tot_gf / psteps, 1)},
+                "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
+                                "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
+                               for r in rows]}
     out = {
         "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
@@ -217,7 +242,7 @@ def main():
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
-        "loss": float(loss), "launch": "hipGraph" if graphed is not None else "eager",
+        "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3, 2),
         "roofline": roof,
     }

@@ -106,7 +106,16 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
         } else {
             mu = *reinterpret_cast<const float4*>(op.a + tx * 4);
         }
-        for (int64_t r = r0 + ty; r < r1; r += rpp) op.apply4(r, tx * 4, f0, f1, mu, is);
+        // two rows in flight per iteration (independent accumulators): more bytes outstanding per lane
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, 0, 0);
+        int64_t r = r0 + ty;
+        for (; r + rpp < r1; r += 2 * rpp) {
+            op.apply4(r, tx * 4, f0, f1, mu, is);
+            op.apply4(r + rpp, tx * 4, g0, g1, mu, is);
+        }
+        if (r < r1) op.apply4(r, tx * 4, f0, f1, mu, is);
+        f0.x += g0.x; f0.y += g0.y; f0.z += g0.z; f0.w += g0.w;
+        f1.x += g1.x; f1.y += g1.y; f1.z += g1.z; f1.w += g1.w;
         float* s = sh + tid * 8;
         s[0] = f0.x; s[1] = f0.y; s[2] = f0.z; s[3] = f0.w;
         s[4] = f1.x; s[5] = f1.y; s[6] = f1.z; s[7] = f1.w;
