@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 (--precision 16 runs only)
 F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
 
 
@@ -88,6 +89,9 @@ def main():
     ap.add_argument("--deep_supervision", action="store_true")
     ap.add_argument("--attention", action="store_true")
     ap.add_argument("--ppm", action="store_true")
+    ap.add_argument("--precision", type=int, default=32, choices=[16, 32],
+                    help="32 = exact fp32 MFMA (BASELINE configs[1], default); 16 = the reference's --precision 16 "
+                         "autocast analogue: conv operands rounded to bf16 in LDS, bf16 MFMA, fp32 accumulate/storage")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,6 +123,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if opt.precision == 16:
+        from xview2_amd import ops as _o
+        _o.MATH_MODE = _o.MATH_BF16
     a = make_args(opt.encoder, opt.type, opt.loss_str or ("dice" if opt.type == "pre" else "focal+dice"),
                   opt.dmg_model, deep_supervision=opt.deep_supervision, attention=opt.attention, ppm=opt.ppm)
     torch.manual_seed(0)
@@ -216,8 +223,9 @@ def main():
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
             traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
         iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": top["kernel"],
+        peak = PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "kernel": top["kernel"],
                 "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
@@ -225,7 +233,7 @@ def main():
                         "kernel with every launch alone on the chip",
                 "isolated": None if iso_top is None else {
                     "achieved": round(iso_top["gflop"] / iso_top["ms"], 2),
-                    "frac": round(iso_top["gflop"] / iso_top["ms"] / PEAK_F32_MFMA_TFLOPS, 4),
+                    "frac": round(iso_top["gflop"] / iso_top["ms"] / peak, 4),
                     "avg_launch_us": round(iso_top["ms"] / iso_top["launches"] * 1e3, 2)},
                 "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
                                      "gflop_per_step": round(tot_gf / psteps, 1)},
@@ -235,12 +243,14 @@ def main():
     out = {
         "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "--type %s%s --encoder %s --loss_str %s%s%s, %dx%d, batch %d per GPU, fp32 train step "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if opt.precision == 32 else "bf16 MFMA operands, f32 accumulate/storage", "data": "synthetic",
+        "config": {"workload": "--type %s%s --encoder %s --loss_str %s%s%s, %dx%d, batch %d per GPU, %s train step "
                                "(fwd+loss+bwd+allreduce+AdamW)" % (
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
-                                   " --attention" if a.attention else "", opt.size, opt.size, opt.batch),
+                                   " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
+                                   "fp32" if opt.precision == 32 else "precision-16 (bf16 MFMA)"),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3, 2),

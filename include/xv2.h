@@ -47,7 +47,11 @@ typedef struct xv2_conv_desc {
     int32_t Cout;               /* output channels, multiple of 32 */
     int32_t KH, KW, stride, pad, dil;
     int32_t OH, OW;             /* output height / width */
+    int32_t math;               /* XV2_MATH_F32 (exact fp32 MFMA) or XV2_MATH_BF16 (operands rounded to bf16 in
+                                   LDS, bf16 MFMA, fp32 accumulate: the reference's --precision 16 autocast) */
 } xv2_conv_desc;
+#define XV2_MATH_F32 0
+#define XV2_MATH_BF16 1
 
 /* weight repacking: w_oihw[Cout][Cin][KH][KW] (the reference's state_dict layout)
  *   -> w_ohwi[Cout][KH*KW][CinP]  (forward operand; CinP = Cin padded to `cin_pad`)

@@ -44,6 +44,8 @@ def prof_time(fn, iters=10):
 
 
 def main():
+    if os.environ.get("XV2_MATH") == "1":
+        ops.MATH_MODE = ops.MATH_BF16
     filt = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 20
     for i, a in enumerate(sys.argv):

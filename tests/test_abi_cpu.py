@@ -28,11 +28,11 @@ def test_header_prototypes_parse_and_bind():
     assert rt is ctypes.c_int and len(argt) == 12
     assert protos["xv2_conv2d_backward_weight_workspace"][0] is ctypes.c_size_t
     # argument validation is reachable without a GPU: a bad descriptor must come back as XV2_EINVAL + message
-    d = _capi.ConvDesc(1, 8, 8, 33, 0, 32, 3, 3, 1, 1, 1, 8, 8)
+    d = _capi.ConvDesc(1, 8, 8, 33, 0, 32, 3, 3, 1, 1, 1, 8, 8, 0)
     f = _capi._func("xv2_conv2d_forward")
     rc = f(ctypes.addressof(d), None, 33, None, 0, None, None, None, 32, None, None, None)
     assert rc == 1 and b"multiples of 32" in _lib.lib().xv2_last_error()
-    assert _capi.query("xv2_conv2d_backward_weight_workspace", _capi.ConvDesc(2, 64, 64, 64, 0, 64, 3, 3, 1, 1, 1, 64, 64)) > 0
+    assert _capi.query("xv2_conv2d_backward_weight_workspace", _capi.ConvDesc(2, 64, 64, 64, 0, 64, 3, 3, 1, 1, 1, 64, 64, 0)) > 0
 
 
 def test_product_path_fails_loudly_without_gpu():

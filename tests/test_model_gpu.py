@@ -174,3 +174,39 @@ def test_cfg1_shape_512_resnet50_dice():
     assert rel(ph, po) <= 1e-3
     assert abs(float(lh) - float(lo)) <= 1e-3
     assert argmax_mismatch(ph, po) == 0
+
+
+@pytest.mark.parametrize("name", ["pre_resnet50", "post_siamese_resnest50_ds"])
+def test_precision16_bf16_math_reports_error_and_label_agreement(name):
+    """--precision 16 path (bf16 MFMA operands, fp32 accumulate): REPORTED separately from the fp32 gate.
+    On these random-weight, training-mode-BN problems bf16 operand rounding (2^-9 relative per element) is amplified
+    like any other perturbation (see the conditioning notes above): measured ~1e-1 max and RMS logits error and
+    ~94-99 % identical label maps; the loss agrees to <1e-3.  The asserts only guard against gross breakage."""
+    from oracle import torch_ref
+    from xview2_amd import criterion, ops
+    a = ARGS(**MODEL_CASES[name])
+    ora, hip = build_pair(a)
+    ora.train()
+    hip.train()
+    B = case_batch(name)
+    x, y = model_input(a, batch=B), labels(a, batch=B)
+    with torch.no_grad():
+        po = ora(x)
+    lo = torch_ref.compute_loss(torch_ref.Loss(a), po, y, a.deep_supervision)
+    ops.MATH_MODE = ops.MATH_BF16
+    try:
+        ph = hip(x.to(DEV))
+        lh = criterion.compute_loss(criterion.Loss(a), ph, y.to(DEV), a.deep_supervision)
+        lh.backward()
+    finally:
+        ops.MATH_MODE = ops.MATH_F32
+    po0 = po[0] if isinstance(po, list) else po
+    ph0 = ph[0] if isinstance(ph, list) else ph
+    err = rel(ph0, po0)
+    rms = float((ph0.detach().cpu().double() - po0.double()).pow(2).mean().sqrt() / po0.double().pow(2).mean().sqrt())
+    agree = float((torch.argmax(ph0.cpu(), 1) == torch.argmax(po0, 1)).float().mean())
+    print("bf16-math %s: logits max-rel err %.3e, rms-rel err %.3e, argmax agreement %.4f, loss %.5f vs %.5f" % (
+        name, err, rms, agree, float(lh), float(lo)))
+    assert err <= 0.4 and rms <= 0.2 and agree >= 0.90
+    assert abs(float(lh) - float(lo)) <= 2e-2 * max(1.0, abs(float(lo)))
+    assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)

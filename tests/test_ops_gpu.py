@@ -348,3 +348,50 @@ def test_loss_deep_supervision_label_stride():
     assert abs(float(lh) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
     for g, r in zip(pg, pr):
         close(g.grad, r.grad, 2e-5, "ds dlogits")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 0, 64, 3, 1, 1), (1, 20, 12, 128, 64, 128, 3, 1, 1),
+                                  (2, 16, 16, 256, 0, 64, 1, 2, 0), (1, 40, 40, 32, 0, 32, 3, 1, 1),
+                                  (2, 8, 8, 512, 0, 512, 3, 1, 1), (1, 17, 19, 64, 0, 128, 3, 2, 1)])
+def test_conv_bf16_math_mode(case):
+    """XV2_MATH_BF16: operands rounded to bf16 (RNE) inside the kernel, bf16 MFMA, fp32 accumulation.  The exact
+    reference is an fp32 convolution of the bf16-rounded operands (products of bf16 numbers are exact in fp32)."""
+    from xview2_amd import ops
+    N, H, W, C0, C1, Cout, k, s, p = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(N, C0 + C1, H, W)
+    w = torch.randn(Cout, C0 + C1, k, k) * 0.05
+    rb = lambda t: t.bfloat16().float()
+    xr, wr = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    g = ops.conv_cfg(k, k, s, p, math=ops.MATH_BF16)
+    a0 = nhwc(x[:, :C0])
+    a1 = nhwc(x[:, C0:]) if C1 else None
+    y, _ = ops._conv_forward(a0, a1, w.to(dev()), g)
+    close(nchw(y), yr, 2e-4, "bf16 fwd")
+    # backward-data: dy and w are the rounded operands
+    dxr = torch.autograd.grad(F.conv2d(xr, wr, None, s, p), xr, rb(dy))[0]
+    dx0, dx1 = ops._conv_backward_data(nhwc(dy), w.to(dev()), g, (N, H, W), C0, C1)
+    dx = nchw(dx0) if not C1 else torch.cat([nchw(dx0), nchw(dx1)], 1)
+    close(dx, dxr, 2e-4, "bf16 dgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 0, 64, 3, 1, 1), (1, 32, 32, 128, 64, 128, 3, 1, 1),
+                                  (2, 16, 16, 256, 0, 64, 1, 1, 0), (1, 64, 64, 64, 0, 32, 3, 1, 1),
+                                  (1, 17, 19, 64, 0, 128, 3, 2, 1)])
+def test_conv_weight_gradient_bf16_math_mode(case):
+    from xview2_amd import ops
+    N, H, W, C0, C1, Cout, k, s, p = case
+    torch.manual_seed(sum(case))
+    rb = lambda t: t.bfloat16().float()
+    x = torch.randn(N, C0 + C1, H, W)
+    w = (torch.randn(Cout, C0 + C1, k, k) * 0.05).requires_grad_(True)
+    y = F.conv2d(rb(x), w, None, s, p)
+    dy = torch.randn_like(y)
+    dwr = torch.autograd.grad(y, w, rb(dy))[0]
+    g = ops.conv_cfg(k, k, s, p, math=ops.MATH_BF16)
+    a0 = nhwc(x[:, :C0])
+    a1 = nhwc(x[:, C0:]) if C1 else None
+    dw = ops._conv_backward_weight_impl(a0, a1, nhwc(dy), w.detach().to(dev()), g)
+    close(dw, dwr, 3e-4, "bf16 wgrad")

@@ -18,7 +18,7 @@ _CT = {
 class ConvDesc(ctypes.Structure):
     """Mirror of xv2_conv_desc."""
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("N", "IH", "IW", "C0", "C1", "Cout", "KH", "KW", "stride", "pad", "dil", "OH", "OW")]
+                ("N", "IH", "IW", "C0", "C1", "Cout", "KH", "KW", "stride", "pad", "dil", "OH", "OW", "math")]
 
     def key(self):
         return tuple(getattr(self, f[0]) for f in self._fields_)

@@ -68,6 +68,7 @@ struct IgemmParams {
     int cpt;           // 32-channel chunks per tap (Ctot/32)
     int ksplit, kt_per_split;
     int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
+    int math;          // 0 = fp32 MFMA, 1 = bf16 MFMA on fp32 operands (fp32 accumulate)
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];
@@ -78,7 +79,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC>
+// bf16-compute variant ("--precision 16"): operands stay fp32 in HBM, are rounded to bf16 (RNE) while being staged
+// into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything outside the MFMA is unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: conflict-free 16-byte fragment reads)
+
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
@@ -235,6 +242,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #if XV2_ABL & 2
         return;
 #endif
+        if constexpr (BF16) {
+            __bf16* a = reinterpret_cast<__bf16*>(smem) + buf * (BM + BN) * LDS_LD_H;
+            __bf16* b = a + BM * LDS_LD_H;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                bf16x4 v = {(__bf16)ra[j].x, (__bf16)ra[j].y, (__bf16)ra[j].z, (__bf16)ra[j].w};
+                *reinterpret_cast<bf16x4*>(a + (r0 + 32 * j) * LDS_LD_H + c4 * 4) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) {
+                bf16x4 v = {(__bf16)rb[j].x, (__bf16)rb[j].y, (__bf16)rb[j].z, (__bf16)rb[j].w};
+                *reinterpret_cast<bf16x4*>(b + (r0 + 32 * j) * LDS_LD_H + c4 * 4) = v;
+            }
+            return;
+        }
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -266,6 +288,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         if (kt + 1 < kt_end) {
             lstore(buf ^ 1);
             if (kt + 2 < kt_end) gload(kt + 2);
+        }
+        if constexpr (BF16) {
+            const __bf16* ha = reinterpret_cast<const __bf16*>(smem) + buf * (BM + BN) * LDS_LD_H;
+            const __bf16* a = ha + (wm * WTM + l31) * LDS_LD_H + 8 * h;
+            const __bf16* b = ha + BM * LDS_LD_H + (wn * WTN + l31) * LDS_LD_H + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[MR], bf[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_LD_H + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_LD_H + ks * 16);
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            continue;
         }
         const float* a = As + buf * BM * LDS_LD + (wm * WTM + l31) * LDS_LD + 4 * h;
         const float* b = Bs + buf * BN * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * h;
@@ -436,11 +478,11 @@ constexpr size_t igemm_smem_bytes() {
     return (size_t)(2 * (BM + BN) * LDS_LD) * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC>
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     constexpr size_t smem = igemm_smem_bytes<BM, BN>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC>;
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16>;
     if (!attr_set) {
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -449,7 +491,8 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static int kid = -1;
     if (kid < 0) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, SMALLC ? "rgb" : "c32");
+        snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
+                 SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"));
         kid = prof_register(nm);
     }
     IgemmParams q = p;
@@ -539,7 +582,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         p.kt_per_split = mk;
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
-        int rc = launch_one<128, 128, 2, 2, false>(p, stream);
+        int rc = p.math ? launch_one<128, 128, 2, 2, false, true>(p, stream)
+                        : launch_one<128, 128, 2, 2, false>(p, stream);
         if (rc) return rc;
         const int M = p.cls[0].M;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256)),
@@ -552,6 +596,17 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (bn == 128) return launch_one<128, 128, 2, 2, true>(p, stream);
         if (bn == 64) return launch_one<128, 64, 2, 2, true>(p, stream);
         return launch_one<128, 32, 4, 1, true>(p, stream);
+    }
+    if (p.math) {
+        if (bn == 128) {
+            if (bm == 128) return launch_one<128, 128, 2, 2, false, true>(p, stream);
+            return launch_one<64, 128, 2, 2, false, true>(p, stream);
+        }
+        if (bn == 64) {
+            if (bm == 128) return launch_one<128, 64, 2, 2, false, true>(p, stream);
+            return launch_one<64, 64, 2, 2, false, true>(p, stream);
+        }
+        return launch_one<128, 32, 4, 1, false, true>(p, stream);
     }
     if (bn == 128) {
         if (bm == 128) return launch_one<128, 128, 2, 2, false>(p, stream);
@@ -577,6 +632,8 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.part = nullptr;
     p.ksplit = 1;
     p.cin_real = 3;
+    p.math = d->math;
+    XV2_CHECK_ARG(d->math == 0 || d->math == 1, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
     p.ncls = 1;

@@ -37,7 +37,11 @@ struct WgradParams {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16 = true: XV2_MATH_BF16 - the fp32 LDS tiles are kept, each lane gathers 8 consecutive pixels of its channel,
+// rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16 (8x fewer matrix instructions, fp32 accumulate).
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     constexpr int MR = BM / WGM / 32, NR = BN / WGN / 32;
     static_assert(WGM * WGN * WK == 4, "4 waves");
@@ -197,6 +201,29 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         }
         const float* a = As + buf * 32 * BM + wm * (MR * 32) + l31;
         const float* bb = Bs + buf * 32 * BN + wn * (NR * 32) + l31;
+        if constexpr (BF16) {
+            static_assert(!BF16 || WK <= 2, "bf16 wgrad splits at most 2 ways over a 32-pixel tile");
+#pragma unroll
+            for (int ks0 = 0; ks0 < 2 / WK; ++ks0) {
+                const int ks = ks0 * WK + wk;
+                bf16x8 af[MR], bf[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) af[i][q] = (__bf16)a[(16 * ks + 8 * h + q) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bf[j][q] = (__bf16)bb[(16 * ks + 8 * h + q) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int s0 = 0; s0 < 16 / WK; ++s0) {
             const int s = s0 * WK + wk;
@@ -343,14 +370,15 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     return pl;
 }
 
-template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC>
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 32 * (BM + BN) * 4;
-    auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC>;
+    auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC, BF16>;
     static int kid = -1;
     if (kid < 0) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, WK, SMALLC ? "rgb" : "c32");
+        snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, WK,
+                 SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"));
         kid = prof_register(nm);
     }
     const double creal = SMALLC ? 3.0 : (double)p.Ctot;
@@ -398,6 +426,11 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     if (pl.smallc) {
         if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
+    } else if (d->math == XV2_MATH_BF16 && !(pl.bm == 32 && pl.bn == 32)) {
+        if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false, true>(p, pl, stream);
+        else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false, true>(p, pl, stream);
+        else if (pl.bm == 64 && pl.bn == 32) rc = launch_wgrad<64, 32, 2, 1, 2, false, true>(p, pl, stream);
+        else rc = launch_wgrad<32, 64, 1, 2, 2, false, true>(p, pl, stream);
     } else if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false>(p, pl, stream);
     else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false>(p, pl, stream);
     else if (pl.bm == 64 && pl.bn == 32) rc = launch_wgrad<64, 32, 2, 1, 2, false>(p, pl, stream);

@@ -50,8 +50,9 @@ def _grad_like(param, like=None):
     return g
 
 
-def conv_cfg(kh, kw=None, stride=1, pad=0, dil=1, groups=1):
-    return SimpleNamespace(kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, dil=dil, groups=groups)
+def conv_cfg(kh, kw=None, stride=1, pad=0, dil=1, groups=1, math=None):
+    return SimpleNamespace(kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, dil=dil, groups=groups,
+                           math=math)
 
 
 def _out_hw(IH, IW, g):
@@ -60,8 +61,13 @@ def _out_hw(IH, IW, g):
     return OH, OW
 
 
+MATH_F32, MATH_BF16 = 0, 1
+MATH_MODE = MATH_F32     # process-wide default (set from --precision by the trainer / bench)
+
+
 def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW):
-    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW)
+    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW,
+                    getattr(g, "math", None) if getattr(g, "math", None) is not None else MATH_MODE)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 every epoch driving ``f1_score`` checkpointing (ModelCheckpoint(monitor="f1_score", mode="max", save_last=True)),
 resume.  Checkpoints keep PL's layout ``{"state_dict": ..., "hyper_parameters": {"args": ...}, "epoch": ...}`` with the
 reference's key names (``model.unet.enc_l1.0.weight`` ...), so files move between the two code bases.
-``precision=16`` (the reference's fp16 AMP) is accepted for CLI compatibility and runs the fp32 kernels."""
+``precision=16`` (the reference's fp16 AMP) selects XV2_MATH_BF16: bf16 MFMA with fp32 accumulation/storage."""
 import os
 
 import torch
@@ -20,6 +20,10 @@ class Trainer:
         self.sync_batchnorm, self.resume = sync_batchnorm, resume_from_checkpoint
         self.checkpointing = bool(checkpoint_callback)
         self.log_every = log_every
+        from . import ops
+        # the reference's --precision 16 is fp16 autocast (convs in half precision, fp32 accumulate, fp32 BN/master
+        # weights); here: bf16 MFMA on bf16-rounded operands with everything else in fp32
+        ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.MATH_F32
         self.rank, self.local_rank, self.world = xdist.init_from_env()
         self.device = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.device)
