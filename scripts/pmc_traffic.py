@@ -28,8 +28,10 @@ def pretty(mangled):
     args = re.findall(r"L([ib])(\d+)E", m.group(2))
     vals = [int(v) for _, v in args]
     if m.group(1) == "igemm":
-        return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], "rgb" if vals[4] else "c32")
-    return "wgrad_kernel<%d,%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], vals[4], "rgb" if vals[5] else "c32")
+        tag = "rgb" if vals[4] else ("c32,bf16" if len(vals) > 5 and vals[5] else "c32")
+        return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], tag)
+    tag = "rgb" if vals[5] else ("c32,bf16" if len(vals) > 6 and vals[6] else "c32")
+    return "wgrad_kernel<%d,%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], vals[4], tag)
 
 
 f, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
