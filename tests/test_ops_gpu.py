@@ -42,6 +42,11 @@ CONV_CASES = [
     (1, 40, 40, 32, 0, 32, 3, 1, 1, 1, 1),
     (2, 8, 8, 512, 0, 512, 3, 1, 1, 1, 1),
     (1, 64, 64, 64, 0, 64, 3, 1, 1, 1, 1),
+    # 32 output channels, W % 32 == 0, H % 4 == 0: the LDS-resident direct kernel (direct_conv.hip)
+    (1, 64, 64, 32, 0, 32, 3, 1, 1, 1, 1),
+    (2, 8, 64, 32, 32, 32, 3, 1, 1, 1, 1),
+    (1, 32, 32, 64, 0, 32, 3, 1, 1, 1, 1),
+    (2, 12, 96, 32, 0, 32, 3, 1, 1, 1, 1),
 ]
 
 

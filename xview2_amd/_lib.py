@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("XV2_LIB", os.path.join(_HERE, "libxv2.so"))
-SOURCES = ["errors.cpp", "igemm_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
+SOURCES = ["errors.cpp", "igemm_conv.hip", "direct_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
            "loss_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -27,7 +27,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "xv2_common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "xv2_common.h"), os.path.join(CSRC, "igemm_params.h"),
                                                       os.path.join(_HERE, "..", "include", "xv2.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

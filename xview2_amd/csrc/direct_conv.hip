@@ -1,0 +1,173 @@
+// Direct 3x3 / stride-1 convolution for 32 -> 32 channel layers (the 1024x1024 decoder level: dec5 forward and
+// backward-data, ResNeSt stem): fp32 MFMA with the WEIGHTS and the INPUT HALO resident in LDS.
+//
+// Why: with only 32 output channels the implicit-GEMM tile re-fetches every input pixel once per tap (9x) for a
+// 128x32 output tile, i.e. 13 FLOP per byte pulled through the per-CU L1/TA path, and that path, not the MFMA
+// pipe, set the pace (measured: 72 TFLOP/s; without the loads 122).  Here a PERSISTENT block loads the whole
+// 32x9x32 weight tensor (41 KB) once and then walks over 4 x 32 pixel output patches: the 6 x 34 pixel halo of a
+// patch (29 KB) is prefetched into registers while the previous patch's 9 taps run out of LDS with shifted
+// fragment addresses - one global byte per ~60 FLOP.  The 32-channel output rows are whole 128-byte lines, so the
+// accumulators are stored straight from registers.
+//
+// Same contract as igemm_kernel for this shape class (tap list with |dh|,|dw| <= 1, bias, BatchNorm partial sums
+// per 128-pixel tile, deterministic).  model/layers.py:92 (ConvLayer 3x3) at decoder level 5 and its backward-data.
+#include "igemm_params.h"
+#include <algorithm>
+
+namespace xv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D_TH = 4, D_TW = 32, D_HW = D_TW + 2, D_HH = D_TH + 2, D_LD = 36;
+constexpr int D_HALO = D_HH * D_HW;                       // 204 pixels
+constexpr int D_HLOADS = (D_HALO * 8 + 255) / 256;        // float4 per thread per halo (7)
+constexpr size_t D_SMEM = (size_t)(D_HALO * D_LD + 9 * 32 * D_LD) * 4 + 4 * 32 * 2 * 4;
+
+__global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                         // [204][36]
+    float* wts = smem + D_HALO * D_LD;          // [9][32][36]
+    float* red = wts + 9 * 32 * D_LD;           // [4][32][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const ClassInfo ci = p.cls[0];
+    const int OH = ci.OHl, OW = ci.OWl;
+    const int tiles_w = OW / D_TW, tiles_h = OH / D_TH;
+
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
+
+    // contiguous range of patches per block (neighbouring patches share halo columns in L2)
+    const int per = (npatches + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = min(p0 + per, npatches);
+    if (p0 >= p1) return;
+
+    // weights, once: [tap][n][32 channels]
+    for (int e = tid; e < 9 * 32 * 8; e += 256) {
+        const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
+        const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
+        *reinterpret_cast<i32x4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+    }
+
+    i32x4 hr[D_HLOADS];
+    auto hload = [&](int patch) {
+        const int tw = patch % tiles_w;
+        const int th = (patch / tiles_w) % tiles_h;
+        const int n = patch / (tiles_w * tiles_h);
+        const int oh0 = th * D_TH, ow0 = tw * D_TW;
+#pragma unroll
+        for (int j = 0; j < D_HLOADS; ++j) {
+            const int e = tid + j * 256;
+            const int px = e >> 3, c4 = e & 7;
+            const int r = px / D_HW, c = px - r * D_HW;
+            const int ih = oh0 - 1 + r, iw = ow0 - 1 + c;
+            const bool ok = e < D_HALO * 8 && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const int off = ok ? ((((n * p.IH + ih) * p.IW + iw) * p.ldA0 + c4 * 4) << 2) : (int)0x80000000;
+            hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+        }
+    };
+    auto hstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < D_HLOADS; ++j) {
+            const int e = tid + j * 256;
+            if (e < D_HALO * 8) *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
+        }
+    };
+
+    hload(p0);
+    hstore();
+    __syncthreads();
+    for (int patch = p0; patch < p1; ++patch) {
+        if (patch + 1 < p1) hload(patch + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // 9 taps x 32 channels out of LDS; wave = output row, lane&31 = output column
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dh = p.taps[t].dh, dw = p.taps[t].dw;
+            const float* a = halo + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LD + 4 * h;
+            const float* b = wts + (t * 32 + l31) * D_LD + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float4 af = *reinterpret_cast<const float4*>(a + kk * 8);
+                const float4 bf = *reinterpret_cast<const float4*>(b + kk * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+            }
+        }
+        // epilogue straight from registers: a pixel's 32 channels are one 128-byte line (lanes 0..31)
+        const int tw = patch % tiles_w;
+        const int th = (patch / tiles_w) % tiles_h;
+        const int n = patch / (tiles_w * tiles_h);
+        const size_t rowpix = ((size_t)n * OH + th * D_TH + wave) * OW + tw * D_TW;
+        const float bv = p.bias ? p.bias[l31] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = (r & 3) + 8 * (r >> 2) + 4 * h;          // pixel column inside the wave's row
+            p.Out0[(rowpix + col) * p.ldo0 + l31] = acc[r] + bv;
+            s1 += acc[r];
+            s2 += acc[r] * acc[r];
+        }
+        if (p.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                red[(wave * 32 + l31) * 2 + 0] = s1;
+                red[(wave * 32 + l31) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();                       // halo fully consumed, red complete
+        if (p.stats && tid < 32) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a1 += red[(w * 32 + tid) * 2 + 0];
+                a2 += red[(w * 32 + tid) * 2 + 1];
+            }
+            float* st = p.stats + ((size_t)patch * 32 + tid) * 2;
+            st[0] = a1;
+            st[1] = a2;
+        }
+        if (patch + 1 < p1) hstore();
+        __syncthreads();
+    }
+}
+
+bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
+    if (smallc || p.math != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
+    const ClassInfo& c = p.cls[0];
+    if (c.ntaps != 9 || c.tap0 != 0 || c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl) return false;
+    if (c.OWl % D_TW != 0 || c.OHl % D_TH != 0 || c.OHl != p.IH || c.OWl != p.IW) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.taps[t].dh < -1 || p.taps[t].dh > 1 || p.taps[t].dw < -1 || p.taps[t].dw > 1) return false;
+    return p.Ctot == 32 && p.C1 == 0;
+}
+
+int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    static int kid = -1;
+    if (!attr_set) {
+        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
+        attr_set = true;
+        kid = prof_register("direct3x3_n32_kernel");
+    }
+    const ClassInfo& c = p.cls[0];
+    const int npatches = c.M / (D_TH * D_TW);
+    const int grid = std::min(npatches, 512);      // persistent: 2 blocks per CU, each walks a run of patches
+    const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
+    const double abytes = 4.0 * ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
+    prof_begin(kid, flops, abytes, stream);
+    hipLaunchKernelGGL(direct3x3_n32_kernel, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+    prof_end(stream);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+}  // namespace xv2

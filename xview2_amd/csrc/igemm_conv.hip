@@ -19,7 +19,7 @@
 // (lane half h owns k = 8*kk + 4*h + s) identically for A and B, which leaves the sum intact.
 // Epilogue: optional bias, scattered NHWC store through a per-row pixel-offset table, and
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
-#include "xv2_common.h"
+#include "igemm_params.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -32,51 +32,8 @@
 
 namespace xv2 {
 
-struct Tap {
-    short dh, dw;
-    int slot;
-};
-
-// one output-parity class of a strided backward-data (a plain convolution has exactly one class)
-struct ClassInfo {
-    int tap0, ntaps;   // slice of taps[]
-    int OHl, OWl;      // logical output grid of the class
-    int M;             // N * OHl * OWl
-    int os0;           // pixel offset of the class inside the output image
-    int nkt;           // K tiles
-    int mtiles;        // ceil(M / BM)
-};
-
-struct IgemmParams {
-    const float* A0;
-    const float* A1;
-    const float* B;
-    const float* bias;
-    float* Out0;
-    float* Out1;
-    float* stats;
-    float* part;       // split-K slabs [ksplit][M][Nout] (ksplit > 1 only)
-    unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
-    int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
-    int ldA0, ldA1;
-    int IH, IW;        // spatial size of A
-    int s_in;
-    int osN, osH, osW; // output pixel index = n*osN + a*osH + b*osW + os0
-    int Nout, N0;      // GEMM N; columns < N0 go to Out0 (ld ldo0), others to Out1 (ldo1)
-    int ldo0, ldo1;
-    int T;             // tap slots per B row
-    int cpt;           // 32-channel chunks per tap (Ctot/32)
-    int ksplit, kt_per_split;
-    int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
-    int math;          // 0 = fp32 MFMA, 1 = bf16 MFMA on fp32 operands (fp32 accumulate)
-    int ncls;
-    ClassInfo cls[4];
-    Tap taps[52];
-};
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
 // bf16-compute variant ("--precision 16"): operands stay fp32 in HBM, are rounded to bf16 (RNE) while being staged
@@ -572,6 +529,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     int bm, bn, ks;
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, p.cls[c].M);
+    if (direct3x3_eligible(p, smallc)) return direct3x3_launch(p, stream);
     pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
     p.ksplit = ks;
     p.part = splitk_ws;

@@ -1,0 +1,55 @@
+// Shared launch parameters of the gather-GEMM convolution kernels (igemm_conv.hip, direct_conv.hip).
+#pragma once
+#include "xv2_common.h"
+
+namespace xv2 {
+
+struct Tap {
+    short dh, dw;
+    int slot;
+};
+
+// one output-parity class of a strided backward-data (a plain convolution has exactly one class)
+struct ClassInfo {
+    int tap0, ntaps;   // slice of taps[]
+    int OHl, OWl;      // logical output grid of the class
+    int M;             // N * OHl * OWl
+    int os0;           // pixel offset of the class inside the output image
+    int nkt;           // K tiles
+    int mtiles;        // ceil(M / BM)
+};
+
+struct IgemmParams {
+    const float* A0;
+    const float* A1;
+    const float* B;
+    const float* bias;
+    float* Out0;
+    float* Out1;
+    float* stats;
+    float* part;       // split-K slabs [ksplit][M][Nout] (ksplit > 1 only)
+    unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
+    int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
+    int ldA0, ldA1;
+    int IH, IW;        // spatial size of A
+    int s_in;
+    int osN, osH, osW; // output pixel index = n*osN + a*osH + b*osW + os0
+    int Nout, N0;      // GEMM N; columns < N0 go to Out0 (ld ldo0), others to Out1 (ldo1)
+    int ldo0, ldo1;
+    int T;             // tap slots per B row
+    int cpt;           // 32-channel chunks per tap (Ctot/32)
+    int ksplit, kt_per_split;
+    int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
+    int math;          // 0 = fp32 MFMA, 1 = bf16 MFMA on fp32 operands (fp32 accumulate)
+    int ncls;
+    ClassInfo cls[4];
+    Tap taps[52];
+};
+
+constexpr int BK = 32;
+
+// direct_conv.hip: 3x3 / stride 1 convolutions 32 -> 32 channels keep the weights and the input halo in LDS
+bool direct3x3_eligible(const IgemmParams& p, bool smallc);
+int direct3x3_launch(const IgemmParams& p, hipStream_t stream);
+
+}  // namespace xv2

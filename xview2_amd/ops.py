@@ -4,6 +4,7 @@ Every Function here owns its backward analytically (no torch op is differentiate
 backward both go through the C ABI.  Activations are NHWC tensors ``[N, H, W, C]`` (contiguous).
 PyTorch is used for device memory, streams and autograd bookkeeping only.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -139,7 +140,7 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
 # Weight gradients are needed only at the optimizer step (or by the gradient all-reduce), so their kernels can run
 # on a side stream concurrently with the backward-data / BatchNorm chain: the tails of the many ~100 us encoder
 # launches overlap instead of serialising.  join_wgrad_stream() is called before anything consumes the gradients.
-ASYNC_WGRAD = True
+ASYNC_WGRAD = os.environ.get("XV2_ASYNC_WGRAD", "1") != "0"
 _wgrad_stream = None
 
 
