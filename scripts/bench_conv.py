@@ -82,7 +82,9 @@ def main():
         tf = prof_time(lambda: ops._conv_forward(x0, x1, w, g, None, True))
         td = prof_time(lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))
         tw = prof_time(lambda: ops._conv_backward_weight(x0, x1, dy, w, g))
-        print("%-30s %8.1f | %8.1f %8.1f %8.1f   %.3f %.3f %.3f" % (name, gf, gf / tf, gf / td, gf / tw, tf, td, tw))
+        tww = timeit(lambda: ops._conv_backward_weight(x0, x1, dy, w, g))   # incl. slab reduce
+        print("%-30s %8.1f | %8.1f %8.1f %8.1f   %.3f %.3f %.3f  (wgrad+reduce %.3f)" %
+              (name, gf, gf / tf, gf / td, gf / tw, tf, td, tw, tww))
         tot[0] += gf; tot[1] += tf; tot[2] += td; tot[3] += tw
     print("sum: %.1f GFLOP  fwd %.1f dgrad %.1f wgrad %.1f TF" % (tot[0], tot[0] / tot[1], tot[0] / tot[2], tot[0] / tot[3]))
 

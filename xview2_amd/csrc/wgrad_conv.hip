@@ -265,6 +265,146 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// All-taps variant for 3x3 / stride 1 / pad 1 layers with few channels (the 1024x1024 decoder level, 32 -> 32).
+// The per-tap kernel above re-reads the dY tile and a shifted X tile for every tap: 8 KB of L2->LDS traffic per
+// 16 MFMAs per wave set, which is what bounds it at ~58 TFLOP/s for a 32x32 tile.  Here one block owns a
+// (32 co x 32 ci) tile for ALL 9 taps (9 accumulators = 144 VGPRs per lane) and walks DOWN a 32-pixel-wide column
+// strip: per output row it pulls ONE new input row (34 pixels incl. halo) into a 4-row LDS ring and one dY row -
+// 8.4 KB per 36 MFMAs per wave.  The 4 waves split the 16 k-steps of a row (WK = 4) and are summed through LDS at
+// the end, so a block emits one slab.  model/layers.py:92 (ConvLayer 3x3) weight gradient.
+__global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * 32 + 4 * 34 * 32];
+    float* dYs = smem;                 // [2][32 px][32 co]
+    float* Xs = smem + 2 * 32 * 32;    // [4 ring rows][34 px][32 ci]
+
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int co0 = tm * 32, cn0 = tn * 32;
+    const int chunks = p.ktiles, rows_per = p.kt_per_split;
+    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int tilesW = p.OW / 32;
+    const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
+    const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
+
+    const float* xsrc;
+    int ldx, xch;
+    if (cn0 < p.C0) {
+        xsrc = p.X0; ldx = p.ldX0; xch = cn0;
+    } else {
+        xsrc = p.X1; ldx = p.ldX1; xch = cn0 - p.C0;
+    }
+    const int px = tid >> 3, c4 = tid & 7;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 rd, rx0, rx1;
+    auto load_dy = [&](int r) {
+        rd = *reinterpret_cast<const float4*>(p.DY + (((size_t)n * p.OH + r) * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4);
+    };
+    auto load_x = [&](int ih) {      // input row ih, pixels ow0-1 .. ow0+32
+        rx0 = zero4;
+        rx1 = zero4;
+        if ((unsigned)ih < (unsigned)p.IH) {
+            const float* row = xsrc + ((size_t)n * p.IH + ih) * p.IW * ldx + xch + c4 * 4;
+            const int iw = ow0 - 1 + px;
+            if (iw >= 0) rx0 = *reinterpret_cast<const float4*>(row + (size_t)iw * ldx);
+            if (tid < 16 && iw + 32 < p.IW) rx1 = *reinterpret_cast<const float4*>(row + (size_t)(iw + 32) * ldx);
+        }
+    };
+    auto store_dy = [&](int buf) { *reinterpret_cast<float4*>(dYs + buf * 1024 + px * 32 + c4 * 4) = rd; };
+    auto store_x = [&](int ih) {
+        float* ring = Xs + ((ih + 4) & 3) * (34 * 32);
+        *reinterpret_cast<float4*>(ring + px * 32 + c4 * 4) = rx0;
+        if (tid < 16) *reinterpret_cast<float4*>(ring + (px + 32) * 32 + c4 * 4) = rx1;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // prologue: rows r0-1, r0, r0+1 and dY(r0)
+    load_x(r0 - 1);
+    store_x(r0 - 1);
+    load_x(r0);
+    store_x(r0);
+    load_x(r0 + 1);
+    store_x(r0 + 1);
+    load_dy(r0);
+    store_dy(0);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            load_dy(r + 1);
+            load_x(r + 2);
+        }
+        const float* a = dYs + buf * 1024 + l31;
+        const float* x0 = Xs + ((r + 3) & 3) * (34 * 32) + l31;   // row r-1
+        const float* x1 = Xs + (r & 3) * (34 * 32) + l31;         // row r
+        const float* x2 = Xs + ((r + 1) & 3) * (34 * 32) + l31;   // row r+1
+#pragma unroll
+        for (int s0 = 0; s0 < 4; ++s0) {
+            const int q = 2 * (s0 * 4 + wk) + h;
+            const float af = a[q * 32];
+            float bf[9];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                bf[kw] = x0[(q + kw) * 32];
+                bf[3 + kw] = x1[(q + kw) * 32];
+                bf[6 + kw] = x2[(q + kw) * 32];
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[t], acc[t], 0, 0, 0);
+        }
+        if (more) {
+            store_dy(buf ^ 1);    // last read in step r-1 (all waves are past its barrier)
+            store_x(r + 2);       // ring slot of row r-2, idem
+        }
+        __syncthreads();
+    }
+
+    // sum the 4 waves' k-partials through LDS (16 KB per tap) and write the block's slab part[y][co][T][Ctot]
+    const size_t rowlen = (size_t)9 * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            const float v = (smem[e] + smem[1024 + e]) + (smem[2048 + e] + smem[3072 + e]);
+            const int r = e >> 6, ln = e & 63;
+            const int row = co0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + (ln & 31)] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// first stage of a two-level slab sum (many slabs, few elements): out2[g][i] = sum over the g-th group of slabs
+__global__ void wgrad_reduce_stage1_kernel(const float* __restrict__ part, int nslab, int per, size_t total,
+                                           float* __restrict__ out2) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int z0 = blockIdx.y * per, z1 = min(z0 + per, nslab);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = z0;
+    for (; z + 4 <= z1; z += 4) {
+        s0 += part[(size_t)z * total + i];
+        s1 += part[(size_t)(z + 1) * total + i];
+        s2 += part[(size_t)(z + 2) * total + i];
+        s3 += part[(size_t)(z + 3) * total + i];
+    }
+    for (; z < z1; ++z) s0 += part[(size_t)z * total + i];
+    out2[(size_t)blockIdx.y * total + i] = (s0 + s1) + (s2 + s3);
+}
+
 // out_oihw[co][ci][t] = sum_z part[z][co][t][ci]   (ci < cin_real)
 // T == 1: input and output orders coincide -> plain streaming sum.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int Cout, int T, int Ctot,
@@ -321,13 +461,58 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t_kernel(const float* __rest
 struct WgradPlan {
     int bm, bn, wk, splitk, kt_per, ktiles, tiles;
     bool smallc;
+    bool alltaps;      // wgrad_alltaps_kernel: ktiles = row chunks per strip, kt_per = rows per chunk
+    int nslab;         // partial slabs the MFMA kernel writes
+    int groups;        // > 0: two-level slab sum with this many intermediate slabs
 };
+
+static int alltaps_max_tiles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("XV2_WGRAD_ALLTAPS");
+        v = e ? atoi(e) : (1 << 30);
+    }
+    return v;
+}
 
 static WgradPlan make_plan(const xv2_conv_desc* d) {
     WgradPlan pl;
     const int Ctot = d->C0 + d->C1;
     pl.smallc = (d->C0 == 4 && d->C1 == 0);
+    pl.alltaps = false;
+    pl.groups = 0;
     const int T = d->KH * d->KW;
+    if (!pl.smallc && d->math == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 &&
+        d->OW % 32 == 0 && d->OH == d->IH && d->OW == d->IW && d->Cout % 32 == 0 && d->C0 % 32 == 0 &&
+        d->C1 % 32 == 0 && d->C0 > 0 && (d->Cout / 32) * (Ctot / 32) <= alltaps_max_tiles()) {
+        pl.alltaps = true;
+        pl.bm = pl.bn = 32;
+        pl.wk = 1;
+        pl.tiles = (d->Cout / 32) * (Ctot / 32);
+        const int strips = d->N * (d->OW / 32);
+        const int cap = 512;                                      // 2 resident blocks per CU (144 accumulator VGPRs)
+        // row chunks per strip: the smallest count whose grid fills whole rounds of resident blocks (>= 90 %)
+        const int maxchunks = std::max(1, d->OH / 8);
+        int chunks = 1;
+        double best_eff = 0.0;
+        for (int c = 1; c <= maxchunks && c <= 64; ++c) {
+            const int rows = (int)cdiv(d->OH, c);
+            if ((int)cdiv(d->OH, rows) != c) continue;
+            const int64_t blocks = (int64_t)pl.tiles * strips * c;
+            const double eff = (double)blocks / (double)(cdiv(blocks, cap) * cap);
+            if (eff > best_eff + 1e-9) {
+                best_eff = eff;
+                chunks = c;
+            }
+            if (eff >= 0.9) break;
+        }
+        pl.kt_per = (int)cdiv(d->OH, chunks);
+        pl.ktiles = (int)cdiv(d->OH, pl.kt_per);
+        pl.splitk = strips * pl.ktiles;
+        pl.nslab = pl.splitk;
+        if (pl.nslab >= 64) pl.groups = 16;
+        return pl;
+    }
     int bm = (d->Cout % 128 == 0) ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
     int bn;
     if (pl.smallc) {
@@ -367,6 +552,7 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     }
     pl.kt_per = (int)cdiv(pl.ktiles, best);
     pl.splitk = (int)cdiv(pl.ktiles, pl.kt_per);
+    pl.nslab = pl.splitk * pl.wk;
     return pl;
 }
 
@@ -408,6 +594,7 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     p.T = d->KH * d->KW;
     p.ktiles = pl.ktiles; p.kt_per_split = pl.kt_per;
     p.tiles_n = pl.smallc ? (int)cdiv(p.T * 4, pl.bn) : p.Ctot / pl.bn;
+    const size_t total = (size_t)d->Cout * p.T * p.Ctot;
     {
         const long long bx0 = (long long)d->N * d->IH * d->IW * ldx0 * 4;
         const long long bx1 = x1 ? (long long)d->N * d->IH * d->IW * ldx1 * 4 : 0;
@@ -423,7 +610,16 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
             p.taps[kh * d->KW + kw].dw = (short)(kw * d->dil - d->pad);
         }
     int rc;
-    if (pl.smallc) {
+    if (pl.alltaps) {
+        static int kid = -1;
+        if (kid < 0) kid = prof_register("wgrad_alltaps_kernel");
+        prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+                   4.0 * ((double)p.M * p.Ctot + (double)p.M * p.Cout + (double)total), stream);
+        hipLaunchKernelGGL(wgrad_alltaps_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        prof_end(stream);
+        XV2_CHECK_LAUNCH();
+        rc = XV2_OK;
+    } else if (pl.smallc) {
         if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
     } else if (d->math == XV2_MATH_BF16 && !(pl.bm == 32 && pl.bn == 32)) {
@@ -437,13 +633,23 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     else if (pl.bm == 32 && pl.bn == 64) rc = launch_wgrad<32, 64, 1, 2, 2, false>(p, pl, stream);
     else rc = launch_wgrad<32, 32, 1, 1, 4, false>(p, pl, stream);
     if (rc) return rc;
-    const size_t total = (size_t)d->Cout * p.T * p.Ctot;
+    const float* slabs = workspace;
+    int nslab = pl.nslab;
+    if (pl.groups > 0) {
+        float* out2 = workspace + (size_t)pl.nslab * total;
+        const int per = (int)cdiv(pl.nslab, pl.groups);
+        const int groups = (int)cdiv(pl.nslab, per);
+        hipLaunchKernelGGL(wgrad_reduce_stage1_kernel, dim3((unsigned)cdiv(total, 256), groups), dim3(256), 0, stream,
+                           workspace, pl.nslab, per, total, out2);
+        slabs = out2;
+        nslab = groups;
+    }
     if (p.T > 1 && p.Ctot % 64 == 0) {
-        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(d->Cout * (p.Ctot / 64)), dim3(256), 0, stream, workspace,
-                           pl.splitk * pl.wk, d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(d->Cout * (p.Ctot / 64)), dim3(256), 0, stream, slabs,
+                           nslab, d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
     } else {
         const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, pl.splitk * pl.wk,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, slabs, nslab,
                            d->Cout, p.T, p.Ctot, cin_real, dw_oihw);
     }
     XV2_CHECK_LAUNCH();
@@ -456,7 +662,7 @@ using namespace xv2;
 
 extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d) {
     const WgradPlan pl = make_plan(d);
-    return (size_t)pl.splitk * pl.wk * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
+    return (size_t)(pl.nslab + pl.groups) * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
 }
 
 extern "C" int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,
