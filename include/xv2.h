@@ -109,6 +109,12 @@ size_t xv2_head_conv_backward_workspace(int64_t npix, int Cin, int Cout);
 #define XV2_BN_SCRATCH_ROWS 64
 int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
                         void* stream);
+/* xv2_bn_reduce_stats + xv2_bn_finalize in ONE launch (single-process nn.BatchNorm2d in training mode; SyncBatchNorm
+ * keeps the two calls with the all-reduce of `sums` between them).  Same outputs as the pair, bit for bit. */
+int xv2_bn_reduce_finalize(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
+                           double count, const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* invstd,
+                           float* scale, float* shift, void* stream);
 /* direct statistics of an NHWC tensor (when no conv epilogue produced them):
  * workspace = xv2_bn_tensor_stats_workspace() bytes (partials followed by the double scratch) */
 int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums,

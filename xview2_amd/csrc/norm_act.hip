@@ -5,6 +5,8 @@
 // un-vendored ResNet/ResNeSt blocks; torch semantics (biased batch variance for normalisation,
 // unbiased for running_var, momentum 0.1, eps 1e-5).
 #include "xv2_common.h"
+#include <mutex>
+#include <cstring>
 #include <algorithm>
 
 namespace xv2 {
@@ -175,11 +177,57 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
     }
 }
 
-// stage 1: grid (ceil(C/32), S): scratch[s][C][2] = sum over tiles t == s (mod S)... contiguous ranges
+// Tile partials -> per-channel sums in ONE launch.  grid (ceil(C/32), S): block (g, s) folds its contiguous range of
+// tiles for 32 channels into scratch[s][C][2]; the LAST block of a channel group to arrive (device-scope ticket)
+// then adds the S scratch rows in index order - so the result does not depend on which block that is - and, when
+// `fin.mean` is set, derives the BatchNorm coefficients and running statistics for its channels on the spot.
+struct BnFinalize {
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    float* mean;      // nullptr: sums only
+    float* invstd;
+    float* scale;
+    float* shift;
+};
+
+// contraction off: the one-launch and the two-launch path inline this into different kernels and must agree bit
+// for bit (hipcc contracts a*b+c by default, and HIP's __dmul_rn & co. are plain operators)
+__device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1, double s2) {
+#pragma clang fp contract(off)
+    const double m = s1 / f.count;
+    const double mm = m * m;
+    double var = s2 / f.count - mm;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)f.eps);
+    f.mean[c] = (float)m;
+    f.invstd[c] = (float)is;
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * (float)is;
+    const float msc = (float)m * sc;
+    f.scale[c] = sc;
+    f.shift[c] = b - msc;
+    if (f.running_mean) {
+        const double vc = var * f.count;
+        const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;
+        const float keep = 1.f - f.momentum;
+        const float km = keep * f.running_mean[c], kv = keep * f.running_var[c];
+        const float am = f.momentum * (float)m, av = f.momentum * (float)unb;
+        f.running_mean[c] = km + am;
+        f.running_var[c] = kv + av;
+    }
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) reduce_stats_stage1(const T* __restrict__ part, int64_t tiles, int C,
-                                                           int S, double* __restrict__ scratch) {
+__global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__ part, int64_t tiles, int C, int S,
+                                                           double* __restrict__ scratch, unsigned* __restrict__ tickets,
+                                                           double* __restrict__ sums, float* __restrict__ f0,
+                                                           float* __restrict__ f1, const BnFinalize fin) {
     __shared__ double sh[256 * 2];
+    __shared__ int is_last;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 channels x 8 row lanes
     const int c = blockIdx.x * 32 + tx;
     const int64_t per = cdiv(tiles, S);
@@ -199,27 +247,68 @@ __global__ void __launch_bounds__(256) reduce_stats_stage1(const T* __restrict__
             b0 += sh[(q * 32 + tx) * 2];
             b1 += sh[(q * 32 + tx) * 2 + 1];
         }
-        scratch[((size_t)blockIdx.y * C + c) * 2] = b0;
-        scratch[((size_t)blockIdx.y * C + c) * 2 + 1] = b1;
+        // device-scope (write-through) stores: a release FENCE here would write back the whole L2 of this XCD,
+        // which still holds the conv output of the previous kernel (measured: +25 us per launch)
+        __hip_atomic_store(&scratch[((size_t)blockIdx.y * C + c) * 2], b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&scratch[((size_t)blockIdx.y * C + c) * 2 + 1], b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (S > 1) {
+        __builtin_amdgcn_s_waitcnt(0);   // the row has reached the device coherence point ...
+        __syncthreads();
+        if (threadIdx.x == 0) {          // ... before the ticket is drawn
+            const unsigned prev = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (prev == (unsigned)(S - 1));
+            if (is_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!is_last) return;
+    } else {
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;
+    const int ch = blockIdx.x * 32 + (threadIdx.x >> 1), which = threadIdx.x & 1;
+    double a = 0.0;
+    if (ch < C) {
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        const size_t i = (size_t)ch * 2 + which, stride = (size_t)C * 2;
+        int r = 0;
+        auto ld = [&](int row) {   // device-scope loads: the rows were written by blocks on other XCDs
+            return __hip_atomic_load(&scratch[(size_t)row * stride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        for (; r + 4 <= S; r += 4) {
+            q0 += ld(r);
+            q1 += ld(r + 1);
+            q2 += ld(r + 2);
+            q3 += ld(r + 3);
+        }
+        for (; r < S; ++r) q0 += ld(r);
+        a = (q0 + q1) + (q2 + q3);
+        sums[i] = a;
+        if (f0 && !which) f0[ch] = (float)a;   // BN backward: dbeta = sum g
+        if (f1 && which) f1[ch] = (float)a;    //              dgamma = sum g*xhat
+    }
+    if (fin.mean) {
+        const double other = __shfl_xor(a, 1, 64);
+        if (ch < C && !which) bn_finalize_channel(fin, ch, a, other);
     }
 }
-__global__ void reduce_stats_stage2(const double* __restrict__ scratch, int C, int S, double* __restrict__ sums,
-                                    float* __restrict__ f0, float* __restrict__ f1) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over C*2
-    if (i >= C * 2) return;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        a0 += scratch[(size_t)s * C * 2 + i];
-        a1 += scratch[(size_t)(s + 1) * C * 2 + i];
-        a2 += scratch[(size_t)(s + 2) * C * 2 + i];
-        a3 += scratch[(size_t)(s + 3) * C * 2 + i];
+
+// ticket counters for reduce_stats_kernel: a zero-initialised device pool handed out round-robin; every user
+// returns its counters to zero, so concurrent launches on different streams never share a live ticket.
+static unsigned* take_tickets(int n) {
+    static unsigned* pool = nullptr;
+    static size_t cursor = 0;
+    static std::mutex mu;
+    constexpr size_t POOL = 1 << 16;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool) {
+        if (hipMalloc(&pool, POOL * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(pool, 0, POOL * sizeof(unsigned)) != hipSuccess) return nullptr;
     }
-    for (; s < S; ++s) a0 += scratch[(size_t)s * C * 2 + i];
-    const double a = (a0 + a1) + (a2 + a3);
-    sums[i] = a;
-    if (f0 && !(i & 1)) f0[i >> 1] = (float)a;   // BN backward: dbeta = sum g
-    if (f1 && (i & 1)) f1[i >> 1] = (float)a;    //              dgamma = sum g*xhat
+    if (cursor + (size_t)n > POOL) cursor = 0;
+    unsigned* p = pool + cursor;
+    cursor += (size_t)n;
+    return p;
 }
 
 // sums of (x - s) and (x - s)^2  ->  sums of x and x^2, in fp64 (no cancellation at this precision)
@@ -233,40 +322,25 @@ __global__ void unshift_stats_kernel(double* __restrict__ sums, const float* __r
 
 template <typename T>
 static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st,
-                        float* f0 = nullptr, float* f1 = nullptr) {
+                        float* f0 = nullptr, float* f1 = nullptr, const BnFinalize* fin = nullptr) {
     int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));
     if (S < 1) S = 1;
-    hipLaunchKernelGGL(reduce_stats_stage1<T>, dim3((unsigned)cdiv(C, 32), S), dim3(256), 0, st, partial, tiles, C, S,
-                       scratch);
-    XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_stats_stage2, dim3((unsigned)cdiv(C * 2, 256)), dim3(256), 0, st, scratch, C, S, sums, f0,
-                       f1);
+    const int groups = (int)cdiv(C, 32);
+    XV2_CHECK_ARG(groups <= 4096, "reduce_stats: C=%d too large", C);
+    unsigned* tickets = S > 1 ? take_tickets(groups) : nullptr;
+    XV2_CHECK_ARG(S == 1 || tickets, "reduce_stats: ticket pool allocation failed");
+    BnFinalize none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(reduce_stats_kernel<T>, dim3((unsigned)groups, S), dim3(256), 0, st, partial, tiles, C, S,
+                       scratch, tickets, sums, f0, f1, fin ? *fin : none);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift, int C) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const BnFinalize fin, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double m = sums[c * 2] / count;
-    double var = sums[c * 2 + 1] / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const double is = 1.0 / sqrt(var + (double)eps);
-    mean[c] = (float)m;
-    invstd[c] = (float)is;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sc = g * (float)is;
-    scale[c] = sc;
-    shift[c] = b - (float)m * sc;
-    if (running_mean) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
+    bn_finalize_channel(fin, c, sums[c * 2], sums[c * 2 + 1]);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -441,6 +515,19 @@ extern "C" int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, d
     return reduce_stats<float>(partial, tiles, C, sums, scratch, (hipStream_t)stream);
 }
 
+extern "C" int xv2_bn_reduce_finalize(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
+                                      double count, const float* gamma, const float* beta, float eps, float momentum,
+                                      float* running_mean, float* running_var, float* mean, float* invstd,
+                                      float* scale, float* shift, void* stream) {
+    XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_reduce_finalize: empty");
+    XV2_CHECK_ARG(mean && invstd && scale && shift, "bn_reduce_finalize: coefficient outputs are required");
+    BnFinalize f;
+    f.count = count; f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
+    f.running_mean = running_mean; f.running_var = running_var;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    return reduce_stats<float>(partial, tiles, C, sums, scratch, (hipStream_t)stream, nullptr, nullptr, &f);
+}
+
 extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
     const ChunkGeom g = chunk_geom(npix, C);
     size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
@@ -481,8 +568,11 @@ extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C,
 extern "C" int xv2_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                                float* scale, float* shift, int C, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums,
-                       count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, C);
+    BnFinalize f;
+    f.count = count; f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
+    f.running_mean = running_mean; f.running_var = running_var;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, f, C);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

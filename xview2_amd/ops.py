@@ -81,9 +81,11 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
     return ohwi, ihwo
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None):
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.  If `ihwo_out` is a list, the backward-data weight
-    packs are produced by the same repack launch and appended to it (one per group)."""
+    packs are produced by the same repack launch and appended to it (one per group).  With `bn` (a BnState that
+    does not synchronise across ranks) the statistics reduction also derives the BatchNorm coefficients in the
+    same launch and the third return value is (mean, invstd, scale, shift)."""
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     Cout_t = weight.shape[0]
@@ -91,6 +93,9 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None)
     OH, OW = _out_hw(IH, IW, g)
     y = _f32((N, OH, OW, Cout_t), x0)
     sums = torch.empty((Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
+    coeffs = None
+    if want_stats and bn is not None and not _sync_group(bn):
+        coeffs = tuple(_f32((Cout_t,), x0) for _ in range(4))
     w = weight.contiguous()
     if G > 1 and x1 is not None:
         raise RuntimeError("grouped convolution over a virtual concat is not supported")
@@ -112,8 +117,16 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None)
              _ws(wsb, x0) if wsb else None)
         if want_stats:
             scratch = torch.empty((64 * Coutg * 2,), dtype=torch.float64, device=x0.device)
-            call("xv2_bn_reduce_stats", part, tiles, Coutg, Ptr(sums, gi * Coutg * 2), scratch)
+            if coeffs is None:
+                call("xv2_bn_reduce_stats", part, tiles, Coutg, Ptr(sums, gi * Coutg * 2), scratch)
+            else:
+                o = gi * Coutg
+                call("xv2_bn_reduce_finalize", part, tiles, Coutg, Ptr(sums, o * 2), scratch, float(N * OH * OW),
+                     _off(bn.weight, o), _off(bn.bias, o), float(bn.eps), float(bn.momentum),
+                     _off(bn.running_mean, o), _off(bn.running_var, o), *(Ptr(t, o) for t in coeffs))
     assert cin_w <= C0g + C1t
+    if bn is not None:
+        return y, sums, coeffs
     return y, sums
 
 
@@ -144,10 +157,26 @@ ASYNC_WGRAD = os.environ.get("XV2_ASYNC_WGRAD", "1") != "0"
 _wgrad_stream = None
 
 
+def _low_priority_stream():
+    """A HIP stream at the LOWEST queue priority: the compute stream's backward-data kernels get the CUs first and
+    the weight-gradient kernels fill in behind them - in particular under the HBM-bound BatchNorm passes, which
+    leave the matrix pipes idle.  (torch.cuda.Stream only exposes 'high' and 'normal'.)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        return torch.cuda.Stream()
+    prio = int(os.environ.get("XV2_WGRAD_PRIORITY", least.value))
+    h = ctypes.c_void_p()
+    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+        return torch.cuda.Stream()
+    return torch.cuda.ExternalStream(h.value)
+
+
 def _side_stream():
     global _wgrad_stream
     if _wgrad_stream is None:
-        _wgrad_stream = torch.cuda.Stream()
+        _wgrad_stream = _low_priority_stream()
     return _wgrad_stream
 
 
@@ -236,11 +265,19 @@ def _bn_eval_coeffs(bn, like):
     return bn.running_mean, invstd, scale, shift
 
 
-def _bn_forward(y, residual, act, bn, sums, training):
-    """y raw [.., C]; returns z and the context needed by _bn_backward"""
+def _off(t, o):
+    return None if t is None else Ptr(t, o)
+
+
+def _bn_forward(y, residual, act, bn, sums, training, coeffs=None):
+    """y raw [.., C]; returns z and the context needed by _bn_backward.  `coeffs`: (mean, invstd, scale, shift)
+    when the statistics reduction already derived them (xv2_bn_reduce_finalize)."""
     C = y.shape[-1]
     npix = y.numel() // C
-    if training:
+    if training and coeffs is not None:
+        mean, invstd, scale, shift = coeffs
+        count = float(npix)
+    elif training:
         if sums is None:
             sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
             ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), y)
@@ -297,8 +334,8 @@ class ConvBnActFn(torch.autograd.Function):
         residual = residual.contiguous() if residual is not None else None
         need_dx = x0.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.ihwo = [] if need_dx else None
-        y, sums = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo)
-        z, stats = _bn_forward(y, residual, act, bn, sums, training)
+        y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
+        z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs)
         ctx.has_res = residual is not None
         # the activation mask of the backward pass is recomputed from y unless a residual entered before it
         ctx.save_for_backward(x0, x1, weight, gamma, y, z if ctx.has_res else None, stats[0], stats[1], stats[3],
