@@ -297,6 +297,33 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
     }
 }
 
+// Many weight tensors in one launch (after the optimizer step every packed layout is stale at once).
+// table[n][8]: {src OIHW pointer, ohwi pointer or 0, ihwo pointer or 0, Cout, Cin, T, cin_pad, first work item};
+// work item = one element of the padded OHWI layout.
+__global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* __restrict__ table, int n, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {            // last entry whose first work item is <= i
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 8 + 7] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const int64_t* e = table + lo * 8;
+        const float* w = reinterpret_cast<const float*>(e[0]);
+        float* ohwi = reinterpret_cast<float*>(e[1]);
+        float* ihwo = reinterpret_cast<float*>(e[2]);
+        const int Cout = (int)e[3], Cin = (int)e[4], T = (int)e[5], CinP = (int)e[6];
+        const int64_t j = i - e[7];
+        const int ci = (int)(j % CinP);
+        const int64_t q = j / CinP;
+        const int t = (int)(q % T);
+        const int co = (int)(q / T);
+        const float v = ci < Cin ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
+        if (ohwi) ohwi[j] = v;
+        if (ihwo) ihwo[((size_t)ci * T + t) * Cout + co] = v;
+    }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float bc2_sqrt, float gscale) {
@@ -426,6 +453,14 @@ extern "C" int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, i
     const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH * KW,
                        cin_pad, w_ohwi, w_ihwo);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_pack_weights_table(const int64_t* table, int n, int64_t total, void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total > 0, "pack_weights_table: empty table");
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 8192);
+    hipLaunchKernelGGL(pack_weights_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, n, total);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

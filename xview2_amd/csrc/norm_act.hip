@@ -17,14 +17,26 @@ namespace xv2 {
 struct ChunkGeom {
     int rpb;        // rows per block
     int64_t chunks;
+    int cgw;        // channels per block (vector path): C, or 256-channel groups for wide tensors; 0 = generic path
+    int groups;
 };
 
+// Vector path: a block covers `cgw` channels (cgw/4 float4 lanes x 256/(cgw/4) row lanes) and `rpb` rows; wide
+// tensors (C a multiple of 256) are cut into 256-channel groups along grid.y so that a block keeps 4 row lanes and
+// the number of row chunks - hence the partial-sum traffic - stays a small fraction of the tensor.
 static ChunkGeom chunk_geom(int64_t npix, int C) {
     ChunkGeom g;
-    int64_t rows_per_pass = (C % 4 == 0 && C / 4 <= 256 && (256 % (C / 4)) == 0) ? 256 / (C / 4) : 4;
-    int64_t rpb = cdiv(npix, 2048);
+    g.cgw = 0;
+    g.groups = 1;
+    if (C % 4 == 0) {
+        if (C > 256 && C % 256 == 0) g.cgw = 256;
+        else if (C / 4 <= 256 && 256 % (C / 4) == 0) g.cgw = C;
+    }
+    if (g.cgw) g.groups = C / g.cgw;
+    const int64_t rows_per_pass = g.cgw ? 256 / (g.cgw / 4) : 4;
+    int64_t rpb = cdiv(npix * g.groups, 2048);
     rpb = cdiv(rpb, rows_per_pass) * rows_per_pass;
-    if (rpb < rows_per_pass * 4) rpb = rows_per_pass * 4;
+    if (rpb < rows_per_pass * 8) rpb = rows_per_pass * 8;
     g.rpb = (int)rpb;
     g.chunks = cdiv(npix, rpb);
     return g;
@@ -89,33 +101,34 @@ struct ColOp {
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, int64_t npix, int C, int rpb,
+__global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, int64_t npix, int C, int rpb, int cgw,
                                                               double* __restrict__ part) {
     __shared__ float sh[256 * 8];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = min(r0 + (int64_t)rpb, npix);
     double* out = part + (size_t)blockIdx.x * C * 2;
-    const int C4 = C / 4;
-    if (C % 4 == 0 && C4 <= 256 && (256 % C4) == 0) {
+    if (cgw) {
+        const int C4 = cgw / 4;
         const int rpp = 256 / C4;
         const int tx = tid % C4, ty = tid / C4;
+        const int cb = blockIdx.y * cgw + tx * 4;     // first of this thread's 4 channels
         float4 f0 = make_float4(0, 0, 0, 0), f1 = make_float4(0, 0, 0, 0);
         float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
         if constexpr (MODE == 1) {
-            mu = *reinterpret_cast<const float4*>(op.mean + tx * 4);
-            is = *reinterpret_cast<const float4*>(op.invstd + tx * 4);
+            mu = *reinterpret_cast<const float4*>(op.mean + cb);
+            is = *reinterpret_cast<const float4*>(op.invstd + cb);
         } else {
-            mu = *reinterpret_cast<const float4*>(op.a + tx * 4);
+            mu = *reinterpret_cast<const float4*>(op.a + cb);
         }
         // two rows in flight per iteration (independent accumulators): more bytes outstanding per lane
         float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, 0, 0);
         int64_t r = r0 + ty;
         for (; r + rpp < r1; r += 2 * rpp) {
-            op.apply4(r, tx * 4, f0, f1, mu, is);
-            op.apply4(r + rpp, tx * 4, g0, g1, mu, is);
+            op.apply4(r, cb, f0, f1, mu, is);
+            op.apply4(r + rpp, cb, g0, g1, mu, is);
         }
-        if (r < r1) op.apply4(r, tx * 4, f0, f1, mu, is);
+        if (r < r1) op.apply4(r, cb, f0, f1, mu, is);
         f0.x += g0.x; f0.y += g0.y; f0.z += g0.z; f0.w += g0.w;
         f1.x += g1.x; f1.y += g1.y; f1.z += g1.z; f1.w += g1.w;
         float* s = sh + tid * 8;
@@ -134,8 +147,8 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                out[(tid * 4 + k) * 2 + 0] = a0[k];
-                out[(tid * 4 + k) * 2 + 1] = a1[k];
+                out[(blockIdx.y * cgw + tid * 4 + k) * 2 + 0] = a0[k];
+                out[(blockIdx.y * cgw + tid * 4 + k) * 2 + 1] = a1[k];
             }
         }
     } else {
@@ -233,11 +246,22 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
     const int64_t per = cdiv(tiles, S);
     const int64_t t0 = (int64_t)blockIdx.y * per, t1 = min(t0 + per, tiles);
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int64_t t = t0 + ty; t < t1; t += 8) {
+    if (c < C) {
+        double e0 = 0.0, e1 = 0.0;
+        int64_t t = t0 + ty;
+        for (; t + 8 < t1; t += 16) {     // two tiles in flight
+            a0 += (double)part[((size_t)t * C + c) * 2];
+            a1 += (double)part[((size_t)t * C + c) * 2 + 1];
+            e0 += (double)part[((size_t)(t + 8) * C + c) * 2];
+            e1 += (double)part[((size_t)(t + 8) * C + c) * 2 + 1];
+        }
+        if (t < t1) {
             a0 += (double)part[((size_t)t * C + c) * 2];
             a1 += (double)part[((size_t)t * C + c) * 2 + 1];
         }
+        a0 += e0;
+        a1 += e1;
+    }
     sh[threadIdx.x * 2] = a0;
     sh[threadIdx.x * 2 + 1] = a1;
     __syncthreads();
@@ -265,24 +289,36 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
     } else {
         __syncthreads();
     }
-    if (threadIdx.x >= 64) return;
-    const int ch = blockIdx.x * 32 + (threadIdx.x >> 1), which = threadIdx.x & 1;
+    // last block: 4 row quarters x (32 channels x 2 statistics); each thread adds its quarter of the S rows with four
+    // loads in flight (device-scope loads cost a memory round trip each), then the quarters are combined in order
+    const int t64 = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 32 + (t64 >> 1), which = t64 & 1;
     double a = 0.0;
     if (ch < C) {
         double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
         const size_t i = (size_t)ch * 2 + which, stride = (size_t)C * 2;
-        int r = 0;
         auto ld = [&](int row) {   // device-scope loads: the rows were written by blocks on other XCDs
             return __hip_atomic_load(&scratch[(size_t)row * stride + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        for (; r + 4 <= S; r += 4) {
+        const int rq = (S + 3) >> 2;
+        int r = quarter * rq;
+        const int rend = min(r + rq, S);
+        for (; r + 4 <= rend; r += 4) {
             q0 += ld(r);
             q1 += ld(r + 1);
             q2 += ld(r + 2);
             q3 += ld(r + 3);
         }
-        for (; r < S; ++r) q0 += ld(r);
+        for (; r < rend; ++r) q0 += ld(r);
         a = (q0 + q1) + (q2 + q3);
+    }
+    __syncthreads();          // sh[] (phase 1) is free again
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    a = (sh[t64] + sh[64 + t64]) + (sh[128 + t64] + sh[192 + t64]);
+    if (ch < C) {
+        const size_t i = (size_t)ch * 2 + which;
         sums[i] = a;
         if (f0 && !which) f0[ch] = (float)a;   // BN backward: dbeta = sum g
         if (f1 && which) f1[ch] = (float)a;    //              dgamma = sum g*xhat
@@ -458,11 +494,11 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __res
                                                                const float* __restrict__ shift,
                                                                const double* __restrict__ sums2, double count, int act,
                                                                int train, float* __restrict__ dy, int lddy,
-                                                               float* __restrict__ dres, int lddres, int64_t npix, int C,
+                                                               float* __restrict__ dres, int lddres, int64_t npix, int cgw,
                                                                int rows_per_block) {
-    const int C4 = C >> 2, rpp = 256 / C4;
+    const int C4 = cgw >> 2, rpp = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
-    const int c = tx * 4;
+    const int c = blockIdx.y * cgw + tx * 4;
     const float inv_count = (float)(1.0 / count);
     float gi[4], mu[4], is[4], sg[4], sgx[4], sc[4], sf[4];
 #pragma unroll
@@ -544,8 +580,8 @@ static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums,
     part = (part + 15) & ~(size_t)15;
     double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
-    hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks), dim3(256), 0, st, op, npix, C, g.rpb,
-                       dpart);
+    hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix, C,
+                       g.rpb, g.cgw, dpart);
     XV2_CHECK_LAUNCH();
     return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
@@ -633,13 +669,14 @@ extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float*
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
     const bool vec = vec_ok(C, {lddz, z ? ldz : 0, ldy, lddy, dres ? lddres : 0}, {dz, z, y, dy, dres});
-    if (vec && C / 4 <= 256 && 256 % (C / 4) == 0) {
-        const int rpp = 256 / (C / 4);
-        int64_t rpb = cdiv(npix, 4096);
+    const ChunkGeom cg = chunk_geom(npix, C);
+    if (vec && cg.cgw) {
+        const int rpp = 256 / (cg.cgw / 4);
+        int64_t rpb = cdiv(npix * cg.groups, 4096);
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
-        hipLaunchKernelGGL(bn_act_bwd_rows_kernel, dim3((unsigned)cdiv(npix, rpb)), dim3(256), 0, (hipStream_t)stream,
-                           dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy,
-                           lddy, dres, lddres, npix, C, (int)rpb);
+        hipLaunchKernelGGL(bn_act_bwd_rows_kernel, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
+                           (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
+                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }

@@ -73,12 +73,101 @@ def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW):
 
 # ------------------------------------------------------------------------------------------------
 # raw (non-autograd) convolution pieces; groups are channel-offset views over the same tensors
+# Packed weight layouts are cached per (weight storage, geometry) and stay valid until the weight changes: a torch-side
+# in-place update bumps `_version`; FlatAdamW (whose kernel torch cannot see) bumps WEIGHT_EPOCH and then refreshes
+# every cached layout with ONE table-driven launch (repack_all) instead of one small launch per layer per step.
+WEIGHT_EPOCH = 0
+PACK_CACHE = os.environ.get("XV2_PACK_CACHE", "1") != "0"
+_packs = {}
+_pack_table = None
+_repack_tick = 0
+
+
+_pack_tick = 0
+PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is dropped (models that went away)
+
+
+class _PackEntry:
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick")
+
+
 def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
+    global _pack_table, _pack_tick
     Cout, Cin, KH, KW = w_oihw.shape
-    ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw) if want_ohwi else None
-    ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw) if want_ihwo else None
-    call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, ohwi, ihwo)
-    return ohwi, ihwo
+    if not PACK_CACHE:
+        ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw) if want_ohwi else None
+        ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw) if want_ihwo else None
+        call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, ohwi, ihwo)
+        return ohwi, ihwo
+    key = (w_oihw.data_ptr(), Cout, Cin, KH, KW, cin_pad)
+    e = _packs.get(key)
+    fresh = e is not None and e.version == w_oihw._version and e.epoch == WEIGHT_EPOCH
+    _pack_tick += 1
+    if fresh and (e.ohwi is not None or not want_ohwi) and (e.ihwo is not None or not want_ihwo):
+        e.tick = _pack_tick
+        return e.ohwi, e.ihwo
+    if e is None:
+        if len(_packs) >= PACK_CACHE_MAX:
+            cut = sorted(v.tick for v in _packs.values())[len(_packs) // 2]
+            for k in [k for k, v in _packs.items() if v.tick < cut]:
+                del _packs[k]
+        e = _PackEntry()
+        e.ohwi = e.ihwo = None
+        e.geom = (Cout, Cin, KH * KW, cin_pad)
+        _packs[key] = e
+        _pack_table = None
+    if want_ohwi and e.ohwi is None:
+        e.ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw)
+        _pack_table = None
+    if want_ihwo and e.ihwo is None:
+        e.ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw)
+        _pack_table = None
+    e.w = w_oihw.detach()
+    e.tick = _pack_tick
+    call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo)
+    e.version, e.epoch = w_oihw._version, WEIGHT_EPOCH
+    return e.ohwi, e.ihwo
+
+
+def weights_changed():
+    """the caller rewrote parameters behind torch's back (FlatAdamW's HIP kernel): cached layouts are stale"""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def repack_all():
+    """refresh every cached layout in one launch on the current stream (call right after weights_changed())"""
+    global _pack_table
+    global _repack_tick
+    if not _packs or not PACK_CACHE:
+        return
+    stale = [k for k, e in _packs.items() if e.tick <= _repack_tick]     # not touched since the last refresh
+    if stale:
+        for k in stale:
+            del _packs[k]
+        _pack_table = None
+    _repack_tick = _pack_tick
+    if not _packs:
+        return
+    if _pack_table is None:
+        rows, start = [], 0
+        for e in _packs.values():
+            Cout, Cin, T, cin_pad = e.geom
+            rows.append([e.w.data_ptr(), e.ohwi.data_ptr() if e.ohwi is not None else 0,
+                         e.ihwo.data_ptr() if e.ihwo is not None else 0, Cout, Cin, T, cin_pad, start])
+            start += Cout * T * cin_pad
+        dev = next(iter(_packs.values())).w.device
+        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start)
+    table, n, total = _pack_table
+    call("xv2_pack_weights_table", table, n, total)
+    for e in _packs.values():
+        e.version, e.epoch = e.w._version, WEIGHT_EPOCH
+
+
+def clear_pack_cache():
+    global _pack_table
+    _packs.clear()
+    _pack_table = None
 
 
 def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None):

@@ -39,6 +39,7 @@ class FlatAdamW:
                 # (ops.grad_slot): autograd then adopts that view as .grad without an accumulation kernel
                 p._xv2_slot = (self, o)
                 p._xv2_epoch = -1
+        ops.clear_pack_cache()         # the parameters just moved to new storage
         self.epoch = 0
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -82,9 +83,12 @@ class FlatAdamW:
             call("xv2_adamw_step_dev", self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_p.numel(),
                  self.lr_dev, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                  self.step_dev, float(grad_scale))
+            ops.weights_changed()
+            ops.repack_all()       # the packed conv-weight layouts, refreshed in one launch
             return
         ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr, self.betas[0], self.betas[1],
                        self.eps, self.weight_decay, self.step_count, grad_scale)
+        ops.weights_changed()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
