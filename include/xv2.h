@@ -78,6 +78,12 @@ size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
                              const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
                              float* workspace, void* stream);
+/* the same, ADDING into dx0 (accumulate bit 0) and/or dx1 (bit 1) instead of overwriting them: the gradient of a
+ * tensor with two consumers (residual shortcut, encoder skip) is summed in the kernel epilogue, not by a separate
+ * elementwise pass */
+int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float* dy, int lddy,
+                                 const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
+                                 int accumulate, float* workspace, void* stream);
 /* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
 size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,

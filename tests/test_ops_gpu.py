@@ -400,3 +400,39 @@ def test_conv_weight_gradient_bf16_math_mode(case):
     a1 = nhwc(x[:, C0:]) if C1 else None
     dw = ops._conv_backward_weight_impl(a0, a1, nhwc(dy), w.detach().to(dev()), g)
     close(dw, dwr, 3e-4, "bf16 wgrad")
+
+
+@pytest.mark.parametrize("downsample", [False, True])
+def test_bottleneck_shortcut_gradient_is_summed_in_the_dgrad_epilogue(downsample):
+    """torchvision Bottleneck wiring: the block input feeds conv1 AND the shortcut.  With the pass-through alias the
+    shortcut's gradient is accumulated by conv1's backward-data kernel (xv2_conv2d_backward_data_acc); the input
+    gradient must equal torch autograd's sum of both paths (eval-mode BN keeps the comparison well conditioned)."""
+    from xview2_amd import encoders
+    torch.manual_seed(3)
+    inpl, planes, stride = (64, 32, 2) if downsample else (128, 32, 1)
+    blk = encoders.Bottleneck(inpl, planes, stride, downsample).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, inpl, 16, 16)
+    # reference: the same arithmetic in plain torch on the CPU
+    xr = x.clone().requires_grad_(True)
+
+    def bn(m, t):
+        return F.batch_norm(t, m.running_mean, m.running_var, m.weight, m.bias, False, 0.1, m.eps)
+    o = F.relu(bn(blk.bn1, F.conv2d(xr, blk.conv1.weight)))
+    o = F.relu(bn(blk.bn2, F.conv2d(o, blk.conv2.weight, None, stride, 1)))
+    idt = xr if not downsample else bn(blk.downsample[1], F.conv2d(xr, blk.downsample[0].weight, None, stride))
+    ref = F.relu(bn(blk.bn3, F.conv2d(o, blk.conv3.weight)) + idt)
+    dout = torch.randn_like(ref)
+    ref.backward(dout)
+    blk = blk.to(dev())
+    # a leaf cannot be aliased by an autograd output: give the block input a producer, like the real encoder
+    leaf = nhwc(x).requires_grad_(True)
+    out = blk(leaf * 1.0)
+    out.backward(nhwc(dout))
+    close(nchw(out), ref, 2e-5, "out")
+    close(nchw(leaf.grad), xr.grad, 5e-5, "dx")

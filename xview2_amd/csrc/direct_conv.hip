@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 }
 
 bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
-    if (smallc || p.math != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
+    if (smallc || p.math != 0 || p.accum != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 9 || c.tap0 != 0 || c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl) return false;
     if (c.OWl % D_TW != 0 || c.OHl % D_TH != 0 || c.OHl != p.IH || c.OWl != p.IW) return false;

@@ -362,8 +362,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             }
-            if (col < p.N0) *reinterpret_cast<float4*>(p.Out0 + (size_t)off * p.ldo0 + col) = v;
-            else *reinterpret_cast<float4*>(p.Out1 + (size_t)off * p.ldo1 + (col - p.N0)) = v;
+            float* o = col < p.N0 ? p.Out0 + (size_t)off * p.ldo0 + col : p.Out1 + (size_t)off * p.ldo1 + (col - p.N0);
+            if (p.accum & (col < p.N0 ? 1 : 2)) {
+                const float4 old = *reinterpret_cast<const float4*>(o);
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            *reinterpret_cast<float4*>(o) = v;
         }
     }
     if (do_stats && tid < BN) {
@@ -386,7 +390,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              int Nout, const float* __restrict__ bias,
                                                              float* __restrict__ out0, int ldo0, int N0,
                                                              float* __restrict__ out1, int ldo1,
-                                                             float* __restrict__ stats) {
+                                                             float* __restrict__ stats, int accum) {
     __shared__ float sh[256 * 8];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
@@ -406,8 +410,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                 s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
                 s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
                 a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
-                if (c < N0) *reinterpret_cast<float4*>(out0 + (size_t)r * ldo0 + c) = a;
-                else *reinterpret_cast<float4*>(out1 + (size_t)r * ldo1 + (c - N0)) = a;
+                float* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
+                if (accum & (c < N0 ? 1 : 2)) {
+                    const float4 old = *reinterpret_cast<const float4*>(o);
+                    a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
+                }
+                *reinterpret_cast<float4*>(o) = a;
             }
         }
         if (stats) {
@@ -546,7 +554,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         const int M = p.cls[0].M;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256)),
                            dim3(256), 0, stream,
-                           splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats);
+                           splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats,
+                           p.accum);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -591,6 +600,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.ksplit = 1;
     p.cin_real = 3;
     p.math = d->math;
+    p.accum = 0;
     XV2_CHECK_ARG(d->math == 0 || d->math == 1, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
@@ -662,10 +672,12 @@ extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int l
 
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]
 static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
-                      float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream) {
+                      float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream,
+                      int accumulate = 0) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    p.accum = accumulate & (dx1 ? 3 : 1);
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_data: Cout=%d must be a multiple of 32", d->Cout);
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
@@ -720,8 +732,10 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     if (need_zero) {
         XV2_CHECK_ARG(lddx0 == d->C0 && (d->C1 == 0 || lddx1 == d->C1),
                       "backward_data: strided outputs unsupported when parity classes are empty");
-        XV2_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)d->N * d->IH * d->IW * d->C0 * 4, stream));
-        if (d->C1) XV2_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)d->N * d->IH * d->IW * d->C1 * 4, stream));
+        // pixels no tap reaches get a zero gradient - or, when accumulating, keep what they hold
+        if (!(p.accum & 1)) XV2_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)d->N * d->IH * d->IW * d->C0 * 4, stream));
+        if (d->C1 && !(p.accum & 2))
+            XV2_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)d->N * d->IH * d->IW * d->C1 * 4, stream));
     }
     if (ncls == 0) return XV2_OK;
     p.ncls = ncls;
@@ -732,6 +746,12 @@ extern "C" int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy,
                                         const float* w_ihwo, float* dx0, int lddx0, float* dx1,
                                         int lddx1, float* workspace, void* stream) {
     return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream);
+}
+
+extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float* dy, int lddy,
+                                            const float* w_ihwo, float* dx0, int lddx0, float* dx1,
+                                            int lddx1, int accumulate, float* workspace, void* stream) {
+    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream, accumulate);
 }
 
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,

@@ -41,6 +41,7 @@ struct IgemmParams {
     int ksplit, kt_per_split;
     int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
     int math;          // 0 = fp32 MFMA, 1 = bf16 MFMA on fp32 operands (fp32 accumulate)
+    int accum;         // bit 0 / 1: ADD the result into Out0 / Out1 (gradient of a tensor with two consumers)
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

@@ -7,6 +7,7 @@ is ONE fused autograd node (ops.ConvBnActFn); activations are NHWC.
 """
 import math
 
+import torch
 from torch import nn
 
 from . import nn as xnn
@@ -30,7 +31,13 @@ class Bottleneck(nn.Module):
                                            nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
+        # the block input has two consumers (conv1 and the shortcut): the shortcut reads conv1's pass-through alias,
+        # so its gradient is added inside conv1's backward-data kernel rather than by a separate elementwise pass
+        fuse = x.is_cuda and torch.is_grad_enabled() and x.requires_grad
+        if fuse:
+            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True)
+        else:
+            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
         out = xnn.conv_bn_act(self.conv2, self.bn2, out, act=ops.ACT_RELU)
         idt = x if self.downsample is None else xnn.conv_bn_act(self.downsample[0], self.downsample[1], x)
         return xnn.conv_bn_act(self.conv3, self.bn3, out, act=ops.ACT_RELU, residual=idt)

@@ -43,11 +43,12 @@ def bump_bn_counter(bn):
     bn._xv2_pending += 1
 
 
-def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None):
-    """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node."""
+def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False):
+    """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node.  passthrough=True returns (out, x0 alias):
+    hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel."""
     bump_bn_counter(bn)
     return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
-                                 ops.BnState(bn, SYNC_BN), act, bn.training)
+                                 ops.BnState(bn, SYNC_BN), act, bn.training, passthrough)
 
 
 def conv(conv_m, x0, x1=None):

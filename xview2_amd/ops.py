@@ -219,13 +219,18 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     return y, sums
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None):
+    """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
+    the convolution's contribution INTO that tensor, which is returned as dx0."""
     N, IH, IW = in_shape
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
     w = weight.contiguous()
     C0g, Coutg = C0t // G, Cout_t // G
-    dx0 = _f32((N, IH, IW, C0t), dy)
+    if add_to0 is not None and not (add_to0.is_contiguous() and tuple(add_to0.shape) == (N, IH, IW, C0t)
+                                    and add_to0.dtype == torch.float32):
+        raise RuntimeError("backward_data: accumulation target has the wrong layout")
+    dx0 = add_to0 if add_to0 is not None else _f32((N, IH, IW, C0t), dy)
     dx1 = _f32((N, IH, IW, C1t), dy) if C1t else None
     for gi in range(G):
         if ihwo_packs:
@@ -234,8 +239,8 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None):
             _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
-        call("xv2_conv2d_backward_data", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
-             _ws(wsb, dy) if wsb else None)
+        call("xv2_conv2d_backward_data_acc", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
+             1 if add_to0 is not None else 0, _ws(wsb, dy) if wsb else None)
     return dx0, dx1
 
 
@@ -416,8 +421,15 @@ class ConvBnActFn(torch.autograd.Function):
     """z = act(BN(conv(cat(x0, x1), W)) [+ residual])  (one autograd node per conv layer)"""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training):
+    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training, passthrough=False):
+        """passthrough: also return x0 itself as a second output.  A caller whose x0 has a SECOND consumer (the
+        residual shortcut of a bottleneck) feeds that consumer from this alias: its gradient then arrives here and
+        the backward-data kernel adds onto it in its epilogue, instead of autograd summing two tensors afterwards.
+        The alias must have exactly one consumer whose gradient tensor is not shared with anybody else."""
         _need_cuda(x0)
+        ctx.set_materialize_grads(False)
+        ctx.passthrough = passthrough
+        x0_in = x0
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         residual = residual.contiguous() if residual is not None else None
@@ -432,23 +444,34 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
         ctx.wparam = weight
+        if passthrough:
+            return z, x0_in
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, dpass=None):
         x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
         g = ctx.g
+        if dz is None:
+            dz = torch.zeros_like(y)
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
                                                ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5])
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            acc = None
+            if dpass is not None and g.groups == 1 and dpass.is_contiguous():
+                acc, dpass = dpass, None          # summed inside the backward-data epilogue
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo)
+                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc)
+            if dpass is not None:
+                dx0 = dx0 + dpass
+        elif dpass is not None:
+            dx0 = dpass
         ctx.ihwo = None
         dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
         ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
-                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None)
+                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None)
 
 
 class ConvFn(torch.autograd.Function):
