@@ -60,8 +60,9 @@ int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int 
                     float* w_ohwi, float* w_ihwo, void* stream);
 /* the same for MANY weights in one launch (all packed layouts go stale together at the optimizer step):
  * table[n][8] int64 in device memory = {w_oihw, w_ohwi or 0, w_ihwo or 0 (pointers), Cout, Cin, KH*KW, cin_pad,
- * first work item}, work items = elements of the padded OHWI layout, numbered consecutively; total = their sum */
-int xv2_pack_weights_table(const int64_t* table, int n, int64_t total, void* stream);
+ * first tile}; an entry owns xv2_pack_weights_tiles() consecutive tiles (one workgroup each), total_tiles = their sum */
+int64_t xv2_pack_weights_tiles(int Cout, int KH, int KW, int cin_pad);
+int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, void* stream);
 
 /* y = conv2d(cat(x0,x1), w) [+ bias]; replaces F.conv2d.  If `stats` != NULL the kernel also
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]

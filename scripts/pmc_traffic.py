@@ -22,6 +22,10 @@ def per_kernel(db, counter):
 
 
 def pretty(mangled):
+    if "wgrad_alltaps_kernel" in mangled:
+        return "wgrad_alltaps_kernel"
+    if "direct3x3_n32_kernel" in mangled:
+        return "direct3x3_n32_kernel"
     m = re.match(r"_ZN3xv2\d+(igemm|wgrad)_kernelI(.*?)EEv", mangled)
     if not m:
         return None

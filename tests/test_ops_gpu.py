@@ -436,3 +436,29 @@ def test_bottleneck_shortcut_gradient_is_summed_in_the_dgrad_epilogue(downsample
     out.backward(nhwc(dout))
     close(nchw(out), ref, 2e-5, "out")
     close(nchw(leaf.grad), xr.grad, 5e-5, "dx")
+
+
+def test_table_driven_repack_matches_single_weight_pack():
+    """ops.repack_all (one launch over every cached layout, what FlatAdamW.step triggers) must reproduce
+    xv2_pack_weight bit for bit: 7x7 RGB stem (Cin 3 padded to 4), 3x3, 1x1, the 2x2 transposed conv, odd sizes."""
+    from xview2_amd import ops
+    from xview2_amd._capi import call
+    ops.clear_pack_cache()
+    torch.manual_seed(5)
+    geoms = [(64, 3, 7, 7, 4), (32, 32, 3, 3, 32), (256, 64, 1, 1, 64), (96, 160, 3, 3, 160), (64, 128, 2, 2, 128),
+             (40, 24, 3, 3, 32), (2048, 512, 1, 1, 512)]
+    ws = [torch.randn(co, ci, kh, kw, device=dev()) for co, ci, kh, kw, _ in geoms]
+    for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
+        ops._pack(w, cp, True, True)
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.25)            # stale now (version bump), refreshed below in one launch
+    ops.weights_changed()
+    ops.repack_all()
+    for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
+        ohwi, ihwo = ops._pack(w, cp, True, True)          # cache hit: the buffers repack_all just wrote
+        r1 = torch.empty_like(ohwi)
+        r2 = torch.empty_like(ihwo)
+        call("xv2_pack_weight", w, co, ci, kh, kw, cp, r1, r2)
+        assert torch.equal(ohwi, r1) and torch.equal(ihwo, r2), (co, ci, kh, kw)
+    ops.clear_pack_cache()

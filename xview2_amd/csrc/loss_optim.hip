@@ -298,30 +298,58 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
 }
 
 // Many weight tensors in one launch (after the optimizer step every packed layout is stale at once).
-// table[n][8]: {src OIHW pointer, ohwi pointer or 0, ihwo pointer or 0, Cout, Cin, T, cin_pad, first work item};
-// work item = one element of the padded OHWI layout.
-__global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* __restrict__ table, int n, int64_t total) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {            // last entry whose first work item is <= i
-            const int mid = (lo + hi + 1) >> 1;
-            if (table[mid * 8 + 7] <= i) lo = mid;
-            else hi = mid - 1;
-        }
-        const int64_t* e = table + lo * 8;
-        const float* w = reinterpret_cast<const float*>(e[0]);
-        float* ohwi = reinterpret_cast<float*>(e[1]);
-        float* ihwo = reinterpret_cast<float*>(e[2]);
-        const int Cout = (int)e[3], Cin = (int)e[4], T = (int)e[5], CinP = (int)e[6];
-        const int64_t j = i - e[7];
-        const int ci = (int)(j % CinP);
-        const int64_t q = j / CinP;
-        const int t = (int)(q % T);
-        const int co = (int)(q / T);
-        const float v = ci < Cin ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
-        if (ohwi) ohwi[j] = v;
-        if (ihwo) ihwo[((size_t)ci * T + t) * Cout + co] = v;
+// table[n][8]: {src OIHW pointer, ohwi pointer or 0, ihwo pointer or 0, Cout, Cin, T, cin_pad, first tile};
+// a tile = 32 output channels x 32 (padded) input channels x up to 9 taps, staged through LDS so that the OIHW
+// reads AND both transposed writes move whole 128-byte lines.
+constexpr int PK_TC = 9;
+__host__ __device__ inline int64_t pack_tiles(int Cout, int CinP, int T) {
+    return (int64_t)((Cout + 31) / 32) * ((CinP + 31) / 32) * ((T + PK_TC - 1) / PK_TC);
+}
+__global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* __restrict__ table, int n) {
+    __shared__ float sh[32 * (32 * PK_TC + 1)];
+    int lo = 0, hi = n - 1;
+    const int64_t tile = blockIdx.x;
+    while (lo < hi) {            // last entry whose first tile is <= this block's tile
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 7] <= tile) lo = mid;
+        else hi = mid - 1;
     }
+    const int64_t* e = table + lo * 8;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    float* ohwi = reinterpret_cast<float*>(e[1]);
+    float* ihwo = reinterpret_cast<float*>(e[2]);
+    const int Cout = (int)e[3], Cin = (int)e[4], T = (int)e[5], CinP = (int)e[6];
+    int j = (int)(tile - e[7]);
+    const int tcs = (T + PK_TC - 1) / PK_TC, cis = (CinP + 31) / 32;
+    const int tcb = j % tcs;
+    j /= tcs;
+    const int cib = j % cis, cob = j / cis;
+    const int t0 = tcb * PK_TC, tc = min(PK_TC, T - t0);
+    const int co0 = cob * 32, ci0 = cib * 32;
+    const int ldco = 32 * tc + 1;
+    const int cnt = 32 * 32 * tc;
+    // OIHW -> LDS[co][ci][t]  (a co row of the tile is 32*tc consecutive floats when tc == T)
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int col = i / (32 * tc), r = i - col * (32 * tc);
+        const int cil = r / tc, tl = r - cil * tc;
+        const int co = co0 + col, ci = ci0 + cil;
+        sh[col * ldco + r] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t0 + tl] : 0.f;
+    }
+    __syncthreads();
+    if (ohwi)
+        for (int i = threadIdx.x; i < cnt; i += 256) {       // (co, t, ci): ci fastest
+            const int cil = i & 31, q = i >> 5;
+            const int tl = q % tc, col = q / tc;
+            const int co = co0 + col, ci = ci0 + cil;
+            if (co < Cout && ci < CinP) ohwi[((size_t)co * T + t0 + tl) * CinP + ci] = sh[col * ldco + cil * tc + tl];
+        }
+    if (ihwo)
+        for (int i = threadIdx.x; i < cnt; i += 256) {       // (ci, t, co): co fastest
+            const int col = i & 31, q = i >> 5;
+            const int tl = q % tc, cil = q / tc;
+            const int co = co0 + col, ci = ci0 + cil;
+            if (co < Cout && ci < CinP) ihwo[((size_t)ci * T + t0 + tl) * Cout + co] = sh[col * ldco + cil * tc + tl];
+        }
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -457,10 +485,13 @@ extern "C" int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, i
     return XV2_OK;
 }
 
-extern "C" int xv2_pack_weights_table(const int64_t* table, int n, int64_t total, void* stream) {
-    XV2_CHECK_ARG(table && n > 0 && total > 0, "pack_weights_table: empty table");
-    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 8192);
-    hipLaunchKernelGGL(pack_weights_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, n, total);
+extern "C" int64_t xv2_pack_weights_tiles(int Cout, int KH, int KW, int cin_pad) {
+    return pack_tiles(Cout, cin_pad, KH * KW);
+}
+
+extern "C" int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "pack_weights_table: bad table");
+    hipLaunchKernelGGL(pack_weights_table_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table, n);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

@@ -155,7 +155,7 @@ def repack_all():
             Cout, Cin, T, cin_pad = e.geom
             rows.append([e.w.data_ptr(), e.ohwi.data_ptr() if e.ohwi is not None else 0,
                          e.ihwo.data_ptr() if e.ihwo is not None else 0, Cout, Cin, T, cin_pad, start])
-            start += Cout * T * cin_pad
+            start += query("xv2_pack_weights_tiles", Cout, T, 1, cin_pad)
         dev = next(iter(_packs.values())).w.device
         _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start)
     table, n, total = _pack_table
