@@ -4,17 +4,27 @@
     python main.py --exec_mode train --type pre --encoder resnet50 --loss_str dice --precision 32 --data synthetic
     torchrun --nproc-per-node 8 main.py --gpus 8 --type post --dmg_model siamese ...       (one process per GPU)
 
-Differences, all forced by the environment: ``--data`` accepts only ``synthetic`` (xBD + cv2/albumentations are not
-available), ``--gpus N`` expects to be launched once per GPU (torchrun) instead of PL's self re-exec, CPU affinity is
-left to the launcher (utils/gpu_affinity.py is NVML-only)."""
+``--data <dir>`` reads xBD tiles laid out like the reference expects (<dir>/{train,test,holdout}/{images,targets}/*.png,
+data_loading/data_module.py:12-14) through a PIL/numpy port of its loader; ``--data synthetic`` generates tiles of the
+same contract.  ``--gpus N`` expects to be launched once per GPU (torchrun) instead of PL's self re-exec.  CPU affinity
+follows main.py:62 (socket_unique_interleaved) with the GPU's NUMA-local cores read from sysfs instead of NVML."""
 import os
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
 import torch
 
 from xview2_amd.data import SyntheticDataModule
+from xview2_amd.data_loading.data_module import DataModule
 from xview2_amd.lightning import Model
 from xview2_amd.trainer import Trainer
+from xview2_amd.utils.gpu_affinity import set_affinity
+
+
+def set_hip_devices(gpus):
+    """main.py:20-23 (CUDA_VISIBLE_DEVICES) for ROCm; a torchrun launch already scopes each rank through LOCAL_RANK"""
+    if torch.cuda.is_available():
+        assert gpus <= torch.cuda.device_count(), "Requested %d gpus, available %d." % (gpus, torch.cuda.device_count())
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", ",".join(str(i) for i in range(gpus)))
 
 
 def transplant_encoder(model, pretrained_sd, dmg_model):
@@ -70,6 +80,11 @@ def main(argv=None):
     if args.interpolate:
         args.deep_supervision = False
         args.dec_interp = False
+    set_hip_devices(args.gpus)
+    try:
+        set_affinity(os.getenv("LOCAL_RANK", "0"), "socket_unique_interleaved")     # main.py:62
+    except (OSError, RuntimeError):
+        pass                                                                        # restricted cpusets: keep the default
     torch.manual_seed(args.seed)
     os.makedirs(args.results, exist_ok=True)
     checkpoint = args.ckpt if args.ckpt is not None and os.path.exists(args.ckpt) else None
@@ -89,8 +104,11 @@ def main(argv=None):
                       sync_batchnorm=args.gpus > 1, accelerator="ddp" if args.gpus > 1 else None,
                       default_root_dir=args.results, checkpoint_callback=args.exec_mode == "train",
                       resume_from_checkpoint=checkpoint)
-    dm = SyntheticDataModule(args, device=trainer.device, rank=trainer.rank, train_size=args.train_size,
-                             eval_size=args.eval_size, steps_per_epoch=args.steps_per_epoch)
+    if args.data == "synthetic":
+        dm = SyntheticDataModule(args, device=trainer.device, rank=trainer.rank, train_size=args.train_size,
+                                 eval_size=args.eval_size, steps_per_epoch=args.steps_per_epoch)
+    else:
+        dm = DataModule(args, device=trainer.device, rank=trainer.rank, world_size=trainer.world)
     if args.exec_mode == "train":
         trainer.fit(model, dm)
     else:

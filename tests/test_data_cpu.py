@@ -1,0 +1,137 @@
+"""Input pipeline and launcher helpers: the PIL/numpy port of data_loading/pytorch_loader.py on
+a generated miniature xBD tree, and the sysfs-based CPU affinity planner."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from xview2_amd.data_loading import pytorch_loader as pl
+from xview2_amd.data_loading.data_module import DataModule
+from xview2_amd.utils import gpu_affinity as ga
+
+S = 600
+
+
+def _tile_tree(root, n=4, S=S):
+    rng = np.random.default_rng(0)
+    for split in ("train", "test", "holdout"):
+        for sub in ("images", "targets"):
+            os.makedirs(os.path.join(root, split, sub), exist_ok=True)
+        for i in range(n):
+            for kind in ("pre", "post"):
+                img = rng.integers(1, 256, (S, S, 3), dtype=np.uint8)
+                Image.fromarray(img).save(os.path.join(root, split, "images", "t%02d_%s_disaster.png" % (i, kind)))
+                m = np.zeros((S, S), np.uint8)
+                if i != 1:       # tile 1 has an empty mask
+                    y, x = 40 + 90 * i, 500 - 100 * i
+                    m[y:y + 30, x:x + 30] = 1 if kind == "pre" else 1 + (i % 4)
+                Image.fromarray(m).save(os.path.join(root, split, "targets", "t%02d_%s_disaster_target.png" % (i, kind)))
+    with open(os.path.join(root, "index.csv"), "w") as f:
+        f.write("idx,1,2,3,4\n0,1,0,0,0\n2,0,0,1,0\n3,0,0,0,0\n")
+    return os.path.join(root, "index.csv")
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("xbd"))
+    return root, _tile_tree(root)
+
+
+def test_load_pair_is_bgr_like_cv2_and_eval_sample_is_normalised_exactly(tree):
+    root, _ = tree
+    ds = pl.TestDataset(os.path.join(root, "holdout"), "post")
+    assert len(ds) == 4
+    s = ds[2]
+    rgb_pre = np.asarray(Image.open(ds.imgs_pre[2]).convert("RGB")).astype(np.float32)
+    rgb_post = np.asarray(Image.open(ds.imgs_post[2]).convert("RGB")).astype(np.float32)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    want = np.concatenate([(x[:, :, ::-1] / 255.0 - mean) / std for x in (rgb_pre, rgb_post)], 2).transpose(2, 0, 1)
+    assert s["image"].dtype == np.float32 and s["image"].shape == (6, S, S)
+    np.testing.assert_allclose(s["image"], want, rtol=0, atol=1e-6)
+    assert s["mask"].dtype == np.uint8 and set(np.unique(s["mask"]).tolist()) == {0, 3}   # the POST label (loader :166)
+    assert pl.TestDataset(os.path.join(root, "holdout"), "pre")[2]["image"].shape == (3, S, S)
+
+
+def test_training_samples_follow_the_index_and_always_contain_buildings(tree):
+    root, csv = tree
+    pl._rng_holder["rng"] = np.random.default_rng(3)
+    pre = pl.TrainPreDataset(os.path.join(root, "train"), "pre", False, csv)
+    post = pl.TrainPostDataset(os.path.join(root, "train"), "post", False, csv)
+    assert pre.idx == [0, 2, 3]            # the idx column (pytorch_loader.py:65-66)
+    assert post.idx == [0, 2]              # rows with any damage class flagged (:104-110)
+    for ds, c in ((pre, 3), (post, 6)):
+        for rep in range(6):
+            s = ds[rep % len(ds)]
+            assert s["image"].shape == (c, 512, 512) and s["image"].dtype == np.float32
+            assert s["mask"].shape == (512, 512) and s["mask"].dtype == np.uint8
+            assert s["mask"].any(), "CropNonEmptyMaskIfExists must keep building pixels in the crop"
+
+
+def test_geometric_augmentations_move_image_and_mask_together():
+    pl._rng_holder["rng"] = np.random.default_rng(0)
+    img = np.zeros((64, 64, 3), np.uint8)
+    mask = np.zeros((64, 64), np.uint8)
+    img[5:9, 50:60] = 200
+    mask[5:9, 50:60] = 1
+    for axis in (0, 1):
+        a, b = pl.flip(img, mask, axis, p=1.0)
+        assert np.array_equal(a[:, :, 0] > 0, b > 0)
+        assert not np.array_equal(b, mask)
+    big_i, big_m = pl.random_scale(np.tile(img, (10, 10, 1)), np.tile(mask, (10, 10)), p=1.0)
+    assert big_i.shape[:2] == big_m.shape and 640 <= big_m.shape[0] <= 832
+    lut = pl.random_brightness_contrast(img, p=1.0)
+    assert lut.dtype == np.uint8 and lut.shape == img.shape
+    noisy = pl.gauss_noise(np.full((32, 32, 3), 128, np.uint8), p=1.0)
+    assert noisy.dtype == np.uint8 and 2.0 < noisy.astype(np.float32).std() < 9.0       # sigma in [sqrt10, sqrt50]
+
+
+def test_build_index_flags_classes_like_generate_idx(tree):
+    root, _ = tree
+    ix = pl.build_index(os.path.join(root, "train"))
+    assert ix["idx"] == [0, 1, 2, 3]
+    assert [ix[c][0] for c in "1234"] == [1, 0, 0, 0] and [ix[c][2] for c in "1234"] == [0, 0, 1, 0]
+    assert [ix[c][1] for c in "1234"] == [0, 0, 0, 0]
+
+
+class _Args:
+    type = "post"
+    batch_size = 2
+    val_batch_size = 3
+    num_workers = 0
+    autoaugment = False
+
+
+def test_data_module_batches_and_rank_sharding(tree, monkeypatch):
+    root, csv = tree
+    monkeypatch.setattr(pl, "DEFAULT_INDEX", csv)
+    a = _Args()
+    a.data = root
+    dm = DataModule(a, device="cpu")
+    b = next(iter(dm.train_dataloader()))
+    assert b["image"].shape == (2, 6, 512, 512) and b["image"].dtype == torch.float32
+    assert b["mask"].shape == (2, 512, 512) and b["mask"].dtype == torch.uint8
+    sizes = [x["image"].shape[0] for x in dm.test_dataloader()]
+    assert sizes == [3, 1]                                     # drop_last False, order kept (data_module.py:23-28)
+    seen = []
+    for r in range(2):
+        dmr = DataModule(a, device="cpu", rank=r, world_size=2)
+        seen.append(sum(x["image"].shape[0] for x in dmr.val_dataloader()))
+    assert seen == [2, 2]                                      # 4 tiles split over 2 ranks
+
+
+def test_affinity_planner_modes():
+    assert ga.parse_cpulist("0-3,8-9\n") == [0, 1, 2, 3, 8, 9]
+    fake = {0: [0, 1, 2, 3, 8, 9, 10, 11], 1: [0, 1, 2, 3, 8, 9, 10, 11],
+            2: [4, 5, 6, 7, 12, 13, 14, 15], 3: [4, 5, 6, 7, 12, 13, 14, 15]}
+    sib = [(i, i + 8) for i in range(8)]
+    plan = lambda i, m: ga.plan_affinity(i, 4, m, lambda k: fake[k], sib)
+    assert plan(2, "socket") == fake[2] and plan(2, "single") == [4]
+    assert [plan(i, "single_unique") for i in range(4)] == [[0], [1], [4], [5]]
+    assert [plan(i, "socket_unique_interleaved") for i in range(4)] == [[0, 2, 8, 10], [1, 3, 9, 11], [4, 6, 12, 14],
+                                                                       [5, 7, 13, 15]]
+    assert plan(3, "socket_unique_continuous") == [6, 7, 14, 15]
+    with pytest.raises(RuntimeError):
+        plan(0, "nonsense")
+    assert set(ga.set_affinity(0, "socket")) <= set(range(os.cpu_count()))      # no GPU here: keeps the current set

@@ -30,3 +30,24 @@ def test_cli_train_eval_and_transplant(tmp_path):
                    "--epochs", "1", "--results", res3, "--ckpt_pre", ck] + common)
     assert os.path.exists(os.path.join(res3, "checkpoints", "last.ckpt"))
     assert mp.model.unet.enc_l1[0].weight.shape == m.model.unet.enc_l1[0].weight.shape
+
+
+def test_cli_trains_and_evaluates_on_png_tiles(tmp_path, monkeypatch):
+    """the PIL/numpy port of data_loading/pytorch_loader.py feeding the HIP path: 512x512 training crops from 640x640
+    PNG tiles (B,G,R order, A.Normalize statistics), full-tile evaluation, .npy probabilities written"""
+    import main as cli
+    from tests.test_data_cpu import _tile_tree
+    from xview2_amd.data_loading import pytorch_loader as pl
+    root = str(tmp_path / "xbd")
+    os.makedirs(root)
+    monkeypatch.setattr(pl, "DEFAULT_INDEX", _tile_tree(root, n=4, S=640))
+    res = str(tmp_path / "run")
+    common = ["--data", root, "--type", "post", "--dmg_model", "siamese", "--encoder", "resnet50", "--precision", "32",
+              "--batch_size", "2", "--val_batch_size", "2", "--num_workers", "0", "--loss_str", "focal+dice"]
+    m = cli.main(["--exec_mode", "train", "--epochs", "1", "--results", res] + common)
+    ck = os.path.join(res, "checkpoints", "last.ckpt")
+    assert os.path.exists(ck)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    res2 = str(tmp_path / "eval")
+    cli.main(["--exec_mode", "eval", "--ckpt", ck, "--results", res2] + common)
+    assert len(os.listdir(os.path.join(res2, "probs"))) == 4

@@ -26,6 +26,9 @@
 #ifndef XV2_SCHED
 #define XV2_SCHED 0
 #endif
+#ifndef XV2_PRIO
+#define XV2_PRIO 0   // experiment: s_setprio level while a wave issues its MFMA burst
+#endif
 #ifndef XV2_ABL
 #define XV2_ABL 0   // debug ablations (scripts/ablate.sh): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 #endif
@@ -268,6 +271,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         }
         const float* a = As + buf * BM * LDS_LD + (wm * WTM + l31) * LDS_LD + 4 * h;
         const float* b = Bs + buf * BN * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * h;
+#if XV2_PRIO
+        __builtin_amdgcn_s_setprio(XV2_PRIO);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float4 af[MR], bf[NR];
@@ -305,6 +311,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
+#endif
+#if XV2_PRIO
+        __builtin_amdgcn_s_setprio(0);
 #endif
         __syncthreads();
     }

@@ -1,0 +1,252 @@
+"""xBD tile loader with the contract of the reference's data_loading/pytorch_loader.py (same class and function
+names, same sample dict, same augmentation recipe) on PIL + numpy - cv2 and albumentations are not in this image.
+
+    sample = {"image": float32 [3|6, H, W] (A.Normalize() statistics), "mask": uint8 [H, W]}
+
+What is reproduced exactly: file discovery (`load_data`, pytorch_loader.py:31-35), the channel order (cv2.imread
+gives B,G,R and the reference normalises those with the R,G,B ImageNet statistics - pytorch_loader.py:38,63,90 - so
+this loader flips PIL's RGB to BGR), the index file semantics (utils/index.csv: `idx` column for localization, the
+union of rows flagged 1..4 for damage, pytorch_loader.py:65-66,104-110), the order and probabilities of the
+augmentations (:57-63,:77-91) and the evaluation dataset (:151-171).  What can only match in distribution: the random
+streams (albumentations draws from `random`, this module from one numpy Generator per worker).
+`--autoaugment` (data_loading/autoaugment.py) is not provided."""
+import os
+from glob import glob
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader, Dataset
+
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+DEFAULT_INDEX = os.environ.get("XV2_INDEX_CSV", "/workspace/xview2/utils/index.csv")   # pytorch_loader.py:64
+
+
+def seed_worker(worker_id):  # pytorch_loader.py:16-19
+    worker_seed = torch.initial_seed() % 2 ** 32
+    np.random.seed(worker_seed)
+    _rng_holder["rng"] = np.random.default_rng(worker_seed)
+
+
+_rng_holder = {"rng": np.random.default_rng(0)}
+
+
+def _rng():
+    return _rng_holder["rng"]
+
+
+def load_data(path, dtype):  # pytorch_loader.py:31-35
+    imgs = sorted(glob(os.path.join(path, "images", "*%s*" % dtype)))
+    lbls = sorted(glob(os.path.join(path, "targets", "*%s*" % dtype)))
+    assert len(imgs) == len(lbls) and len(imgs) > 0
+    return imgs, lbls
+
+
+def load_pair(img, lbl):
+    """cv2.imread semantics: 8-bit B,G,R image; label read unchanged (single-channel uint8)"""
+    im = np.asarray(Image.open(img).convert("RGB"))[:, :, ::-1]
+    lb = np.asarray(Image.open(lbl))
+    if lb.ndim == 3:
+        lb = lb[:, :, 0]
+    return np.ascontiguousarray(im), np.ascontiguousarray(lb.astype(np.uint8))
+
+
+def read_index(path):
+    """utils/index.csv: header idx,1,2,3,4 (utils/generate_idx.py:35-41) -> dict of int lists"""
+    cols = None
+    rows = []
+    with open(path) as f:
+        for line in f:
+            parts = line.strip().split(",")
+            if not parts or parts == [""]:
+                continue
+            if cols is None:
+                cols = parts
+                continue
+            rows.append([int(float(v)) for v in parts])
+    arr = np.array(rows, dtype=np.int64).reshape(-1, len(cols))
+    return {c: arr[:, i].tolist() for i, c in enumerate(cols)}
+
+
+def build_index(train_path, out_csv=None):
+    """utils/generate_idx.py without its exclusion list: tiles with a >= 512 x 512 foreground overlap, flagged by
+    the damage classes their post mask contains."""
+    imgs_pre, _ = load_data(train_path, "pre")
+    imgs_post, lbls_post = load_data(train_path, "post")
+    rows = []
+    for idx in range(len(imgs_post)):
+        pre, _ = load_pair(imgs_pre[idx], lbls_post[idx])
+        post, lbl = load_pair(imgs_post[idx], lbls_post[idx])
+        ok = []
+        for im in (pre, post):
+            ys, xs = np.where(im.max(2) > 0)
+            ok.append((ys.min(), ys.max(), xs.min(), xs.max()) if ys.size else None)
+        if None in ok:
+            continue
+        h = min(ok[0][1], ok[1][1]) - max(ok[0][0], ok[1][0])
+        w = min(ok[0][3], ok[1][3]) - max(ok[0][2], ok[1][2])
+        if h < 512 or w < 512:
+            continue
+        present = set(np.unique(lbl).tolist())
+        rows.append([idx] + [1 if c in present else 0 for c in (1, 2, 3, 4)])
+    if out_csv:
+        with open(out_csv, "w") as f:
+            f.write("idx,1,2,3,4\n")
+            for r in rows:
+                f.write(",".join(str(v) for v in r) + "\n")
+    arr = np.array(rows, dtype=np.int64).reshape(-1, 5)
+    return {c: arr[:, i].tolist() for i, c in enumerate(("idx", "1", "2", "3", "4"))}
+
+
+# ---- augmentations (albumentations 0.5 recipes named in pytorch_loader.py:57-63) ---------------------------------
+def random_scale(img, mask, p=0.2, scale_limit=(0.0, 0.3)):
+    """A.RandomScale(p=0.2, scale_limit=(0, 0.3), interpolation=cv2.INTER_CUBIC); masks use nearest"""
+    if _rng().random() >= p:
+        return img, mask
+    s = 1.0 + _rng().uniform(*scale_limit)
+    h, w = mask.shape[:2]
+    nh, nw = int(round(h * s)), int(round(w * s))
+    chans = [np.asarray(Image.fromarray(np.ascontiguousarray(img[:, :, i:i + 3])).resize((nw, nh), Image.BICUBIC))
+             for i in range(0, img.shape[2], 3)]
+    mask = np.asarray(Image.fromarray(mask).resize((nw, nh), Image.NEAREST))
+    return np.concatenate(chans, 2), mask
+
+
+def crop_non_empty_mask_if_exists(img, mask, height=512, width=512):
+    """A.CropNonEmptyMaskIfExists(p=1): a window around a random foreground pixel, else a random window"""
+    H, W = mask.shape[:2]
+    if H < height or W < width:
+        raise ValueError("crop %dx%d larger than the tile %dx%d" % (height, width, H, W))
+    ys, xs = np.nonzero(mask)
+    if ys.size:
+        k = int(_rng().integers(0, ys.size))
+        y0 = int(np.clip(ys[k] - _rng().integers(0, height), 0, H - height))
+        x0 = int(np.clip(xs[k] - _rng().integers(0, width), 0, W - width))
+    else:
+        y0 = int(_rng().integers(0, H - height + 1))
+        x0 = int(_rng().integers(0, W - width + 1))
+    return img[y0:y0 + height, x0:x0 + width], mask[y0:y0 + height, x0:x0 + width]
+
+
+def flip(img, mask, axis, p=0.33):
+    if _rng().random() >= p:
+        return img, mask
+    return np.ascontiguousarray(np.flip(img, axis)), np.ascontiguousarray(np.flip(mask, axis))
+
+
+def gauss_noise(img, p=0.1, var_limit=(10.0, 50.0)):
+    if _rng().random() >= p:
+        return img
+    sigma = _rng().uniform(*var_limit) ** 0.5
+    noisy = img.astype(np.float32) + _rng().normal(0.0, sigma, img.shape).astype(np.float32)
+    return np.clip(noisy, 0, 255).astype(np.uint8)
+
+
+def random_brightness_contrast(img, p=0.2, limit=0.2):
+    if _rng().random() >= p:
+        return img
+    alpha = 1.0 + _rng().uniform(-limit, limit)
+    beta = _rng().uniform(-limit, limit)
+    lut = np.clip(np.arange(256, dtype=np.float32) * alpha + beta * 255.0, 0, 255).astype(np.uint8)
+    return lut[img]
+
+
+def normalize(img):
+    """A.Normalize(): (img / 255 - mean) / std, statistics applied in STORED channel order (B,G,R here)"""
+    return (img.astype(np.float32) / 255.0 - MEAN) / STD
+
+
+class _TrainBase(Dataset):
+    def __init__(self, autoaugment):
+        if autoaugment:
+            raise NotImplementedError("--autoaugment (data_loading/autoaugment.py) is not provided")
+
+    def _augment(self, img, mask):
+        img, mask = random_scale(img, mask)
+        img, mask = crop_non_empty_mask_if_exists(img, mask)
+        img, mask = flip(img, mask, 1)      # HorizontalFlip
+        img, mask = flip(img, mask, 0)      # VerticalFlip
+        parts = [img[:, :, i:i + 3] for i in range(0, img.shape[2], 3)]
+        parts = [gauss_noise(p) for p in parts]                 # drawn per image, like two A.GaussNoise calls
+        parts = [random_brightness_contrast(p) for p in parts]
+        parts = [normalize(p) for p in parts]
+        img = np.concatenate(parts, 2)
+        return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": np.ascontiguousarray(mask)}
+
+
+class TrainPreDataset(_TrainBase):  # pytorch_loader.py:53-94
+    def __init__(self, path, _, autoaugment=False, index_csv=None):
+        super().__init__(autoaugment)
+        self.imgs_pre, self.lbls_pre = load_data(path, "pre")
+        self.idx = _index(path, index_csv)["idx"]
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        img, lbl = load_pair(self.imgs_pre[self.idx[i]], self.lbls_pre[self.idx[i]])
+        return self._augment(img, lbl)
+
+
+class TrainPostDataset(_TrainBase):  # pytorch_loader.py:97-148
+    def __init__(self, path, _, autoaugment=False, index_csv=None):
+        super().__init__(autoaugment)
+        self.imgs_pre, self.lbls_pre = load_data(path, "pre")
+        self.imgs_post, self.lbls_post = load_data(path, "post")
+        assert len(self.imgs_pre) == len(self.imgs_post)
+        assert len(self.imgs_post) == len(self.lbls_post)
+        ix = _index(path, index_csv)
+        keep = set()
+        for c in ("1", "2", "3", "4"):
+            keep.update(i for i, f in zip(ix["idx"], ix[c]) if f == 1)
+        self.idx = sorted(keep)
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        k = self.idx[i]
+        img_pre, _ = load_pair(self.imgs_pre[k], self.lbls_pre[k])
+        img_post, lbl = load_pair(self.imgs_post[k], self.lbls_post[k])
+        return self._augment(np.concatenate((img_pre, img_post), 2), lbl)
+
+
+class TestDataset(Dataset):  # pytorch_loader.py:151-171
+    def __init__(self, path, mode, _=False):
+        self.mode = mode
+        self.imgs_pre, self.lbls_pre = load_data(path, "pre")
+        self.imgs_post, self.lbls_post = load_data(path, "post")
+        assert len(self.imgs_pre) == len(self.imgs_post)
+        assert len(self.imgs_post) == len(self.lbls_post)
+
+    def __len__(self):
+        return len(self.imgs_pre)
+
+    def __getitem__(self, i):
+        img, lbl = load_pair(self.imgs_pre[i], self.lbls_pre[i])
+        img = normalize(img)
+        if self.mode == "post":
+            img_post, lbl = load_pair(self.imgs_post[i], self.lbls_post[i])
+            img = np.concatenate((img, normalize(img_post)), 2)
+        return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": lbl}
+
+
+def _index(path, index_csv):
+    csv = index_csv or DEFAULT_INDEX
+    if os.path.exists(csv):
+        return read_index(csv)
+    local = os.path.join(path, "index.csv")
+    if os.path.exists(local):
+        return read_index(local)
+    return build_index(path, local if os.access(path, os.W_OK) else None)
+
+
+def fetch_pytorch_loader(path, mode, training, loader_kwargs, autoaugment=False):  # pytorch_loader.py:22-28
+    if not training:
+        dataset = TestDataset
+    elif mode == "pre":
+        dataset = TrainPreDataset
+    else:
+        dataset = TrainPostDataset
+    return DataLoader(dataset(path, mode, autoaugment), worker_init_fn=seed_worker, **loader_kwargs)
