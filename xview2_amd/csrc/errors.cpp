@@ -21,6 +21,8 @@ extern "C" int xv2_version(void) { return 1; }
 namespace xv2 {
 struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
+static int g_prof_only = -1;
+static bool g_prof_open = false;   // >= 0: bracket only launches of this kernel id
 static std::vector<std::string> g_prof_names;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -38,18 +40,24 @@ int prof_register(const char* name) {
     return (int)g_prof_names.size() - 1;
 }
 void prof_begin(int kid, double flops, double bytes, hipStream_t stream) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || (g_prof_only >= 0 && kid != g_prof_only)) {
+        g_prof_open = false;
+        return;
+    }
+    g_prof_open = true;
     ProfRec r{kid, flops, bytes, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, stream);
     g_prof_recs.push_back(r);
 }
 void prof_end(hipStream_t stream) {
-    if (!g_prof_on || g_prof_recs.empty()) return;
+    if (!g_prof_on || !g_prof_open || g_prof_recs.empty()) return;
+    g_prof_open = false;
     (void)hipEventRecord(g_prof_recs.back().b, stream);
 }
 }  // namespace xv2
 extern "C" int xv2_prof_enable(int on) {
     xv2::g_prof_on = on != 0;
+    xv2::g_prof_only = on >= 2 ? on - 2 : -1;
     if (on) {
         xv2::g_prof_recs.clear();
         xv2::g_prof_pool_next = 0;

@@ -251,18 +251,14 @@ ASYNC_WGRAD = os.environ.get("XV2_ASYNC_WGRAD", "1") != "0"
 _wgrad_stream = None
 
 
-def _low_priority_stream():
-    """A HIP stream at the LOWEST queue priority: the compute stream's backward-data kernels get the CUs first and
-    the weight-gradient kernels fill in behind them - in particular under the HBM-bound BatchNorm passes, which
-    leave the matrix pipes idle.  (torch.cuda.Stream only exposes 'high' and 'normal'.)"""
+def _priority_stream(prio):
+    """experiment hook (XV2_WGRAD_PRIORITY): a HIP stream at an explicit queue priority (1 = lowest, -1 = highest).
+    Measured: no gain on one GPU, and at the LOWEST priority the step with RCCL collectives in it (SyncBatchNorm,
+    gradient buckets) slows from 38 to 58 ms - so the default is an ordinary stream."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
-    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-        return torch.cuda.Stream()
-    prio = int(os.environ.get("XV2_WGRAD_PRIORITY", least.value))
     h = ctypes.c_void_p()
-    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, int(prio)) != 0 or not h.value:   # 1 = hipStreamNonBlocking
         return torch.cuda.Stream()
     return torch.cuda.ExternalStream(h.value)
 
@@ -270,7 +266,8 @@ def _low_priority_stream():
 def _side_stream():
     global _wgrad_stream
     if _wgrad_stream is None:
-        _wgrad_stream = _low_priority_stream()
+        prio = os.environ.get("XV2_WGRAD_PRIORITY")
+        _wgrad_stream = _priority_stream(prio) if prio is not None else torch.cuda.Stream()
     return _wgrad_stream
 
 
