@@ -1,0 +1,44 @@
+"""Tile / split-K sweep of the implicit-GEMM kernel per layer shape (forward and backward-data), against the cost
+model's own choice.  usage: python scripts/sweep_tiles.py [filter]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xview2_amd import ops
+from scripts.bench_conv import SHAPES, prof_time
+
+CANDS = [(128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 2), (128, 128, 3), (128, 128, 4), (128, 128, 6)]
+
+
+def main():
+    filt = sys.argv[1:]
+    dev = "cuda:0"
+    ops.PACK_CACHE = False
+    for (name, N, H, W, C0, C1, Co, k, s, p) in SHAPES:
+        if filt and not any(f in name for f in filt):
+            continue
+        g = ops.conv_cfg(k, k, s, p)
+        x0 = torch.randn(N, H, W, C0, device=dev)
+        x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
+        w = torch.randn(Co, C0 + C1, k, k, device=dev) * 0.05
+        OH, OW = ops._out_hw(H, W, g)
+        dy = torch.randn(N, OH, OW, Co, device=dev)
+        for what, fn in (("fwd", lambda: ops._conv_forward(x0, x1, w, g, None, True)),
+                         ("dgrad", lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))):
+            os.environ.pop("XV2_FORCE_TILE", None)
+            base = prof_time(fn, 10)
+            res = []
+            for c in CANDS:
+                os.environ["XV2_FORCE_TILE"] = "%d,%d,%d" % c
+                try:
+                    res.append((prof_time(fn, 10), c))
+                except RuntimeError:
+                    pass
+            os.environ.pop("XV2_FORCE_TILE", None)
+            base = min(base, prof_time(fn, 10))       # again at the end: clocks have settled by now
+            res.sort()
+            print("%-28s %-5s model %.3f ms | best %.3f %s  (%+.1f%%) | %s" % (
+                name, what, base, res[0][0], res[0][1], 100 * (res[0][0] / base - 1),
+                " ".join("%s:%.3f" % ("x".join(map(str, c)), t) for t, c in res[:4])))
+
+
+if __name__ == "__main__":
+    main()

@@ -498,6 +498,16 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& b
         bm = 128;
         return;
     }
+    if (const char* f = getenv("XV2_FORCE_TILE")) {      // tuning sweeps (scripts/sweep_tiles.py): "bm,bn,ksplit"
+        int fbm = 0, fbn = 0, fks = 0;
+        if (sscanf(f, "%d,%d,%d", &fbm, &fbn, &fks) == 3 && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) &&
+            Nout % fbn == 0 && fks >= 1) {
+            bm = fbm;
+            bn = fbn;
+            if (fks > 1 && fbm == 128 && fbn == 128 && nkt / fks >= 2) ksplit = fks;
+            return;
+        }
+    }
     // Cost model in "rounds": the chip holds `cap` blocks at once (LDS-limited: 2 per CU for the 128x128, 64x128 and
     // 128x64 tiles, 4 per CU for 64x64); a launch takes ceil(blocks / cap) rounds of (tile rows x K share) work.
     // Candidates: 128-row tile, 64-row tile (measured ~8 % less efficient per FLOP), and for bn == 128 the 128-row
@@ -548,6 +558,9 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, p.cls[c].M);
     if (direct3x3_eligible(p, smallc)) return direct3x3_launch(p, stream);
     pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
+    if (getenv("XV2_DEBUG_TILE"))
+        fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
+                splitk_ws != nullptr, bm, bn, ks);
     p.ksplit = ks;
     p.part = splitk_ws;
     p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);

@@ -243,29 +243,48 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int lds, flo
 }
 
 // -------------------------------------------------------------------------- split attention
-constexpr int SPLAT_CHUNKS = 64;
-// part[n][chunk][C2] = column sums of x[n, rows of chunk, :]
+constexpr int SPLAT_CHUNKS = 256;
+// part[n][chunk][C2] = column sums over the chunk's rows of a (b == null) or of a * b, a: [N][hw][C2],
+// b: [N][hw][Cb] broadcast over the C2/Cb radix groups (column c of a pairs with column c % Cb of b).
+// grid (chunks, column groups, N); a block = (cgw/4 float4 lanes) x (256/(cgw/4) row lanes), cgw = min(C2, 256):
+// 16-byte loads, two rows in flight per lane, LDS fold of the row lanes.
 __global__ void __launch_bounds__(256) splat_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                            int64_t hw, int C2, int rows_per_chunk,
+                                                            int64_t hw, int C2, int Cb, int cgw, int rows_per_chunk,
                                                             float* __restrict__ part) {
-    // a: tensor [N][hw][C2]; if b != null the summed quantity is a*b (same layout for the first C2/..)
-    __shared__ float sh[256];
-    const int n = blockIdx.y, chunk = blockIdx.x;
+    __shared__ float4 sh[256];
+    const int n = blockIdx.z, chunk = blockIdx.x;
+    const int C4 = cgw >> 2, rpp = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    const int c = blockIdx.y * cgw + tx * 4;
+    const int cb = b ? c % Cb : 0;
     const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int cb = 0; cb < C2; cb += 64) {
-        const int c = cb + tx;
-        float s = 0.f;
-        if (c < C2)
-            for (int64_t r = r0 + ty; r < r1; r += 4) {
-                const size_t o = ((size_t)n * hw + r) * C2 + c;
-                s += b ? a[o] * b[o] : a[o];
-            }
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        if (ty == 0 && c < C2)
-            part[((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c] = sh[tx] + sh[64 + tx] + sh[128 + tx] + sh[192 + tx];
-        __syncthreads();
+    const float* pa = a + (size_t)n * hw * C2 + c;
+    const float* pb = b ? b + (size_t)n * hw * Cb + cb : nullptr;
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+    auto term = [&](int64_t r, float4& s) {
+        float4 v = *reinterpret_cast<const float4*>(pa + r * C2);
+        if (pb) {
+            const float4 w = *reinterpret_cast<const float4*>(pb + r * Cb);
+            v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    };
+    int64_t r = r0 + ty;
+    for (; r + rpp < r1; r += 2 * rpp) {
+        term(r, s0);
+        term(r + rpp, s1);
+    }
+    if (r < r1) term(r, s0);
+    s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+    sh[threadIdx.x] = s0;
+    __syncthreads();
+    if (ty == 0) {
+        float4 t = sh[tx];
+        for (int q = 1; q < rpp; ++q) {
+            const float4 u = sh[q * C4 + tx];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(part + ((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c) = t;
     }
 }
 __global__ void splat_gap_finish_kernel(const float* __restrict__ part, int N, int C, int chunks, float inv_hw,
@@ -273,44 +292,34 @@ __global__ void splat_gap_finish_kernel(const float* __restrict__ part, int N, i
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i % C;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) {
+    float s = 0.f, t = 0.f;
+    int k = 0;
+    for (; k + 2 <= chunks; k += 2) {      // two chains: the loads of consecutive chunks overlap
+        const float* p = part + ((size_t)n * SPLAT_CHUNKS + k) * 2 * C;
+        s += p[c] + p[C + c];
+        t += p[2 * C + c] + p[3 * C + c];
+    }
+    if (k < chunks) {
         const float* p = part + ((size_t)n * SPLAT_CHUNKS + k) * 2 * C;
         s += p[c] + p[C + c];
     }
+    s += t;
     gap[i] = s * inv_hw;
 }
-// datt[n][r*C+c] = sum_hw dout[n,hw,c] * x[n,hw,r*C+c]
-__global__ void __launch_bounds__(256) splat_datt_partial_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ dout, int64_t hw, int C,
-                                                                  int rows_per_chunk, float* __restrict__ part) {
-    __shared__ float sh[256];
-    const int n = blockIdx.y, chunk = blockIdx.x, C2 = 2 * C;
-    const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int cb = 0; cb < C2; cb += 64) {
-        const int c = cb + tx;
-        float s = 0.f;
-        if (c < C2) {
-            const int cc = c < C ? c : c - C;
-            for (int64_t r = r0 + ty; r < r1; r += 4)
-                s += x[((size_t)n * hw + r) * C2 + c] * dout[((size_t)n * hw + r) * C + cc];
-        }
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        if (ty == 0 && c < C2)
-            part[((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c] = sh[tx] + sh[64 + tx] + sh[128 + tx] + sh[192 + tx];
-        __syncthreads();
-    }
-}
+// datt[n][r*C+c] = sum_hw dout[n,hw,c] * x[n,hw,r*C+c]: splat_colsum_kernel(a = x, b = dout), then this fold
 __global__ void splat_datt_finish_kernel(const float* __restrict__ part, int N, int C2, int chunks,
                                          float* __restrict__ datt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C2) return;
     const int n = i / C2, c = i % C2;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
-    datt[i] = s;
+    float s = 0.f, t = 0.f;
+    int k = 0;
+    for (; k + 2 <= chunks; k += 2) {
+        s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
+        t += part[((size_t)n * SPLAT_CHUNKS + k + 1) * C2 + c];
+    }
+    if (k < chunks) s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
+    datt[i] = s + t;
 }
 __global__ void splat_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ att, int64_t hw,
                                        int C, float* __restrict__ out, int64_t total4) {
@@ -364,14 +373,28 @@ __global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict
     s = wave_sum(s);
     if (lane == 0) y[wid] = s + (b ? b[o] : 0.f);
 }
-__global__ void linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                     float* __restrict__ dx, int N, int Cin, int Cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Cin) return;
-    const int n = i / Cin, c = i % Cin;
-    float s = 0.f;
-    for (int o = 0; o < Cout; ++o) s += dy[n * Cout + o] * w[(size_t)o * Cin + c];
-    dx[i] = s;
+// dx[n][c] = sum_o dy[n][o] * w[o][c]: block = 64 columns x 4 output lanes, each lane with 4 independent chains
+// (the one-thread-per-element form was a 1024-deep dependent load chain: 110 us for a 1 MFLOP product)
+__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int N, int Cin, int Cout) {
+    __shared__ float sh[256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, n = blockIdx.y;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < Cin) {
+        const float* g = dy + (size_t)n * Cout;
+        int o = ty;
+        for (; o + 12 < Cout; o += 16) {
+            s0 += g[o] * w[(size_t)o * Cin + c];
+            s1 += g[o + 4] * w[(size_t)(o + 4) * Cin + c];
+            s2 += g[o + 8] * w[(size_t)(o + 8) * Cin + c];
+            s3 += g[o + 12] * w[(size_t)(o + 12) * Cin + c];
+        }
+        for (; o < Cout; o += 4) s0 += g[o] * w[(size_t)o * Cin + c];
+    }
+    sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < Cin) dx[(size_t)n * Cin + c] = (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                      float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout) {
@@ -542,19 +565,27 @@ extern "C" size_t xv2_splat_gap_workspace(int N, int64_t hw, int C) {
     (void)hw;
     return (size_t)N * SPLAT_CHUNKS * 2 * C * sizeof(float);
 }
-static inline int splat_rows(int64_t hw, int& chunks) {
-    int rpc = (int)cdiv(hw, SPLAT_CHUNKS);
-    if (rpc < 4) rpc = 4;
+// rows per chunk: enough chunks to fill the chip (~2048 blocks over chunks x column groups x N), at least 8 rows per
+// row lane, at most SPLAT_CHUNKS chunks
+static inline int splat_rows(int64_t hw, int C2, int N, int& chunks, int& cgw) {
+    cgw = std::min(C2, 256);
+    const int rpp = 256 / (cgw / 4), groups = C2 / cgw;
+    int64_t want = std::max<int64_t>(1, 2048 / std::max(1, groups * N));
+    want = std::min<int64_t>(want, SPLAT_CHUNKS);
+    int64_t rpc = cdiv(hw, want);
+    rpc = std::max<int64_t>(cdiv(rpc, rpp) * rpp, (int64_t)rpp * 8);
     chunks = (int)cdiv(hw, rpc);
-    return rpc;
+    return (int)rpc;
 }
+static inline bool splat_vec_ok(int C) { return C % 4 == 0 && ((2 * C) % 256 == 0 || (2 * C <= 256 && 256 % (2 * C / 4) == 0)); }
 extern "C" int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, float* gap, float* workspace,
                                      void* stream) {
-    int chunks;
-    const int rpc = splat_rows(hw, chunks);
+    XV2_CHECK_ARG(splat_vec_ok(C), "splat_gap: unsupported channel count %d", C);
+    int chunks, cgw;
+    const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, N), dim3(256), 0, st, x, (const float*)nullptr, hw, 2 * C,
-                       rpc, workspace);
+    hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, (const float*)nullptr, hw,
+                       2 * C, 0, cgw, rpc, workspace);
     XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, st, workspace, N, C,
                        chunks, 1.f / (float)hw, gap);
@@ -576,10 +607,11 @@ extern "C" int xv2_splat_apply_backward(const float* x, const float* att, const 
     XV2_CHECK_ARG(C % 4 == 0, "splat_apply: C must be a multiple of 4");
     hipStream_t st = (hipStream_t)stream;
     if (datt) {
-        int chunks;
-        const int rpc = splat_rows(hw, chunks);
-        hipLaunchKernelGGL(splat_datt_partial_kernel, dim3(chunks, N), dim3(256), 0, st, x, dout, hw, C, rpc,
-                           workspace);
+        XV2_CHECK_ARG(splat_vec_ok(C), "splat_apply: unsupported channel count %d", C);
+        int chunks, cgw;
+        const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
+        hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, dout, hw, 2 * C, C,
+                           cgw, rpc, workspace);
         XV2_CHECK_LAUNCH();
         hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(N * 2 * C, 256)), dim3(256), 0, st,
                            workspace, N, 2 * C, chunks, datt);
@@ -604,8 +636,8 @@ extern "C" int xv2_linear_backward(const float* x, const float* w, const float* 
                                    int N, int Cin, int Cout, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(N * Cin, 256)), dim3(256), 0, st, w, dy, dx, N,
-                           Cin, Cout);
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(Cin, 64), N), dim3(256), 0, st, w, dy, dx, N, Cin,
+                           Cout);
         XV2_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)cdiv(Cout * (Cin + 1), 256)), dim3(256), 0, st, x, dy, dw,

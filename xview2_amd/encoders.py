@@ -123,7 +123,11 @@ class StBottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
+        # conv1's pass-through alias feeds the shortcut (see Bottleneck.forward): one gradient sum less per block
+        if x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True)
+        else:
+            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
         out = self.conv2(out)
         if self.avd:
             out = ops.AvgPoolFn.apply(out, 3, self.avd_stride, 1, False, True)

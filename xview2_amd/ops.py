@@ -753,6 +753,7 @@ class SplitAttentionFn(torch.autograd.Function):
         ctx.save_for_backward(x, gap, w1m, h1, a1, g1, st[0], st[1], w2m, att, st[3], st[4])
         ctx.count, ctx.bn1, ctx.training = st[2], bn1, training
         ctx.shapes = (w1.shape, w2.shape)
+        ctx.params = (w1, b1, w2, b2)      # their gradients go straight into the flat gradient buffer (grad_slot)
         return out
 
     @staticmethod
@@ -767,11 +768,15 @@ class SplitAttentionFn(torch.autograd.Function):
         call("xv2_splat_apply_backward", x, att, dout, None, N, hw, C, None, datt, ws)
         dlogits = _f32((N, C2), x)
         call("xv2_rsoftmax_backward", att, datt, dlogits, N, C)
-        da1, dw2, db2 = _f32((N, inter), x), torch.empty_like(w2m), _f32((C2,), x)
+        pw1, pb1, pw2, pb2 = ctx.params
+        ctx.params = None
+        da1, dw2 = _f32((N, inter), x), _grad_like(pw2)
+        db2 = _grad_like(pb2) if pb2 is not None else _f32((C2,), x)
         call("xv2_linear_backward", a1, w2m, dlogits, da1, dw2, db2, N, inter, C2)
         dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count, scale1, shift1), g1, ACT_RELU,
                                          ctx.bn1, ctx.training, False)
-        dgap, dw1, db1 = _f32((N, C), x), torch.empty_like(w1m), _f32((inter,), x)
+        dgap, dw1 = _f32((N, C), x), _grad_like(pw1)
+        db1 = _grad_like(pb1) if pb1 is not None else _f32((inter,), x)
         call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
         dx = torch.empty_like(x)
         call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws)
