@@ -287,39 +287,39 @@ __global__ void __launch_bounds__(256) splat_colsum_kernel(const float* __restri
         *reinterpret_cast<float4*>(part + ((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c) = t;
     }
 }
-__global__ void splat_gap_finish_kernel(const float* __restrict__ part, int N, int C, int chunks, float inv_hw,
-                                        float* __restrict__ gap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i % C;
+// folds of the chunk partials: block = 64 columns x 4 chunk lanes (grid: column blocks x N), two chains per lane
+__device__ __forceinline__ float splat_fold(const float* __restrict__ col, size_t stride, int chunks, float* sh) {
+    const int ty = threadIdx.x >> 6;
     float s = 0.f, t = 0.f;
-    int k = 0;
-    for (; k + 2 <= chunks; k += 2) {      // two chains: the loads of consecutive chunks overlap
-        const float* p = part + ((size_t)n * SPLAT_CHUNKS + k) * 2 * C;
-        s += p[c] + p[C + c];
-        t += p[2 * C + c] + p[3 * C + c];
+    int k = ty;
+    for (; k + 4 < chunks; k += 8) {
+        s += col[(size_t)k * stride];
+        t += col[(size_t)(k + 4) * stride];
     }
-    if (k < chunks) {
-        const float* p = part + ((size_t)n * SPLAT_CHUNKS + k) * 2 * C;
-        s += p[c] + p[C + c];
-    }
-    s += t;
-    gap[i] = s * inv_hw;
+    if (k < chunks) s += col[(size_t)k * stride];
+    sh[threadIdx.x] = s + t;
+    __syncthreads();
+    const int tx = threadIdx.x & 63;
+    return (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
+}
+__global__ void __launch_bounds__(256) splat_gap_finish_kernel(const float* __restrict__ part, int N, int C, int chunks,
+                                                                float inv_hw, float* __restrict__ gap) {
+    __shared__ float sh[256], sh2[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), n = blockIdx.y;
+    const int cc = min(c, C - 1);
+    const float* p = part + (size_t)n * SPLAT_CHUNKS * 2 * C;
+    const float a = splat_fold(p + cc, (size_t)2 * C, chunks, sh);          // radix 0
+    const float b = splat_fold(p + C + cc, (size_t)2 * C, chunks, sh2);     // radix 1
+    if (threadIdx.x < 64 && c < C) gap[(size_t)n * C + c] = (a + b) * inv_hw;
 }
 // datt[n][r*C+c] = sum_hw dout[n,hw,c] * x[n,hw,r*C+c]: splat_colsum_kernel(a = x, b = dout), then this fold
-__global__ void splat_datt_finish_kernel(const float* __restrict__ part, int N, int C2, int chunks,
-                                         float* __restrict__ datt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C2) return;
-    const int n = i / C2, c = i % C2;
-    float s = 0.f, t = 0.f;
-    int k = 0;
-    for (; k + 2 <= chunks; k += 2) {
-        s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
-        t += part[((size_t)n * SPLAT_CHUNKS + k + 1) * C2 + c];
-    }
-    if (k < chunks) s += part[((size_t)n * SPLAT_CHUNKS + k) * C2 + c];
-    datt[i] = s + t;
+__global__ void __launch_bounds__(256) splat_datt_finish_kernel(const float* __restrict__ part, int N, int C2,
+                                                                 int chunks, float* __restrict__ datt) {
+    __shared__ float sh[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), n = blockIdx.y;
+    const int cc = min(c, C2 - 1);
+    const float a = splat_fold(part + (size_t)n * SPLAT_CHUNKS * C2 + cc, (size_t)C2, chunks, sh);
+    if (threadIdx.x < 64 && c < C2) datt[(size_t)n * C2 + c] = a;
 }
 __global__ void splat_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ att, int64_t hw,
                                        int C, float* __restrict__ out, int64_t total4) {
@@ -587,7 +587,7 @@ extern "C" int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, f
     hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, (const float*)nullptr, hw,
                        2 * C, 0, cgw, rpc, workspace);
     XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, st, workspace, N, C,
+    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, 64), N), dim3(256), 0, st, workspace, N, C,
                        chunks, 1.f / (float)hw, gap);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
@@ -613,7 +613,7 @@ extern "C" int xv2_splat_apply_backward(const float* x, const float* att, const 
         hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, dout, hw, 2 * C, C,
                            cgw, rpc, workspace);
         XV2_CHECK_LAUNCH();
-        hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(N * 2 * C, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(2 * C, 64), N), dim3(256), 0, st,
                            workspace, N, 2 * C, chunks, datt);
         XV2_CHECK_LAUNCH();
     }
