@@ -135,3 +135,33 @@ def test_affinity_planner_modes():
     with pytest.raises(RuntimeError):
         plan(0, "nonsense")
     assert set(ga.set_affinity(0, "socket")) <= set(range(os.cpu_count()))      # no GPU here: keeps the current set
+
+
+def test_autoaugment_policy_keeps_geometry_of_image_and_mask_together(tree):
+    from xview2_amd.data_loading import autoaugment as aa
+    assert len(aa.POLICY) == 25 and aa.magnitude("rotate", 9) == 30 and aa.magnitude("posterize", 8) == 4
+    assert abs(aa.magnitude("solarize", 5) - (256 - 5 * 256 / 9)) < 1e-9 and aa.magnitude("equalize", 3) == 0
+    img = np.zeros((128, 128, 3), np.uint8)
+    img[20:60, 70:110] = 255
+    mask = (img[:, :, 0] > 0).astype(np.uint8)
+    pim, pmask = Image.fromarray(img), Image.fromarray(mask)
+    for op, idx in (("rotate", 9), ("shearX", 5), ("translateX", 3), ("shearY", 7)):
+        for sign in (1, -1):
+            a = np.asarray(aa.apply_op(pim, op, aa.magnitude(op, idx), sign))
+            b = np.asarray(aa.apply_op(pmask, op, aa.magnitude(op, idx), sign))
+            inter = ((a[:, :, 0] > 127) & (b > 0)).sum()
+            assert inter >= 0.9 * (b > 0).sum() > 0, (op, sign)          # same warp for tile and mask
+    for op in ("posterize", "solarize", "autocontrast", "equalize", "invert", "color", "contrast", "sharpness"):
+        out = aa.apply_op(pim, op, aa.magnitude(op, 4), 1)
+        assert out.size == pim.size and out.mode == "RGB"
+    pol = aa.ImageNetPolicy(rng=np.random.default_rng(1))
+    for _ in range(30):
+        o = pol(pim, pmask, pim)
+        assert len(o) == 3 and o[1].mode == pmask.mode and o[0].size == pim.size
+    assert len(pol(pim, pmask)) == 2
+    # and through the dataset: 6-channel sample, crop kept, mask still uint8
+    root, csv = tree
+    pl._rng_holder["rng"] = np.random.default_rng(5)
+    ds = pl.TrainPostDataset(os.path.join(root, "train"), "post", True, csv)
+    s = ds[0]
+    assert s["image"].shape == (6, 512, 512) and s["mask"].shape == (512, 512) and s["mask"].dtype == np.uint8

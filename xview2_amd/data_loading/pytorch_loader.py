@@ -9,7 +9,7 @@ this loader flips PIL's RGB to BGR), the index file semantics (utils/index.csv: 
 union of rows flagged 1..4 for damage, pytorch_loader.py:65-66,104-110), the order and probabilities of the
 augmentations (:57-63,:77-91) and the evaluation dataset (:151-171).  What can only match in distribution: the random
 streams (albumentations draws from `random`, this module from one numpy Generator per worker).
-`--autoaugment` (data_loading/autoaugment.py) is not provided."""
+`--autoaugment` selects data_loading/autoaugment.py's policy instead of flips/noise/brightness, as in the reference."""
 import os
 from glob import glob
 
@@ -159,10 +159,20 @@ def normalize(img):
 
 class _TrainBase(Dataset):
     def __init__(self, autoaugment):
-        if autoaugment:
-            raise NotImplementedError("--autoaugment (data_loading/autoaugment.py) is not provided")
+        self.use_autoaugment = bool(autoaugment)
+        if self.use_autoaugment:
+            from .autoaugment import ImageNetPolicy
+            self.autoaugment = ImageNetPolicy()
 
     def _augment(self, img, mask):
+        if self.use_autoaugment:        # pytorch_loader.py:75-84,:125-138: no zoom / flips / noise in this mode
+            img, mask = crop_non_empty_mask_if_exists(img, mask)
+            parts = [Image.fromarray(np.ascontiguousarray(img[:, :, i:i + 3])) for i in range(0, img.shape[2], 3)]
+            out = self.autoaugment(parts[0], Image.fromarray(np.ascontiguousarray(mask)), *parts[1:])
+            mask = np.asarray(out[1])
+            parts = [normalize(np.asarray(p)) for p in (out[0],) + tuple(out[2:])]
+            img = np.concatenate(parts, 2)
+            return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": np.ascontiguousarray(mask)}
         img, mask = random_scale(img, mask)
         img, mask = crop_non_empty_mask_if_exists(img, mask)
         img, mask = flip(img, mask, 1)      # HorizontalFlip
