@@ -74,6 +74,14 @@ size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
                        int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
                        float* stats, float* workspace, void* stream);
+/* inference form of conv + nn.BatchNorm2d (eval) [+ residual] + activation in ONE launch: the running statistics are
+ * folded to per-channel scale/shift (xv2_bn_eval_coeffs) and applied in the convolution epilogue,
+ * z = act(conv(x) * scale + shift [+ residual]); the raw convolution output is never written.  Same arithmetic, bit
+ * for bit, as xv2_conv2d_forward followed by xv2_bn_act_forward.  act = XV2_ACT_*. */
+int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
+                             int ldx1, const float* w_ohwi, const float* scale, const float* shift,
+                             const float* residual, int ldres, int act, float* z, int ldz,
+                             float* workspace, void* stream);
 /* dx = conv2d_backward_input(dy, w); dx0/dx1 receive the channel ranges of the two sources */
 size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
@@ -252,6 +260,11 @@ int xv2_loss_backward(const float* logits, const uint8_t* labels, int N, int C, 
 /* argmax over channels of NCHW logits (utils/f1.py:14,36): first maximum wins (torch.argmax) */
 int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint8_t* labels,
                     void* stream);
+/* F1 bookkeeping (utils/f1.py:27-47): counts[(c-1)*3 + {tp, fn, fp}] += ... for classes c = 1..n_class-1 over two
+ * uint8 label maps; masked != 0 counts only pixels whose target is > 0 (damage task).  `counts` (int64, device) is
+ * accumulated into, never cleared. */
+int xv2_f1_counts(const uint8_t* pred, const uint8_t* target, int64_t total, int n_class, int masked,
+                  int64_t* counts, void* stream);
 
 /* ---- optimizer (model/plt.py:154 torch.optim.AdamW) ---------------------------------------- */
 int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -272,3 +272,38 @@ def test_cfg2_full_size_eval_properties():
         t0 = tta(x[:1])
         t1 = torch.flip(tta(torch.flip(x[:1], [3])), [3])
         assert rel(t1, t0) <= 1e-5          # same four forward passes, summed in a different order
+
+
+@pytest.mark.parametrize("name", ["pre_resnet50", "pre_resnest50", "post_fused_resnet50_decinterp", "pre_resnet50_ds_attn"])
+def test_fused_inference_path_is_bit_identical_to_the_unfused_eval_forward(name):
+    """eval + no_grad runs every conv + BatchNorm (+ residual) + activation as ONE launch (xv2_conv2d_forward_fused,
+    folded coefficients cached); it must reproduce the conv -> bn_act two-launch eval forward bit for bit, also after
+    a training step changed weights and running statistics (cache invalidation)."""
+    from xview2_amd import criterion, nn as xnn, ops
+    from xview2_amd.optim import FlatAdamW
+    a = ARGS(**MODEL_CASES[name])
+    _, hip = build_pair(a)
+    x, y = model_input(a, batch=2).to(DEV), labels(a, batch=2).to(DEV)
+
+    def both():
+        hip.eval()
+        with torch.no_grad():
+            xnn.FUSED_INFERENCE = False
+            ref = hip(x)
+            xnn.FUSED_INFERENCE = True
+            out = hip(x)
+        return ref, out
+    try:
+        r0, o0 = both()
+        assert torch.equal(r0, o0)
+        hip.train()
+        opt = FlatAdamW(hip.parameters(), lr=1e-2)
+        opt.zero_grad()
+        loss = criterion.compute_loss(criterion.Loss(a), hip(x), y, a.deep_supervision)
+        loss.backward()
+        opt.step()
+        r1, o1 = both()
+        assert torch.equal(r1, o1)
+        assert not torch.equal(r1, r0)          # the step really changed the network
+    finally:
+        xnn.FUSED_INFERENCE = True

@@ -462,3 +462,43 @@ def test_table_driven_repack_matches_single_weight_pack():
         call("xv2_pack_weight", w, co, ci, kh, kw, cp, r1, r2)
         assert torch.equal(ohwi, r1) and torch.equal(ihwo, r2), (co, ci, kh, kw)
     ops.clear_pack_cache()
+
+
+@pytest.mark.parametrize("task,loss_str", [("pre", "dice"), ("post", "focal+dice"), ("post", "mse"), ("post", "coral")])
+def test_f1_device_counts_match_the_reference_bookkeeping(task, loss_str):
+    """utils/f1.py:27-56 on the GPU: labels from the HIP argmax (or the mse / coral decoding) and ONE integer-atomic
+    counting launch per batch must give exactly the tp/fp/fn of the reference's per-class masked comparisons, and
+    therefore the same F1 (the CPU branch of xview2_amd.utils.f1.F1 is that reference formula)."""
+    from types import SimpleNamespace
+    from xview2_amd.utils.f1 import F1
+    torch.manual_seed(11)
+    a = SimpleNamespace(type=task, loss_str=loss_str)
+    C = 2 if task == "pre" else {"mse": 1, "coral": 3}.get(loss_str, 4)
+    dev_f1, cpu_f1 = F1(a), F1(a)
+    for _ in range(3):
+        logits = torch.randn(2, C, 96, 160) * (2.5 if loss_str == "mse" else 1.0) + (2.0 if loss_str == "mse" else 0.0)
+        tgt = torch.randint(0, 2 if task == "pre" else 5, (2, 96, 160), dtype=torch.uint8)
+        dev_f1.update(logits.to(dev()), tgt.to(dev()))
+        # reference bookkeeping in plain torch on the CPU
+        t = tgt.long()
+        if task == "post":
+            if loss_str == "mse":
+                lab = torch.round(torch.relu(logits[:, 0])) + 1
+                lab[lab > 4] = 4
+            elif loss_str == "coral":
+                lab = torch.sum(torch.sigmoid(logits) > 0.5, dim=1) + 1
+            else:
+                lab = torch.argmax(logits, 1) + 1
+            m = t > 0
+            t, lab = t[m], lab[m]
+        else:
+            lab = torch.argmax(logits, 1)
+        for i in range(cpu_f1.n_class - 1):
+            c = i + 1
+            cpu_f1.tp[i] += float(((lab == c) & (t == c)).sum())
+            cpu_f1.fn[i] += float(((lab != c) & (t == c)).sum())
+            cpu_f1.fp[i] += float(((lab == c) & (t != c)).sum())
+    cnt = dev_f1.counts.cpu().double().view(-1, 3)
+    assert torch.equal(cnt[:, 0], cpu_f1.tp) and torch.equal(cnt[:, 1], cpu_f1.fn) and torch.equal(cnt[:, 2], cpu_f1.fp)
+    d, c = dev_f1.compute(), cpu_f1.compute()
+    assert torch.equal(torch.as_tensor(d[0]), torch.as_tensor(c[0]))

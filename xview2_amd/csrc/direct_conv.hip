@@ -106,11 +106,18 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int n = patch / (tiles_w * tiles_h);
         const size_t rowpix = ((size_t)n * OH + th * D_TH + wave) * OW + tw * D_TW;
         const float bv = p.bias ? p.bias[l31] : 0.f;
+        const float esc = p.ep_scale ? p.ep_scale[l31] : 0.f, esf = p.ep_scale ? p.ep_shift[l31] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int col = (r & 3) + 8 * (r >> 2) + 4 * h;          // pixel column inside the wave's row
-            p.Out0[(rowpix + col) * p.ldo0 + l31] = acc[r] + bv;
+            float v = acc[r] + bv;
+            if (p.ep_scale) {        // inference: folded BatchNorm (+ residual) + activation
+                v = __fmaf_rn(v, esc, esf);
+                if (p.ep_res) v += p.ep_res[(rowpix + col) * p.ep_ldres + l31];
+                v = apply_act(v, p.ep_act);
+            }
+            p.Out0[(rowpix + col) * p.ldo0 + l31] = v;
             s1 += acc[r];
             s2 += acc[r] * acc[r];
         }

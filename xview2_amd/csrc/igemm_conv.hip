@@ -371,6 +371,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             }
+            if (p.ep_scale) {     // same arithmetic as bn_act_fwd_kernel on the materialised conv output
+                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + col);
+                const float4 sf = *reinterpret_cast<const float4*>(p.ep_shift + col);
+                v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
+                v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
+                if (p.ep_res) {
+                    const float4 r = *reinterpret_cast<const float4*>(p.ep_res + (size_t)off * p.ep_ldres + col);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                v.x = apply_act(v.x, p.ep_act); v.y = apply_act(v.y, p.ep_act);
+                v.z = apply_act(v.z, p.ep_act); v.w = apply_act(v.w, p.ep_act);
+            }
             float* o = col < p.N0 ? p.Out0 + (size_t)off * p.ldo0 + col : p.Out1 + (size_t)off * p.ldo1 + (col - p.N0);
             if (p.accum & (col < p.N0 ? 1 : 2)) {
                 const float4 old = *reinterpret_cast<const float4*>(o);
@@ -399,7 +411,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              int Nout, const float* __restrict__ bias,
                                                              float* __restrict__ out0, int ldo0, int N0,
                                                              float* __restrict__ out1, int ldo1,
-                                                             float* __restrict__ stats, int accum) {
+                                                             float* __restrict__ stats, int accum,
+                                                             const float* __restrict__ ep_scale,
+                                                             const float* __restrict__ ep_shift,
+                                                             const float* __restrict__ ep_res, int ep_ldres, int ep_act) {
     __shared__ float sh[256 * 8];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
@@ -419,6 +434,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                 s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
                 s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
                 a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+                if (ep_scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(ep_scale + c);
+                    const float4 sf = *reinterpret_cast<const float4*>(ep_shift + c);
+                    a.x = __fmaf_rn(a.x, sc.x, sf.x); a.y = __fmaf_rn(a.y, sc.y, sf.y);
+                    a.z = __fmaf_rn(a.z, sc.z, sf.z); a.w = __fmaf_rn(a.w, sc.w, sf.w);
+                    if (ep_res) {
+                        const float4 rr = *reinterpret_cast<const float4*>(ep_res + (size_t)r * ep_ldres + c);
+                        a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
+                    }
+                    a.x = apply_act(a.x, ep_act); a.y = apply_act(a.y, ep_act);
+                    a.z = apply_act(a.z, ep_act); a.w = apply_act(a.w, ep_act);
+                }
                 float* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
                 if (accum & (c < N0 ? 1 : 2)) {
                     const float4 old = *reinterpret_cast<const float4*>(o);
@@ -577,7 +604,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256)),
                            dim3(256), 0, stream,
                            splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats,
-                           p.accum);
+                           p.accum, p.ep_scale, p.ep_shift, p.ep_res, p.ep_ldres, p.ep_act);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -623,6 +650,8 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.cin_real = 3;
     p.math = d->math;
     p.accum = 0;
+    p.ep_scale = p.ep_shift = p.ep_res = nullptr;
+    p.ep_ldres = p.ep_act = 0;
     XV2_CHECK_ARG(d->math == 0 || d->math == 1, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
@@ -650,12 +679,26 @@ extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {
     return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK));
 }
 
-extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
-                                  int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
-                                  float* stats, float* workspace, void* stream) {
+struct FwdEpilogue {
+    const float* scale;
+    const float* shift;
+    const float* res;
+    int ldres, act;
+};
+
+static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
+                             const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
+                             float* workspace, void* stream, const FwdEpilogue* ep) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    if (ep) {
+        XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
+        XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(ep->scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(ep->shift) & 15) == 0 &&
+                          (!ep->res || (ep->ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(ep->res) & 15) == 0)),
+                      "conv2d_forward_fused: epilogue operands must be 16-byte aligned");
+        p.ep_scale = ep->scale; p.ep_shift = ep->shift; p.ep_res = ep->res; p.ep_ldres = ep->ldres; p.ep_act = ep->act;
+    }
     const bool smallc = is_rgb(d);
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
@@ -690,6 +733,20 @@ extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int l
         p.bytesA0 = (unsigned)b0; p.bytesA1 = (unsigned)b1; p.bytesB = (unsigned)bw;
     }
     return igemm_launch(p, smallc, workspace, (hipStream_t)stream);
+}
+
+extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
+                                  int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
+                                  float* stats, float* workspace, void* stream) {
+    return conv_forward_impl(d, x0, ldx0, x1, ldx1, w_ohwi, bias, y, ldy, stats, workspace, stream, nullptr);
+}
+
+extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
+                                        int ldx1, const float* w_ohwi, const float* scale, const float* shift,
+                                        const float* residual, int ldres, int act, float* z, int ldz,
+                                        float* workspace, void* stream) {
+    FwdEpilogue ep{scale, shift, residual, ldres, act};
+    return conv_forward_impl(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, z, ldz, nullptr, workspace, stream, &ep);
 }
 
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]

@@ -42,6 +42,11 @@ struct IgemmParams {
     int cin_real;      // real (unpadded) channels of a 4-channel RGB source, for FLOP accounting
     int math;          // 0 = fp32 MFMA, 1 = bf16 MFMA on fp32 operands (fp32 accumulate)
     int accum;         // bit 0 / 1: ADD the result into Out0 / Out1 (gradient of a tensor with two consumers)
+    // inference epilogue (eval-mode BatchNorm folded to per-channel scale/shift): out = act(conv*scale + shift [+ res])
+    const float* ep_scale;
+    const float* ep_shift;
+    const float* ep_res;
+    int ep_ldres, ep_act;
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

@@ -459,6 +459,49 @@ extern "C" int xv2_loss_backward(const float* logits, const uint8_t* labels, int
     return XV2_OK;
 }
 
+// tp / fn / fp per class over label maps (utils/f1.py:27-47): counts[(c-1)*3 + {0,1,2}] += #{pred==c & tgt==c},
+// #{pred!=c & tgt==c}, #{pred==c & tgt!=c} for c = 1..ncls-1; masked != 0 restricts to pixels with tgt > 0 (damage
+// task).  Integer atomics: exact and order-independent.
+__global__ void __launch_bounds__(256) f1_counts_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ tgt,
+                                                        int64_t total, int ncls, int masked,
+                                                        unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int sh[12];
+    if (threadIdx.x < 12) sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int loc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) loc[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = pred[i], t = tgt[i];
+        if (masked && t == 0) continue;
+#pragma unroll
+        for (int c = 1; c <= 4; ++c) {
+            if (c >= ncls) break;
+            loc[(c - 1) * 3 + 0] += (p == c && t == c);
+            loc[(c - 1) * 3 + 1] += (p != c && t == c);
+            loc[(c - 1) * 3 + 2] += (p == c && t != c);
+        }
+    }
+    const int n = (ncls - 1) * 3;
+    for (int k = 0; k < n; ++k) {
+        unsigned int v = loc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < n && sh[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
+extern "C" int xv2_f1_counts(const uint8_t* pred, const uint8_t* target, int64_t total, int n_class, int masked,
+                             int64_t* counts, void* stream) {
+    XV2_CHECK_ARG(n_class >= 2 && n_class <= 5 && total > 0, "f1_counts: n_class=%d unsupported (2..5)", n_class);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256 * 8), 2048);
+    hipLaunchKernelGGL(f1_counts_kernel, dim3(std::max(grid, 1)), dim3(256), 0, (hipStream_t)stream, pred, target, total,
+                       n_class, masked, reinterpret_cast<unsigned long long*>(counts));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
 extern "C" int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint8_t* labels,
                                void* stream) {
     XV2_CHECK_ARG(C >= 2 && C <= 4, "argmax: C=%d unsupported (2..4)", C);

@@ -48,6 +48,11 @@ class GraphedStep:
                 dst.copy_(src)
         self.opt.sync_lr()
         self.graph.replay()
+        # the replay rewrote parameters and BatchNorm running statistics without passing through Python: cached
+        # derived data (folded inference coefficients, packed weights seen by later EAGER calls) is stale
+        from . import ops
+        ops.weights_changed()
+        ops.bn_stats_changed()
         self.opt.step_count += 1
         for bn in self._bumped:                          # host-side num_batches_tracked bookkeeping
             bn._xv2_pending += 1

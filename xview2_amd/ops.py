@@ -5,6 +5,7 @@ backward both go through the C ABI.  Activations are NHWC tensors ``[N, H, W, C]
 PyTorch is used for device memory, streams and autograd bookkeeping only.
 """
 import os
+import weakref
 from types import SimpleNamespace
 
 import torch
@@ -170,11 +171,13 @@ def clear_pack_cache():
     _pack_table = None
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None):
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.  If `ihwo_out` is a list, the backward-data weight
     packs are produced by the same repack launch and appended to it (one per group).  With `bn` (a BnState that
     does not synchronise across ranks) the statistics reduction also derives the BatchNorm coefficients in the
-    same launch and the third return value is (mean, invstd, scale, shift)."""
+    same launch and the third return value is (mean, invstd, scale, shift).  `fused` = (scale, shift, residual, act):
+    inference form, the folded BatchNorm / residual / activation run in the convolution epilogue and y IS the
+    activated output (xv2_conv2d_forward_fused)."""
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     Cout_t = weight.shape[0]
@@ -185,6 +188,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     coeffs = None
     if want_stats and bn is not None and not _sync_group(bn):
         coeffs = tuple(_f32((Cout_t,), x0) for _ in range(4))
+        bn_stats_changed()
     w = weight.contiguous()
     if G > 1 and x1 is not None:
         raise RuntimeError("grouped convolution over a virtual concat is not supported")
@@ -201,6 +205,12 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             tiles = query("xv2_conv2d_forward_stats_tiles", d)
             part = _f32((tiles, Coutg, 2), x0)
         wsb = query("xv2_conv2d_forward_workspace", d)
+        if fused is not None:
+            fsc, fsh, fres, fact = fused
+            call("xv2_conv2d_forward_fused", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi, Ptr(fsc, gi * Coutg),
+                 Ptr(fsh, gi * Coutg), None if fres is None else Ptr(fres, gi * Coutg), Cout_t, fact,
+                 Ptr(y, gi * Coutg), Cout_t, _ws(wsb, x0) if wsb else None)
+            continue
         call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
              None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part,
              _ws(wsb, x0) if wsb else None)
@@ -335,6 +345,7 @@ def _sync_group(bn):
 def _bn_train_coeffs(sums, count, bn, like):
     """sums: double [C,2] local; returns mean, invstd, scale, shift, global count"""
     C = sums.shape[0]
+    bn_stats_changed()
     if _sync_group(bn):
         # every rank holds the same per-GPU batch (weak scaling), so the global count is local*world and the
         # exchange is ONE in-place all-reduce of the fp64 (sum, sum-of-squares) vector - no host round trip
@@ -344,6 +355,35 @@ def _bn_train_coeffs(sums, count, bn, like):
     call("xv2_bn_finalize", sums, float(count), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
          bn.running_mean, bn.running_var, mean, invstd, scale, shift, C)
     return mean, invstd, scale, shift, float(count)
+
+
+BN_STATS_EPOCH = 0        # bumped whenever a training-mode BatchNorm kernel rewrites running statistics in place
+_eval_coeffs = {}         # running_mean storage -> (validity key, scale, shift)
+
+
+def bn_stats_changed():
+    global BN_STATS_EPOCH
+    BN_STATS_EPOCH += 1
+
+
+def _bn_eval_scale_shift(bn, like):
+    """(scale, shift) of an eval-mode BatchNorm, cached until a parameter or a running statistic changes"""
+    key = (bn.running_mean._version, bn.running_var._version,
+           bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
+           WEIGHT_EPOCH, BN_STATS_EPOCH, float(bn.eps))
+    slot = bn.running_mean.data_ptr()
+    hit = _eval_coeffs.get(slot)
+    # the address alone is not an identity (the allocator hands a freed model's buffers to the next one): the entry
+    # must belong to this very buffer object
+    if hit is not None and hit[0] == key and hit[3]() is bn.running_mean:
+        return hit[1], hit[2]
+    if len(_eval_coeffs) > 16384:
+        _eval_coeffs.clear()
+    C = bn.running_mean.shape[0]
+    scale, shift = _f32((C,), like), _f32((C,), like)
+    call("xv2_bn_eval_coeffs", bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), scale, shift, C)
+    _eval_coeffs[slot] = (key, scale, shift, weakref.ref(bn.running_mean))
+    return scale, shift
 
 
 def _bn_eval_coeffs(bn, like):
@@ -411,6 +451,18 @@ class BnState:
         self.running_mean, self.running_var = m.running_mean, m.running_var
         self.eps, self.momentum = m.eps, m.momentum
         self.sync = sync
+
+
+def conv_bn_act_infer(x0, x1, weight, residual, g, bn, act):
+    """eval-mode conv + BatchNorm (+ residual) + activation without autograd: one launch per layer, the folded
+    coefficients are cached.  Bit-identical to the ConvBnActFn forward in eval mode."""
+    _need_cuda(x0)
+    x0 = x0.contiguous()
+    x1 = x1.contiguous() if x1 is not None else None
+    residual = residual.contiguous() if residual is not None else None
+    scale, shift = _bn_eval_scale_shift(bn, x0)
+    z, _ = _conv_forward(x0, x1, weight, g, None, want_stats=False, fused=(scale, shift, residual, act))
+    return z
 
 
 # ------------------------------------------------------------------------------------------------
@@ -896,6 +948,12 @@ def argmax_labels(logits, add=0):
     out = torch.empty((N, H, W), dtype=torch.uint8, device=logits.device)
     call("xv2_argmax_nchw", logits, N, C, H * W, add, out)
     return out
+
+
+def f1_counts(pred_u8, target_u8, n_class, masked, counts):
+    """counts[(c-1)*3 + (tp, fn, fp)] += ... (utils/f1.py:27-47) over two uint8 label maps, one launch"""
+    _need_cuda(pred_u8)
+    call("xv2_f1_counts", pred_u8, target_u8, pred_u8.numel(), int(n_class), 1 if masked else 0, counts)
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):

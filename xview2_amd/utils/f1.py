@@ -27,9 +27,22 @@ class F1:
         self.tp = torch.zeros(self.n_class - 1, dtype=torch.float64)
         self.fp = torch.zeros(self.n_class - 1, dtype=torch.float64)
         self.fn = torch.zeros(self.n_class - 1, dtype=torch.float64)
+        self.counts = None      # device int64 [(n_class-1)*3] (tp, fn, fp per class), filled by xv2_f1_counts
 
     def update(self, preds, targets):
         # softmax is monotone per pixel, so argmax(softmax(x)) == argmax(x) (utils/f1.py:29,36)
+        if preds.is_cuda:
+            # one counting launch on the label maps, no host round trip per class
+            if self.n_class == 5:
+                lab = convert_to_labels(self.loss_str, preds)
+            else:
+                lab = ops.argmax_labels(preds)
+            lab = lab.to(torch.uint8).contiguous()
+            tgt = targets.to(torch.uint8).contiguous()
+            if self.counts is None:
+                self.counts = torch.zeros((self.n_class - 1) * 3, dtype=torch.int64, device=preds.device)
+            ops.f1_counts(lab, tgt, self.n_class, self.n_class == 5, self.counts)
+            return
         targets = targets.long()
         if self.n_class == 5:
             lab = convert_to_labels(self.loss_str, preds)
@@ -45,6 +58,9 @@ class F1:
 
     def compute(self):
         tp, fp, fn = self.tp.clone(), self.fp.clone(), self.fn.clone()
+        if self.counts is not None:
+            c = self.counts.cpu().double().view(-1, 3)
+            tp, fn, fp = tp + c[:, 0], fn + c[:, 1], fp + c[:, 2]
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             buf = torch.stack([tp, fp, fn])
             if torch.cuda.is_available() and dist.get_backend() == "nccl":
