@@ -170,6 +170,20 @@ int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz
                               const double* sums2, double count, int act,
                               int train, float* dy, int lddy, float* dres, int lddres,
                               int64_t npix, int C, void* stream);
+/* Mask forms for layers whose activation follows a residual add (z = act(BN(y) + residual), the bottleneck tail):
+ * the forward also writes one byte per 4 channels, bit k = (z[4j + k] > 0), and the backward passes read that byte
+ * instead of re-reading z (0.25 instead of 4 bytes per element in each pass).  C % 4 == 0, dense rows (ld == C for
+ * the mask indexing), ReLU / LeakyReLU only.  Results are bit-identical to the z forms. */
+int xv2_bn_act_forward_mask(const float* y, int ldy, const float* scale, const float* shift,
+                            const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
+                            uint8_t* zmask, void* stream);
+int xv2_bn_act_backward_reduce_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+                                    const float* mean, const float* invstd, int act, int64_t npix, int C,
+                                    double* sums2, float* dgamma, float* dbeta, float* workspace, void* stream);
+int xv2_bn_act_backward_apply_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+                                   const float* mean, const float* invstd, const float* gamma,
+                                   const double* sums2, double count, int act, int train, float* dy,
+                                   int lddy, float* dres, int lddres, int64_t npix, int C, void* stream);
 
 /* ---- pooling / resampling ----------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order) */

@@ -53,6 +53,8 @@ struct ColOp {
     const float* scale;   // MODE1 with z == nullptr: the activation mask is recomputed from y*scale+shift
     const float* shift;
     int lda, ldz, ldy, act;
+    int zbits;   // z is not the activated output but a byte per float4 of it: bit k = (z[4*j + k] > 0)
+    int c4tot;   // float4 per row (mask indexing)
     __device__ __forceinline__ void apply(int64_t row, int c, float& f0, float& f1) const {
         if constexpr (MODE == 0) {
             // shifted sums (shift = the tensor's first row): avoids the E[x^2]-E[x]^2 cancellation when
@@ -81,7 +83,11 @@ struct ColOp {
             const float4 d = *reinterpret_cast<const float4*>(a + row * lda + c);
             const float4 yy = *reinterpret_cast<const float4*>(y + row * ldy + c);
             float gx, gy, gz, gw;
-            if (z) {
+            if (z && zbits) {
+                const unsigned m = reinterpret_cast<const uint8_t*>(z)[row * c4tot + (c >> 2)];
+                gx = d.x * act_grad_from_output((m & 1u) ? 1.f : -1.f, act); gy = d.y * act_grad_from_output((m & 2u) ? 1.f : -1.f, act);
+                gz = d.z * act_grad_from_output((m & 4u) ? 1.f : -1.f, act); gw = d.w * act_grad_from_output((m & 8u) ? 1.f : -1.f, act);
+            } else if (z) {
                 const float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
                 gx = d.x * act_grad_from_output(zz.x, act); gy = d.y * act_grad_from_output(zz.y, act);
                 gz = d.z * act_grad_from_output(zz.z, act); gw = d.w * act_grad_from_output(zz.w, act);
@@ -395,7 +401,8 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ res, int ldr, int act,
-                                                          float* __restrict__ z, int ldz, int64_t npix, int C) {
+                                                          float* __restrict__ z, int ldz, int64_t npix, int C,
+                                                          uint8_t* __restrict__ zmask) {
     if constexpr (VEC) {
         const int C4 = C >> 2;
         const int64_t total = npix * C4;
@@ -414,6 +421,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
             }
             o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
             *reinterpret_cast<float4*>(z + row * ldz + c) = o;
+            if (zmask) zmask[i] = (uint8_t)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
         }
     } else {
         const int64_t total = npix * C;
@@ -438,7 +446,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ shift,
                                                           const double* __restrict__ sums2, double count, int act,
                                                           int train, float* __restrict__ dy, int lddy,
-                                                          float* __restrict__ dres, int lddres, int64_t npix, int C) {
+                                                          float* __restrict__ dres, int lddres, int64_t npix, int C,
+                                                          int zbits) {
     const float inv_count = (float)(1.0 / count);
     constexpr int V = VEC ? 4 : 1;
     const int CV = C / V;
@@ -450,7 +459,13 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
         const bool need_y = train || !z;
         if constexpr (VEC) {
             *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + row * lddz + c);
-            if (z) *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
+            if (z && zbits) {
+                const unsigned m = reinterpret_cast<const uint8_t*>(z)[i];
+#pragma unroll
+                for (int k = 0; k < V; ++k) zz[k] = ((m >> k) & 1u) ? 1.f : -1.f;
+            } else if (z) {
+                *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
+            }
             if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + row * ldy + c);
         } else {
             d[0] = dz[row * lddz + c];
@@ -495,7 +510,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __res
                                                                const double* __restrict__ sums2, double count, int act,
                                                                int train, float* __restrict__ dy, int lddy,
                                                                float* __restrict__ dres, int lddres, int64_t npix, int cgw,
-                                                               int rows_per_block) {
+                                                               int rows_per_block, int zbits, int c4tot) {
     const int C4 = cgw >> 2, rpp = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
     const int c = blockIdx.y * cgw + tx * 4;
@@ -517,7 +532,13 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __res
     for (int64_t r = r0 + ty; r < r1; r += rpp) {
         float d[4], zz[4], yy[4], o[4], g[4];
         *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + r * lddz + c);
-        if (z) *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + r * ldz + c);
+        if (z && zbits) {
+            const unsigned m = reinterpret_cast<const uint8_t*>(z)[r * c4tot + (c >> 2)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zz[k] = ((m >> k) & 1u) ? 1.f : -1.f;
+        } else if (z) {
+            *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + r * ldz + c);
+        }
         if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + r * ldy + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -592,7 +613,7 @@ extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C,
     ColOp<0> op;
     op.a = x; op.lda = ldx; op.z = nullptr; op.y = nullptr; op.mean = nullptr; op.invstd = nullptr;
     op.scale = op.shift = nullptr;
-    op.ldz = op.ldy = 0; op.act = 0;
+    op.ldz = op.ldy = 0; op.act = 0; op.zbits = 0; op.c4tot = 0;
     int rc = column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(unshift_stats_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, x,
@@ -631,44 +652,78 @@ static inline bool vec_ok(int C, std::initializer_list<int> lds, std::initialize
     return true;
 }
 
-extern "C" int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
-                                  const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
-                                  void* stream) {
+static int bn_act_forward_impl(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
+                               int ldr, int act, float* z, int ldz, int64_t npix, int C, uint8_t* zmask, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_forward: empty");
     const bool vec = vec_ok(C, {ldy, ldz, residual ? ldr : 0}, {y, z, residual, scale, shift});
+    XV2_CHECK_ARG(!zmask || (vec && act != XV2_ACT_SIGMOID), "bn_act_forward_mask: needs C %% 4 == 0, aligned rows, ReLU-type activation");
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
         hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C);
+                           shift, residual, ldr, act, z, ldz, npix, C, zmask);
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C);
+                           shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 
-extern "C" int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                                          const float* mean, const float* invstd, const float* scale,
-                                          const float* shift, int act, int64_t npix, int C, double* sums2,
-                                          float* dgamma, float* dbeta, float* workspace, void* stream) {
+extern "C" int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
+                                  const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
+                                  void* stream) {
+    return bn_act_forward_impl(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, C, nullptr, stream);
+}
+
+extern "C" int xv2_bn_act_forward_mask(const float* y, int ldy, const float* scale, const float* shift,
+                                       const float* residual, int ldr, int act, float* z, int ldz, int64_t npix,
+                                       int C, uint8_t* zmask, void* stream) {
+    XV2_CHECK_ARG(zmask, "bn_act_forward_mask: mask output is required");
+    return bn_act_forward_impl(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, C, zmask, stream);
+}
+
+static int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, int zbits, const float* y, int ldy,
+                              const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                              int64_t npix, int C, double* sums2, float* dgamma, float* dbeta, float* workspace,
+                              void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_reduce: empty");
+    XV2_CHECK_ARG(!zbits || (C % 4 == 0 && chunk_geom(npix, C).cgw && act != XV2_ACT_SIGMOID),
+                  "bn backward (mask form): unsupported channel count %d / activation", C);
     XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && (!z || ldz % 4 == 0) && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
     ColOp<1> op;
     op.a = dz; op.lda = lddz; op.z = z; op.ldz = ldz; op.y = y; op.ldy = ldy; op.mean = mean; op.invstd = invstd;
     op.scale = scale; op.shift = shift;
     op.act = act;
+    op.zbits = zbits; op.c4tot = C / 4;
     return column_sums<1>(op, npix, C, sums2, workspace, (hipStream_t)stream, dbeta, dgamma);
 }
 
-extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                                         const float* mean, const float* invstd, const float* gamma,
-                                         const float* scale, const float* shift, const double* sums2, double count,
-                                         int act, int train, float* dy, int lddy, float* dres, int lddres,
-                                         int64_t npix, int C, void* stream) {
+extern "C" int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                          const float* mean, const float* invstd, const float* scale,
+                                          const float* shift, int act, int64_t npix, int C, double* sums2,
+                                          float* dgamma, float* dbeta, float* workspace, void* stream) {
+    return bn_bwd_reduce_impl(dz, lddz, z, ldz, 0, y, ldy, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
+                              dbeta, workspace, stream);
+}
+
+extern "C" int xv2_bn_act_backward_reduce_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+                                               const float* mean, const float* invstd, int act, int64_t npix, int C,
+                                               double* sums2, float* dgamma, float* dbeta, float* workspace,
+                                               void* stream) {
+    XV2_CHECK_ARG(zmask, "bn_act_backward_reduce_mask: mask is required");
+    return bn_bwd_reduce_impl(dz, lddz, reinterpret_cast<const float*>(zmask), 4, 1, y, ldy, mean, invstd, nullptr,
+                              nullptr, act, npix, C, sums2, dgamma, dbeta, workspace, stream);
+}
+
+static int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, int zbits, const float* y, int ldy,
+                             const float* mean, const float* invstd, const float* gamma, const float* scale,
+                             const float* shift, const double* sums2, double count, int act, int train, float* dy,
+                             int lddy, float* dres, int lddres, int64_t npix, int C, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
-    const bool vec = vec_ok(C, {lddz, z ? ldz : 0, ldy, lddy, dres ? lddres : 0}, {dz, z, y, dy, dres});
+    const bool vec = vec_ok(C, {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
+                            {dz, zbits ? nullptr : z, y, dy, dres});
+    XV2_CHECK_ARG(!zbits || (vec && act != XV2_ACT_SIGMOID), "bn backward (mask form): needs C %% 4 == 0, aligned rows, ReLU-type activation");
     const ChunkGeom cg = chunk_geom(npix, C);
     if (vec && cg.cgw) {
         const int rpp = 256 / (cg.cgw / 4);
@@ -676,17 +731,37 @@ extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float*
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
-                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb);
+                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
         hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
-                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C,
+                           zbits);
     else
         hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
-                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C);
+                           y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C,
+                           0);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
+}
+
+extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                                         const float* mean, const float* invstd, const float* gamma,
+                                         const float* scale, const float* shift, const double* sums2, double count,
+                                         int act, int train, float* dy, int lddy, float* dres, int lddres,
+                                         int64_t npix, int C, void* stream) {
+    return bn_bwd_apply_impl(dz, lddz, z, ldz, 0, y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train,
+                             dy, lddy, dres, lddres, npix, C, stream);
+}
+
+extern "C" int xv2_bn_act_backward_apply_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+                                              const float* mean, const float* invstd, const float* gamma,
+                                              const double* sums2, double count, int act, int train, float* dy,
+                                              int lddy, float* dres, int lddres, int64_t npix, int C, void* stream) {
+    XV2_CHECK_ARG(zmask, "bn_act_backward_apply_mask: mask is required");
+    return bn_bwd_apply_impl(dz, lddz, reinterpret_cast<const float*>(zmask), 4, 1, y, ldy, mean, invstd, gamma, nullptr,
+                             nullptr, sums2, count, act, train, dy, lddy, dres, lddres, npix, C, stream);
 }

@@ -400,9 +400,19 @@ def _off(t, o):
     return None if t is None else Ptr(t, o)
 
 
-def _bn_forward(y, residual, act, bn, sums, training, coeffs=None):
+ZMASK = os.environ.get("XV2_ZMASK", "1") != "0"
+
+
+def _mask_ok(C, act):
+    """layers whose activation follows a residual add can hand the backward pass a byte mask instead of z"""
+    return (ZMASK and act in (ACT_RELU, ACT_LEAKY) and C % 4 == 0 and
+            (C % 256 == 0 or (C // 4 <= 256 and 256 % (C // 4) == 0)))
+
+
+def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False):
     """y raw [.., C]; returns z and the context needed by _bn_backward.  `coeffs`: (mean, invstd, scale, shift)
-    when the statistics reduction already derived them (xv2_bn_reduce_finalize)."""
+    when the statistics reduction already derived them (xv2_bn_reduce_finalize).  want_mask: also return the
+    1-bit-per-element sign mask of z (a byte per 4 channels) as a third value, or None if the shape has no mask form."""
     C = y.shape[-1]
     npix = y.numel() // C
     if training and coeffs is not None:
@@ -418,12 +428,21 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None):
         mean, invstd, scale, shift = _bn_eval_coeffs(bn, y)
         count = float(npix)
     z = torch.empty_like(y)
+    if want_mask:
+        zmask = None
+        if _mask_ok(C, act):
+            zmask = torch.empty((npix * (C // 4),), dtype=torch.uint8, device=y.device)
+            call("xv2_bn_act_forward_mask", y, C, scale, shift, residual, C, act, z, C, npix, C, zmask)
+        else:
+            call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
+        return z, (mean, invstd, count, scale, shift), zmask
     call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
     return z, (mean, invstd, count, scale, shift)
 
 
 def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
-    """z may be None (layers without a residual input): the activation mask is then recomputed from y"""
+    """z may be None (layers without a residual input): the activation mask is then recomputed from y; a uint8 `z` is
+    the byte mask written by xv2_bn_act_forward_mask"""
     mean, invstd, count, scale, shift = stats
     C = y.shape[-1]
     npix = y.numel() // C
@@ -431,14 +450,22 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
     sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
     ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
-    call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
-         dbeta, ws)
+    masked = z is not None and z.dtype == torch.uint8
+    if masked:
+        call("xv2_bn_act_backward_reduce_mask", dz, C, z, y, C, mean, invstd, act, npix, C, sums2, dgamma, dbeta, ws)
+    else:
+        call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
+             dbeta, ws)
     if training and _sync_group(bn):
         dist.all_reduce(sums2)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, scale, shift, sums2, float(count), act,
-         1 if training else 0, dy, C, dres, C, npix, C)
+    if masked:
+        call("xv2_bn_act_backward_apply_mask", dz, C, z, y, C, mean, invstd, gamma, sums2, float(count), act,
+             1 if training else 0, dy, C, dres, C, npix, C)
+    else:
+        call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, scale, shift, sums2, float(count),
+             act, 1 if training else 0, dy, C, dres, C, npix, C)
     return dy, dres, dgamma, dbeta
 
 
@@ -485,11 +512,16 @@ class ConvBnActFn(torch.autograd.Function):
         need_dx = x0.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.ihwo = [] if need_dx else None
         y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
-        z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs)
         ctx.has_res = residual is not None
-        # the activation mask of the backward pass is recomputed from y unless a residual entered before it
-        ctx.save_for_backward(x0, x1, weight, gamma, y, z if ctx.has_res else None, stats[0], stats[1], stats[3],
-                              stats[4])
+        if ctx.has_res:
+            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True)
+        else:
+            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs)
+            zmask = None
+        # the activation mask of the backward pass is recomputed from y unless a residual entered before it; then it
+        # comes from the byte mask written next to z (or from z itself for shapes without a mask form)
+        ctx.save_for_backward(x0, x1, weight, gamma, y, (zmask if zmask is not None else z) if ctx.has_res else None,
+                              stats[0], stats[1], stats[3], stats[4])
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
         ctx.wparam = weight
