@@ -93,6 +93,27 @@ int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
 int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float* dy, int lddy,
                                  const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
                                  int accumulate, float* workspace, void* stream);
+/* Backward-data that ALSO takes the BatchNorm-backward statistics of the layer whose output feeds this convolution
+ * (dx IS that layer's dz): with its conv output bn_y and coefficients the epilogue accumulates, per M tile,
+ * partials[tile][C0][2] = (sum g, sum g * xhat), g = dx * act'(bn_y * scale + shift), xhat = (bn_y - mean) * invstd -
+ * what xv2_bn_act_backward_reduce would compute with a separate pass over dz and y.  Only layers WITHOUT a residual
+ * before the activation.  `*_bn_tiles` returns the tile count of the plan, or 0 if the shape has no fused form
+ * (stride 2, two sources, split-K plan, bf16 math): then use the plain calls.  Fold the partials with
+ * xv2_bn_backward_reduce_partials (scratch as for xv2_bn_reduce_stats). */
+int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace);
+int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
+                                float* dx0, int lddx0, int accumulate, const float* bn_y, int ld_bn_y,
+                                const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                                const float* bn_shift, int bn_act, float* partials, float* workspace,
+                                void* stream);
+int64_t xv2_conv_transpose2d_backward_data_bn_tiles(const xv2_conv_desc* d);
+int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy,
+                                          const float* w_ohwi, float* dx, int lddx, const float* bn_y,
+                                          int ld_bn_y, const float* bn_mean, const float* bn_invstd,
+                                          const float* bn_scale, const float* bn_shift, int bn_act,
+                                          float* partials, void* stream);
+int xv2_bn_backward_reduce_partials(const float* partial, int64_t tiles, int C, double* sums2, float* dgamma,
+                                    float* dbeta, double* scratch, void* stream);
 /* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
 size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,

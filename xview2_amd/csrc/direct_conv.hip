@@ -107,6 +107,9 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const size_t rowpix = ((size_t)n * OH + th * D_TH + wave) * OW + tw * D_TW;
         const float bv = p.bias ? p.bias[l31] : 0.f;
         const float esc = p.ep_scale ? p.ep_scale[l31] : 0.f, esf = p.ep_scale ? p.ep_shift[l31] : 0.f;
+        const bool bnb = p.bnb_y != nullptr;     // BN-backward statistics of the producer layer (IgemmParams::bnb_*)
+        const float bmu = bnb ? p.bnb_mean[l31] : 0.f, bis = bnb ? p.bnb_invstd[l31] : 0.f;
+        const float bsc = bnb ? p.bnb_scale[l31] : 0.f, bsf = bnb ? p.bnb_shift[l31] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -118,8 +121,15 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
                 v = apply_act(v, p.ep_act);
             }
             p.Out0[(rowpix + col) * p.ldo0 + l31] = v;
-            s1 += acc[r];
-            s2 += acc[r] * acc[r];
+            if (bnb) {
+                const float yv = p.bnb_y[(rowpix + col) * p.bnb_ldy + l31];
+                const float g = v * act_grad_from_pre(__fmaf_rn(yv, bsc, bsf), p.bnb_act);
+                s1 += g;
+                s2 += g * ((yv - bmu) * bis);
+            } else {
+                s1 += acc[r];
+                s2 += acc[r] * acc[r];
+            }
         }
         if (p.stats) {
             s1 += __shfl_xor(s1, 32, 64);

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     // two thirds of the kernel.  BatchNorm partial sums are taken from the registers on the way.
     constexpr int CLD = BN + 4;
     float* Cs = smem;
-    const bool do_stats = p.stats && p.ksplit == 1;
+    const bool do_stats = p.stats && p.ksplit == 1 && !p.bnb_y;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int cl = wn * WTN + j * 32 + l31;
@@ -356,6 +356,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     {
         constexpr int F4R = BN / 4;
         float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
+        // BN-backward statistics of the producer layer (see IgemmParams::bnb_*): a thread keeps ONE group of 4
+        // channels through the loop (256 % F4R == 0), so its coefficients are loaded once
+        const bool bnb = p.bnb_y && !slab;
+        float4 bmu = make_float4(0, 0, 0, 0), bis = bmu, bsc = bmu, bsf = bmu, bs1 = bmu, bs2 = bmu;
+        if (bnb) {
+            const int bc = n0 + (tid % F4R) * 4;
+            bmu = *reinterpret_cast<const float4*>(p.bnb_mean + bc);
+            bis = *reinterpret_cast<const float4*>(p.bnb_invstd + bc);
+            bsc = *reinterpret_cast<const float4*>(p.bnb_scale + bc);
+            bsf = *reinterpret_cast<const float4*>(p.bnb_shift + bc);
+        }
 #pragma unroll 4
         for (int e = tid; e < BM * F4R; e += 256) {
             const int row = e / F4R, c = (e % F4R) * 4;
@@ -389,6 +400,36 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             *reinterpret_cast<float4*>(o) = v;
+            if (bnb) {
+                const float4 yv = *reinterpret_cast<const float4*>(p.bnb_y + (size_t)off * p.bnb_ldy + col);
+                const float gx = v.x * act_grad_from_pre(__fmaf_rn(yv.x, bsc.x, bsf.x), p.bnb_act);
+                const float gy = v.y * act_grad_from_pre(__fmaf_rn(yv.y, bsc.y, bsf.y), p.bnb_act);
+                const float gz = v.z * act_grad_from_pre(__fmaf_rn(yv.z, bsc.z, bsf.z), p.bnb_act);
+                const float gw = v.w * act_grad_from_pre(__fmaf_rn(yv.w, bsc.w, bsf.w), p.bnb_act);
+                bs1.x += gx; bs1.y += gy; bs1.z += gz; bs1.w += gw;
+                bs2.x += gx * ((yv.x - bmu.x) * bis.x); bs2.y += gy * ((yv.y - bmu.y) * bis.y);
+                bs2.z += gz * ((yv.z - bmu.z) * bis.z); bs2.w += gw * ((yv.w - bmu.w) * bis.w);
+            }
+        }
+        if (bnb) {
+            __syncthreads();                       // every thread is done reading Cs: reuse it for the fold
+            float* sb = smem + tid * 8;
+            sb[0] = bs1.x; sb[1] = bs1.y; sb[2] = bs1.z; sb[3] = bs1.w;
+            sb[4] = bs2.x; sb[5] = bs2.y; sb[6] = bs2.z; sb[7] = bs2.w;
+            __syncthreads();
+            if (tid < BN) {
+                constexpr int RL = 256 / F4R;      // row lanes holding the same channel group
+                const int grp = tid >> 2, comp = tid & 3;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < RL; ++q) {
+                    s1 += smem[(grp + F4R * q) * 8 + comp];
+                    s2 += smem[(grp + F4R * q) * 8 + 4 + comp];
+                }
+                float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
+                st[0] = s1;
+                st[1] = s2;
+            }
         }
     }
     if (do_stats && tid < BN) {
@@ -583,6 +624,17 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     int bm, bn, ks;
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, p.cls[c].M);
+    if (p.plan_tiles) {      // dry run for the fused BN-backward statistics: which tiling would this launch use?
+        *p.plan_tiles = 0;
+        if (p.ncls != 1 || smallc || p.Out1) return XV2_OK;
+        if (direct3x3_eligible(p, smallc)) {
+            *p.plan_tiles = p.cls[0].M / 128;
+            return XV2_OK;
+        }
+        pick_tile(maxM, p.Nout, smallc, splitk_ws ? p.cls[0].nkt : 0, bm, bn, ks);
+        if (ks == 1 && bn >= 64) *p.plan_tiles = cdiv(maxM, bm);
+        return XV2_OK;
+    }
     if (direct3x3_eligible(p, smallc)) return direct3x3_launch(p, stream);
     pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
     if (getenv("XV2_DEBUG_TILE"))
@@ -652,6 +704,9 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.accum = 0;
     p.ep_scale = p.ep_shift = p.ep_res = nullptr;
     p.ep_ldres = p.ep_act = 0;
+    p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
+    p.bnb_ldy = p.bnb_act = 0;
+    p.plan_tiles = nullptr;
     XV2_CHECK_ARG(d->math == 0 || d->math == 1, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
@@ -679,6 +734,23 @@ extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {
     return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK));
 }
 
+struct BnbArgs {          // producer-layer BatchNorm backward statistics (IgemmParams::bnb_*)
+    const float* y;
+    int ldy;
+    const float* mean;
+    const float* invstd;
+    const float* scale;
+    const float* shift;
+    int act;
+    float* partials;
+};
+static void set_bnb(IgemmParams& p, const BnbArgs* b) {
+    if (!b) return;
+    p.bnb_y = b->y; p.bnb_ldy = b->ldy; p.bnb_mean = b->mean; p.bnb_invstd = b->invstd;
+    p.bnb_scale = b->scale; p.bnb_shift = b->shift; p.bnb_act = b->act;
+    p.stats = b->partials;
+}
+
 struct FwdEpilogue {
     const float* scale;
     const float* shift;
@@ -688,10 +760,12 @@ struct FwdEpilogue {
 
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
-                             float* workspace, void* stream, const FwdEpilogue* ep) {
+                             float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
+                             long long* plan = nullptr) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    p.plan_tiles = plan;
     if (ep) {
         XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
         XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(ep->scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(ep->shift) & 15) == 0 &&
@@ -707,6 +781,7 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
                   "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
+    set_bnb(p, bnb);
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
     p.ldA0 = ldx0; p.ldA1 = ldx1;
     p.IH = d->IH; p.IW = d->IW; p.s_in = d->stride;
@@ -752,11 +827,13 @@ extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const float* x0,
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]
 static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
                       float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream,
-                      int accumulate = 0) {
+                      int accumulate = 0, const BnbArgs* bnb = nullptr, long long* plan = nullptr) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    p.plan_tiles = plan;
     p.accum = accumulate & (dx1 ? 3 : 1);
+    set_bnb(p, bnb);
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_data: Cout=%d must be a multiple of 32", d->Cout);
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
@@ -808,7 +885,7 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
             c.nkt = c.ntaps * p.cpt;
             p.cls[ncls++] = c;
         }
-    if (need_zero) {
+    if (need_zero && !plan) {
         XV2_CHECK_ARG(lddx0 == d->C0 && (d->C1 == 0 || lddx1 == d->C1),
                       "backward_data: strided outputs unsupported when parity classes are empty");
         // pixels no tap reaches get a zero gradient - or, when accumulating, keep what they hold
@@ -831,6 +908,55 @@ extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float*
                                             const float* w_ihwo, float* dx0, int lddx0, float* dx1,
                                             int lddx1, int accumulate, float* workspace, void* stream) {
     return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream, accumulate);
+}
+
+// ---- backward-data that also takes the BatchNorm-backward statistics of the layer feeding this convolution ------
+static float* const kPlanPtr = reinterpret_cast<float*>(64);   // dry runs never dereference operands
+
+extern "C" int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace) {
+    if (d->stride != 1 || d->C1 != 0 || d->math != 0) return 0;
+    long long tiles = 0;
+    if (dgrad_impl(d, kPlanPtr, d->Cout, kPlanPtr, kPlanPtr, d->C0, nullptr, 0, has_workspace ? kPlanPtr : nullptr, nullptr,
+                   accumulate, nullptr, &tiles) != XV2_OK)
+        return 0;
+    return tiles;
+}
+
+extern "C" int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
+                                           float* dx0, int lddx0, int accumulate, const float* bn_y, int ld_bn_y,
+                                           const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                                           const float* bn_shift, int bn_act, float* partials, float* workspace,
+                                           void* stream) {
+    XV2_CHECK_ARG(xv2_conv2d_backward_data_bn_tiles(d, accumulate, workspace != nullptr) > 0,
+                  "backward_data_bn: this shape has no fused statistics form (query xv2_conv2d_backward_data_bn_tiles)");
+    XV2_CHECK_ARG(bn_y && bn_mean && bn_invstd && bn_scale && bn_shift && partials && ld_bn_y % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(bn_y) & 15) == 0,
+                  "backward_data_bn: BatchNorm operands missing or misaligned");
+    BnbArgs b{bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
+    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, nullptr, 0, workspace, (hipStream_t)stream, accumulate, &b);
+}
+
+extern "C" int64_t xv2_conv_transpose2d_backward_data_bn_tiles(const xv2_conv_desc* d) {
+    if (d->math != 0) return 0;
+    long long tiles = 0;
+    if (conv_forward_impl(d, kPlanPtr, d->C0, nullptr, 0, kPlanPtr, nullptr, kPlanPtr, d->Cout, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, &tiles) != XV2_OK)
+        return 0;
+    return tiles;
+}
+
+extern "C" int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy,
+                                                     const float* w_ohwi, float* dx, int lddx, const float* bn_y,
+                                                     int ld_bn_y, const float* bn_mean, const float* bn_invstd,
+                                                     const float* bn_scale, const float* bn_shift, int bn_act,
+                                                     float* partials, void* stream) {
+    XV2_CHECK_ARG(xv2_conv_transpose2d_backward_data_bn_tiles(d) > 0,
+                  "conv_transpose2d_backward_data_bn: this shape has no fused statistics form");
+    XV2_CHECK_ARG(bn_y && bn_mean && bn_invstd && bn_scale && bn_shift && partials && ld_bn_y % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(bn_y) & 15) == 0,
+                  "conv_transpose2d_backward_data_bn: BatchNorm operands missing or misaligned");
+    BnbArgs b{bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
+    return conv_forward_impl(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream, nullptr, &b);
 }
 
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,

@@ -47,6 +47,16 @@ struct IgemmParams {
     const float* ep_shift;
     const float* ep_res;
     int ep_ldres, ep_act;
+    // BatchNorm-backward statistics of the layer that PRODUCED this convolution's input, taken in the backward-data
+    // epilogue: the result v is that layer's dz; with its conv output y and coefficients the epilogue accumulates
+    // g = v * act'(y*scale+shift) and g * xhat per channel into stats[tile][Nout][2] (no separate pass over dz, y)
+    const float* bnb_y;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    int bnb_ldy, bnb_act;
+    long long* plan_tiles;   // dry run: report the M-tile count of the plan (0 = no fused BN-backward form) and launch nothing
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

@@ -585,6 +585,12 @@ extern "C" int xv2_bn_reduce_finalize(const float* partial, int64_t tiles, int C
     return reduce_stats<float>(partial, tiles, C, sums, scratch, (hipStream_t)stream, nullptr, nullptr, &f);
 }
 
+extern "C" int xv2_bn_backward_reduce_partials(const float* partial, int64_t tiles, int C, double* sums2, float* dgamma,
+                                               float* dbeta, double* scratch, void* stream) {
+    XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_backward_reduce_partials: empty");
+    return reduce_stats<float>(partial, tiles, C, sums2, scratch, (hipStream_t)stream, dbeta, dgamma);
+}
+
 extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
     const ChunkGeom g = chunk_geom(npix, C);
     size_t part = (size_t)g.chunks * C * 2 * sizeof(double);

@@ -229,9 +229,10 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     return y, sums
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
-    the convolution's contribution INTO that tensor, which is returned as dx0."""
+    the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
+    that produced source 0 - its BatchNorm-backward statistics are taken in the same epilogue when the plan allows."""
     N, IH, IW = in_shape
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
@@ -249,8 +250,17 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
             _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
+        acc = 1 if add_to0 is not None else 0
+        if bnrec is not None and G == 1 and C1t == 0:
+            tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
+            if tiles > 0:
+                part = _f32((tiles, C0t, 2), dy)
+                call("xv2_conv2d_backward_data_bn", d, dy, Cout_t, ihwo, dx0, C0t, acc, bnrec.y, C0t, bnrec.mean,
+                     bnrec.invstd, bnrec.scale, bnrec.shift, bnrec.act, part, _ws(wsb, dy) if wsb else None)
+                bnrec.part, bnrec.tiles, bnrec.token = part, tiles, (dx0.data_ptr(), dx0._version)
+                continue
         call("xv2_conv2d_backward_data_acc", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
-             1 if add_to0 is not None else 0, _ws(wsb, dy) if wsb else None)
+             acc, _ws(wsb, dy) if wsb else None)
     return dx0, dx1
 
 
@@ -401,6 +411,28 @@ def _off(t, o):
 
 
 ZMASK = os.environ.get("XV2_ZMASK", "1") != "0"
+# Producer-layer BatchNorm-backward statistics inside the consumer's backward-data epilogue: implemented and exact,
+# but measured 0.3 ms/step SLOWER on cfg2 (the extra read of y lengthens the serial epilogue of big-activation
+# layers by about what the separate HBM-speed pass cost, and there are 8x more partial rows to fold): off by default.
+FUSE_BN_BWD = os.environ.get("XV2_FUSE_BN_BWD", "0") != "0"
+
+
+class _BnRec:
+    """What a conv+BN layer leaves on its output tensor so that the ONE convolution consuming it can take this
+    layer's BatchNorm-backward statistics in its backward-data epilogue (xv2_conv2d_backward_data_bn).  The consumer
+    stores the per-tile partials here together with a token identifying the gradient tensor they were computed on;
+    the producer's backward uses them only if it is handed exactly that tensor, unmodified."""
+    __slots__ = ("y", "mean", "invstd", "scale", "shift", "act", "C", "part", "tiles", "token")
+
+    def __init__(self, y, mean, invstd, scale, shift, act):
+        self.y, self.mean, self.invstd, self.scale, self.shift, self.act = y, mean, invstd, scale, shift, act
+        self.C = y.shape[-1]
+        self.part, self.tiles, self.token = None, 0, None
+
+
+def _bn_rec_of(x, C):
+    rec = getattr(x, "_xv2_bnrec", None) if FUSE_BN_BWD else None
+    return rec if rec is not None and rec.C == C else None
 
 
 def _mask_ok(C, act):
@@ -440,7 +472,7 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
     return z, (mean, invstd, count, scale, shift)
 
 
-def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
+def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None):
     """z may be None (layers without a residual input): the activation mask is then recomputed from y; a uint8 `z` is
     the byte mask written by xv2_bn_act_forward_mask"""
     mean, invstd, count, scale, shift = stats
@@ -451,7 +483,16 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res):
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
     ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
     masked = z is not None and z.dtype == torch.uint8
-    if masked:
+    pre = None
+    if rec is not None and rec.part is not None:
+        # statistics already taken by the consumer's backward-data epilogue - valid only for that very tensor
+        if z is None and rec.token == (dz.data_ptr(), dz._version):
+            pre = (rec.part, rec.tiles)
+        rec.part, rec.token = None, None
+    if pre is not None:
+        scratch = torch.empty((64 * C * 2,), dtype=torch.float64, device=y.device)
+        call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, scratch)
+    elif masked:
         call("xv2_bn_act_backward_reduce_mask", dz, C, z, y, C, mean, invstd, act, npix, C, sums2, dgamma, dbeta, ws)
     else:
         call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
@@ -506,6 +547,7 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.passthrough = passthrough
         x0_in = x0
+        ctx.src_rec = _bn_rec_of(x0, x0.shape[-1]) if (x1 is None and g.groups == 1) else None
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         residual = residual.contiguous() if residual is not None else None
@@ -525,6 +567,10 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
         ctx.wparam = weight
+        ctx.rec = None
+        if FUSE_BN_BWD and not ctx.has_res:
+            ctx.rec = _BnRec(y, stats[0], stats[1], stats[3], stats[4], act)
+            z._xv2_bnrec = ctx.rec
         if passthrough:
             return z, x0_in
         return z
@@ -536,14 +582,17 @@ class ConvBnActFn(torch.autograd.Function):
         if dz is None:
             dz = torch.zeros_like(y)
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
-                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5])
+                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec)
+        ctx.rec = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             acc = None
             if dpass is not None and g.groups == 1 and dpass.is_contiguous():
                 acc, dpass = dpass, None          # summed inside the backward-data epilogue
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc)
+                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
+                                           ctx.src_rec if dpass is None else None)
+            ctx.src_rec = None
             if dpass is not None:
                 dx0 = dx0 + dpass
         elif dpass is not None:
@@ -561,6 +610,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, g):
         _need_cuda(x0)
+        ctx.src_rec = _bn_rec_of(x0, x0.shape[-1]) if (x1 is None and g.groups == 1) else None
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         y, _ = _conv_forward(x0, x1, weight, g, bias, want_stats=False)
@@ -577,7 +627,8 @@ class ConvFn(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0)
+                                           x1.shape[3] if x1 is not None else 0, None, None, ctx.src_rec)
+        ctx.src_rec = None
         dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
         ctx.wparam = None
         db = None
@@ -597,6 +648,7 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         _need_cuda(x)
+        ctx.src_rec = _bn_rec_of(x, x.shape[-1])
         x = x.contiguous()
         N, H, W, Cin = x.shape
         Cout = weight.shape[1]
@@ -620,7 +672,15 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ohwi, _ = _pack(weight.contiguous(), Cout, True, False)
             dx = torch.empty_like(x)
-            call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
+            rec, ctx.src_rec = ctx.src_rec, None
+            tiles = query("xv2_conv_transpose2d_backward_data_bn_tiles", d) if rec is not None else 0
+            if tiles > 0:      # the producer layer's BatchNorm-backward statistics ride along in the epilogue
+                part = _f32((tiles, Cin, 2), x)
+                call("xv2_conv_transpose2d_backward_data_bn", d, dy, Cout, ohwi, dx, Cin, rec.y, Cin, rec.mean,
+                     rec.invstd, rec.scale, rec.shift, rec.act, part)
+                rec.part, rec.tiles, rec.token = part, tiles, (dx.data_ptr(), dx._version)
+            else:
+                call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
         if ctx.needs_input_grad[1]:
             dw = _grad_like(ctx.wparam)
             ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
