@@ -124,3 +124,96 @@ def test_hipgraph_replay_matches_eager_steps():
     assert res["eager"][0][2:] == res["graph"][0][2:]
     assert torch.equal(res["eager"][1], res["graph"][1])
     assert res["eager"][2] == res["graph"][2] == 5
+
+
+def _two_rank_worker(rank, world, port, outdir):
+    """one of two processes sharing cuda:0 (gloo carries the device tensors): a SyncBatchNorm + bucketed-reducer
+    training step of the HIP path on this rank's half of a global batch of 4"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from tests.golden.cases import ARGS, labels, model_input
+    from xview2_amd import criterion, dist as xdist, networks, nn as xnn
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = ARGS(encoder="resnet50", loss_str="ce", type="pre")
+        x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
+        torch.manual_seed(0)
+        m = networks.UNetLoc(a)
+        deterministic_init_(m, 1)
+        m.cuda().train()
+        opt = FlatAdamW(m.parameters(), lr=1e-3)
+        red = xdist.GradReducer(opt, bucket_bytes=16 << 20)
+        assert red.enabled and xnn.SYNC_BN
+        xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
+        opt.zero_grad()
+        red.prepare()
+        logits = m(xs)
+        loss = criterion.Loss(a)(logits, ys)
+        loss.backward()
+        scale = red.finish()
+        g = (opt.flat_g * scale).cpu()
+        opt.step(scale)
+        torch.cuda.synchronize()
+        sd = m.state_dict()
+        torch.save((rank, float(loss.detach()), logits.detach().cpu(), g, sd["unet.enc_l2.1.0.bn1.running_var"].cpu(),
+                    sd["unet.enc_l1.1.running_mean"].cpu(), opt.flat_p.cpu()), os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        xnn.SYNC_BN = False
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path):
+    """SURVEY 8e equivalence: 2 ranks x batch 2 with SyncBatchNorm and averaged gradients == 1 process x batch 4
+    (cross-entropy is a per-pixel mean, so the mean of the rank losses is the global loss).  Both ranks run the HIP
+    path on cuda:0; gloo carries the fp64 statistics and the gradient buckets."""
+    import torch.multiprocessing as mp
+    from tests.golden.cases import ARGS, labels, model_input
+    from xview2_amd import criterion, networks
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    ctx = mp.get_context("spawn")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    # single process, global batch
+    a = ARGS(encoder="resnet50", loss_str="ce", type="pre")
+    x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
+    torch.manual_seed(0)
+    m = networks.UNetLoc(a)
+    deterministic_init_(m, 1)
+    m.cuda().train()
+    opt = FlatAdamW(m.parameters(), lr=1e-3)
+    opt.zero_grad()
+    logits = m(x)
+    loss = criterion.Loss(a)(logits, y)
+    loss.backward()
+    opt._gather_foreign_grads()      # the head conv's gradients are adopted into the flat buffer at step time
+    g = opt.flat_g.cpu().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    sd = m.state_dict()
+
+    def rel(u, v):
+        return float((u.double() - v.double()).abs().max()) / max(float(v.double().abs().max()), 1e-12)
+    assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss)) <= 1e-5 * abs(float(loss))
+    both = torch.cat([res[0][2], res[1][2]], 0)
+    assert rel(both, logits.detach().cpu()) <= 1e-4                      # batch statistics were global on both ranks
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][6], res[1][6])   # ranks end up identical
+    assert rel(res[0][4], sd["unet.enc_l2.1.0.bn1.running_var"].cpu()) <= 1e-5
+    gr = res[0][3]
+    cos = float((gr.double() * g.double()).sum() / (gr.double().norm() * g.double().norm()))
+    assert cos > 0.9999 and rel(gr, g) <= 1e-2, (cos, rel(gr, g))       # fp32 + training-mode BN conditioning
+    # first AdamW step moves every weight by ~lr * sign(g): a near-zero gradient whose sign differs costs 2 * lr
+    assert rel(res[0][6], opt.flat_p.cpu()) <= 2.5e-3
