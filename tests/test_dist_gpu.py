@@ -126,7 +126,7 @@ def test_hipgraph_replay_matches_eager_steps():
     assert res["eager"][2] == res["graph"][2] == 5
 
 
-def _two_rank_worker(rank, world, port, outdir):
+def _two_rank_worker(rank, world, port, outdir, encoder="resnet50"):
     """one of two processes sharing cuda:0 (gloo carries the device tensors): a SyncBatchNorm + bucketed-reducer
     training step of the HIP path on this rank's half of a global batch of 4"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -139,7 +139,7 @@ def _two_rank_worker(rank, world, port, outdir):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        a = ARGS(encoder="resnet50", loss_str="ce", type="pre")
+        a = ARGS(encoder=encoder, loss_str="ce", type="pre")
         x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
         torch.manual_seed(0)
         m = networks.UNetLoc(a)
@@ -159,14 +159,16 @@ def _two_rank_worker(rank, world, port, outdir):
         opt.step(scale)
         torch.cuda.synchronize()
         sd = m.state_dict()
-        torch.save((rank, float(loss.detach()), logits.detach().cpu(), g, sd["unet.enc_l2.1.0.bn1.running_var"].cpu(),
+        key = "unet.enc_l2.1.0.bn1.running_var" if encoder == "resnet50" else "unet.enc_l2.1.0.conv2.bn1.running_var"
+        torch.save((rank, float(loss.detach()), logits.detach().cpu(), g, sd[key].cpu(),
                     sd["unet.enc_l1.1.running_mean"].cpu(), opt.flat_p.cpu()), os.path.join(outdir, "rank%d.pt" % rank))
     finally:
         xnn.SYNC_BN = False
         dist.destroy_process_group()
 
 
-def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path):
+@pytest.mark.parametrize("encoder", ["resnet50", "resnest50"])
+def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path, encoder):
     """SURVEY 8e equivalence: 2 ranks x batch 2 with SyncBatchNorm and averaged gradients == 1 process x batch 4
     (cross-entropy is a per-pixel mean, so the mean of the rank losses is the global loss).  Both ranks run the HIP
     path on cuda:0; gloo carries the fp64 statistics and the gradient buckets."""
@@ -180,7 +182,7 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, str(tmp_path), encoder)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -188,7 +190,7 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path)
         assert p.exitcode == 0
     res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
     # single process, global batch
-    a = ARGS(encoder="resnet50", loss_str="ce", type="pre")
+    a = ARGS(encoder=encoder, loss_str="ce", type="pre")
     x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
     torch.manual_seed(0)
     m = networks.UNetLoc(a)
@@ -211,9 +213,11 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path)
     both = torch.cat([res[0][2], res[1][2]], 0)
     assert rel(both, logits.detach().cpu()) <= 1e-4                      # batch statistics were global on both ranks
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][6], res[1][6])   # ranks end up identical
-    assert rel(res[0][4], sd["unet.enc_l2.1.0.bn1.running_var"].cpu()) <= 1e-5
+    key = "unet.enc_l2.1.0.bn1.running_var" if encoder == "resnet50" else "unet.enc_l2.1.0.conv2.bn1.running_var"
+    assert rel(res[0][4], sd[key].cpu()) <= (1e-5 if encoder == "resnet50" else 1e-3)
     gr = res[0][3]
     cos = float((gr.double() * g.double()).sum() / (gr.double().norm() * g.double().norm()))
-    assert cos > 0.9999 and rel(gr, g) <= 1e-2, (cos, rel(gr, g))       # fp32 + training-mode BN conditioning
+    # fp32 + training-mode BN conditioning (ResNeSt's split-attention BatchNorm sees 4 values per channel here)
+    assert cos > 0.9999 and rel(gr, g) <= (1e-2 if encoder == "resnet50" else 3e-2), (cos, rel(gr, g))
     # first AdamW step moves every weight by ~lr * sign(g): a near-zero gradient whose sign differs costs 2 * lr
     assert rel(res[0][6], opt.flat_p.cpu()) <= 2.5e-3
