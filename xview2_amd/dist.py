@@ -88,11 +88,15 @@ class GradReducer:
         sl = self.opt.flat_g[s:e]
         if self.on_gpu:
             from . import ops
-            ops.join_wgrad_stream()                        # weight gradients are produced on ops' side stream
             ev = torch.cuda.Event()
-            ev.record()                                    # bucket's gradients are complete on the compute stream
+            ev.record()                                    # gradients written on the compute stream are complete
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
+                # weight gradients are produced on ops' side stream: only the COLLECTIVE waits for it (every
+                # kernel of this bucket is already enqueued there), the compute stream keeps running backward
+                wgs = ops.wgrad_stream()
+                if wgs is not None:
+                    self.side.wait_stream(wgs)
                 self.handles.append(dist.all_reduce(sl, async_op=True))
         else:
             self.handles.append(dist.all_reduce(sl, async_op=True))

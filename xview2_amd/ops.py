@@ -291,6 +291,11 @@ def _side_stream():
     return _wgrad_stream
 
 
+def wgrad_stream():
+    """the side stream weight-gradient kernels run on, or None if none was needed yet"""
+    return _wgrad_stream
+
+
 _join_queued = False
 
 
