@@ -114,7 +114,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        from xview2_amd.dist import nccl_options
+        _o = nccl_options()
+        if _o is not None:
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, pg_options=_o)
+        else:
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         _ops.FORCE_COLLECTIVES = True
     if opt.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (opt.gpus, world))

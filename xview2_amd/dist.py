@@ -19,6 +19,19 @@ import torch.distributed as dist
 from . import nn as xnn
 
 
+def nccl_options():
+    """RCCL kernels on a high-priority stream (XV2_NCCL_HIGH_PRIO=1): experiment hook for the latency of the ~126
+    small SyncBatchNorm collectives per step"""
+    if os.environ.get("XV2_NCCL_HIGH_PRIO", "0") != "1":
+        return None
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def init_from_env(backend=None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -31,7 +44,11 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        opts = nccl_options() if backend == "nccl" else None
+        if opts is not None:
+            dist.init_process_group(backend, rank=rank, world_size=world, pg_options=opts)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 
