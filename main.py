@@ -48,30 +48,35 @@ def transplant_encoder(model, pretrained_sd, dmg_model):
     return copied
 
 
+# Launcher flags of the reference (main.py:29-53): same names, types, choices and defaults; help strings are ours.
+_LAUNCH_FLAGS = [
+    ("exec_mode", dict(type=str, choices=["train", "eval"], default="train", help="train a model or evaluate a checkpoint")),
+    ("data", dict(type=str, default="/data", help="xBD directory with train/ test/ holdout/, or 'synthetic'")),
+    ("results", dict(type=str, default="/results", help="where checkpoints, logs and predictions go")),
+    ("gpus", dict(type=int, default=1, help="GPUs of this node (one process each, e.g. under torchrun)")),
+    ("num_workers", dict(type=int, default=8, help="loader worker processes")),
+    ("batch_size", dict(type=int, default=16, help="samples per training step and GPU")),
+    ("val_batch_size", dict(type=int, default=13, help="samples per evaluation step and GPU")),
+    ("precision", dict(type=int, default=16, choices=[16, 32], help="32: exact fp32; 16: bf16 matrix math")),
+    ("epochs", dict(type=int, default=250, help="training epochs")),
+    ("patience", dict(type=int, default=100, help="early-stopping patience (epochs)")),
+    ("ckpt", dict(type=str, default=None, help="checkpoint to resume from / to evaluate")),
+    ("logname", dict(type=str, default="logs", help="stem of the JSON-lines log file")),
+    ("ckpt_pre", dict(type=str, default=None,
+                      help="localization checkpoint whose encoder initialises the damage model")),
+    ("type", dict(type=str, choices=["pre", "post"], help="pre: building localization; post: damage assessment")),
+    ("seed", dict(type=int, default=1)),
+    # synthetic-data knobs (not in the reference)
+    ("train_size", dict(type=int, default=512)),
+    ("eval_size", dict(type=int, default=1024)),
+    ("steps_per_epoch", dict(type=int, default=8)),
+]
+
+
 def build_parser():
     parser = ArgumentParser(formatter_class=ArgumentDefaultsHelpFormatter)
-    arg = parser.add_argument
-    arg("--exec_mode", type=str, choices=["train", "eval"], default="train", help="Execution mode of main script")
-    arg("--data", type=str, default="/data", help="Path to the data directory ('synthetic' for generated tiles)")
-    arg("--results", type=str, default="/results", help="Path to the results directory")
-    arg("--gpus", type=int, default=1, help="Number of gpus to use")
-    arg("--num_workers", type=int, default=8, help="Number of subprocesses to use for data loading")
-    arg("--batch_size", type=int, default=16, help="Training batch size")
-    arg("--val_batch_size", type=int, default=13, help="Evaluation batch size")
-    arg("--precision", type=int, default=16, choices=[16, 32], help="Numerical precision")
-    arg("--epochs", type=int, default=250, help="Max number of epochs")
-    arg("--patience", type=int, default=100, help="Early stopping patience")
-    arg("--ckpt", type=str, default=None, help="Path to pretrained checkpoint")
-    arg("--logname", type=str, default="logs", help="Name of logging file")
-    arg("--ckpt_pre", type=str, default=None,
-        help="Path to pretrained checkpoint of localization model used to initialize network for damage assesment")
-    arg("--type", type=str, choices=["pre", "post"],
-        help="Type of task to run; pre - localization, post - damage assesment")
-    arg("--seed", type=int, default=1)
-    # synthetic-data knobs (not in the reference)
-    arg("--train_size", type=int, default=512)
-    arg("--eval_size", type=int, default=1024)
-    arg("--steps_per_epoch", type=int, default=8)
+    for flag, kw in _LAUNCH_FLAGS:
+        parser.add_argument("--" + flag, **kw)
     return Model.add_model_specific_args(parser)
 
 
