@@ -357,7 +357,8 @@ def test_loss_deep_supervision_label_stride():
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 0, 64, 3, 1, 1), (1, 20, 12, 128, 64, 128, 3, 1, 1),
                                   (2, 16, 16, 256, 0, 64, 1, 2, 0), (1, 40, 40, 32, 0, 32, 3, 1, 1),
-                                  (2, 8, 8, 512, 0, 512, 3, 1, 1), (1, 17, 19, 64, 0, 128, 3, 2, 1)])
+                                  (2, 8, 8, 512, 0, 512, 3, 1, 1), (1, 17, 19, 64, 0, 128, 3, 2, 1),
+                                  (1, 64, 64, 32, 0, 32, 3, 1, 1), (2, 12, 96, 32, 0, 32, 3, 1, 1)])   # direct kernel
 def test_conv_bf16_math_mode(case):
     """XV2_MATH_BF16: operands rounded to bf16 (RNE) inside the kernel, bf16 MFMA, fp32 accumulation.  The exact
     reference is an fp32 convolution of the bf16-rounded operands (products of bf16 numbers are exact in fp32)."""
@@ -384,7 +385,8 @@ def test_conv_bf16_math_mode(case):
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, 0, 64, 3, 1, 1), (1, 32, 32, 128, 64, 128, 3, 1, 1),
                                   (2, 16, 16, 256, 0, 64, 1, 1, 0), (1, 64, 64, 64, 0, 32, 3, 1, 1),
-                                  (1, 17, 19, 64, 0, 128, 3, 2, 1)])
+                                  (1, 17, 19, 64, 0, 128, 3, 2, 1), (2, 48, 64, 32, 0, 32, 3, 1, 1),
+                                  (1, 24, 96, 32, 32, 64, 3, 1, 1)])      # the last four: all-taps kernel, bf16
 def test_conv_weight_gradient_bf16_math_mode(case):
     from xview2_amd import ops
     N, H, W, C0, C1, Cout, k, s, p = case

@@ -23,6 +23,12 @@ constexpr int D_HALO = D_HH * D_HW;                       // 204 pixels
 constexpr int D_HLOADS = (D_HALO * 8 + 255) / 256;        // float4 per thread per halo (7)
 constexpr size_t D_SMEM = (size_t)(D_HALO * D_LD + 9 * 32 * D_LD) * 4 + 4 * 32 * 2 * 4;
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16 = true (XV2_MATH_BF16, "--precision 16"): the same LDS-resident fp32 halo and weights, but a lane gathers 8
+// consecutive channels, rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 2 matrix
+// instructions per tap instead of 16, which leaves the kernel HBM-bound.
+template <bool BF16>
 __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
@@ -88,6 +94,21 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dh = p.taps[t].dh, dw = p.taps[t].dw;
+            if constexpr (BF16) {
+                const float* a = halo + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LD + 8 * h;
+                const float* b = wts + (t * 32 + l31) * D_LD + 8 * h;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(a + kk * 16), a1 = *reinterpret_cast<const float4*>(a + kk * 16 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(b + kk * 16), b1 = *reinterpret_cast<const float4*>(b + kk * 16 + 4);
+                    const bf16x8 af = {(__bf16)a0.x, (__bf16)a0.y, (__bf16)a0.z, (__bf16)a0.w,
+                                       (__bf16)a1.x, (__bf16)a1.y, (__bf16)a1.z, (__bf16)a1.w};
+                    const bf16x8 bf = {(__bf16)b0.x, (__bf16)b0.y, (__bf16)b0.z, (__bf16)b0.w,
+                                       (__bf16)b1.x, (__bf16)b1.y, (__bf16)b1.z, (__bf16)b1.w};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                }
+                continue;
+            }
             const float* a = halo + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LD + 4 * h;
             const float* b = wts + (t * 32 + l31) * D_LD + 4 * h;
 #pragma unroll
@@ -157,7 +178,7 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 }
 
 bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
-    if (smallc || p.math != 0 || p.accum != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
+    if (smallc || p.accum != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 9 || c.tap0 != 0 || c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl) return false;
     if (c.OWl % D_TW != 0 || c.OHl % D_TH != 0 || c.OHl != p.IH || c.OWl != p.IW) return false;
@@ -168,20 +189,26 @@ bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
 
 int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
-    static int kid = -1;
+    static int kid = -1, kid16 = -1;
     if (!attr_set) {
-        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel),
+        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
+        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
         attr_set = true;
         kid = prof_register("direct3x3_n32_kernel");
+        kid16 = prof_register("direct3x3_n32_kernel<bf16>");
     }
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / (D_TH * D_TW);
     const int grid = std::min(npatches, 512);      // persistent: 2 blocks per CU, each walks a run of patches
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = 4.0 * ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
-    prof_begin(kid, flops, abytes, stream);
-    hipLaunchKernelGGL(direct3x3_n32_kernel, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+    prof_begin(p.math ? kid16 : kid, flops, abytes, stream);
+    if (p.math)
+        hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+    else
+        hipLaunchKernelGGL(direct3x3_n32_kernel<false>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
     prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;

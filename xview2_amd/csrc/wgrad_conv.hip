@@ -273,10 +273,16 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // strip: per output row it pulls ONE new input row (34 pixels incl. halo) into a 4-row LDS ring and one dY row -
 // 8.4 KB per 36 MFMAs per wave.  The 4 waves split the 16 k-steps of a row (WK = 4) and are summed through LDS at
 // the end, so a block emits one slab.  model/layers.py:92 (ConvLayer 3x3) weight gradient.
+// BF16 = true (XV2_MATH_BF16): same data movement; a wave takes one 16-pixel k-group of the row and every other tap
+// (5 or 4 accumulators), gathers 8 pixels of its channel per lane out of the fp32 LDS rows, rounds them to bf16 and
+// issues v_mfma_f32_32x32x16_bf16.  Pixel rows are padded to 36 floats so the two lane halves (8 pixels apart) fall
+// into different banks.
+template <bool BF16>
 __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * 32 + 4 * 34 * 32];
-    float* dYs = smem;                 // [2][32 px][32 co]
-    float* Xs = smem + 2 * 32 * 32;    // [4 ring rows][34 px][32 ci]
+    constexpr int LDP = BF16 ? 36 : 32;
+    __shared__ __attribute__((aligned(16))) float smem[(2 * 32 + 4 * 34) * LDP < 4096 ? 4096 : (2 * 32 + 4 * 34) * LDP];
+    float* dYs = smem;                  // [2][32 px][LDP]
+    float* Xs = smem + 2 * 32 * LDP;    // [4 ring rows][34 px][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -312,16 +318,17 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
             if (tid < 16 && iw + 32 < p.IW) rx1 = *reinterpret_cast<const float4*>(row + (size_t)(iw + 32) * ldx);
         }
     };
-    auto store_dy = [&](int buf) { *reinterpret_cast<float4*>(dYs + buf * 1024 + px * 32 + c4 * 4) = rd; };
+    auto store_dy = [&](int buf) { *reinterpret_cast<float4*>(dYs + buf * (32 * LDP) + px * LDP + c4 * 4) = rd; };
     auto store_x = [&](int ih) {
-        float* ring = Xs + ((ih + 4) & 3) * (34 * 32);
-        *reinterpret_cast<float4*>(ring + px * 32 + c4 * 4) = rx0;
-        if (tid < 16) *reinterpret_cast<float4*>(ring + (px + 32) * 32 + c4 * 4) = rx1;
+        float* ring = Xs + ((ih + 4) & 3) * (34 * LDP);
+        *reinterpret_cast<float4*>(ring + px * LDP + c4 * 4) = rx0;
+        if (tid < 16) *reinterpret_cast<float4*>(ring + (px + 32) * LDP + c4 * 4) = rx1;
     };
 
-    f32x16 acc[9];
+    constexpr int NACC = BF16 ? 5 : 9;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -342,10 +349,33 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
             load_dy(r + 1);
             load_x(r + 2);
         }
-        const float* a = dYs + buf * 1024 + l31;
-        const float* x0 = Xs + ((r + 3) & 3) * (34 * 32) + l31;   // row r-1
-        const float* x1 = Xs + (r & 3) * (34 * 32) + l31;         // row r
-        const float* x2 = Xs + ((r + 1) & 3) * (34 * 32) + l31;   // row r+1
+        const float* a = dYs + buf * (32 * LDP) + l31;
+        const float* x0 = Xs + ((r + 3) & 3) * (34 * LDP) + l31;   // row r-1
+        const float* x1 = Xs + (r & 3) * (34 * LDP) + l31;         // row r
+        const float* x2 = Xs + ((r + 1) & 3) * (34 * LDP) + l31;   // row r+1
+        if constexpr (BF16) {
+            const int q0 = 16 * (wk & 1) + 8 * h;      // this lane's 8 pixels of the wave's k-group
+            const int odd = wk >> 1;                   // taps 0,2,4,6,8 (odd == 0) or 1,3,5,7
+            bf16x8 af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = (__bf16)a[(q0 + j) * LDP];
+            const float* rows[3] = {x0, x1, x2};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float v[10];           // pixels q0 .. q0+9 of input row r-1+kh (the three horizontal taps overlap)
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = rows[kh][(q0 + j) * LDP];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t = kh * 3 + kw;
+                    if ((t & 1) != odd) continue;      // wave-uniform
+                    bf16x8 bf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[j] = (__bf16)v[j + kw];
+                    acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t >> 1], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int s0 = 0; s0 < 4; ++s0) {
             const int q = 2 * (s0 * 4 + wk) + h;
@@ -372,8 +402,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
     float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+        if constexpr (BF16) {
+            // the two waves that own tap t (k-groups 0 and 1) deposit it; the other two slots stay zero
+            const bool mine = (wk >> 1) == (t & 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = acc[t][r];
+            for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = mine ? acc[(t >> 1) < NACC ? (t >> 1) : 0][r] : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = acc[t < NACC ? t : 0][r];
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -482,7 +519,7 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     pl.alltaps = false;
     pl.groups = 0;
     const int T = d->KH * d->KW;
-    if (!pl.smallc && d->math == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 &&
+    if (!pl.smallc && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 &&
         d->OW % 32 == 0 && d->OH == d->IH && d->OW == d->IW && d->Cout % 32 == 0 && d->C0 % 32 == 0 &&
         d->C1 % 32 == 0 && d->C0 > 0 && (d->Cout / 32) * (Ctot / 32) <= alltaps_max_tiles()) {
         pl.alltaps = true;
@@ -490,7 +527,8 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
         pl.wk = 1;
         pl.tiles = (d->Cout / 32) * (Ctot / 32);
         const int strips = d->N * (d->OW / 32);
-        const int cap = 512;                                      // 2 resident blocks per CU (144 accumulator VGPRs)
+        // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80)
+        const int cap = d->math ? 1024 : 512;
         // row chunks per strip: the smallest count whose grid fills whole rounds of resident blocks (>= 90 %)
         const int maxchunks = std::max(1, d->OH / 8);
         int chunks = 1;
@@ -611,11 +649,17 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         }
     int rc;
     if (pl.alltaps) {
-        static int kid = -1;
-        if (kid < 0) kid = prof_register("wgrad_alltaps_kernel");
-        prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+        static int kid = -1, kid16 = -1;
+        if (kid < 0) {
+            kid = prof_register("wgrad_alltaps_kernel");
+            kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
+        }
+        prof_begin(d->math ? kid16 : kid, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    4.0 * ((double)p.M * p.Ctot + (double)p.M * p.Cout + (double)total), stream);
-        hipLaunchKernelGGL(wgrad_alltaps_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        if (d->math)
+            hipLaunchKernelGGL(wgrad_alltaps_kernel<true>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL(wgrad_alltaps_kernel<false>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         prof_end(stream);
         XV2_CHECK_LAUNCH();
         rc = XV2_OK;
