@@ -80,8 +80,8 @@ def cpu_baseline(a, size, batch, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)      # >= 20 timed steps ...
+    ap.add_argument("--warmup", type=int, default=5)      # ... after >= 5 warm-ups
     ap.add_argument("--encoder", default="resnet50")
     ap.add_argument("--type", default="pre", choices=["pre", "post"])
     ap.add_argument("--dmg_model", default="siamese")
