@@ -89,7 +89,7 @@ PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is
 
 
 class _PackEntry:
-    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick")
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner")
 
 
 def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
@@ -108,6 +108,8 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
         e.tick = _pack_tick
         return e.ohwi, e.ihwo
     if e is None:
+        if len(_packs) % 64 == 63:
+            _drop_dead_packs()
         if len(_packs) >= PACK_CACHE_MAX:
             cut = sorted(v.tick for v in _packs.values())[len(_packs) // 2]
             for k in [k for k, v in _packs.items() if v.tick < cut]:
@@ -124,10 +126,21 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
         e.ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw)
         _pack_table = None
     e.w = w_oihw.detach()
+    base = w_oihw._base if w_oihw._base is not None else w_oihw
+    e.owner = weakref.ref(base)        # the parameter; once it is gone the entry only wastes memory
     e.tick = _pack_tick
     call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo)
     e.version, e.epoch = w_oihw._version, WEIGHT_EPOCH
     return e.ohwi, e.ihwo
+
+
+def _drop_dead_packs():
+    global _pack_table
+    dead = [k for k, e in _packs.items() if e.owner() is None]
+    for k in dead:
+        del _packs[k]
+    if dead:
+        _pack_table = None
 
 
 def weights_changed():
@@ -142,6 +155,7 @@ def repack_all():
     global _repack_tick
     if not _packs or not PACK_CACHE:
         return
+    _drop_dead_packs()
     stale = [k for k, e in _packs.items() if e.tick <= _repack_tick]     # not touched since the last refresh
     if stale:
         for k in stale:
