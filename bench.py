@@ -203,6 +203,9 @@ def main():
         # HIP events around the dominant kernel's launches (all MFMA launches if no warm-up named one), inside the
         # timed region, on the stream each launch goes to
         _capi.query("xv2_prof_enable", 2 + dom_kid if dom_kid >= 0 else 1)
+        # every 7th launch of it (7 is coprime with the launches per step, so the sample rotates through all layers
+        # over the timed steps): the records cost ~3 us each on the stream, 0.5 ms/step if every launch is bracketed
+        _capi.query("xv2_prof_stride", 7 if dom_kid >= 0 and opt.steps >= 7 else 1)
     t0 = time.time()
     for _ in range(opt.steps):
         loss = run()
@@ -216,6 +219,7 @@ def main():
             timed = collect()
             dom_row = dict(timed[0], steps=opt.steps) if timed else None
             _capi.query("xv2_prof_enable", 0)
+            _capi.query("xv2_prof_stride", 1)
             if dom_kid >= 0:
                 # per-kernel table of the co-scheduled step: an extra, untimed pass with every launch bracketed
                 psteps = min(opt.steps, 4)
@@ -267,7 +271,7 @@ def main():
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                 "launches_timed": top["launches"],
-                "note": "achieved/avg_launch_us: HIP events around this kernel's launches inside the timed region "
+                "note": "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
                         "(weight-gradient kernels co-scheduled on a side stream); 'isolated' = same kernel with every "
                         "launch alone on the chip; per_kernel/all_mfma_kernels: an extra untimed pass with every "
                         "MFMA launch bracketed",

@@ -321,6 +321,9 @@ int xv2_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  * xv2_prof_enable: 0 = off, 1 = every MFMA launch, 2 + kid = only launches of kernel id `kid` (the timed region
  * of bench.py brackets just the dominant kernel: 400 event records per step cost 1.3 ms, 160 cost a third). */
 int xv2_prof_enable(int on);
+/* bracket only every n-th eligible launch (n coprime with the launches per step rotates through the layers): the
+ * event records themselves cost ~3 us each on the stream */
+int xv2_prof_stride(int n);
 int xv2_prof_num_kernels(void);
 const char* xv2_prof_kernel_name(int kid);
 int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* total_algorithmic_bytes,

@@ -22,7 +22,9 @@ namespace xv2 {
 struct ProfRec { int kid; double flops, bytes; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static int g_prof_only = -1;
-static bool g_prof_open = false;   // >= 0: bracket only launches of this kernel id
+static bool g_prof_open = false;
+static int g_prof_stride = 1;   // bracket every n-th eligible launch
+static long g_prof_seen = 0;   // >= 0: bracket only launches of this kernel id
 static std::vector<std::string> g_prof_names;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -40,7 +42,7 @@ int prof_register(const char* name) {
     return (int)g_prof_names.size() - 1;
 }
 void prof_begin(int kid, double flops, double bytes, hipStream_t stream) {
-    if (!g_prof_on || (g_prof_only >= 0 && kid != g_prof_only)) {
+    if (!g_prof_on || (g_prof_only >= 0 && kid != g_prof_only) || (g_prof_seen++ % g_prof_stride) != 0) {
         g_prof_open = false;
         return;
     }
@@ -62,6 +64,11 @@ extern "C" int xv2_prof_enable(int on) {
         xv2::g_prof_recs.clear();
         xv2::g_prof_pool_next = 0;
     }
+    return XV2_OK;
+}
+extern "C" int xv2_prof_stride(int n) {
+    xv2::g_prof_stride = n > 1 ? n : 1;
+    xv2::g_prof_seen = 0;
     return XV2_OK;
 }
 extern "C" int xv2_prof_num_kernels(void) { return (int)xv2::g_prof_names.size(); }
