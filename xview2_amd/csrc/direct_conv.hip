@@ -58,20 +58,29 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     }
 
     i32x4 hr[D_HLOADS];
+    // this thread's D_HLOADS halo elements: (row, column) inside the 6 x 34 halo and the byte offset relative to the
+    // patch origin - fixed for the whole kernel
+    int hrow[D_HLOADS], hcol[D_HLOADS], hrel[D_HLOADS];
+#pragma unroll
+    for (int j = 0; j < D_HLOADS; ++j) {
+        const int e = tid + j * 256;
+        const int px = e >> 3, c4 = e & 7;
+        hrow[j] = px / D_HW;
+        hcol[j] = px - hrow[j] * D_HW;
+        hrel[j] = e < D_HALO * 8 ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * 4) << 2 : 0;
+        if (e >= D_HALO * 8) hrow[j] = -(1 << 20);      // never valid
+    }
     auto hload = [&](int patch) {
         const int tw = patch % tiles_w;
         const int th = (patch / tiles_w) % tiles_h;
         const int n = patch / (tiles_w * tiles_h);
         const int oh0 = th * D_TH, ow0 = tw * D_TW;
+        const int base = (((n * p.IH + oh0) * p.IW + ow0) * p.ldA0) << 2;
 #pragma unroll
         for (int j = 0; j < D_HLOADS; ++j) {
-            const int e = tid + j * 256;
-            const int px = e >> 3, c4 = e & 7;
-            const int r = px / D_HW, c = px - r * D_HW;
-            const int ih = oh0 - 1 + r, iw = ow0 - 1 + c;
-            const bool ok = e < D_HALO * 8 && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            const int off = ok ? ((((n * p.IH + ih) * p.IW + iw) * p.ldA0 + c4 * 4) << 2) : (int)0x80000000;
-            hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+            const int ih = oh0 - 1 + hrow[j], iw = ow0 - 1 + hcol[j];
+            const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
         }
     };
     auto hstore = [&]() {
@@ -81,6 +90,13 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
             if (e < D_HALO * 8) *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
         }
     };
+
+    // per-lane channel constants of the epilogue (lane & 31 = output channel), loaded once
+    const float bv = p.bias ? p.bias[l31] : 0.f;
+    const float esc = p.ep_scale ? p.ep_scale[l31] : 0.f, esf = p.ep_scale ? p.ep_shift[l31] : 0.f;
+    const bool bnb = p.bnb_y != nullptr;     // BN-backward statistics of the producer layer (IgemmParams::bnb_*)
+    const float bmu = bnb ? p.bnb_mean[l31] : 0.f, bis = bnb ? p.bnb_invstd[l31] : 0.f;
+    const float bsc = bnb ? p.bnb_scale[l31] : 0.f, bsf = bnb ? p.bnb_shift[l31] : 0.f;
 
     hload(p0);
     hstore();
@@ -126,11 +142,6 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int th = (patch / tiles_w) % tiles_h;
         const int n = patch / (tiles_w * tiles_h);
         const size_t rowpix = ((size_t)n * OH + th * D_TH + wave) * OW + tw * D_TW;
-        const float bv = p.bias ? p.bias[l31] : 0.f;
-        const float esc = p.ep_scale ? p.ep_scale[l31] : 0.f, esf = p.ep_scale ? p.ep_shift[l31] : 0.f;
-        const bool bnb = p.bnb_y != nullptr;     // BN-backward statistics of the producer layer (IgemmParams::bnb_*)
-        const float bmu = bnb ? p.bnb_mean[l31] : 0.f, bis = bnb ? p.bnb_invstd[l31] : 0.f;
-        const float bsc = bnb ? p.bnb_scale[l31] : 0.f, bsf = bnb ? p.bnb_shift[l31] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
