@@ -305,17 +305,22 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     float4 rd, rx0, rx1;
-    auto load_dy = [&](int r) {
-        rd = *reinterpret_cast<const float4*>(p.DY + (((size_t)n * p.OH + r) * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4);
-    };
+    // per-thread element pointers at image row 0 of sample n; a row step is ONE uniform pitch away (the 64-bit
+    // index arithmetic of three loads per row was a third of this kernel's vector instructions)
+    const float* dy0 = p.DY + ((size_t)n * p.OH * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4;
+    const size_t dy_pitch = (size_t)p.OW * p.ldDY;
+    const int iw = ow0 - 1 + px;
+    const float* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c4 * 4;       // halo pixel px
+    const size_t x_pitch = (size_t)p.IW * ldx;
+    const bool xa_ok = iw >= 0, xb_ok = tid < 16 && iw + 32 < p.IW;                        // halo pixels 32, 33
+    auto load_dy = [&](int r) { rd = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch); };
     auto load_x = [&](int ih) {      // input row ih, pixels ow0-1 .. ow0+32
         rx0 = zero4;
         rx1 = zero4;
         if ((unsigned)ih < (unsigned)p.IH) {
-            const float* row = xsrc + ((size_t)n * p.IH + ih) * p.IW * ldx + xch + c4 * 4;
-            const int iw = ow0 - 1 + px;
-            if (iw >= 0) rx0 = *reinterpret_cast<const float4*>(row + (size_t)iw * ldx);
-            if (tid < 16 && iw + 32 < p.IW) rx1 = *reinterpret_cast<const float4*>(row + (size_t)(iw + 32) * ldx);
+            const float* row = xa0 + (size_t)ih * x_pitch;
+            if (xa_ok) rx0 = *reinterpret_cast<const float4*>(row);
+            if (xb_ok) rx1 = *reinterpret_cast<const float4*>(row + (size_t)32 * ldx);
         }
     };
     auto store_dy = [&](int buf) { *reinterpret_cast<float4*>(dYs + buf * (32 * LDP) + px * LDP + c4 * 4) = rd; };
