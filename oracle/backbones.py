@@ -11,6 +11,9 @@ ones: conv1, bn1, layer1.0.conv2.weight, layer1.0.downsample.0.weight, and for R
 conv1.0/3/6, layerX.Y.conv2.{conv,bn0,fc1,bn1,fc2}, downsample.1/2) and are anchored on the
 reference's call sites only: attribute names used by get_encoder (unet.py:66-84), the channel plan
 [64|128,256,512,1024,2048] (unet.py:49-54) and the per-image FLOP counts of SURVEY.md section 8.
+What IS machine-checked (tests/test_oracle_published_pins.py): the published parameter counts of all seven
+architectures (torchvision / ResNeSt model zoos), state_dict sizes and key grammar, the published multiply-accumulate
+counts at the model zoos' crop sizes, stride placement (v1.5) and the SURVEY FLOP figures - structure, not values.
 """
 import math
 

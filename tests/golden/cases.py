@@ -36,6 +36,10 @@ MODEL_CASES = {
     "post_parallelEnc_resnet50_aspp": dict(type="post", dmg_model="parallelEnc", aspp=True, loss_str="focal+dice"),
     "post_diff_resnet50": dict(type="post", dmg_model="diff", loss_str="focal+dice"),
     "post_siamese_coral": dict(type="post", dmg_model="siamese", loss_str="coral"),
+    # BASELINE configs[3] / configs[4] with their stated encoders (64x64 tiles)
+    "post_siamese_resnest101": dict(type="post", dmg_model="siamese", encoder="resnest101", loss_str="focal+dice"),
+    "post_fused_resnest200_attn_ds": dict(type="post", dmg_model="fused", encoder="resnest200", attention=True,
+                                          ppm=True, deep_supervision=True, loss_str="focal+dice"),
 }
 
 LOSS_CASES = {

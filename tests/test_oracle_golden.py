@@ -15,7 +15,8 @@ from xview2_amd.weights import deterministic_init_
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
 FAST = ["pre_resnet50", "pre_resnet50_ds_attn", "pre_resnest50", "post_siamese_resnest50_ds",
         "post_fused_resnest50_attn_ds", "post_siameseEnc_resnet50", "pre_resnet50_ppm", "pre_resnet50_aspp_dil2",
-        "pre_resnet50_decinterp", "post_parallel_resnet50", "post_siamese_coral"]
+        "pre_resnet50_decinterp", "post_parallel_resnet50", "post_siamese_coral",
+        "post_siamese_resnest101", "post_fused_resnest200_attn_ds"]
 
 
 def check_summary(t, ref, tol, what):
