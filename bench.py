@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Headline benchmark: training images/sec of the U-Net hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched once per rank by torchrun)
+    python bench.py --gpus N --steps K --warmup W
+        N>1 without a torchrun environment: bench.py re-launches itself as N ranks (one process per GPU, like the
+        reference's Trainer(accelerator="ddp"), main.py:106-107) and FAILS if fewer than N GPUs / ranks come up.
+    python bench.py --phase encoder-forward --encoder resnest50 [--precision 16]
+        north_star target figure: MFMA utilisation of the resnest50 encoder forward (model/unet.py:45-52).
 
 N=1 workload = BASELINE.json configs[1]: --type pre --encoder resnet50 --loss_str dice, 1024x1024, batch 2 per GPU,
 fp32, synthetic tiles (seeded uniform-uint8 RGB normalised with ImageNet mean/std, rectangle masks), key-seeded
@@ -9,12 +13,18 @@ random weights.  One step = forward + loss + backward (+ RCCL gradient all-reduc
 N>1) + fused AdamW step, everything through the HIP C ABI.  Weak scaling: per-GPU batch fixed.
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline:     dominant kernel's algorithmic conv FLOPs / its HIP-event time, against the fp32 MFMA peak
-  cpu_baseline: the CPU oracle (PyTorch fp32 restatement of the reference path) timed on the host cores.
+  cpu_baseline: the CPU oracle (PyTorch fp32 restatement of the reference path) timed on the host cores
+                (1 warm-up + median of 3 steps at the same shape),
+  parity:       first HIP training step vs the oracle's first step on the SAME batch and weights at full size: loss,
+                logits (max-abs error / max-abs reference), argmax label maps, parameter gradients.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,6 +36,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 (--precision 16 runs only)
 F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
+F_ENC_GFLOP_PER_IMG = {"resnet50": 170.8, "resnest50": 224.3}   # encoder forward only
 
 
 def synthetic_batch(args_ns, batch, size, seed, device):
@@ -56,8 +67,20 @@ def make_args(encoder="resnet50", ttype="pre", loss_str="dice", dmg_model="siame
     return SimpleNamespace(**d)
 
 
-def cpu_baseline(a, size, batch, seed):
-    """one fwd+loss+bwd+AdamW step of the CPU oracle at the SAME shape (bounded sample: a single step)"""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(a, size, batch, seed, timed_steps=3):
+    """fwd+loss+bwd+AdamW steps of the CPU oracle at the SAME shape, batch and weights (bounded sample: one warm-up
+    step, then the median of `timed_steps`).  The warm-up step starts from the weights and batch the HIP path's
+    first step sees, so its loss / logits / gradients are the full-size parity reference (second return value)."""
     from oracle import torch_ref
     from xview2_amd.weights import deterministic_init_
     torch.manual_seed(0)
@@ -65,16 +88,159 @@ def cpu_baseline(a, size, batch, seed):
     deterministic_init_(m, 1)
     m.train()
     x, y = synthetic_batch(a, batch, size, seed, "cpu")
-    opt = torch.optim.AdamW(m.parameters(), lr=3e-4)
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.0)
     loss_fn = torch_ref.Loss(a)
-    t0 = time.time()
-    loss = torch_ref.compute_loss(loss_fn, m(x), y, a.deep_supervision)
-    loss.backward()
-    opt.step()
-    dt = time.time() - t0
+    times, ref = [], None
+    for it in range(1 + timed_steps):
+        opt.zero_grad()
+        t0 = time.time()
+        pred = m(x)
+        loss = torch_ref.compute_loss(loss_fn, pred, y, a.deep_supervision)
+        loss.backward()
+        if it == 0:
+            p0 = pred[0] if isinstance(pred, list) else pred
+            ref = {"loss": float(loss), "logits": p0.detach().clone(),
+                   "grads": {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}}
+        opt.step()
+        times.append(time.time() - t0)
+    dt = statistics.median(times[1:]) if timed_steps else times[0]
     return {"value": batch / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 training step (fwd+loss+bwd+AdamW) of the PyTorch-CPU oracle, %s %dx%dx%d fp32, no warm-up"
-                      % (a.encoder, batch, size, size), "seconds": dt, "loss": float(loss)}
+            "cpu": cpu_model_name(),
+            "sample": "PyTorch-CPU oracle, %s %dx%dx%d fp32 training step (fwd+loss+bwd+AdamW): 1 warm-up step, then the "
+                      "median of %d steps" % (a.encoder, batch, size, size, timed_steps),
+            "seconds": dt, "seconds_all": [round(t, 3) for t in times], "loss": ref["loss"]}, ref
+
+
+def parity_block(ref, hip, precision):
+    """full-size first-step comparison of the HIP path with the CPU oracle (same batch, same key-seeded weights)"""
+    lo, lh = ref["loss"], hip["loss"]
+    zo, zh = ref["logits"].double(), hip["logits"].double().cpu()
+    zmax = max(float(zo.abs().max()), 1e-12)
+    logits_rel = float((zh - zo).abs().max()) / zmax
+    ao, ah = torch.argmax(ref["logits"], 1), hip["labels"].cpu().long()
+    top2 = torch.topk(ref["logits"], 2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1]) / zmax
+    diff = ao != ah
+    rels, num, den = [], 0.0, 0.0
+    for k, go in ref["grads"].items():
+        gh = hip["grads"].get(k)
+        if gh is None:
+            continue
+        go = go.double()
+        d = float((gh.double().cpu() - go).norm())
+        n = float(go.norm())
+        num += d * d
+        den += n * n
+        if n > 0:
+            rels.append((d / n, k))
+    rels.sort()
+    gate = 1e-3 if precision == 32 else None
+    out = {"hip_first_loss": lh, "oracle_loss": lo, "rel": abs(lh - lo) / max(abs(lo), 1e-12),
+           "logits_rel": logits_rel, "argmax_mismatch_px": int(diff.sum()),
+           "argmax_mismatch_px_outside_ties": int((diff & (gap > 1e-3)).sum()), "pixels": int(diff.numel()),
+           "grad_rel_global": (num / max(den, 1e-300)) ** 0.5,
+           "grad_rel_median": rels[len(rels) // 2][0] if rels else None,
+           "grad_rel_max": rels[-1][0] if rels else None, "grad_rel_max_key": rels[-1][1] if rels else None,
+           "tensors": len(rels), "gate": gate,
+           "what": "first training step at the bench shape, HIP path vs CPU oracle: loss rel, logits max-abs error / "
+                   "max-abs reference, argmax label maps (ties = top-2 gap <= 1e-3 of the logit range), per-tensor "
+                   "||g_hip - g_cpu|| / ||g_cpu|| of every parameter gradient"}
+    if gate is not None:
+        out["pass"] = bool(out["rel"] <= gate and logits_rel <= gate and out["argmax_mismatch_px_outside_ties"] == 0)
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """--gpus N>1 outside a torchrun environment: become the launcher (the reference spawns its own ranks too)"""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible - refusing to report a %d-GPU number" % (n, have, n))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def collect_prof(_capi):
+    rows = []
+    for kid in range(_capi.query("xv2_prof_num_kernels")):
+        tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
+                    ctypes.addressof(n))
+        if n.value:
+            rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
+                         "gflop": fl.value / 1e9, "mbytes": by.value / 1e6, "launches": n.value})
+    rows.sort(key=lambda r: -r["ms"])
+    return rows
+
+
+def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
+    """north_star target: MFMA utilisation of the (training-mode) encoder forward, model/unet.py:45-52 -> enc_l1..5.
+    utilisation = conv FLOPs of the encoder (224.3 GFLOP/img for resnest50 at 1024x1024) / time / dense
+    MFMA peak of the math mode; two clocks: the whole forward (HIP events around enc_l1..enc_l5, BatchNorm / pooling /
+    split-attention kernels included) and the sum of the MFMA kernels' own HIP-event times."""
+    from xview2_amd import _capi, networks, nn as xnn, ops
+    from xview2_amd.weights import deterministic_init_
+    a = make_args(encoder, "pre", "dice")
+    old_mode = ops.MATH_MODE
+    set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        model = networks.UNetLoc(a)
+        deterministic_init_(model, 1)
+        model.to(dev).train()
+        x, _ = synthetic_batch(a, batch, size, 1, dev)
+
+        def fwd():
+            with torch.no_grad():
+                return model.unet._encode(xnn.to_nhwc_image(x))
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fwd()
+        e1.record()
+        torch.cuda.synchronize()
+        wall_ms = e0.elapsed_time(e1) / iters
+        _capi.query("xv2_prof_enable", 1)
+        for _ in range(iters):
+            fwd()
+        torch.cuda.synchronize()
+        rows = collect_prof(_capi)
+        _capi.query("xv2_prof_enable", 0)
+    finally:
+        ops.MATH_MODE = old_mode
+        ops.set_storage_dtype(None) if hasattr(ops, "set_storage_dtype") else None
+    gf = F_ENC_GFLOP_PER_IMG.get(encoder, 0.0) * batch * (size / 1024.0) ** 2
+    peak = PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS
+    mfma_ms = sum(r["ms"] for r in rows) / iters
+    counted = sum(r["gflop"] for r in rows) / iters
+    return {"encoder": encoder, "precision": precision, "batch": batch, "size": size,
+            "gflop_per_pass": round(gf, 1), "gflop_counted_by_launches": round(counted, 1), "peak_tflops": peak,
+            "forward_ms": round(wall_ms, 3), "mfma_kernels_ms": round(mfma_ms, 3),
+            "mfma_util_whole_forward": round(gf / wall_ms / peak, 4),
+            "mfma_util_in_mfma_kernels": round(gf / mfma_ms / peak, 4) if mfma_ms else None,
+            "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
+                            "ms_per_pass": round(r["ms"] / iters, 3), "launches_per_pass": r["launches"] / iters}
+                           for r in rows]}
+
+
+def set_precision(precision):
+    from xview2_amd import ops
+    ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.MATH_F32
+    if hasattr(ops, "set_storage_dtype"):
+        ops.set_storage_dtype(torch.bfloat16 if precision == 16 else None)
 
 
 def main():
@@ -91,10 +257,14 @@ def main():
     ap.add_argument("--ppm", action="store_true")
     ap.add_argument("--precision", type=int, default=32, choices=[16, 32],
                     help="32 = exact fp32 MFMA (BASELINE configs[1], default); 16 = the reference's --precision 16 "
-                         "autocast analogue: conv operands rounded to bf16 in LDS, bf16 MFMA, fp32 accumulate/storage")
+                         "analogue: bf16 activations in HBM, bf16 MFMA, fp32 accumulate / statistics / master weights")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch")
+    ap.add_argument("--phase", default="train", choices=["train", "encoder-forward"],
+                    help="encoder-forward: only the north_star figure (MFMA utilisation of the encoder forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder-probe", action="store_true",
+                    help="skip the resnest50 encoder-forward utilisation block of the default line")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
     ap.add_argument("--graph", action="store_true",
@@ -104,11 +274,19 @@ def main():
                     help="debug: run the RCCL gradient/SyncBN collectives even with one rank (overhead probe)")
     opt = ap.parse_args()
 
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(opt.gpus)
+
     from xview2_amd import _capi, criterion, dist as xdist, networks
     from xview2_amd.optim import FlatAdamW
     from xview2_amd.weights import deterministic_init_
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     rank, local, world = xdist.init_from_env()
+    if opt.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong rank count"
+                         % (opt.gpus, world))
     if opt.force_collectives and world == 1:
         from xview2_amd import ops as _ops
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -121,16 +299,28 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         _ops.FORCE_COLLECTIVES = True
-    if opt.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (opt.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    n_ranks_seen = 1
+    if world > 1:
+        # what RCCL itself says about the job: a SUM all-reduce of 1 over the communicator the step will use
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        n_ranks_seen = int(one.item())
+        if n_ranks_seen != opt.gpus:
+            raise SystemExit("RCCL sees %d ranks, --gpus %d" % (n_ranks_seen, opt.gpus))
 
-    if opt.precision == 16:
-        from xview2_amd import ops as _o
-        _o.MATH_MODE = _o.MATH_BF16
+    if opt.phase == "encoder-forward":
+        enc = encoder_forward_probe(opt.encoder, opt.precision, opt.size, opt.batch, dev, iters=max(3, opt.steps))
+        if rank == 0:
+            print(json.dumps({"metric": "MFMA utilisation of the %s encoder forward" % opt.encoder,
+                              "value": enc["mfma_util_whole_forward"], "unit": "fraction of dense MFMA peak",
+                              "n_gpus": world, "higher_is_better": True,
+                              "dtype": "f32" if opt.precision == 32 else "bf16", "data": "synthetic",
+                              "encoder_forward": enc}))
+        return
+
+    set_precision(opt.precision)
     a = make_args(opt.encoder, opt.type, opt.loss_str or ("dice" if opt.type == "pre" else "focal+dice"),
                   opt.dmg_model, deep_supervision=opt.deep_supervision, attention=opt.attention, ppm=opt.ppm)
     torch.manual_seed(0)
@@ -141,13 +331,16 @@ def main():
     optim = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.0)
     reducer = xdist.GradReducer(optim)
     x, y = synthetic_batch(a, opt.batch, opt.size, 1 + rank, dev)
+    last = {}
 
     def step():
         optim.zero_grad()
         reducer.prepare()
-        loss = criterion.compute_loss(loss_fn, model(x), y, a.deep_supervision)
+        pred = model(x)
+        loss = criterion.compute_loss(loss_fn, pred, y, a.deep_supervision)
         loss.backward()
         optim.step(reducer.finish())
+        last["pred"] = pred
         return loss
 
     def barrier():
@@ -172,20 +365,24 @@ def main():
     # region then brackets ONLY that kernel's launches, which keeps the event overhead out of the headline number
     if prof and graphed is None and opt.warmup > 0:
         _capi.query("xv2_prof_enable", 1)
-    for _ in range(opt.warmup):
-        run()
+    hip_first = None
 
-    def collect():
-        rows = []
-        for kid in range(_capi.query("xv2_prof_num_kernels")):
-            tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
-                        ctypes.addressof(n))
-            if n.value:
-                rows.append({"kernel": _capi.query("xv2_prof_kernel_name", kid).decode(), "ms": tms.value,
-                             "gflop": fl.value / 1e9, "mbytes": by.value / 1e6, "launches": n.value})
-        rows.sort(key=lambda r: -r["ms"])
-        return rows
+    def grab_first(loss):
+        """the FIRST step (initial weights, rank-0 batch = the oracle's batch): what the parity block compares"""
+        pred = last["pred"]
+        p0 = (pred[0] if isinstance(pred, list) else pred).detach()
+        names = {id(p): k for k, p in model.named_parameters()}
+        g = optim.flat_g
+        grads = {names[id(p)]: g[o:o + p.numel()].view(p.shape).clone()
+                 for p, o in zip(optim.params, optim.offsets) if id(p) in names}
+        return {"loss": float(loss.detach()), "logits": p0.float().clone(), "labels": _xops.argmax_labels(p0.float()),
+                "grads": grads}
+
+    for i in range(opt.warmup):
+        l0 = run()
+        if i == 0 and graphed is None and world == 1:
+            hip_first = grab_first(l0)
+    last.clear()
 
     dom_kid = -1
     if prof and graphed is None:
@@ -211,12 +408,14 @@ def main():
         loss = run()
     barrier()
     dt = time.time() - t0
+    if hip_first is None and world == 1 and graphed is None and opt.warmup == 0:
+        sys.stderr.write("no warm-up step: the parity block needs the first step outside the timed region\n")
     rows, iso = [], []
     psteps = opt.steps
     dom_row = None
     if prof:
         if graphed is None:
-            timed = collect()
+            timed = collect_prof(_capi)
             dom_row = dict(timed[0], steps=opt.steps) if timed else None
             _capi.query("xv2_prof_enable", 0)
             _capi.query("xv2_prof_stride", 1)
@@ -227,7 +426,7 @@ def main():
                 for _ in range(psteps):
                     step()
                 torch.cuda.synchronize()
-                rows = collect()
+                rows = collect_prof(_capi)
                 _capi.query("xv2_prof_enable", 0)
             else:
                 rows = timed
@@ -241,7 +440,7 @@ def main():
         for _ in range(isteps):
             step()
         torch.cuda.synchronize()
-        iso = collect()
+        iso = collect_prof(_capi)
         _capi.query("xv2_prof_enable", 0)
         _xops.ASYNC_WGRAD = True
         if not rows:
@@ -266,7 +465,10 @@ def main():
         iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
         peak = PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "kernel": top["kernel"],
+                "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command on an earlier run (PMC collection is not possible inside this process)",
+                "kernel": top["kernel"],
                 "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
@@ -284,24 +486,39 @@ def main():
                 "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
                                 "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
                                for r in rows]}
+    model_tf = value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3
     out = {
         "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
-        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": round(ms, 3),
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": opt.steps, "warmup": opt.warmup,
+        "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if opt.precision == 32 else "bf16 MFMA operands, f32 accumulate/storage", "data": "synthetic",
+        "dtype": "f32" if opt.precision == 32 else "bf16", "data": "synthetic",
         "config": {"workload": "--type %s%s --encoder %s --loss_str %s%s%s, %dx%d, batch %d per GPU, %s train step "
                                "(fwd+loss+bwd+allreduce+AdamW)" % (
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
-                                   "fp32" if opt.precision == 32 else "precision-16 (bf16 MFMA)"),
+                                   "fp32" if opt.precision == 32 else
+                                   "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
-        "model_tflops": round(value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3, 2),
+        "model_tflops": round(model_tf, 2),
+        "conv_roofline_frac_whole_step": round(
+            model_tf / world / (PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS), 4),
         "roofline": roof,
     }
+    if rank == 0 and world == 1 and not opt.no_encoder_probe:
+        # north_star target figure (configs[2] model): MFMA utilisation of the resnest50 encoder forward, both math modes
+        del model, optim, reducer
+        torch.cuda.empty_cache()
+        out["encoder_forward"] = [encoder_forward_probe("resnest50", pr, opt.size, opt.batch, dev) for pr in (32, 16)]
     if rank == 0 and not opt.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
+        cb, ref = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
+        out["cpu_baseline"] = cb
+        if hip_first is not None and (opt.cpu_size or opt.size) == opt.size:
+            out["parity"] = parity_block(ref, hip_first, opt.precision)
+            if out["parity"].get("pass") is False:
+                sys.stderr.write("PARITY GATE FAILED: %s\n" % json.dumps(out["parity"]))
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():

@@ -51,3 +51,27 @@ def test_cli_trains_and_evaluates_on_png_tiles(tmp_path, monkeypatch):
     res2 = str(tmp_path / "eval")
     cli.main(["--exec_mode", "eval", "--ckpt", ck, "--results", res2] + common)
     assert len(os.listdir(os.path.join(res2, "probs"))) == 4
+
+
+def test_resume_continues_the_uninterrupted_run_bit_for_bit(tmp_path):
+    """checkpoint + --ckpt resume: optimizer moments, the DEVICE step counter of the fused AdamW (bias correction) and
+    the Noam schedule position are restored, so 1 epoch + resume + 1 epoch ends on exactly the parameters of an
+    uninterrupted 2-epoch run (the synthetic loader replays the same batches each epoch; every kernel is deterministic)"""
+    import shutil
+    import main as cli
+    common = ["--data", "synthetic", "--encoder", "resnet50", "--precision", "32", "--batch_size", "2",
+              "--val_batch_size", "2", "--train_size", "64", "--eval_size", "64", "--steps_per_epoch", "3",
+              "--exec_mode", "train", "--type", "pre", "--loss_str", "dice", "--use_scheduler", "--warmup", "1",
+              "--final_lr", "1e-5"]
+    full = cli.main(common + ["--epochs", "2", "--results", str(tmp_path / "full")])
+    cli.main(common + ["--epochs", "1", "--results", str(tmp_path / "half")])
+    ck = str(tmp_path / "half.ckpt")
+    shutil.copy(os.path.join(str(tmp_path / "half"), "checkpoints", "last.ckpt"), ck)
+    # (the 1-epoch run only covers the warm-up phase of the Noam schedule, which does not depend on --epochs)
+    blob = torch.load(ck, map_location="cpu", weights_only=False)
+    assert blob["global_step"] == 3 and blob["optimizer_states"][0]["step"] == 3
+    resumed = cli.main(common + ["--epochs", "2", "--results", str(tmp_path / "res"), "--ckpt", ck])
+    a, b = full.state_dict(), resumed.state_dict()
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from .pytorch_loader import fetch_pytorch_loader
+from .pytorch_loader import fetch_pytorch_loader, seed_worker
 
 
 class _OnDevice:
@@ -14,6 +14,11 @@ class _OnDevice:
 
     def __len__(self):
         return len(self.loader)
+
+    def set_epoch(self, epoch):
+        sampler = getattr(self.loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
 
     def __iter__(self):
         for batch in self.loader:
@@ -36,14 +41,20 @@ class DataModule:
         kwargs = dict(kwargs)
         if self.world_size > 1:     # what PL's ddp accelerator adds: one shard of the dataset per rank
             from torch.utils.data.distributed import DistributedSampler
+            # the dataset is built once and re-wrapped with the sampler (no second glob / index parse)
             probe = fetch_pytorch_loader(path, self.args.type, training, {"batch_size": 1},
                                          getattr(self.args, "autoaugment", False)).dataset
             kwargs["sampler"] = DistributedSampler(probe, self.world_size, self.rank, shuffle=kwargs.pop("shuffle"))
-        loader = fetch_pytorch_loader(path, self.args.type, training, kwargs, getattr(self.args, "autoaugment", False))
+            loader = torch.utils.data.DataLoader(probe, worker_init_fn=seed_worker, **kwargs)
+        else:
+            loader = fetch_pytorch_loader(path, self.args.type, training, kwargs,
+                                          getattr(self.args, "autoaugment", False))
         return _OnDevice(loader, self.device)
 
     def train_dataloader(self):
-        return self._loader(self.train_path, True, self.train_loader_kwargs)
+        if getattr(self, "_train", None) is None:
+            self._train = self._loader(self.train_path, True, self.train_loader_kwargs)
+        return self._train
 
     def val_dataloader(self):
         return self._loader(self.val_path, False, self.test_loader_kwargs)

@@ -241,7 +241,12 @@ class Model(_Base):
             optimizer = builders[name](self.parameters())
         if not self.args.use_scheduler:
             return optimizer
-        per_rank_steps = max(1, getattr(self.args, "steps_per_epoch", 1) // max(1, getattr(self.args, "gpus", 1)))
+        # model/plt.py:170 uses len(self.train_dataloader()) // gpus on the UNSHARDED loader; here the trainer hands
+        # over the length of the loader this rank really iterates (already one shard per rank: no second division)
+        per_rank_steps = getattr(self, "steps_per_epoch_hint", None)
+        if per_rank_steps is None:     # configure_optimizers() called outside a Trainer: the synthetic-data knob
+            per_rank_steps = getattr(self.args, "steps_per_epoch", 1)
+        per_rank_steps = max(1, int(per_rank_steps))
         noam = NoamLR(optimizer=optimizer, warmup_epochs=self.args.warmup, total_epochs=self.args.epochs,
                       steps_per_epoch=per_rank_steps, init_lr=self.args.init_lr, max_lr=self.args.lr,
                       final_lr=self.args.final_lr)

@@ -327,6 +327,11 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
     # weights' second contribution) involves an accumulation kernel on the compute stream and stays in order.
     out = grad_slot(weight if wparam is None else wparam) if ASYNC_WGRAD else None
     if out is None:
+        # Second (third ...) gradient of a SHARED weight in this step (SiameseUNet, ParallelUNet): the first one may
+        # still be in flight on the side stream, and autograd's accumulation / the reducer's copy of the slot run on
+        # the compute stream - order them behind the side stream before the new contribution is produced.
+        if ASYNC_WGRAD and _wgrad_stream is not None and x0.is_cuda:
+            torch.cuda.current_stream().wait_stream(_wgrad_stream)
         return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam)
     if not _join_queued:
         # the compute stream re-joins the side stream when this backward pass ends, whoever consumes the gradients

@@ -99,3 +99,7 @@ class FlatAdamW:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups[0]["lr"] = sd["lr"]
+        if self.step_dev is not None:
+            # the GPU kernel takes its bias correction from the device-resident counter
+            self.step_dev.fill_(int(sd["step"]))
+            self.sync_lr()

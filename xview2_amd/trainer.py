@@ -46,6 +46,12 @@ class Trainer:
     def fit(self, model, datamodule):
         model.to(self.device)
         start_epoch = 0
+        # the loader (dataset index, worker pool, sampler) is built once; its length is this rank's steps per epoch
+        train_loader = datamodule.train_dataloader()
+        try:
+            model.steps_per_epoch_hint = len(train_loader)
+        except TypeError:
+            model.steps_per_epoch_hint = None
         opt_cfg = model.configure_optimizers()
         if isinstance(opt_cfg, dict):
             optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
@@ -59,12 +65,19 @@ class Trainer:
             if isinstance(optimizer, FlatAdamW) and ckpt.get("optimizer_states"):
                 st = ckpt["optimizer_states"][0]
                 optimizer.load_state_dict({k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in st.items()})
+            if scheduler is not None:
+                # NoamLR counts from 1 (its constructor steps once): after n optimizer steps it stands at n + 1
+                scheduler.step(self.global_step + 1)
+                if isinstance(optimizer, FlatAdamW):
+                    optimizer.sync_lr()
         flat = isinstance(optimizer, FlatAdamW)
         reducer = xdist.GradReducer(optimizer, sync_bn=self.sync_batchnorm or self.world > 1) if flat else None
         for epoch in range(start_epoch, self.max_epochs):
             model.current_epoch = epoch
             model.train()
-            for i, batch in enumerate(datamodule.train_dataloader()):
+            if hasattr(train_loader, "set_epoch"):
+                train_loader.set_epoch(epoch)        # DistributedSampler reshuffles per epoch (PL's ddp does this)
+            for i, batch in enumerate(train_loader):
                 optimizer.zero_grad()
                 if reducer:
                     reducer.prepare()

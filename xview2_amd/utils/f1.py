@@ -14,6 +14,8 @@ def convert_to_labels(loss_str, logits):  # utils/f1.py:7-15
         return preds
     if loss_str == "coral":
         return torch.sum(torch.sigmoid(logits) > 0.5, dim=1) + 1
+    if not logits.is_cuda:      # host-side bookkeeping of already-downloaded logits
+        return torch.argmax(logits, 1) + 1
     return ops.argmax_labels(logits, add=1).long()
 
 
@@ -49,7 +51,7 @@ class F1:
             mask = targets > 0
             targets, lab = targets[mask], lab[mask]
         else:
-            lab = ops.argmax_labels(preds).long()
+            lab = torch.argmax(preds, 1)
         for i in range(self.n_class - 1):
             c = i + 1
             self.tp[i] += float(((lab == c) & (targets == c)).sum())

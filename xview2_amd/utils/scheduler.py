@@ -11,7 +11,8 @@ class NoamLR:
         self.init_lr, self.max_lr, self.final_lr = init_lr, max_lr, final_lr
         self.warmup_steps = int(warmup_epochs * steps_per_epoch)
         self.total_steps = total_epochs * steps_per_epoch
-        self.linear_increment = (max_lr - init_lr) / self.warmup_steps
+        # --warmup 0: the reference's numpy division yields inf with a warning and the branch is never taken
+        self.linear_increment = (max_lr - init_lr) / self.warmup_steps if self.warmup_steps else 0.0
         self.exponential_gamma = (final_lr / max_lr) ** (1 / (self.total_steps - self.warmup_steps))
         self.current_step = 0
         self.lr = [init_lr] * self.n
