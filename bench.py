@@ -203,22 +203,28 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
         def fwd():
             with torch.no_grad():
                 return model.unet._encode(xnn.to_nhwc_image(x))
-        for _ in range(3):
-            fwd()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fwd()
-        e1.record()
-        torch.cuda.synchronize()
-        wall_ms = e0.elapsed_time(e1) / iters
-        _capi.query("xv2_prof_enable", 1)
-        for _ in range(iters):
-            fwd()
-        torch.cuda.synchronize()
-        rows = collect_prof(_capi)
-        _capi.query("xv2_prof_enable", 0)
+
+        def measure():
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fwd()
+            e1.record()
+            torch.cuda.synchronize()
+            wall = e0.elapsed_time(e1) / iters
+            _capi.query("xv2_prof_enable", 1)
+            for _ in range(iters):
+                fwd()
+            torch.cuda.synchronize()
+            rws = collect_prof(_capi)
+            _capi.query("xv2_prof_enable", 0)
+            return wall, rws
+        wall_ms, rows = measure()                 # training mode: batch-statistics BatchNorm (what a train step runs)
+        model.eval()
+        wall_eval, rows_eval = measure()          # inference: running statistics folded into the conv epilogue
     finally:
         ops.MATH_MODE = old_mode
         ops.set_storage_dtype(None) if hasattr(ops, "set_storage_dtype") else None
@@ -231,6 +237,12 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
             "forward_ms": round(wall_ms, 3), "mfma_kernels_ms": round(mfma_ms, 3),
             "mfma_util_whole_forward": round(gf / wall_ms / peak, 4),
             "mfma_util_in_mfma_kernels": round(gf / mfma_ms / peak, 4) if mfma_ms else None,
+            "eval_mode": {"forward_ms": round(wall_eval, 3),
+                          "mfma_kernels_ms": round(sum(r["ms"] for r in rows_eval) / iters, 3),
+                          "mfma_util_whole_forward": round(gf / wall_eval / peak, 4),
+                          "note": "model.eval(): BatchNorm folded into the convolution epilogue, one launch per conv"},
+            "note": "training-mode forward (batch statistics: conv+stats, BN apply, split attention, pooling kernels "
+                    "all inside forward_ms); utilisation = SURVEY 8(a) conv FLOPs / time / dense MFMA peak",
             "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
                             "ms_per_pass": round(r["ms"] / iters, 3), "launches_per_pass": r["launches"] / iters}
                            for r in rows]}

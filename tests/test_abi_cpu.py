@@ -106,3 +106,16 @@ def test_noam_schedule_matches_reference_golden():
         s.step()
         got.append(s.get_lr()[0])
     assert max(abs(a - b) for a, b in zip(got, gold)) < 1e-12
+
+
+def test_bench_refuses_to_run_more_ranks_than_gpus():
+    """`python bench.py --gpus 8` outside torchrun must launch 8 ranks or FAIL - never print an n_gpus=1 line"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], capture_output=True,
+                       text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and "{" not in r.stdout

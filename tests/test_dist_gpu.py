@@ -221,3 +221,55 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path,
     assert cos > 0.9999 and rel(gr, g) <= (1e-2 if encoder == "resnet50" else 3e-2), (cos, rel(gr, g))
     # first AdamW step moves every weight by ~lr * sign(g): a near-zero gradient whose sign differs costs 2 * lr
     assert rel(res[0][6], opt.flat_p.cpu()) <= 2.5e-3
+
+
+def _run_bench(*argv, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    return r, (json.loads(line) if line else None)
+
+
+def test_bench_refuses_a_rank_count_it_cannot_deliver():
+    """`bench.py --gpus N` launches its own N ranks (reference: PL ddp self re-exec, main.py:106-107) and must FAIL -
+    not silently run one rank - when N GPUs are not there, or when the torchrun world differs from --gpus"""
+    have = torch.cuda.device_count()
+    r, line = _run_bench("--gpus", str(have + 1), "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0 and line is None and "refusing" in (r.stderr + r.stdout)
+    env_world = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env_world,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL over xGMI); the 1-GPU box cannot run it")
+def test_bench_self_launches_two_ranks_over_rccl():
+    r, line = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "256", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["global_batch"] == 4
+    assert line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size():
+    """the default bench line at a reduced tile (256 x 256 so that the CPU oracle leg takes seconds): contract keys,
+    the first-step parity block against the oracle and the resnest50 encoder-forward utilisation block"""
+    r, line = _run_bench("--steps", "3", "--warmup", "2", "--size", "256")
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "encoder_forward"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["cpu_baseline"]["kind"] == "port"
+    par = line["parity"]
+    assert par["pass"] is True and par["rel"] <= 1e-3 and par["logits_rel"] <= 1e-3
+    assert par["argmax_mismatch_px_outside_ties"] == 0 and par["tensors"] > 100
+    enc = {e["precision"]: e for e in line["encoder_forward"]}
+    assert enc[32]["encoder"] == "resnest50" and 0 < enc[32]["mfma_util_whole_forward"] < 1
+    assert abs(enc[32]["gflop_counted_by_launches"] / enc[32]["gflop_per_pass"] - 1) < 0.02

@@ -10,6 +10,8 @@ guards the logits: ResNeSt's split attention normalises a batch of TWO values pe
 [B=2, C] GAP vector), which makes its training-mode forward chaotic in fp32 (the CPU oracle is ~5e-2 from its
 own fp64 run); there the gate is 3x that fp32 self-error, elsewhere the plain 1e-3 applies."""
 import copy
+import json
+import os
 
 import pytest
 import torch
@@ -23,13 +25,32 @@ CASES = ["pre_resnet50", "pre_resnet50_ds_attn", "pre_resnet50_ppm", "pre_resnet
          "pre_resnet50_dil4_noskip", "pre_resnet50_decinterp", "pre_resnest50", "pre_resnest50_dil2",
          "pre_resnest101_attn", "post_siamese_resnest50_ds", "post_siameseEnc_resnet50",
          "post_fused_resnest50_attn_ds", "post_fused_resnet50_decinterp", "post_fusedEnc_resnet50",
-         "post_parallel_resnet50", "post_parallelEnc_resnet50_aspp", "post_diff_resnet50", "post_siamese_coral"]
+         "post_parallel_resnet50", "post_parallelEnc_resnet50_aspp", "post_diff_resnet50", "post_siamese_coral",
+         "post_siamese_resnest101", "post_fused_resnest200_attn_ds"]
 
 
 def case_batch(name):
     # ResNeSt's SplAt bn1 normalises one value per image: batch 2 is chaotic in fp32 (see module docstring),
     # batch 8 is well conditioned and gets the plain 1e-3 gate
     return 8 if "resnest" in name else 2
+
+
+# (case, batch): every case at its well-conditioned batch, and every ResNeSt case ALSO at batch 2 - the per-GPU batch
+# of all BASELINE configurations - where the gate is explicitly 3 x the CPU oracle's own fp32-vs-fp64 error
+TRAIN_CASES = [(n, case_batch(n)) for n in CASES if n != "post_fused_resnest200_attn_ds"] + \
+              [(n, 2) for n in CASES if "resnest" in n]
+
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_rows.jsonl")
+
+
+def log_parity(row):
+    """one JSON line per model case; scripts/parity_table.py turns the file into profiles/parity_rNN.md"""
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as fh:
+            fh.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
 
 
 def build_pair(a, seed=1):
@@ -63,8 +84,8 @@ def argmax_mismatch(lh, lo, margin=1e-3):
     return int(bad.sum())
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_train_step_parity(name):
+@pytest.mark.parametrize("name,batch", TRAIN_CASES, ids=["%s-b%d" % c for c in TRAIN_CASES])
+def test_train_step_parity(name, batch):
     from oracle import torch_ref
     from xview2_amd import criterion
     a = ARGS(**MODEL_CASES[name])
@@ -72,7 +93,7 @@ def test_train_step_parity(name):
     ora64 = copy.deepcopy(ora).double()
     ora.train()
     hip.train()
-    x, y = model_input(a, batch=case_batch(name)), labels(a, batch=case_batch(name))
+    x, y = model_input(a, batch=batch), labels(a, batch=batch)
     lo_fn, lh_fn = torch_ref.Loss(a), criterion.Loss(a)
     po = ora(x)
     loss_o = torch_ref.compute_loss(lo_fn, po, y, a.deep_supervision)
@@ -95,9 +116,20 @@ def test_train_step_parity(name):
         assert o.shape == h.shape
         assert rel(h, q) <= gate, "%s logits[%d]: hip-vs-f64 %.3e > gate %.3e (cpu32-vs-f64 %.3e)" % (
             name, i, rel(h, q), gate, cond)
-    if cond <= 3e-4:   # well-conditioned: the plain 1e-3 gate against the fp32 oracle and exact label maps
+    strict = cond <= 3e-4
+    row = {"case": name, "batch": batch, "mode": "train", "cond_cpu32_vs_f64": cond,
+           "branch": "strict 1e-3 vs cpu32 + exact argmax" if strict else "3 x cond vs f64",
+           "hip_vs_f64": max(rel(h, q) for h, q in zip(ph, p64)), "hip_vs_cpu32": rel(ph[0], po[0]),
+           "argmax_mismatch_outside_ties": argmax_mismatch(ph[0], po[0]),
+           "argmax_mismatch_cpu32_vs_f64": int((torch.argmax(po[0], 1) != torch.argmax(p64[0], 1)).sum()),
+           "loss_hip": float(loss_h), "loss_cpu32": float(loss_o), "loss_f64": float(loss64)}
+    if strict:   # well-conditioned: the plain 1e-3 gate against the fp32 oracle and exact label maps
         assert rel(ph[0], po[0]) <= 1e-3
         assert argmax_mismatch(ph[0], po[0]) == 0
+    elif batch == 2 and "resnest" in name:
+        # BASELINE's per-GPU batch on a ResNeSt model: SplAt bn1 normalises TWO values per channel, the fp32
+        # reference path itself is this far from fp64 - the explicit gate is 3 x that, nothing tighter exists
+        assert cond > 3e-4 and row["hip_vs_f64"] <= 3.0 * cond
     assert abs(float(loss_h) - float(loss64)) <= max(1e-3, 3.0 * abs(float(loss_o) - float(loss64))) * max(
         1.0, abs(float(loss64)))
     # gradients (aliased FusedUNet entries share storage: named_parameters de-duplicates them)
@@ -127,6 +159,10 @@ def test_train_step_parity(name):
     loose = [r for r in ratios if r[1] > 10.0 * r[2] + 2e-3]
     # (single-element tensors - the 1-channel psi BatchNorm - are sums with near-total cancellation: loose only)
     bad = [r for r in ratios if r[1] > 10.0 * r[2] + 3e-2 and r[4] > 1]
+    row.update(grad_tensors=len(ratios), grad_median_ratio_hip_over_cpu32=med, grad_loose=len(loose),
+               grad_median_err_hip=sorted(r[1] for r in ratios)[len(ratios) // 2],
+               grad_median_err_cpu32=sorted(r[2] for r in ratios)[len(ratios) // 2])
+    log_parity(row)
     assert not bad and len(loose) <= max(3, len(ratios) // 20) and med <= 2.0, "%s: median hip/cpu32 error ratio %.2f; offenders (ratio, hip, cpu32, key): %s" % (
         name, med, bad[-5:])
     # BN running statistics after one training step
@@ -151,6 +187,9 @@ def test_eval_forward_parity(name):
         o, h, q = ora(x), hip(x.to(DEV)), ora64(x.double())
     assert torch.is_tensor(h) and o.shape == h.shape      # eval returns a Tensor even with deep supervision
     cond = rel(o, q)
+    log_parity({"case": name, "batch": case_batch(name), "mode": "eval", "cond_cpu32_vs_f64": cond,
+                "branch": "strict 1e-3 vs cpu32 + exact argmax" if cond <= 3e-4 else "3 x cond vs f64",
+                "hip_vs_f64": rel(h, q), "hip_vs_cpu32": rel(h, o), "argmax_mismatch_outside_ties": argmax_mismatch(h, o)})
     assert rel(h, q) <= max(1e-3, 3.0 * cond), "hip-vs-f64 %.3e, cpu32-vs-f64 %.3e" % (rel(h, q), cond)
     if cond <= 3e-4:
         assert rel(h, o) <= 1e-3
@@ -168,15 +207,39 @@ def test_cfg1_shape_512_resnet50_dice():
     x, y = model_input(a, batch=1, size=512), labels(a, batch=1, size=512)
     po = ora(x)
     lo = torch_ref.Loss(a)(po, y)
+    lo.backward()
     ph = hip(x.to(DEV))
     lh = criterion.Loss(a)(ph, y.to(DEV))
     lh.backward()
     assert rel(ph, po) <= 1e-3
     assert abs(float(lh) - float(lo)) <= 1e-3
     assert argmax_mismatch(ph, po) == 0
+    # parameter gradients against the oracle's: per tensor ||g_hip - g_cpu|| / ||g_cpu||.  At 512 x 512 the BatchNorm
+    # statistics average 1k..65k values per channel, so (unlike the 64 x 64 cases above) the problem is well conditioned
+    # and fp32-vs-fp32 agreement is direct: median <= 1e-3, no tensor off by more than 2e-2, whole gradient <= 2e-3
+    go = dict(ora.named_parameters())
+    errs, num, den = [], 0.0, 0.0
+    for k, p in hip.named_parameters():
+        g = go[k].grad
+        assert (g is None) == (p.grad is None), k
+        if g is None or float(g.norm()) == 0.0:
+            continue
+        d, n = float((p.grad.detach().cpu().double() - g.double()).norm()), float(g.double().norm())
+        errs.append((d / n, k))
+        num, den = num + d * d, den + n * n
+    errs.sort()
+    total = (num / den) ** 0.5
+    log_parity({"case": "cfg1 pre/resnet50/dice 1x512x512", "batch": 1, "mode": "train", "hip_vs_cpu32": rel(ph, po),
+                "branch": "strict 1e-3 vs cpu32 + exact argmax", "argmax_mismatch_outside_ties": 0,
+                "loss_hip": float(lh), "loss_cpu32": float(lo), "grad_tensors": len(errs),
+                "grad_median_err_hip_vs_cpu32": errs[len(errs) // 2][0], "grad_max_err_hip_vs_cpu32": errs[-1][0],
+                "grad_max_key": errs[-1][1], "grad_global_err_hip_vs_cpu32": total})
+    assert len(errs) > 100
+    assert errs[len(errs) // 2][0] <= 1e-3 and errs[-1][0] <= 2e-2 and total <= 2e-3, (errs[len(errs) // 2], errs[-3:], total)
 
 
-@pytest.mark.parametrize("name", ["pre_resnet50", "post_siamese_resnest50_ds"])
+@pytest.mark.parametrize("name", ["pre_resnet50", "post_siamese_resnest50_ds", "pre_resnest50",
+                                  "post_fused_resnest50_attn_ds"])
 def test_precision16_bf16_math_reports_error_and_label_agreement(name):
     """--precision 16 path (bf16 MFMA operands, fp32 accumulate): REPORTED separately from the fp32 gate.
     On these random-weight, training-mode-BN problems bf16 operand rounding (2^-9 relative per element) is amplified
