@@ -9,10 +9,11 @@ LeakyReLU through ops.ConvBnActFn (virtual concat of (upsampled, skip) for the f
 add before the ReLU for the bottleneck's last 1x1), ops.ConvTranspose2x2Fn, ops.HeadConvFn.
 Tolerances are those of the op-level tests: 2e-4 (outputs) / 5e-4 (gradients) of the tensor's max magnitude.
 One effect only exists at size: among 10^7..10^8 pre-activations a handful lie within rounding distance of zero, and
-there the ReLU / LeakyReLU derivative (1 vs 0 / 0.01) legitimately differs between two fp32 evaluations.  Those
-elements are identified exactly (sign(z_hip) != sign(z_ref)), must be near-ties of the REFERENCE pre-activation and
-rare (< 2e-5 of the tensor); the input-gradient check excludes the k x k footprint of such pixels and bounds the error
-inside it instead."""
+there the ReLU / LeakyReLU derivative (1 vs 0 / 0.01) legitimately differs between two fp32 evaluations; a single such
+element moves a weight gradient by up to 1e-2 of its maximum (dy enters dw un-averaged).  Those elements are identified
+exactly (sign(z_hip) != sign(pre-activation of the reference)), must be near-ties of the REFERENCE pre-activation and
+rare (< 2e-5 of the tensor); the reference backward then differentiates the activation with the HIP path's own
+mask, so every gradient comparison is between smooth functions and keeps the op-level tolerances."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -89,16 +90,6 @@ def test_cfg2_conv_layer_at_true_size(case):
     w = torch.randn(Cout, C0 + C1, k, k) * (2.0 / (k * k * (C0 + C1))) ** 0.5
     gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
     act_t, act_h = (F.relu, ops.ACT_RELU) if with_res else (lambda v: F.leaky_relu(v, 0.01), ops.ACT_LEAKY)
-    # host reference
-    xr = (torch.cat([x0, x1], 1) if C1 else x0).clone().requires_grad_(True)
-    wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    rm, rv = torch.zeros(Cout), torch.ones(Cout)
-    yr = F.batch_norm(F.conv2d(xr, wr, None, s, pad), rm, rv, gr, br, True, 0.1, 1e-5)
-    res = torch.randn_like(yr) if with_res else None
-    rr = res.clone().requires_grad_(True) if with_res else None
-    zr = act_t(yr + rr if with_res else yr)
-    dz = torch.randn_like(zr)
-    zr.backward(dz)
     # HIP path
     bnm = torch.nn.BatchNorm2d(Cout).to(DEV)
     with torch.no_grad():
@@ -107,35 +98,38 @@ def test_cfg2_conv_layer_at_true_size(case):
     wg = w.to(DEV).requires_grad_(True)
     a0 = nhwc(x0).requires_grad_(True)
     a1 = nhwc(x1).requires_grad_(True) if C1 else None
+    res = torch.randn(B, Cout, (H + 2 * pad - k) // s + 1, (H + 2 * pad - k) // s + 1) if with_res else None
     r2 = nhwc(res).requires_grad_(True) if with_res else None
     z = ops.ConvBnActFn.apply(a0, a1, wg, bnm.weight, bnm.bias, r2, ops.conv_cfg(k, k, s, pad), ops.BnState(bnm),
                               act_h, True)
+    dz = torch.randn(z.shape[0], z.shape[3], z.shape[1], z.shape[2])
     z.backward(nhwc(dz))
     torch.cuda.synchronize()
     zh = nchw(z)
-    close(zh, zr, 2e-4, name + " z")
-    close(bnm.running_var, rv, 2e-4, name + " running_var")
+    # host reference
+    xr = (torch.cat([x0, x1], 1) if C1 else x0).clone().requires_grad_(True)
+    wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    yr = F.batch_norm(F.conv2d(xr, wr, None, s, pad), rm, rv, gr, br, True, 0.1, 1e-5)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    pre = yr + rr if with_res else yr
+    close(zh, act_t(pre), 2e-4, name + " z")
     # activation-derivative flips at near-zero pre-activations (see the module docstring)
-    flips = (zh > 0) != (zr > 0)
+    flips = (zh > 0) != (pre.detach() > 0)
     nflip = int(flips.sum())
     assert nflip <= 2e-5 * flips.numel() + 2, "%s: %d sign flips" % (name, nflip)
     if nflip:
-        pre = (yr + rr if with_res else yr).detach()
-        assert float(pre[flips].abs().max()) <= 1e-4 * float(pre.abs().max()), name + ": a flip away from zero"
-    touched = F.conv_transpose2d(flips.any(1, keepdim=True).float(), torch.ones(1, 1, k, k), stride=s, padding=pad,
-                                 output_padding=(H + 2 * pad - k) % s) > 0
-    assert touched.shape[-1] == H
+        assert float(pre.detach()[flips].abs().max()) <= 1e-4 * float(pre.detach().abs().max()), name + ": a flip away from zero"
+    slope = torch.where(zh > 0, 1.0, 0.0 if with_res else 0.01)      # the HIP path's own activation mask
+    (pre * slope).backward(dz)
+    close(bnm.running_var, rv, 2e-4, name + " running_var")
     dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
-    keep = (~touched).expand_as(dx)
-    scale = float(xr.grad.abs().max())
-    err = (dx.double() - xr.grad.double()).abs() / scale
-    assert float(err[keep].max()) <= 5e-4, "%s dx: rel-to-max error %.3e (%d flips)" % (name, float(err[keep].max()), nflip)
-    assert float(err.max()) <= 0.1 and float((~keep).float().mean()) <= 5e-3, name + " dx inside the flip footprint"
+    close(dx, xr.grad, 5e-4, name + " dx")
     close(wg.grad, wr.grad, 5e-4, name + " dw")
     close(bnm.weight.grad, gr.grad, 5e-4, name + " dgamma")
     close(bnm.bias.grad, br.grad, 5e-4, name + " dbeta")
-    if with_res:      # dres IS the activation-masked gradient: compare it away from the flipped elements
-        close(nchw(r2.grad)[~flips], rr.grad[~flips], 1e-6, name + " dres")
+    if with_res:
+        close(nchw(r2.grad), rr.grad, 1e-6, name + " dres")
 
 
 @pytest.mark.parametrize("shape", CONVT, ids=["convT %d->%d @%d" % c for c in CONVT])
@@ -166,16 +160,19 @@ def test_cfg2_stem_and_head_at_true_size():
     w = torch.randn(64, 3, 7, 7) * 0.1
     wr = w.clone().requires_grad_(True)
     bnr = torch.nn.BatchNorm2d(64)
-    zr = F.relu(bnr(F.conv2d(x, wr, None, 2, 3)))
-    dz = torch.randn_like(zr)
-    zr.backward(dz)
+    pre = bnr(F.conv2d(x, wr, None, 2, 3))
+    dz = torch.randn_like(pre)
     bng = torch.nn.BatchNorm2d(64).to(DEV)
     a = ops.nchw_to_nhwc(x.to(DEV), 4)
     wg = w.to(DEV).requires_grad_(True)
     z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, None, ops.conv_cfg(7, 7, 2, 3), ops.BnState(bng),
                               ops.ACT_RELU, True)
     z.backward(nhwc(dz))
-    close(nchw(z), zr, 2e-4, "stem z")
+    zh = nchw(z)
+    close(zh, F.relu(pre), 2e-4, "stem z")
+    flips = (zh > 0) != (pre.detach() > 0)
+    assert int(flips.sum()) <= 2e-5 * flips.numel() + 2
+    (pre * (zh > 0).float()).backward(dz)         # ReLU differentiated with the HIP path's mask (module docstring)
     close(wg.grad, wr.grad, 5e-4, "stem dw")
     close(bng.weight.grad, bnr.weight.grad, 5e-4, "stem dgamma")
     # 1x1 head 32 -> 2 on 1024 x 1024, NCHW logits (model/layers.py:180)

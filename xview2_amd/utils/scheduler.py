@@ -13,7 +13,9 @@ class NoamLR:
         self.total_steps = total_epochs * steps_per_epoch
         # --warmup 0: the reference's numpy division yields inf with a warning and the branch is never taken
         self.linear_increment = (max_lr - init_lr) / self.warmup_steps if self.warmup_steps else 0.0
-        self.exponential_gamma = (final_lr / max_lr) ** (1 / (self.total_steps - self.warmup_steps))
+        decay_steps = self.total_steps - self.warmup_steps
+        # no decay phase (--epochs == --warmup): the reference's numpy power gives 0.0 with a warning, never used
+        self.exponential_gamma = (final_lr / max_lr) ** (1 / decay_steps) if decay_steps else 0.0
         self.current_step = 0
         self.lr = [init_lr] * self.n
         # torch's _LRScheduler.__init__ (the reference's base class, utils/scheduler.py:43) performs one
