@@ -52,15 +52,24 @@ typedef struct xv2_conv_desc {
 } xv2_conv_desc;
 #define XV2_MATH_F32 0
 #define XV2_MATH_BF16 1
+/* bf16 STORAGE (the --precision 16 path proper, reference main.py:36,99): activations, their gradients and the packed
+ * weight layouts are bf16 in HBM (every `void*` activation / packed-weight argument below then points to bf16),
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, BatchNorm statistics / coefficients, biases, weight gradients and the
+ * master weights stay fp32.  The 4-channel RGB source of the stems stays an fp32 image with fp32 packed weights. */
+#define XV2_MATH_BF16_STORE 2
+
+/* element type of activation tensors for the non-convolution entry points (`dtype` arguments) */
+#define XV2_F32 0
+#define XV2_BF16 1
 
 /* weight repacking: w_oihw[Cout][Cin][KH][KW] (the reference's state_dict layout)
  *   -> w_ohwi[Cout][KH*KW][CinP]  (forward operand; CinP = Cin padded to `cin_pad`)
  *   -> w_ihwo[CinP][KH*KW][Cout]  (backward-data operand)                                  */
 int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad,
-                    float* w_ohwi, float* w_ihwo, void* stream);
+                    void* w_ohwi, void* w_ihwo, int dtype, void* stream);
 /* the same for MANY weights in one launch (all packed layouts go stale together at the optimizer step):
- * table[n][8] int64 in device memory = {w_oihw, w_ohwi or 0, w_ihwo or 0 (pointers), Cout, Cin, KH*KW, cin_pad,
- * first tile}; an entry owns xv2_pack_weights_tiles() consecutive tiles (one workgroup each), total_tiles = their sum */
+ * table[n][8] int64 in device memory = {w_oihw, w_ohwi or 0, w_ihwo or 0 (pointers), Cout, Cin,
+ * KH*KW | (dtype of the packed layouts << 16), cin_pad, first tile}; an entry owns xv2_pack_weights_tiles() consecutive tiles (one workgroup each), total_tiles = their sum */
 int64_t xv2_pack_weights_tiles(int Cout, int KH, int KW, int cin_pad);
 int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, void* stream);
 
@@ -71,27 +80,27 @@ int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
 /* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
  * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
 size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
-int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
-                       int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
+int xv2_conv2d_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
+                       int ldx1, const void* w_ohwi, const float* bias, void* y, int ldy,
                        float* stats, float* workspace, void* stream);
 /* inference form of conv + nn.BatchNorm2d (eval) [+ residual] + activation in ONE launch: the running statistics are
  * folded to per-channel scale/shift (xv2_bn_eval_coeffs) and applied in the convolution epilogue,
  * z = act(conv(x) * scale + shift [+ residual]); the raw convolution output is never written.  Same arithmetic, bit
  * for bit, as xv2_conv2d_forward followed by xv2_bn_act_forward.  act = XV2_ACT_*. */
-int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
-                             int ldx1, const float* w_ohwi, const float* scale, const float* shift,
-                             const float* residual, int ldres, int act, float* z, int ldz,
+int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
+                             int ldx1, const void* w_ohwi, const float* scale, const float* shift,
+                             const void* residual, int ldres, int act, void* z, int ldz,
                              float* workspace, void* stream);
 /* dx = conv2d_backward_input(dy, w); dx0/dx1 receive the channel ranges of the two sources */
 size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d);
-int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
-                             const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
+int xv2_conv2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
+                             const void* w_ihwo, void* dx0, int lddx0, void* dx1, int lddx1,
                              float* workspace, void* stream);
 /* the same, ADDING into dx0 (accumulate bit 0) and/or dx1 (bit 1) instead of overwriting them: the gradient of a
  * tensor with two consumers (residual shortcut, encoder skip) is summed in the kernel epilogue, not by a separate
  * elementwise pass */
-int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float* dy, int lddy,
-                                 const float* w_ihwo, float* dx0, int lddx0, float* dx1, int lddx1,
+int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy,
+                                 const void* w_ihwo, void* dx0, int lddx0, void* dx1, int lddx1,
                                  int accumulate, float* workspace, void* stream);
 /* Backward-data that ALSO takes the BatchNorm-backward statistics of the layer whose output feeds this convolution
  * (dx IS that layer's dz): with its conv output bn_y and coefficients the epilogue accumulates, per M tile,
@@ -116,8 +125,8 @@ int xv2_bn_backward_reduce_partials(const float* partial, int64_t tiles, int C, 
                                     float* dbeta, double* scratch, void* stream);
 /* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
 size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
-int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,
-                               const float* x1, int ldx1, const float* dy, int lddy,
+int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
+                               const void* x1, int ldx1, const void* dy, int lddy,
                                float* dw_oihw, int cin_real, float* workspace, void* stream);
 
 /* nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83).  `d` describes the
@@ -125,22 +134,22 @@ int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0
  * channels, Cout = conv-transpose input channels): forward of the transposed conv is the
  * backward-data of `d`, and vice versa; weights are the torch tensor [Cin_T][Cout_T][2][2]
  * viewed as OIHW of `d`. */
-int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,
-                                 const float* w_ihwo, float* y, int ldy, void* stream);
-int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
-                                       const float* w_ohwi, float* dx, int lddx, void* stream);
-int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const float* x, int ldx,
-                                         const float* dy, int lddy, float* dw, float* workspace,
+int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,
+                                 const void* w_ihwo, void* y, int ldy, void* stream);
+int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
+                                       const void* w_ohwi, void* dx, int lddx, void* stream);
+int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const void* x, int ldx,
+                                         const void* dy, int lddy, float* dw, float* workspace,
                                          void* stream);
 
 /* 1x1 convolution with a handful of output channels (segmentation heads n_class<=4,
  * model/layers.py:177,180; attention psi conv model/layers.py:145).  NHWC in; output either
  * NHWC (nchw_out=0) or NCHW (nchw_out=1, the layout model/unet.py:191-197 returns). */
-int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
-                          const float* w, const float* bias, float* y, int nchw_out, void* stream);
-int xv2_head_conv_backward(const float* x, int ldx, const float* dy, int64_t npix, int64_t hw,
-                           int Cin, int Cout, const float* w, int nchw_dy, float* dx, int lddx,
-                           float* dw, float* dbias, float* workspace, void* stream);
+int xv2_head_conv_forward(const void* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
+                          const float* w, const float* bias, float* y, int nchw_out, int dtype, void* stream);
+int xv2_head_conv_backward(const void* x, int ldx, const float* dy, int64_t npix, int64_t hw,
+                           int Cin, int Cout, const float* w, int nchw_dy, void* dx, int lddx,
+                           float* dw, float* dbias, float* workspace, int dtype, void* stream);
 size_t xv2_head_conv_backward_workspace(int64_t npix, int Cin, int Cout);
 
 /* ---- batch norm + activation (nn.BatchNorm2d + ReLU/LeakyReLU, everywhere) -------------- */
@@ -170,53 +179,54 @@ int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
                        const float* running_var, float eps, float* scale, float* shift, int C,
                        void* stream);
 /* z = act(y*scale[c] + shift[c] (+ residual)) */
-int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
-                       const float* residual, int ldr, int act, float* z, int ldz,
-                       int64_t npix, int C, void* stream);
+int xv2_bn_act_forward(const void* y, int ldy, const float* scale, const float* shift,
+                       const void* residual, int ldr, int act, void* z, int ldz,
+                       int64_t npix, int C, int dtype, void* stream);
 /* backward: pass 1 -> sums2[C][2] = (sum g, sum g*xhat), g = dz*act'; the activation mask comes from the saved
  * output z, or - when z is NULL (no residual) - is recomputed from y*scale+shift, which saves a third of the
  * HBM traffic.  dgamma/dbeta (optional) receive the fp32 copies of the LOCAL sums. */
-int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz,
-                               const float* y, int ldy, const float* mean, const float* invstd,
+int xv2_bn_act_backward_reduce(const void* dz, int lddz, const void* z, int ldz,
+                               const void* y, int ldy, const float* mean, const float* invstd,
                                const float* scale, const float* shift, int act, int64_t npix, int C,
                                double* sums2, float* dgamma, float* dbeta, float* workspace,
-                               void* stream);
+                               int dtype, void* stream);
 size_t xv2_bn_backward_workspace(int64_t npix, int C);
 /* pass 2 -> dy (and dresidual = g if requested).  dgamma = sums2[:,1], dbeta = sums2[:,0] of
  * the LOCAL rank (torch SyncBatchNorm semantics); sums2 passed here may be all-reduced.
  * `count` is the (global) number of elements per channel; eval-mode BN passes train=0. */
-int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y,
+int xv2_bn_act_backward_apply(const void* dz, int lddz, const void* z, int ldz, const void* y,
                               int ldy, const float* mean, const float* invstd,
                               const float* gamma, const float* scale, const float* shift,
                               const double* sums2, double count, int act,
-                              int train, float* dy, int lddy, float* dres, int lddres,
-                              int64_t npix, int C, void* stream);
+                              int train, void* dy, int lddy, void* dres, int lddres,
+                              int64_t npix, int C, int dtype, void* stream);
 /* Mask forms for layers whose activation follows a residual add (z = act(BN(y) + residual), the bottleneck tail):
  * the forward also writes one byte per 4 channels, bit k = (z[4j + k] > 0), and the backward passes read that byte
  * instead of re-reading z (0.25 instead of 4 bytes per element in each pass).  C % 4 == 0, dense rows (ld == C for
  * the mask indexing), ReLU / LeakyReLU only.  Results are bit-identical to the z forms. */
-int xv2_bn_act_forward_mask(const float* y, int ldy, const float* scale, const float* shift,
-                            const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
-                            uint8_t* zmask, void* stream);
-int xv2_bn_act_backward_reduce_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+int xv2_bn_act_forward_mask(const void* y, int ldy, const float* scale, const float* shift,
+                            const void* residual, int ldr, int act, void* z, int ldz, int64_t npix, int C,
+                            uint8_t* zmask, int dtype, void* stream);
+int xv2_bn_act_backward_reduce_mask(const void* dz, int lddz, const uint8_t* zmask, const void* y, int ldy,
                                     const float* mean, const float* invstd, int act, int64_t npix, int C,
-                                    double* sums2, float* dgamma, float* dbeta, float* workspace, void* stream);
-int xv2_bn_act_backward_apply_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+                                    double* sums2, float* dgamma, float* dbeta, float* workspace, int dtype,
+                                    void* stream);
+int xv2_bn_act_backward_apply_mask(const void* dz, int lddz, const uint8_t* zmask, const void* y, int ldy,
                                    const float* mean, const float* invstd, const float* gamma,
-                                   const double* sums2, double count, int act, int train, float* dy,
-                                   int lddy, float* dres, int lddres, int64_t npix, int C, void* stream);
+                                   const double* sums2, double count, int act, int train, void* dy,
+                                   int lddy, void* dres, int lddres, int64_t npix, int C, int dtype, void* stream);
 
 /* ---- pooling / resampling ----------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order) */
-int xv2_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, float* y, uint8_t* idx,
-                             void* stream);
-int xv2_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int N, int H, int W, int C,
-                              float* dx, void* stream);
+int xv2_maxpool3x3s2_forward(const void* x, int N, int H, int W, int C, void* y, uint8_t* idx,
+                             int dtype, void* stream);
+int xv2_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, int N, int H, int W, int C,
+                              void* dx, int dtype, void* stream);
 /* nn.AvgPool2d(k, s, pad, count_include_pad) (ResNeSt avd / avg_down shortcuts) */
-int xv2_avgpool_forward(const float* x, int N, int H, int W, int C, int k, int s, int pad,
-                        int count_include_pad, int OH, int OW, float* y, void* stream);
-int xv2_avgpool_backward(const float* dy, int N, int H, int W, int C, int k, int s, int pad,
-                         int count_include_pad, int OH, int OW, float* dx, void* stream);
+int xv2_avgpool_forward(const void* x, int N, int H, int W, int C, int k, int s, int pad,
+                        int count_include_pad, int OH, int OW, void* y, int dtype, void* stream);
+int xv2_avgpool_backward(const void* dy, int N, int H, int W, int C, int k, int s, int pad,
+                         int count_include_pad, int OH, int OW, void* dx, int dtype, void* stream);
 /* F.adaptive_avg_pool2d(x, bins) (model/layers.py:14; bins=1 is the split-attention GAP) */
 int xv2_adaptive_avgpool_forward(const float* x, int ldx, int N, int H, int W, int C, int bins,
                                  float* y, void* stream);
@@ -230,8 +240,8 @@ int xv2_bilinear_backward(const float* dy, int lddy, int N, int IH, int IW, int 
 
 /* ---- split attention (ResNeSt SplAtConv2d, radix 2) --------------------------------------- */
 /* gap[n][c] = mean_{hw}(x[n,hw,c] + x[n,hw,C+c]) for x NHWC with 2C channels */
-int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, float* gap, float* workspace,
-                          void* stream);
+int xv2_splat_gap_forward(const void* x, int N, int64_t hw, int C, float* gap, float* workspace,
+                          int dtype, void* stream);
 size_t xv2_splat_gap_workspace(int N, int64_t hw, int C);
 /* small dense layers on [N][Cin] vectors (fc1/fc2 are 1x1 convs on 1x1 maps) */
 int xv2_linear_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin,
@@ -243,22 +253,22 @@ int xv2_rsoftmax_forward(const float* logits, float* att, int N, int C, void* st
 int xv2_rsoftmax_backward(const float* att, const float* datt, float* dlogits, int N, int C,
                           void* stream);
 /* out[n,hw,c] = att[n][c]*x[n,hw,c] + att[n][C+c]*x[n,hw,C+c] */
-int xv2_splat_apply_forward(const float* x, const float* att, int N, int64_t hw, int C,
-                            float* out, void* stream);
+int xv2_splat_apply_forward(const void* x, const float* att, int N, int64_t hw, int C,
+                            void* out, int dtype, void* stream);
 /* dx (2C channels) += / = ; datt[n][2C] (reduction over hw); dgap adds the GAP branch */
-int xv2_splat_apply_backward(const float* x, const float* att, const float* dout,
-                             const float* dgap, int N, int64_t hw, int C, float* dx, float* datt,
-                             float* workspace, void* stream);
+int xv2_splat_apply_backward(const void* x, const float* att, const void* dout,
+                             const float* dgap, int N, int64_t hw, int C, void* dx, float* datt,
+                             float* workspace, int dtype, void* stream);
 
 /* ---- attention gate glue (model/layers.py:161-166) ---------------------------------------- */
 /* r = relu(a + b) */
-int xv2_add_relu_forward(const float* a, const float* b, float* r, int64_t n, void* stream);
-int xv2_add_relu_backward(const float* r, const float* dr, float* dab, int64_t n, void* stream);
+int xv2_add_relu_forward(const void* a, const void* b, void* r, int64_t n, int dtype, void* stream);
+int xv2_add_relu_backward(const void* r, const void* dr, void* dab, int64_t n, int dtype, void* stream);
 /* out[p][c] = skip[p][c] * gate[p] */
-int xv2_gate_mul_forward(const float* skip, int lds, const float* gate, float* out, int64_t npix,
-                         int C, void* stream);
-int xv2_gate_mul_backward(const float* skip, int lds, const float* gate, const float* dout,
-                          float* dskip, float* dgate, int64_t npix, int C, void* stream);
+int xv2_gate_mul_forward(const void* skip, int lds, const float* gate, void* out, int64_t npix,
+                         int C, int dtype, void* stream);
+int xv2_gate_mul_backward(const void* skip, int lds, const float* gate, const void* dout,
+                          void* dskip, float* dgate, int64_t npix, int C, int dtype, void* stream);
 /* generic elementwise helpers */
 int xv2_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int xv2_axpby(float alpha, const float* a, float beta, const float* b, float* out, int64_t n,
@@ -270,8 +280,8 @@ int xv2_nchw_to_nhwc(const float* x, int64_t x_batch_stride, int N, int C, int H
                      float* y, int Cp, void* stream);
 int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, int W, float* y, void* stream);
 /* strided channel copy: dst[p][doff + c] = src[p][soff + c] (materialised concat) */
-int xv2_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t npix, int C,
-                      void* stream);
+int xv2_copy_channels(const void* src, int lds, void* dst, int ldd, int64_t npix, int C,
+                      int dtype, void* stream);
 
 /* ---- losses (model/loss.py:78-101 + monai 0.4.0 DiceLoss/FocalLoss, Ohem == mean CE) ------- */
 #define XV2_LOSS_DICE 1

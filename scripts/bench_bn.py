@@ -40,13 +40,16 @@ def timeit(fn, iters=10):
 
 
 def main():
+    import sys
     dev = "cuda:0"
+    half = "--bf16" in sys.argv
+    dt, code, esz = (torch.bfloat16, 1, 2) if half else (torch.float32, 0, 4)
     tot = [0.0, 0.0, 0.0]
     print("%-20s %8s | %8s %8s %8s  GB/s   us: fwd reduce apply" % ("layer", "MB", "fwd", "reduce", "apply"))
     for name, npix, C, cnt, res in SHAPES:
-        y = torch.randn(npix, C, device=dev)
-        dz = torch.randn(npix, C, device=dev)
-        r = torch.randn(npix, C, device=dev) if res else None
+        y = torch.randn(npix, C, device=dev).to(dt)
+        dz = torch.randn(npix, C, device=dev).to(dt)
+        r = torch.randn(npix, C, device=dev).to(dt) if res else None
         z = torch.empty_like(y)
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if res else None
@@ -54,13 +57,13 @@ def main():
         sums2 = torch.empty(C, 2, dtype=torch.float64, device=dev)
         dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
         ws = torch.empty(query("xv2_bn_backward_workspace", npix, C) // 4 + 4, device=dev)
-        mb = npix * C * 4 / 1e6
+        mb = npix * C * esz / 1e6
         zz = z if res else None
-        tf = timeit(lambda: call("xv2_bn_act_forward", y, C, scale, shift, r, C, ops.ACT_RELU, z, C, npix, C))
+        tf = timeit(lambda: call("xv2_bn_act_forward", y, C, scale, shift, r, C, ops.ACT_RELU, z, C, npix, C, code))
         tr = timeit(lambda: call("xv2_bn_act_backward_reduce", dz, C, zz, C, y, C, mean, invstd, scale, shift,
-                                 ops.ACT_RELU, npix, C, sums2, dg, db, ws))
+                                 ops.ACT_RELU, npix, C, sums2, dg, db, ws, code))
         ta = timeit(lambda: call("xv2_bn_act_backward_apply", dz, C, zz, C, y, C, mean, invstd, gamma, scale, shift,
-                                 sums2, float(npix), ops.ACT_RELU, 1, dy, C, dres, C, npix, C))
+                                 sums2, float(npix), ops.ACT_RELU, 1, dy, C, dres, C, npix, C, code))
         nf, nr, na = (3 if res else 2), (3 if res else 2), (5 if res else 3)
         print("%-20s %8.1f | %8.0f %8.0f %8.0f         %7.1f %7.1f %7.1f   x%d" %
               (name, mb, nf * mb / tf, nr * mb / tr, na * mb / ta, tf * 1e3, tr * 1e3, ta * 1e3, cnt))

@@ -262,11 +262,14 @@ def test_cfg1_shape_512_resnet50_dice():
 
 @pytest.mark.parametrize("name", ["pre_resnet50", "post_siamese_resnest50_ds", "pre_resnest50",
                                   "post_fused_resnest50_attn_ds"])
-def test_precision16_bf16_math_reports_error_and_label_agreement(name):
-    """--precision 16 path (bf16 MFMA operands, fp32 accumulate): REPORTED separately from the fp32 gate.
-    On these random-weight, training-mode-BN problems bf16 operand rounding (2^-9 relative per element) is amplified
-    like any other perturbation (see the conditioning notes above): measured ~1e-1 max and RMS logits error and
-    ~94-99 % identical label maps; the loss agrees to <1e-3.  The asserts only guard against gross breakage."""
+def test_precision16_bf16_storage_loss_and_label_agreement(name):
+    """--precision 16 path (XV2_MATH_BF16_STORE: bf16 activations / gradients / packed weights in HBM, bf16 MFMA, fp32
+    accumulation, statistics and master weights): REPORTED separately from the fp32 gate.  bf16 rounding
+    (2^-9 relative per stored element) is a perturbation ~1e4 x fp32's, and these random-weight training-mode-BN
+    problems amplify perturbations (see the conditioning notes above), so the logits are compared loosely; the
+    gates are the ones that matter for training: the LOSS within 1e-2 relative of the fp32 oracle, label-map agreement
+    above the measured floor, finite gradients whose direction agrees with the fp32 HIP path (cosine >= 0.90 over the
+    whole gradient)."""
     from oracle import torch_ref
     from xview2_amd import criterion, ops
     a = ARGS(**MODEL_CASES[name])
@@ -278,22 +281,36 @@ def test_precision16_bf16_math_reports_error_and_label_agreement(name):
     with torch.no_grad():
         po = ora(x)
     lo = torch_ref.compute_loss(torch_ref.Loss(a), po, y, a.deep_supervision)
+    # fp32 HIP gradients as the direction reference
+    hip.zero_grad()
+    l32 = criterion.compute_loss(criterion.Loss(a), hip(x.to(DEV)), y.to(DEV), a.deep_supervision)
+    l32.backward()
+    g32 = torch.cat([p.grad.flatten().double() for p in hip.parameters() if p.grad is not None]).cpu()
+    hip.zero_grad()
     ops.MATH_MODE = ops.MATH_BF16
+    ops.set_storage_dtype(torch.bfloat16)
     try:
         ph = hip(x.to(DEV))
         lh = criterion.compute_loss(criterion.Loss(a), ph, y.to(DEV), a.deep_supervision)
         lh.backward()
     finally:
         ops.MATH_MODE = ops.MATH_F32
+        ops.set_storage_dtype(None)
+    g16 = torch.cat([p.grad.flatten().double() for p in hip.parameters() if p.grad is not None]).cpu()
     po0 = po[0] if isinstance(po, list) else po
     ph0 = ph[0] if isinstance(ph, list) else ph
     err = rel(ph0, po0)
     rms = float((ph0.detach().cpu().double() - po0.double()).pow(2).mean().sqrt() / po0.double().pow(2).mean().sqrt())
     agree = float((torch.argmax(ph0.cpu(), 1) == torch.argmax(po0, 1)).float().mean())
-    print("bf16-math %s: logits max-rel err %.3e, rms-rel err %.3e, argmax agreement %.4f, loss %.5f vs %.5f" % (
-        name, err, rms, agree, float(lh), float(lo)))
-    assert err <= 0.4 and rms <= 0.2 and agree >= 0.90
-    assert abs(float(lh) - float(lo)) <= 2e-2 * max(1.0, abs(float(lo)))
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    loss_rel = abs(float(lh) - float(lo)) / max(abs(float(lo)), 1e-12)
+    print("bf16-storage %s: logits max-rel err %.3e, rms-rel err %.3e, argmax agreement %.4f, loss %.5f vs %.5f (rel %.2e), "
+          "gradient cosine vs fp32 %.4f" % (name, err, rms, agree, float(lh), float(lo), loss_rel, cos))
+    log_parity({"case": name, "batch": B, "mode": "train bf16-storage", "hip_vs_cpu32": err, "logits_rms_rel": rms,
+                "argmax_agreement": agree, "loss_hip": float(lh), "loss_cpu32": float(lo), "loss_rel": loss_rel,
+                "grad_cosine_vs_fp32_hip": cos, "branch": "bf16: loss 1e-2, agreement floor, gradient cosine"})
+    assert loss_rel <= 1e-2
+    assert agree >= 0.85 and cos >= 0.90
     assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)
 
 

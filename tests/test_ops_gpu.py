@@ -450,20 +450,25 @@ def test_table_driven_repack_matches_single_weight_pack():
     geoms = [(64, 3, 7, 7, 4), (32, 32, 3, 3, 32), (256, 64, 1, 1, 64), (96, 160, 3, 3, 160), (64, 128, 2, 2, 128),
              (40, 24, 3, 3, 32), (2048, 512, 1, 1, 512)]
     ws = [torch.randn(co, ci, kh, kw, device=dev()) for co, ci, kh, kw, _ in geoms]
-    for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
-        ops._pack(w, cp, True, True)
-    with torch.no_grad():
-        for w in ws:
-            w.mul_(1.5).add_(0.25)            # stale now (version bump), refreshed below in one launch
-    ops.weights_changed()
-    ops.repack_all()
-    for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
-        ohwi, ihwo = ops._pack(w, cp, True, True)          # cache hit: the buffers repack_all just wrote
-        r1 = torch.empty_like(ohwi)
-        r2 = torch.empty_like(ihwo)
-        call("xv2_pack_weight", w, co, ci, kh, kw, cp, r1, r2)
-        assert torch.equal(ohwi, r1) and torch.equal(ihwo, r2), (co, ci, kh, kw)
-    ops.clear_pack_cache()
+    for half in (False, True):          # fp32 layouts and the bf16 layouts of XV2_MATH_BF16_STORE (RGB stem stays fp32)
+        for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
+            ops._pack(w, cp, True, True, half)
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5).add_(0.25)            # stale now (version bump), refreshed below in one launch
+        ops.weights_changed()
+        ops.repack_all()
+        for w, (co, ci, kh, kw, cp) in zip(ws, geoms):
+            ohwi, ihwo = ops._pack(w, cp, True, True, half)          # cache hit: the buffers repack_all just wrote
+            assert ohwi.dtype == (torch.bfloat16 if half and cp != 4 else torch.float32)
+            r1 = torch.empty_like(ohwi)
+            r2 = torch.empty_like(ihwo)
+            call("xv2_pack_weight", w, co, ci, kh, kw, cp, r1, r2, 1 if ohwi.dtype == torch.bfloat16 else 0)
+            assert torch.equal(ohwi, r1) and torch.equal(ihwo, r2), (co, ci, kh, kw)
+            if half and cp != 4:      # bf16 layout == round-to-nearest-even of the fp32 layout
+                f1, _ = ops._pack(w, cp, True, True, False)
+                assert torch.equal(ohwi, f1.to(torch.bfloat16))
+        ops.clear_pack_cache()
 
 
 @pytest.mark.parametrize("task,loss_str", [("pre", "dice"), ("post", "focal+dice"), ("post", "mse"), ("post", "coral")])
@@ -535,3 +540,173 @@ def test_bn_backward_statistics_taken_in_the_consumer_dgrad_epilogue(shape):
     for name, u, v in zip(("dx", "dw1", "dgamma1", "dbeta1", "dw2"), res[True], res[False]):
         close(u, v, 2e-5, name)
     assert torch.equal(res[True][4], res[False][4])        # the second layer itself is untouched
+
+
+# ---- bf16 STORAGE (XV2_MATH_BF16_STORE, the --precision 16 path): activations, gradients and packed weights are bf16
+# in HBM.  Reference = the same fp32 PyTorch ops evaluated on the bf16-rounded operands; what differs is the rounding
+# of the stored results (2^-9 relative per element) and of the intermediate y before BatchNorm.
+def bf16_close(a, b, tol, what):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    rms = float((a - b).pow(2).mean().sqrt()) / max(float(b.pow(2).mean().sqrt()), 1e-12)
+    assert err <= tol and rms <= tol / 3, "%s: max-rel %.3e rms-rel %.3e (tol %.1e)" % (what, err, rms, tol)
+
+
+def hnhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+
+
+BF16_CONV_CASES = [
+    (2, 16, 16, 32, 0, 32, 3, 1, 1, 1, 1),
+    (2, 20, 12, 64, 0, 64, 3, 1, 1, 1, 1),
+    (1, 17, 19, 64, 0, 128, 3, 2, 1, 1, 1),
+    (2, 16, 16, 128, 0, 256, 1, 1, 0, 1, 1),
+    (2, 16, 16, 256, 0, 64, 1, 2, 0, 1, 1),
+    (2, 12, 12, 64, 32, 64, 3, 1, 1, 1, 1),
+    (1, 12, 12, 128, 256, 128, 3, 1, 1, 1, 1),
+    (2, 16, 16, 64, 0, 128, 3, 1, 1, 1, 2),
+    (2, 8, 8, 512, 0, 512, 3, 1, 1, 1, 1),
+    (1, 64, 64, 32, 0, 32, 3, 1, 1, 1, 1),       # direct 3x3 kernel
+    (2, 32, 64, 64, 0, 64, 3, 1, 1, 1, 1),       # all-taps weight gradient
+    (2, 8, 64, 32, 32, 32, 3, 1, 1, 1, 1),
+    (1, 32, 32, 32, 0, 96, 1, 1, 0, 1, 1),       # 32-wide output tiles (128x32 tile, partial B pass)
+]
+
+
+@pytest.mark.parametrize("case", BF16_CONV_CASES)
+def test_bf16_storage_conv_bn_act_forward_backward(case):
+    from xview2_amd import ops
+    N, H, W, C0, C1, Cout, k, s, p, d, G = case
+    torch.manual_seed(sum(case) + 1)
+    r16 = lambda t: t.to(torch.bfloat16).float()                                  # noqa: E731
+    x0 = r16(torch.randn(N, C0, H, W))
+    x1 = r16(torch.randn(N, C1, H, W)) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, k, k) * (2.0 / (k * k * (C0 + C1) / G)) ** 0.5
+    gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    bnm = torch.nn.BatchNorm2d(Cout).to(dev())
+    with torch.no_grad():
+        bnm.weight.copy_(gamma)
+        bnm.bias.copy_(beta)
+    wg = w.to(dev()).requires_grad_(True)
+    a0 = hnhwc(x0).requires_grad_(True)
+    a1 = hnhwc(x1).requires_grad_(True) if C1 else None
+    z = ops.ConvBnActFn.apply(a0, a1, wg, bnm.weight, bnm.bias, None, ops.conv_cfg(k, k, s, p, d, G), ops.BnState(bnm),
+                              ops.ACT_LEAKY, True)
+    assert z.dtype == torch.bfloat16
+    dz = r16(torch.randn(z.shape[0], z.shape[3], z.shape[1], z.shape[2]))
+    z.backward(hnhwc(dz))
+    assert a0.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    zh = nchw(z.float())
+    # reference: fp32 ops on the bf16-rounded operands; the LeakyReLU derivative uses the HIP path's own mask - with
+    # y stored in bf16, ~0.3 % of the pre-activations change sign against an fp32 evaluation, and one flipped
+    # element moves dy by ~|dz| (see tests/test_conv_shapes_gpu.py)
+    xr = xin.clone().requires_grad_(True)
+    wr = r16(w).requires_grad_(True)              # the kernels multiply the bf16-rounded weights
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    pre = F.batch_norm(F.conv2d(xr, wr, None, s, p, d, G), None, None, gr, br, True, 0.1, 1e-5)
+    bf16_close(zh, F.leaky_relu(pre, 0.01), 2e-2, "z")
+    flips = (zh > 0) != (pre.detach() > 0)
+    assert float(flips.float().mean()) <= 2e-2
+    assert float(pre.detach()[flips].abs().max() if flips.any() else 0.0) <= 3e-2 * float(pre.detach().abs().max())
+    (pre * torch.where(zh > 0, 1.0, 0.01)).backward(dz)
+    dx = nchw(a0.grad.float()) if not C1 else torch.cat([nchw(a0.grad.float()), nchw(a1.grad.float())], 1)
+    bf16_close(dx, xr.grad, 3e-2, "dx")
+    bf16_close(wg.grad, wr.grad, 3e-2, "dw")
+    bf16_close(bnm.weight.grad, gr.grad, 3e-2, "dgamma")
+    bf16_close(bnm.bias.grad, br.grad, 3e-2, "dbeta")
+
+
+def test_bf16_storage_stem_residual_convt_pool_head():
+    from xview2_amd import ops
+    torch.manual_seed(21)
+    r16 = lambda t: t.to(torch.bfloat16).float()                                  # noqa: E731
+    old = ops.STORAGE
+    ops.set_storage_dtype(torch.bfloat16)
+    try:
+        # RGB stem: fp32 image in, bf16 activations out
+        x = torch.randn(2, 3, 40, 36)
+        w = torch.randn(64, 3, 7, 7) * 0.1
+        wr = w.clone().requires_grad_(True)
+        bnr = torch.nn.BatchNorm2d(64)
+        pre = bnr(F.conv2d(x, wr, None, 2, 3))
+        dz = r16(torch.randn_like(pre))
+        bng = torch.nn.BatchNorm2d(64).to(dev())
+        a = ops.nchw_to_nhwc(x.to(dev()), 4)
+        wg = w.to(dev()).requires_grad_(True)
+        z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, None, ops.conv_cfg(7, 7, 2, 3), ops.BnState(bng),
+                                  ops.ACT_RELU, True)
+        assert z.dtype == torch.bfloat16
+        z.backward(hnhwc(dz))
+        zh = nchw(z.float())
+        bf16_close(zh, F.relu(pre), 2e-2, "stem z")
+        (pre * (zh > 0).float()).backward(dz)
+        bf16_close(wg.grad, wr.grad, 3e-2, "stem dw")
+    finally:
+        ops.set_storage_dtype(old)
+    # residual + ReLU tail with the byte mask, bf16 residual gradient
+    N, C, Co, H, W = 2, 64, 256, 12, 12
+    x, res = r16(torch.randn(N, C, H, W)), r16(torch.randn(N, Co, H, W))
+    w = torch.randn(Co, C, 1, 1) * 0.1
+    xr, rr, wr = x.clone().requires_grad_(True), res.clone().requires_grad_(True), r16(w).requires_grad_(True)
+    bnr = torch.nn.BatchNorm2d(Co)
+    pre = bnr(F.conv2d(xr, wr)) + rr
+    dz = r16(torch.randn_like(pre))
+    bng = torch.nn.BatchNorm2d(Co).to(dev())
+    a, r2, wg = hnhwc(x).requires_grad_(True), hnhwc(res).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, r2, ops.conv_cfg(1, 1, 1, 0), ops.BnState(bng),
+                              ops.ACT_RELU, True)
+    z.backward(hnhwc(dz))
+    zh = nchw(z.float())
+    bf16_close(zh, F.relu(pre), 2e-2, "res z")
+    (pre * (zh > 0).float()).backward(dz)
+    bf16_close(nchw(a.grad.float()), xr.grad, 3e-2, "res dx")
+    bf16_close(nchw(r2.grad.float()), rr.grad, 1e-2, "dres")
+    bf16_close(wg.grad, wr.grad, 3e-2, "res dw")
+    # transposed conv
+    x = r16(torch.randn(2, 128, 6, 10))
+    w = torch.randn(128, 64, 2, 2) * (1.0 / 128) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), r16(w).requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2)
+    dy = r16(torch.randn_like(yr))
+    yr.backward(dy)
+    a, wg = hnhwc(x).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    y = ops.ConvTranspose2x2Fn.apply(a, wg)
+    assert y.dtype == torch.bfloat16
+    y.backward(hnhwc(dy))
+    bf16_close(nchw(y.float()), yr, 1e-2, "convT y")
+    bf16_close(nchw(a.grad.float()), xr.grad, 1e-2, "convT dx")
+    bf16_close(wg.grad, wr.grad, 1e-2, "convT dw")
+    # max-pool (exact on bf16 values), avg-pool, head conv (fp32 logits)
+    x = r16(torch.randn(2, 32, 18, 22))
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = r16(torch.randn_like(yr))
+    yr.backward(dy)
+    a = hnhwc(x).requires_grad_(True)
+    y = ops.MaxPool3x3s2Fn.apply(a)
+    y.backward(hnhwc(dy))
+    close(nchw(y.float()), yr, 0, "maxpool bf16")
+    bf16_close(nchw(a.grad.float()), xr.grad, 1e-2, "maxpool dx")
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, 2, 1, False, True)
+    yr.backward(dy)
+    a = hnhwc(x).requires_grad_(True)
+    y = ops.AvgPoolFn.apply(a, 3, 2, 1, False, True)
+    y.backward(hnhwc(dy))
+    bf16_close(nchw(y.float()), yr, 1e-2, "avgpool bf16")
+    bf16_close(nchw(a.grad.float()), xr.grad, 1e-2, "avgpool dx")
+    xh = r16(torch.randn(2, 64, 24, 20))
+    wh, bh = torch.randn(4, 64, 1, 1) * 0.1, torch.randn(4)
+    xr, whr, bhr = xh.clone().requires_grad_(True), wh.clone().requires_grad_(True), bh.clone().requires_grad_(True)
+    yr = F.conv2d(xr, whr, bhr)
+    dyh = torch.randn_like(yr)
+    yr.backward(dyh)
+    ah, wgh, bgh = hnhwc(xh).requires_grad_(True), wh.to(dev()).requires_grad_(True), bh.to(dev()).requires_grad_(True)
+    y = ops.HeadConvFn.apply(ah, wgh, bgh, True)
+    assert y.dtype == torch.float32
+    y.backward(dyh.to(dev()))
+    close(y.cpu(), yr, 1e-5, "head y bf16-in")
+    bf16_close(nchw(ah.grad.float()), xr.grad, 1e-2, "head dx")
+    close(wgh.grad, whr.grad, 1e-4, "head dw")

@@ -13,6 +13,7 @@
 // per 128-pixel tile, deterministic).  model/layers.py:92 (ConvLayer 3x3) at decoder level 5 and its backward-data.
 #include "igemm_params.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace xv2 {
 
@@ -28,8 +29,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // BF16 = true (XV2_MATH_BF16, "--precision 16"): the same LDS-resident fp32 halo and weights, but a lane gathers 8
 // consecutive channels, rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 2 matrix
 // instructions per tap instead of 16, which leaves the kernel HBM-bound.
-template <bool BF16>
+// HS = true (XV2_MATH_BF16_STORE): input, weights, output (and the inference residual) are bf16 in HBM; a halo element
+// (4 channels) is one 8-byte load widened to fp32 on its way into the same LDS image, the output row is rounded to bf16
+// and the BatchNorm statistics are taken on the rounded values.
+template <bool BF16, bool HS = false>
 __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
+    constexpr int ESH = HS ? 1 : 2;
+    typedef typename std::conditional<HS, bf16_t, float>::type OT;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
     float* wts = smem + D_HALO * D_LD;          // [9][32][36]
@@ -53,8 +60,13 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     // weights, once: [tap][n][32 channels]
     for (int e = tid; e < 9 * 32 * 8; e += 256) {
         const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
-        const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
-        *reinterpret_cast<i32x4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+        const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << ESH;
+        if constexpr (HS) {
+            const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsB, off, 0, 0);
+            *reinterpret_cast<float4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = bf16x4_to_f32((unsigned)v.x, (unsigned)v.y);
+        } else {
+            *reinterpret_cast<i32x4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+        }
     }
 
     i32x4 hr[D_HLOADS];
@@ -67,7 +79,7 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int px = e >> 3, c4 = e & 7;
         hrow[j] = px / D_HW;
         hcol[j] = px - hrow[j] * D_HW;
-        hrel[j] = e < D_HALO * 8 ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * 4) << 2 : 0;
+        hrel[j] = e < D_HALO * 8 ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * 4) << ESH : 0;
         if (e >= D_HALO * 8) hrow[j] = -(1 << 20);      // never valid
     }
     auto hload = [&](int patch) {
@@ -75,19 +87,30 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int th = (patch / tiles_w) % tiles_h;
         const int n = patch / (tiles_w * tiles_h);
         const int oh0 = th * D_TH, ow0 = tw * D_TW;
-        const int base = (((n * p.IH + oh0) * p.IW + ow0) * p.ldA0) << 2;
+        const int base = (((n * p.IH + oh0) * p.IW + ow0) * p.ldA0) << ESH;
 #pragma unroll
         for (int j = 0; j < D_HLOADS; ++j) {
             const int ih = oh0 - 1 + hrow[j], iw = ow0 - 1 + hcol[j];
             const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
+            if constexpr (HS) {
+                const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
+                hr[j].x = v.x;
+                hr[j].y = v.y;
+            } else {
+                hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
+            }
         }
     };
     auto hstore = [&]() {
 #pragma unroll
         for (int j = 0; j < D_HLOADS; ++j) {
             const int e = tid + j * 256;
-            if (e < D_HALO * 8) *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
+            if (e < D_HALO * 8) {
+                if constexpr (HS)
+                    *reinterpret_cast<float4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = bf16x4_to_f32((unsigned)hr[j].x, (unsigned)hr[j].y);
+                else
+                    *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
+            }
         }
     };
 
@@ -149,18 +172,19 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
             float v = acc[r] + bv;
             if (p.ep_scale) {        // inference: folded BatchNorm (+ residual) + activation
                 v = __fmaf_rn(v, esc, esf);
-                if (p.ep_res) v += p.ep_res[(rowpix + col) * p.ep_ldres + l31];
+                if (p.ep_res) v += ld1(reinterpret_cast<const OT*>(p.ep_res) + (rowpix + col) * p.ep_ldres + l31);
                 v = apply_act(v, p.ep_act);
             }
-            p.Out0[(rowpix + col) * p.ldo0 + l31] = v;
+            st1(reinterpret_cast<OT*>(p.Out0) + (rowpix + col) * p.ldo0 + l31, v);
             if (bnb) {
                 const float yv = p.bnb_y[(rowpix + col) * p.bnb_ldy + l31];
                 const float g = v * act_grad_from_pre(__fmaf_rn(yv, bsc, bsf), p.bnb_act);
                 s1 += g;
                 s2 += g * ((yv - bmu) * bis);
             } else {
-                s1 += acc[r];
-                s2 += acc[r] * acc[r];
+                const float sv = HS ? bf16_round(acc[r]) : acc[r];
+                s1 += sv;
+                s2 += sv * sv;
             }
         }
         if (p.stats) {
@@ -200,23 +224,29 @@ bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
 
 int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
-    static int kid = -1, kid16 = -1;
+    static int kid = -1, kid16 = -1, kid16s = -1;
     if (!attr_set) {
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
+        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
         attr_set = true;
         kid = prof_register("direct3x3_n32_kernel");
         kid16 = prof_register("direct3x3_n32_kernel<bf16>");
+        kid16s = prof_register("direct3x3_n32_kernel<bf16hbm>");
     }
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / (D_TH * D_TW);
     const int grid = std::min(npatches, 512);      // persistent: 2 blocks per CU, each walks a run of patches
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
-    const double abytes = 4.0 * ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
-    prof_begin(p.math ? kid16 : kid, flops, abytes, stream);
-    if (p.math)
+    const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
+                          ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
+    prof_begin(p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
+    if (p.math == XV2_MATH_BF16_STORE)
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+    else if (p.math)
         hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
     else
         hipLaunchKernelGGL(direct3x3_n32_kernel<false>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);

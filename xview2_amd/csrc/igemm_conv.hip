@@ -22,6 +22,7 @@
 #include "igemm_params.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #ifndef XV2_SCHED
 #define XV2_SCHED 0
@@ -45,13 +46,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: conflict-free 16-byte fragment reads)
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false>
+// HS = true (XV2_MATH_BF16_STORE): activations and packed weights are bf16 IN HBM.  A K-tile row (32 channels) is then
+// 64 bytes = 4 lanes x 16 bytes, so a pass of the 256 threads covers 64 rows and the loaded registers go to the bf16 LDS
+// image as they are (no conversion anywhere on the operand path); the output tile is rounded to bf16 in the epilogue
+// and the BatchNorm statistics are taken on the ROUNDED values (what the next kernel will read).  The 4-channel RGB
+// source (SMALLC) stays an fp32 image with fp32 weights and exact-fp32 MFMA; only its output is bf16.
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;
+    constexpr bool HIN = HS && !SMALLC;                 // bf16 operands in HBM
+    constexpr int LPR = HIN ? 4 : 8;                    // lanes per 32-channel row (16-byte loads)
+    constexpr int RPP = 256 / LPR;                      // rows per pass of the block
+    constexpr int EPL = 32 / LPR;                       // elements per lane per row
+    constexpr int ESH = HIN ? 1 : 2;                    // log2(bytes per element)
+    constexpr int AROWS = (BM + RPP - 1) / RPP, BROWS = (BN + RPP - 1) / RPP;
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(MR >= 1 && NR >= 1, "wave tile");
+    static_assert(!HIN || BF16, "bf16 operands imply the bf16 MFMA");
+    typedef typename std::conditional<HS, bf16_t, float>::type OT;   // output / residual element type
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][LDS_LD]
@@ -80,14 +93,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const int kt_begin = blockIdx.z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, ci.nkt);
 
-    const int c4 = tid & 7, r0 = tid >> 3;
+    const int c4 = tid % LPR, r0 = tid / LPR;
     const int ohw = ci.OHl * ci.OWl;
 
     int a_n[AROWS], a_h[AROWS], a_w[AROWS];
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
-        const int m = m0 + r0 + 32 * j;
-        if (m < ci.M) {
+        const int m = m0 + r0 + RPP * j;
+        if (m < ci.M && r0 + RPP * j < BM) {
             const int n = m / ohw;
             const int rem = m - n * ohw;
             const int a = rem / ci.OWl;
@@ -121,7 +134,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             a_msk[j] = mk;
         }
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) b_off[j] = (n0 + r0 + 32 * j) * (p.T * p.Ctot) + c4 * 4;
+        for (int j = 0; j < BROWS; ++j) b_off[j] = (n0 + r0 + RPP * j) * (p.T * p.Ctot) + c4 * EPL;
         rsA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
         rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1 ? p.A1 : p.A0), 0, p.A1 ? p.bytesA1 : p.bytesA0, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
@@ -159,11 +172,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             const int dpix = t.dh * p.IW + t.dw;
             const bool first = cc < p.C0;
             const int ld = first ? p.ldA0 : p.ldA1;
-            const int ch = (first ? cc : cc - p.C0) + c4 * 4;
+            const int ch = (first ? cc : cc - p.C0) + c4 * EPL;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
                 const bool ok = (a_msk[j] >> tap) & 1u;
-                const int off = ok ? (((a_pix[j] + dpix) * ld + ch) << 2) : (int)0x80000000;
+                const int off = ok ? (((a_pix[j] + dpix) * ld + ch) << ESH) : (int)0x80000000;
                 const i32x4 v = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 0, 0)
                                       : __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0);
                 ra[j] = __builtin_bit_cast(float4, v);
@@ -171,7 +184,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             const int kb = t.slot * p.Ctot + cc;
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
-                const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << 2, 0, 0);
+                const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << ESH, 0, 0);
                 rb[j] = __builtin_bit_cast(float4, v);
             }
         } else {
@@ -193,7 +206,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tok) v = *reinterpret_cast<const float4*>(p.B + ((size_t)(n0 + r0 + 32 * j) * p.T + t.slot) * 4);
+                if (tok) v = *reinterpret_cast<const float4*>(p.B + ((size_t)(n0 + r0 + RPP * j) * p.T + t.slot) * 4);
                 rb[j] = v;
             }
         }
@@ -202,6 +215,20 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #if XV2_ABL & 2
         return;
 #endif
+        if constexpr (HIN) {
+            // bf16 in HBM: the 16 loaded bytes ARE 8 consecutive channels of the LDS image
+            __bf16* a = reinterpret_cast<__bf16*>(smem) + buf * (BM + BN) * LDS_LD_H;
+            __bf16* b = a + BM * LDS_LD_H;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j)
+                if (BM % RPP == 0 || r0 + RPP * j < BM)
+                    *reinterpret_cast<float4*>(a + (r0 + RPP * j) * LDS_LD_H + c4 * 8) = ra[j];
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j)
+                if (BN % RPP == 0 || r0 + RPP * j < BN)
+                    *reinterpret_cast<float4*>(b + (r0 + RPP * j) * LDS_LD_H + c4 * 8) = rb[j];
+            return;
+        }
         if constexpr (BF16) {
             __bf16* a = reinterpret_cast<__bf16*>(smem) + buf * (BM + BN) * LDS_LD_H;
             __bf16* b = a + BM * LDS_LD_H;
@@ -339,8 +366,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 Cs[row * CLD + cl] = acc[i][j][r];
-                s1 += acc[i][j][r];
-                s2 += acc[i][j][r] * acc[i][j][r];
+                const float sv = (HS && do_stats) ? bf16_round(acc[i][j][r]) : acc[i][j][r];
+                s1 += sv;
+                s2 += sv * sv;
             }
         }
         if (do_stats) {
@@ -388,19 +416,20 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
                 v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
                 if (p.ep_res) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.ep_res + (size_t)off * p.ep_ldres + col);
+                    const float4 r = ld4(reinterpret_cast<const OT*>(p.ep_res) + (size_t)off * p.ep_ldres + col);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 v.x = apply_act(v.x, p.ep_act); v.y = apply_act(v.y, p.ep_act);
                 v.z = apply_act(v.z, p.ep_act); v.w = apply_act(v.w, p.ep_act);
             }
-            float* o = col < p.N0 ? p.Out0 + (size_t)off * p.ldo0 + col : p.Out1 + (size_t)off * p.ldo1 + (col - p.N0);
+            OT* o = col < p.N0 ? reinterpret_cast<OT*>(p.Out0) + (size_t)off * p.ldo0 + col
+                               : reinterpret_cast<OT*>(p.Out1) + (size_t)off * p.ldo1 + (col - p.N0);
             if (p.accum & (col < p.N0 ? 1 : 2)) {
-                const float4 old = *reinterpret_cast<const float4*>(o);
+                const float4 old = ld4(o);
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
-            *reinterpret_cast<float4*>(o) = v;
-            if (bnb) {
+            st4(o, v);
+            if (bnb) {      // (fp32 storage only: the *_bn_tiles queries return 0 otherwise)
                 const float4 yv = *reinterpret_cast<const float4*>(p.bnb_y + (size_t)off * p.bnb_ldy + col);
                 const float gx = v.x * act_grad_from_pre(__fmaf_rn(yv.x, bsc.x, bsf.x), p.bnb_act);
                 const float gy = v.y * act_grad_from_pre(__fmaf_rn(yv.y, bsc.y, bsf.y), p.bnb_act);
@@ -448,14 +477,15 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 // Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
 // for 64-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.
 constexpr int SPLITK_ROWS = 64;
+template <typename OT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M,
                                                              int Nout, const float* __restrict__ bias,
-                                                             float* __restrict__ out0, int ldo0, int N0,
-                                                             float* __restrict__ out1, int ldo1,
+                                                             OT* __restrict__ out0, int ldo0, int N0,
+                                                             OT* __restrict__ out1, int ldo1,
                                                              float* __restrict__ stats, int accum,
                                                              const float* __restrict__ ep_scale,
                                                              const float* __restrict__ ep_shift,
-                                                             const float* __restrict__ ep_res, int ep_ldres, int ep_act) {
+                                                             const OT* __restrict__ ep_res, int ep_ldres, int ep_act) {
     __shared__ float sh[256 * 8];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
@@ -472,8 +502,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                     const float4 v = *reinterpret_cast<const float4*>(part + z * slab + (size_t)r * Nout + c);
                     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                 }
-                s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-                s2.x += a.x * a.x; s2.y += a.y * a.y; s2.z += a.z * a.z; s2.w += a.w * a.w;
+                {      // statistics on the values as they will be stored
+                    const float4 q = make_float4(Elem<OT>::round(a.x), Elem<OT>::round(a.y), Elem<OT>::round(a.z), Elem<OT>::round(a.w));
+                    s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+                    s2.x += q.x * q.x; s2.y += q.y * q.y; s2.z += q.z * q.z; s2.w += q.w * q.w;
+                }
                 a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
                 if (ep_scale) {
                     const float4 sc = *reinterpret_cast<const float4*>(ep_scale + c);
@@ -481,18 +514,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                     a.x = __fmaf_rn(a.x, sc.x, sf.x); a.y = __fmaf_rn(a.y, sc.y, sf.y);
                     a.z = __fmaf_rn(a.z, sc.z, sf.z); a.w = __fmaf_rn(a.w, sc.w, sf.w);
                     if (ep_res) {
-                        const float4 rr = *reinterpret_cast<const float4*>(ep_res + (size_t)r * ep_ldres + c);
+                        const float4 rr = ld4(ep_res + (size_t)r * ep_ldres + c);
                         a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
                     }
                     a.x = apply_act(a.x, ep_act); a.y = apply_act(a.y, ep_act);
                     a.z = apply_act(a.z, ep_act); a.w = apply_act(a.w, ep_act);
                 }
-                float* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
+                OT* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
                 if (accum & (c < N0 ? 1 : 2)) {
-                    const float4 old = *reinterpret_cast<const float4*>(o);
+                    const float4 old = ld4(o);
                     a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
                 }
-                *reinterpret_cast<float4*>(o) = a;
+                st4(o, a);
             }
         }
         if (stats) {
@@ -520,11 +553,11 @@ constexpr size_t igemm_smem_bytes() {
     return (size_t)(2 * (BM + BN) * LDS_LD) * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false>
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     constexpr size_t smem = igemm_smem_bytes<BM, BN>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16>;
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS>;
     if (!attr_set) {
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -534,7 +567,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     if (kid < 0) {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (BF16 ? "c32,bf16" : "c32")));
         kid = prof_register(nm);
     }
     IgemmParams q = p;
@@ -548,9 +581,10 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     }
     const int grid = maxtiles * (q.Nout / BN);
     // algorithmic bytes: input pixels x channels + weights + output, each once
-    double abytes = 4.0 * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
+    const double ein = (HS && !SMALLC) ? 2.0 : 4.0, eout = HS ? 2.0 : 4.0;
+    double abytes = ein * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
                                (SMALLC ? q.cin_real : q.Ctot) + (double)q.Nout * q.T * (SMALLC ? q.cin_real : q.Ctot));
-    for (int c = 0; c < q.ncls; ++c) abytes += 4.0 * (double)q.cls[c].M * q.Nout;
+    for (int c = 0; c < q.ncls; ++c) abytes += eout * (double)q.cls[c].M * q.Nout;
     prof_begin(kid, flops, abytes, stream);
     hipLaunchKernelGGL(kern, dim3(grid, q.ncls, q.ksplit), dim3(256), smem, stream, q);
     prof_end(stream);
@@ -649,21 +683,43 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         p.kt_per_split = mk;
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
-        int rc = p.math ? launch_one<128, 128, 2, 2, false, true>(p, stream)
-                        : launch_one<128, 128, 2, 2, false>(p, stream);
+        int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                 : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
+                                               : launch_one<128, 128, 2, 2, false>(p, stream);
         if (rc) return rc;
         const int M = p.cls[0].M;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256)),
-                           dim3(256), 0, stream,
-                           splitk_ws, p.ksplit, M, p.Nout, p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats,
-                           p.accum, p.ep_scale, p.ep_shift, p.ep_res, p.ep_ldres, p.ep_act);
+        const dim3 rgrid((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256));
+        if (p.math == XV2_MATH_BF16_STORE)
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
+                               p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum,
+                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
+                               p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum, p.ep_scale, p.ep_shift,
+                               p.ep_res, p.ep_ldres, p.ep_act);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
     if (smallc) {
+        if (p.math == XV2_MATH_BF16_STORE) {
+            if (bn == 128) return launch_one<128, 128, 2, 2, true, false, true>(p, stream);
+            if (bn == 64) return launch_one<128, 64, 2, 2, true, false, true>(p, stream);
+            return launch_one<128, 32, 4, 1, true, false, true>(p, stream);
+        }
         if (bn == 128) return launch_one<128, 128, 2, 2, true>(p, stream);
         if (bn == 64) return launch_one<128, 64, 2, 2, true>(p, stream);
         return launch_one<128, 32, 4, 1, true>(p, stream);
+    }
+    if (p.math == XV2_MATH_BF16_STORE) {
+        if (bn == 128) {
+            if (bm == 128) return launch_one<128, 128, 2, 2, false, true, true>(p, stream);
+            return launch_one<64, 128, 2, 2, false, true, true>(p, stream);
+        }
+        if (bn == 64) {
+            if (bm == 128) return launch_one<128, 64, 2, 2, false, true, true>(p, stream);
+            return launch_one<64, 64, 2, 2, false, true, true>(p, stream);
+        }
+        return launch_one<128, 32, 4, 1, false, true, true>(p, stream);
     }
     if (p.math) {
         if (bn == 128) {
@@ -707,7 +763,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
     p.bnb_ldy = p.bnb_act = 0;
     p.plan_tiles = nullptr;
-    XV2_CHECK_ARG(d->math == 0 || d->math == 1, "conv: unknown math mode %d", d->math);
+    XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_BF16_STORE, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
     p.ncls = 1;
@@ -715,6 +771,12 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
 }
 
 static inline bool is_rgb(const xv2_conv_desc* d) { return d->C0 == 4 && d->C1 == 0; }
+// bytes per element of the activations / packed weights a convolution reads (the RGB image and its weights stay fp32)
+static inline long long esz_in(const xv2_conv_desc* d) { return (d->math == XV2_MATH_BF16_STORE && !is_rgb(d)) ? 2 : 4; }
+static inline bool out_aligned(const xv2_conv_desc* d, const void* p, int ld) {
+    const uintptr_t mask = d->math == XV2_MATH_BF16_STORE ? 7 : 15;      // 4-element vector stores
+    return ld % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & mask) == 0;
+}
 static inline int fwd_nkt(const xv2_conv_desc* d) {
     return is_rgb(d) ? (int)cdiv(d->KH * d->KW * 4, BK) : d->KH * d->KW * ((d->C0 + d->C1) / BK);
 }
@@ -769,7 +831,7 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     if (ep) {
         XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
         XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(ep->scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(ep->shift) & 15) == 0 &&
-                          (!ep->res || (ep->ldres % 4 == 0 && (reinterpret_cast<uintptr_t>(ep->res) & 15) == 0)),
+                          (!ep->res || out_aligned(d, ep->res, ep->ldres)),
                       "conv2d_forward_fused: epilogue operands must be 16-byte aligned");
         p.ep_scale = ep->scale; p.ep_shift = ep->shift; p.ep_res = ep->res; p.ep_ldres = ep->ldres; p.ep_act = ep->act;
     }
@@ -777,7 +839,10 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
-    XV2_CHECK_ARG(ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "conv2d_forward: output must be 16-byte aligned");
+    XV2_CHECK_ARG(out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
+    XV2_CHECK_ARG(esz_in(d) == 4 || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
+                                     (reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ohwi) & 15) == 0),
+                  "conv2d_forward: bf16 operands must be 16-byte aligned with row strides that are multiples of 8");
     XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
                   "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
@@ -801,8 +866,9 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     c.nkt = fwd_nkt(d);
     {
         const long long pixels = (long long)d->N * d->IH * d->IW;
-        const long long b0 = pixels * ldx0 * 4, b1 = x1 ? pixels * ldx1 * 4 : 0;
-        const long long bw = (long long)d->Cout * p.T * p.Ctot * 4;
+        const long long es = esz_in(d);
+        const long long b0 = pixels * ldx0 * es, b1 = x1 ? pixels * ldx1 * es : 0;
+        const long long bw = (long long)d->Cout * p.T * p.Ctot * es;
         XV2_CHECK_ARG(b0 < (1ll << 31) && b1 < (1ll << 31) && bw < (1ll << 31) && p.T <= 32 || smallc,
                       "conv2d_forward: operands of 2 GiB or more (or more than 32 taps) are not supported");
         p.bytesA0 = (unsigned)b0; p.bytesA1 = (unsigned)b1; p.bytesB = (unsigned)bw;
@@ -810,18 +876,20 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     return igemm_launch(p, smallc, workspace, (hipStream_t)stream);
 }
 
-extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
-                                  int ldx1, const float* w_ohwi, const float* bias, float* y, int ldy,
+extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
+                                  int ldx1, const void* w_ohwi, const float* bias, void* y, int ldy,
                                   float* stats, float* workspace, void* stream) {
-    return conv_forward_impl(d, x0, ldx0, x1, ldx1, w_ohwi, bias, y, ldy, stats, workspace, stream, nullptr);
+    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, bias, (float*)y, ldy,
+                             stats, workspace, stream, nullptr);
 }
 
-extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1,
-                                        int ldx1, const float* w_ohwi, const float* scale, const float* shift,
-                                        const float* residual, int ldres, int act, float* z, int ldz,
+extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
+                                        int ldx1, const void* w_ohwi, const float* scale, const float* shift,
+                                        const void* residual, int ldres, int act, void* z, int ldz,
                                         float* workspace, void* stream) {
-    FwdEpilogue ep{scale, shift, residual, ldres, act};
-    return conv_forward_impl(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, z, ldz, nullptr, workspace, stream, &ep);
+    FwdEpilogue ep{scale, shift, (const float*)residual, ldres, act};
+    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)z, ldz,
+                             nullptr, workspace, stream, &ep);
 }
 
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]
@@ -838,9 +906,11 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
     XV2_CHECK_ARG(s <= 2, "backward_data: stride %d unsupported (1 or 2)", s);
-    XV2_CHECK_ARG(lddx0 % 4 == 0 && (reinterpret_cast<uintptr_t>(dx0) & 15) == 0 &&
-                      (!dx1 || (lddx1 % 4 == 0 && (reinterpret_cast<uintptr_t>(dx1) & 15) == 0)),
-                  "backward_data: outputs must be 16-byte aligned");
+    XV2_CHECK_ARG(out_aligned(d, dx0, lddx0) && (!dx1 || out_aligned(d, dx1, lddx1)),
+                  "backward_data: output rows must be aligned to 4 elements");
+    const long long es = d->math == XV2_MATH_BF16_STORE ? 2 : 4;
+    XV2_CHECK_ARG(es == 4 || (lddy % 8 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ihwo) & 15) == 0),
+                  "backward_data: bf16 operands must be 16-byte aligned with row strides that are multiples of 8");
     p.A0 = dy; p.A1 = nullptr; p.B = w_ihwo;
     p.C0 = d->Cout; p.C1 = 0; p.Ctot = d->Cout; p.ldA0 = lddy; p.ldA1 = 0;
     p.IH = d->OH; p.IW = d->OW; p.s_in = 1;
@@ -850,8 +920,8 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     p.cpt = p.Ctot / BK;
     p.osN = d->IH * d->IW; p.osH = s * d->IW; p.osW = s;
     {
-        const long long b0 = (long long)d->N * d->OH * d->OW * lddy * 4;
-        const long long bw = (long long)(d->C0 + d->C1) * p.T * d->Cout * 4;
+        const long long b0 = (long long)d->N * d->OH * d->OW * lddy * es;
+        const long long bw = (long long)(d->C0 + d->C1) * p.T * d->Cout * es;
         XV2_CHECK_ARG(b0 < (1ll << 31) && bw < (1ll << 31) && p.T <= 32,
                       "backward_data: operands of 2 GiB or more (or more than 32 taps) are not supported");
         p.bytesA0 = (unsigned)b0; p.bytesA1 = 0; p.bytesB = (unsigned)bw;
@@ -889,25 +959,27 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
         XV2_CHECK_ARG(lddx0 == d->C0 && (d->C1 == 0 || lddx1 == d->C1),
                       "backward_data: strided outputs unsupported when parity classes are empty");
         // pixels no tap reaches get a zero gradient - or, when accumulating, keep what they hold
-        if (!(p.accum & 1)) XV2_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)d->N * d->IH * d->IW * d->C0 * 4, stream));
+        if (!(p.accum & 1)) XV2_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)d->N * d->IH * d->IW * d->C0 * es, stream));
         if (d->C1 && !(p.accum & 2))
-            XV2_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)d->N * d->IH * d->IW * d->C1 * 4, stream));
+            XV2_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)d->N * d->IH * d->IW * d->C1 * es, stream));
     }
     if (ncls == 0) return XV2_OK;
     p.ncls = ncls;
     return igemm_launch(p, false, (s == 1) ? workspace : nullptr, stream);
 }
 
-extern "C" int xv2_conv2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
-                                        const float* w_ihwo, float* dx0, int lddx0, float* dx1,
+extern "C" int xv2_conv2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
+                                        const void* w_ihwo, void* dx0, int lddx0, void* dx1,
                                         int lddx1, float* workspace, void* stream) {
-    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream);
+    return dgrad_impl(d, (const float*)dy, lddy, (const float*)w_ihwo, (float*)dx0, lddx0, (float*)dx1, lddx1, workspace,
+                      (hipStream_t)stream);
 }
 
-extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const float* dy, int lddy,
-                                            const float* w_ihwo, float* dx0, int lddx0, float* dx1,
+extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy,
+                                            const void* w_ihwo, void* dx0, int lddx0, void* dx1,
                                             int lddx1, int accumulate, float* workspace, void* stream) {
-    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, dx1, lddx1, workspace, (hipStream_t)stream, accumulate);
+    return dgrad_impl(d, (const float*)dy, lddy, (const float*)w_ihwo, (float*)dx0, lddx0, (float*)dx1, lddx1, workspace,
+                      (hipStream_t)stream, accumulate);
 }
 
 // ---- backward-data that also takes the BatchNorm-backward statistics of the layer feeding this convolution ------
@@ -959,13 +1031,13 @@ extern "C" int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, con
     return conv_forward_impl(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream, nullptr, &b);
 }
 
-extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const float* x, int ldx,
-                                            const float* w_ihwo, float* y, int ldy, void* stream) {
+extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,
+                                            const void* w_ihwo, void* y, int ldy, void* stream) {
     XV2_CHECK_ARG(d->C1 == 0, "conv_transpose2d: single output tensor expected");
-    return dgrad_impl(d, x, ldx, w_ihwo, y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
+    return dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const float* dy, int lddy,
-                                                  const float* w_ohwi, float* dx, int lddx, void* stream) {
+extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
+                                                  const void* w_ohwi, void* dx, int lddx, void* stream) {
     return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
 }

@@ -283,8 +283,9 @@ __global__ void argmax_kernel(const float* __restrict__ logits, int64_t total, i
     }
 }
 
+template <typename OT>
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int T, int CinP,
-                                   float* __restrict__ ohwi, float* __restrict__ ihwo) {
+                                   OT* __restrict__ ohwi, OT* __restrict__ ihwo) {
     const size_t total = (size_t)Cout * T * CinP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i % CinP);
@@ -292,8 +293,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
         const int t = (int)(q % T);
         const int co = (int)(q / T);
         const float v = ci < Cin ? w[((size_t)co * Cin + ci) * T + t] : 0.f;
-        if (ohwi) ohwi[i] = v;
-        if (ihwo) ihwo[((size_t)ci * T + t) * Cout + co] = v;
+        if (ohwi) st1(ohwi + i, v);
+        if (ihwo) st1(ihwo + ((size_t)ci * T + t) * Cout + co, v);
     }
 }
 
@@ -318,7 +319,8 @@ __global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* 
     const float* w = reinterpret_cast<const float*>(e[0]);
     float* ohwi = reinterpret_cast<float*>(e[1]);
     float* ihwo = reinterpret_cast<float*>(e[2]);
-    const int Cout = (int)e[3], Cin = (int)e[4], T = (int)e[5], CinP = (int)e[6];
+    const int Cout = (int)e[3], Cin = (int)e[4], T = (int)(e[5] & 0xffff), CinP = (int)e[6];
+    const bool half = ((e[5] >> 16) & 0xff) == XV2_BF16;      // packed layouts of this entry are bf16
     int j = (int)(tile - e[7]);
     const int tcs = (T + PK_TC - 1) / PK_TC, cis = (CinP + 31) / 32;
     const int tcb = j % tcs;
@@ -341,14 +343,22 @@ __global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* 
             const int cil = i & 31, q = i >> 5;
             const int tl = q % tc, col = q / tc;
             const int co = co0 + col, ci = ci0 + cil;
-            if (co < Cout && ci < CinP) ohwi[((size_t)co * T + t0 + tl) * CinP + ci] = sh[col * ldco + cil * tc + tl];
+            if (co < Cout && ci < CinP) {
+                const size_t o = ((size_t)co * T + t0 + tl) * CinP + ci;
+                if (half) reinterpret_cast<bf16_t*>(ohwi)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
+                else ohwi[o] = sh[col * ldco + cil * tc + tl];
+            }
         }
     if (ihwo)
         for (int i = threadIdx.x; i < cnt; i += 256) {       // (ci, t, co): co fastest
             const int col = i & 31, q = i >> 5;
             const int tl = q % tc, cil = q / tc;
             const int co = co0 + col, ci = ci0 + cil;
-            if (co < Cout && ci < CinP) ihwo[((size_t)ci * T + t0 + tl) * Cout + co] = sh[col * ldco + cil * tc + tl];
+            if (co < Cout && ci < CinP) {
+                const size_t o = ((size_t)ci * T + t0 + tl) * Cout + co;
+                if (half) reinterpret_cast<bf16_t*>(ihwo)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
+                else ihwo[o] = sh[col * ldco + cil * tc + tl];
+            }
         }
 }
 
@@ -517,13 +527,14 @@ extern "C" int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, in
     return XV2_OK;
 }
 
-extern "C" int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad, float* w_ohwi,
-                               float* w_ihwo, void* stream) {
+extern "C" int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad, void* w_ohwi,
+                               void* w_ihwo, int dtype, void* stream) {
     XV2_CHECK_ARG(cin_pad >= Cin, "pack_weight: cin_pad < Cin");
+    XV2_CHECK_DTYPE(dtype);
     const size_t total = (size_t)Cout * KH * KW * cin_pad;
     const int grid = (int)std::min<size_t>(cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH * KW,
-                       cin_pad, w_ohwi, w_ihwo);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                                                 Cout, Cin, KH * KW, cin_pad, (T*)w_ohwi, (T*)w_ihwo));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

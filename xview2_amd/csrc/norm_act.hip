@@ -43,11 +43,11 @@ static ChunkGeom chunk_geom(int64_t npix, int C) {
 }
 
 // MODE 0: tensor stats (x, x*x).  MODE 1: BN backward (g, g*xhat).
-template <int MODE>
+template <int MODE, typename T>
 struct ColOp {
-    const float* a;   // MODE0: x          MODE1: dz
-    const float* z;   // MODE1
-    const float* y;   // MODE1
+    const T* a;   // MODE0: x          MODE1: dz
+    const T* z;   // MODE1
+    const T* y;   // MODE1
     const float* mean;
     const float* invstd;
     const float* scale;   // MODE1 with z == nullptr: the activation mask is recomputed from y*scale+shift
@@ -59,14 +59,14 @@ struct ColOp {
         if constexpr (MODE == 0) {
             // shifted sums (shift = the tensor's first row): avoids the E[x^2]-E[x]^2 cancellation when
             // |mean| >> std (e.g. split-attention bn1 over a handful of near-equal GAP values)
-            const float v = a[row * lda + c] - a[c];
+            const float v = ld1(a + row * lda + c) - ld1(a + c);
             f0 += v;
             f1 += v * v;
         } else {
-            const float yv = y[row * ldy + c];
-            const float ag = z ? act_grad_from_output(z[row * ldz + c], act)
+            const float yv = ld1(y + row * ldy + c);
+            const float ag = z ? act_grad_from_output(ld1(z + row * ldz + c), act)
                                : act_grad_from_pre(__fmaf_rn(yv, scale[c], shift[c]), act);
-            const float g = a[row * lda + c] * ag;
+            const float g = ld1(a + row * lda + c) * ag;
             const float xh = (yv - mean[c]) * invstd[c];
             f0 += g;
             f1 += g * xh;
@@ -75,20 +75,20 @@ struct ColOp {
     __device__ __forceinline__ void apply4(int64_t row, int c, float4& f0, float4& f1, const float4& mu,
                                            const float4& is) const {
         if constexpr (MODE == 0) {
-            float4 v = *reinterpret_cast<const float4*>(a + row * lda + c);
+            float4 v = ld4(a + row * lda + c);
             v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;   // mu = first row (shift)
             f0.x += v.x; f0.y += v.y; f0.z += v.z; f0.w += v.w;
             f1.x += v.x * v.x; f1.y += v.y * v.y; f1.z += v.z * v.z; f1.w += v.w * v.w;
         } else {
-            const float4 d = *reinterpret_cast<const float4*>(a + row * lda + c);
-            const float4 yy = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            const float4 d = ld4(a + row * lda + c);
+            const float4 yy = ld4(y + row * ldy + c);
             float gx, gy, gz, gw;
             if (z && zbits) {
                 const unsigned m = reinterpret_cast<const uint8_t*>(z)[row * c4tot + (c >> 2)];
                 gx = d.x * act_grad_from_output((m & 1u) ? 1.f : -1.f, act); gy = d.y * act_grad_from_output((m & 2u) ? 1.f : -1.f, act);
                 gz = d.z * act_grad_from_output((m & 4u) ? 1.f : -1.f, act); gw = d.w * act_grad_from_output((m & 8u) ? 1.f : -1.f, act);
             } else if (z) {
-                const float4 zz = *reinterpret_cast<const float4*>(z + row * ldz + c);
+                const float4 zz = ld4(z + row * ldz + c);
                 gx = d.x * act_grad_from_output(zz.x, act); gy = d.y * act_grad_from_output(zz.y, act);
                 gz = d.z * act_grad_from_output(zz.z, act); gw = d.w * act_grad_from_output(zz.w, act);
             } else {
@@ -106,8 +106,8 @@ struct ColOp {
     }
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, int64_t npix, int C, int rpb, int cgw,
+template <int MODE, typename T>
+__global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op, int64_t npix, int C, int rpb, int cgw,
                                                               double* __restrict__ part) {
     __shared__ float sh[256 * 8];
     const int tid = threadIdx.x;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE> op, in
             mu = *reinterpret_cast<const float4*>(op.mean + cb);
             is = *reinterpret_cast<const float4*>(op.invstd + cb);
         } else {
-            mu = *reinterpret_cast<const float4*>(op.a + cb);
+            mu = ld4(op.a + cb);
         }
         // two rows in flight per iteration (independent accumulators): more bytes outstanding per lane
         float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, 0, 0);
@@ -396,12 +396,12 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
     shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
+template <bool VEC, typename T>
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y, int ldy,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
-                                                          const float* __restrict__ res, int ldr, int act,
-                                                          float* __restrict__ z, int ldz, int64_t npix, int C,
+                                                          const T* __restrict__ res, int ldr, int act,
+                                                          T* __restrict__ z, int ldz, int64_t npix, int C,
                                                           uint8_t* __restrict__ zmask) {
     if constexpr (VEC) {
         const int C4 = C >> 2;
@@ -409,18 +409,18 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / C4;
             const int c = (int)(i - row * C4) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            const float4 v = ld4(y + row * ldy + c);
             const float4 sc = *reinterpret_cast<const float4*>(scale + c);
             const float4 sh = *reinterpret_cast<const float4*>(shift + c);
             float4 o;
             o.x = __fmaf_rn(v.x, sc.x, sh.x); o.y = __fmaf_rn(v.y, sc.y, sh.y);
             o.z = __fmaf_rn(v.z, sc.z, sh.z); o.w = __fmaf_rn(v.w, sc.w, sh.w);
             if (res) {
-                const float4 r = *reinterpret_cast<const float4*>(res + row * ldr + c);
+                const float4 r = ld4(res + row * ldr + c);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
-            *reinterpret_cast<float4*>(z + row * ldz + c) = o;
+            st4(z + row * ldz + c, o);
             if (zmask) zmask[i] = (uint8_t)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
         }
     } else {
@@ -428,25 +428,25 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / C;
             const int c = (int)(i - row * C);
-            float o = __fmaf_rn(y[row * ldy + c], scale[c], shift[c]);
-            if (res) o += res[row * ldr + c];
-            z[row * ldz + c] = apply_act(o, act);
+            float o = __fmaf_rn(ld1(y + row * ldy + c), scale[c], shift[c]);
+            if (res) o += ld1(res + row * ldr + c);
+            st1(z + row * ldz + c, apply_act(o, act));
         }
     }
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict__ dz, int lddz,
-                                                          const float* __restrict__ z, int ldz,
-                                                          const float* __restrict__ y, int ldy,
+template <bool VEC, typename T>
+__global__ void __launch_bounds__(256) bn_act_bwd_kernel(const T* __restrict__ dz, int lddz,
+                                                          const T* __restrict__ z, int ldz,
+                                                          const T* __restrict__ y, int ldy,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const double* __restrict__ sums2, double count, int act,
-                                                          int train, float* __restrict__ dy, int lddy,
-                                                          float* __restrict__ dres, int lddres, int64_t npix, int C,
+                                                          int train, T* __restrict__ dy, int lddy,
+                                                          T* __restrict__ dres, int lddres, int64_t npix, int C,
                                                           int zbits) {
     const float inv_count = (float)(1.0 / count);
     constexpr int V = VEC ? 4 : 1;
@@ -458,19 +458,19 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
         float d[V], zz[V], yy[V], o[V], g[V];
         const bool need_y = train || !z;
         if constexpr (VEC) {
-            *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + row * lddz + c);
+            *reinterpret_cast<float4*>(d) = ld4(dz + row * lddz + c);
             if (z && zbits) {
                 const unsigned m = reinterpret_cast<const uint8_t*>(z)[i];
 #pragma unroll
                 for (int k = 0; k < V; ++k) zz[k] = ((m >> k) & 1u) ? 1.f : -1.f;
             } else if (z) {
-                *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + row * ldz + c);
+                *reinterpret_cast<float4*>(zz) = ld4(z + row * ldz + c);
             }
-            if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + row * ldy + c);
+            if (need_y) *reinterpret_cast<float4*>(yy) = ld4(y + row * ldy + c);
         } else {
-            d[0] = dz[row * lddz + c];
-            if (z) zz[0] = z[row * ldz + c];
-            if (need_y) yy[0] = y[row * ldy + c];
+            d[0] = ld1(dz + row * lddz + c);
+            if (z) zz[0] = ld1(z + row * ldz + c);
+            if (need_y) yy[0] = ld1(y + row * ldy + c);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -487,11 +487,11 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
             }
         }
         if constexpr (VEC) {
-            *reinterpret_cast<float4*>(dy + row * lddy + c) = *reinterpret_cast<float4*>(o);
-            if (dres) *reinterpret_cast<float4*>(dres + row * lddres + c) = *reinterpret_cast<float4*>(g);
+            st4(dy + row * lddy + c, *reinterpret_cast<float4*>(o));
+            if (dres) st4(dres + row * lddres + c, *reinterpret_cast<float4*>(g));
         } else {
-            dy[row * lddy + c] = o[0];
-            if (dres) dres[row * lddres + c] = g[0];
+            st1(dy + row * lddy + c, o[0]);
+            if (dres) st1(dres + row * lddres + c, g[0]);
         }
     }
 }
@@ -499,17 +499,18 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const float* __restrict
 // Streaming form for C % 4 == 0 with C/4 dividing 256 (every conv layer of the U-Net): a thread owns ONE group of
 // 4 channels for its whole life, so the seven per-channel coefficient vectors are loaded once into registers and
 // the loop body is 2-3 16-byte loads + one 16-byte store per element vector (HBM-bound).
-__global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __restrict__ dz, int lddz,
-                                                               const float* __restrict__ z, int ldz,
-                                                               const float* __restrict__ y, int ldy,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restrict__ dz, int lddz,
+                                                               const T* __restrict__ z, int ldz,
+                                                               const T* __restrict__ y, int ldy,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                const double* __restrict__ sums2, double count, int act,
-                                                               int train, float* __restrict__ dy, int lddy,
-                                                               float* __restrict__ dres, int lddres, int64_t npix, int cgw,
+                                                               int train, T* __restrict__ dy, int lddy,
+                                                               T* __restrict__ dres, int lddres, int64_t npix, int cgw,
                                                                int rows_per_block, int zbits, int c4tot) {
     const int C4 = cgw >> 2, rpp = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
@@ -531,15 +532,15 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __res
     const bool need_y = train || !z;
     for (int64_t r = r0 + ty; r < r1; r += rpp) {
         float d[4], zz[4], yy[4], o[4], g[4];
-        *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(dz + r * lddz + c);
+        *reinterpret_cast<float4*>(d) = ld4(dz + r * lddz + c);
         if (z && zbits) {
             const unsigned m = reinterpret_cast<const uint8_t*>(z)[r * c4tot + (c >> 2)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) zz[k] = ((m >> k) & 1u) ? 1.f : -1.f;
         } else if (z) {
-            *reinterpret_cast<float4*>(zz) = *reinterpret_cast<const float4*>(z + r * ldz + c);
+            *reinterpret_cast<float4*>(zz) = ld4(z + r * ldz + c);
         }
-        if (need_y) *reinterpret_cast<float4*>(yy) = *reinterpret_cast<const float4*>(y + r * ldy + c);
+        if (need_y) *reinterpret_cast<float4*>(yy) = ld4(y + r * ldy + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             g[k] = d[k] * (z ? act_grad_from_output(zz[k], act) : act_grad_from_pre(__fmaf_rn(yy[k], sc[k], sf[k]), act));
@@ -550,8 +551,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const float* __res
                 o[k] = gi[k] * g[k];
             }
         }
-        *reinterpret_cast<float4*>(dy + r * lddy + c) = *reinterpret_cast<float4*>(o);
-        if (dres) *reinterpret_cast<float4*>(dres + r * lddres + c) = *reinterpret_cast<float4*>(g);
+        st4(dy + r * lddy + c, *reinterpret_cast<float4*>(o));
+        if (dres) st4(dres + r * lddres + c, *reinterpret_cast<float4*>(g));
     }
 }
 
@@ -599,16 +600,16 @@ extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
 }
 extern "C" size_t xv2_bn_backward_workspace(int64_t npix, int C) { return xv2_bn_tensor_stats_workspace(npix, C); }
 
-template <int MODE>
-static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st,
+template <int MODE, typename T>
+static int column_sums(const ColOp<MODE, T>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st,
                        float* f0 = nullptr, float* f1 = nullptr) {
     const ChunkGeom g = chunk_geom(npix, C);
     size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
     double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
-    hipLaunchKernelGGL(column_partials_kernel<MODE>, dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix, C,
-                       g.rpb, g.cgw, dpart);
+    hipLaunchKernelGGL((column_partials_kernel<MODE, T>), dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix,
+                       C, g.rpb, g.cgw, dpart);
     XV2_CHECK_LAUNCH();
     return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
@@ -616,11 +617,11 @@ static int column_sums(const ColOp<MODE>& op, int64_t npix, int C, double* sums,
 extern "C" int xv2_bn_tensor_stats(const float* x, int ldx, int64_t npix, int C, double* sums, float* workspace,
                                    void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_tensor_stats: empty");
-    ColOp<0> op;
+    ColOp<0, float> op;
     op.a = x; op.lda = ldx; op.z = nullptr; op.y = nullptr; op.mean = nullptr; op.invstd = nullptr;
     op.scale = op.shift = nullptr;
     op.ldz = op.ldy = 0; op.act = 0; op.zbits = 0; op.c4tot = 0;
-    int rc = column_sums<0>(op, npix, C, sums, workspace, (hipStream_t)stream);
+    int rc = column_sums<0, float>(op, npix, C, sums, workspace, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(unshift_stats_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, x,
                        (double)npix, C);
@@ -649,45 +650,53 @@ extern "C" int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return XV2_OK;
 }
 
-static inline bool vec_ok(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+// 4-channel vector accesses: 16 bytes in fp32, 8 bytes in bf16
+static inline bool vec_ok(int C, size_t esz, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
     if (C % 4) return false;
     for (int l : lds)
         if (l % 4) return false;
     for (const void* p : ptrs)
-        if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return false;
+        if (p && (reinterpret_cast<uintptr_t>(p) & (4 * esz - 1))) return false;
     return true;
 }
 
-static int bn_act_forward_impl(const float* y, int ldy, const float* scale, const float* shift, const float* residual,
-                               int ldr, int act, float* z, int ldz, int64_t npix, int C, uint8_t* zmask, void* stream) {
+template <typename T>
+static int bn_act_forward_impl(const T* y, int ldy, const float* scale, const float* shift, const T* residual,
+                               int ldr, int act, T* z, int ldz, int64_t npix, int C, uint8_t* zmask, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_forward: empty");
-    const bool vec = vec_ok(C, {ldy, ldz, residual ? ldr : 0}, {y, z, residual, scale, shift});
+    const bool vec = vec_ok(C, sizeof(T), {ldy, ldz, residual ? ldr : 0}, {y, z, residual}) &&
+                     vec_ok(C, 4, {}, {scale, shift});
     XV2_CHECK_ARG(!zmask || (vec && act != XV2_ACT_SIGMOID), "bn_act_forward_mask: needs C %% 4 == 0, aligned rows, ReLU-type activation");
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
+        hipLaunchKernelGGL((bn_act_fwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
                            shift, residual, ldr, act, z, ldz, npix, C, zmask);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
+        hipLaunchKernelGGL((bn_act_fwd_kernel<false, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
                            shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 
-extern "C" int xv2_bn_act_forward(const float* y, int ldy, const float* scale, const float* shift,
-                                  const float* residual, int ldr, int act, float* z, int ldz, int64_t npix, int C,
-                                  void* stream) {
-    return bn_act_forward_impl(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, C, nullptr, stream);
+extern "C" int xv2_bn_act_forward(const void* y, int ldy, const float* scale, const float* shift,
+                                  const void* residual, int ldr, int act, void* z, int ldz, int64_t npix, int C,
+                                  int dtype, void* stream) {
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_act_forward_impl<T>((const T*)y, ldy, scale, shift, (const T*)residual, ldr, act,
+                                                           (T*)z, ldz, npix, C, nullptr, stream));
 }
 
-extern "C" int xv2_bn_act_forward_mask(const float* y, int ldy, const float* scale, const float* shift,
-                                       const float* residual, int ldr, int act, float* z, int ldz, int64_t npix,
-                                       int C, uint8_t* zmask, void* stream) {
+extern "C" int xv2_bn_act_forward_mask(const void* y, int ldy, const float* scale, const float* shift,
+                                       const void* residual, int ldr, int act, void* z, int ldz, int64_t npix,
+                                       int C, uint8_t* zmask, int dtype, void* stream) {
     XV2_CHECK_ARG(zmask, "bn_act_forward_mask: mask output is required");
-    return bn_act_forward_impl(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, C, zmask, stream);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_act_forward_impl<T>((const T*)y, ldy, scale, shift, (const T*)residual, ldr, act,
+                                                           (T*)z, ldz, npix, C, zmask, stream));
 }
 
-static int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz, int zbits, const float* y, int ldy,
+template <typename T>
+static int bn_bwd_reduce_impl(const T* dz, int lddz, const T* z, int ldz, int zbits, const T* y, int ldy,
                               const float* mean, const float* invstd, const float* scale, const float* shift, int act,
                               int64_t npix, int C, double* sums2, float* dgamma, float* dbeta, float* workspace,
                               void* stream) {
@@ -696,38 +705,43 @@ static int bn_bwd_reduce_impl(const float* dz, int lddz, const float* z, int ldz
                   "bn backward (mask form): unsupported channel count %d / activation", C);
     XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && (!z || ldz % 4 == 0) && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
-    ColOp<1> op;
+    ColOp<1, T> op;
     op.a = dz; op.lda = lddz; op.z = z; op.ldz = ldz; op.y = y; op.ldy = ldy; op.mean = mean; op.invstd = invstd;
     op.scale = scale; op.shift = shift;
     op.act = act;
     op.zbits = zbits; op.c4tot = C / 4;
-    return column_sums<1>(op, npix, C, sums2, workspace, (hipStream_t)stream, dbeta, dgamma);
+    return column_sums<1, T>(op, npix, C, sums2, workspace, (hipStream_t)stream, dbeta, dgamma);
 }
 
-extern "C" int xv2_bn_act_backward_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+extern "C" int xv2_bn_act_backward_reduce(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy,
                                           const float* mean, const float* invstd, const float* scale,
                                           const float* shift, int act, int64_t npix, int C, double* sums2,
-                                          float* dgamma, float* dbeta, float* workspace, void* stream) {
-    return bn_bwd_reduce_impl(dz, lddz, z, ldz, 0, y, ldy, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
-                              dbeta, workspace, stream);
+                                          float* dgamma, float* dbeta, float* workspace, int dtype, void* stream) {
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_bwd_reduce_impl<T>((const T*)dz, lddz, (const T*)z, ldz, 0, (const T*)y, ldy, mean,
+                                                          invstd, scale, shift, act, npix, C, sums2, dgamma, dbeta,
+                                                          workspace, stream));
 }
 
-extern "C" int xv2_bn_act_backward_reduce_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+extern "C" int xv2_bn_act_backward_reduce_mask(const void* dz, int lddz, const uint8_t* zmask, const void* y, int ldy,
                                                const float* mean, const float* invstd, int act, int64_t npix, int C,
                                                double* sums2, float* dgamma, float* dbeta, float* workspace,
-                                               void* stream) {
+                                               int dtype, void* stream) {
     XV2_CHECK_ARG(zmask, "bn_act_backward_reduce_mask: mask is required");
-    return bn_bwd_reduce_impl(dz, lddz, reinterpret_cast<const float*>(zmask), 4, 1, y, ldy, mean, invstd, nullptr,
-                              nullptr, act, npix, C, sums2, dgamma, dbeta, workspace, stream);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_bwd_reduce_impl<T>((const T*)dz, lddz, reinterpret_cast<const T*>(zmask), 4, 1,
+                                                          (const T*)y, ldy, mean, invstd, nullptr, nullptr, act, npix, C,
+                                                          sums2, dgamma, dbeta, workspace, stream));
 }
 
-static int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz, int zbits, const float* y, int ldy,
+template <typename T>
+static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbits, const T* y, int ldy,
                              const float* mean, const float* invstd, const float* gamma, const float* scale,
-                             const float* shift, const double* sums2, double count, int act, int train, float* dy,
-                             int lddy, float* dres, int lddres, int64_t npix, int C, void* stream) {
+                             const float* shift, const double* sums2, double count, int act, int train, T* dy,
+                             int lddy, T* dres, int lddres, int64_t npix, int C, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
-    const bool vec = vec_ok(C, {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
+    const bool vec = vec_ok(C, sizeof(T), {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
                             {dz, zbits ? nullptr : z, y, dy, dres});
     XV2_CHECK_ARG(!zbits || (vec && act != XV2_ACT_SIGMOID), "bn backward (mask form): needs C %% 4 == 0, aligned rows, ReLU-type activation");
     const ChunkGeom cg = chunk_geom(npix, C);
@@ -735,7 +749,7 @@ static int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz,
         const int rpp = 256 / (cg.cgw / 4);
         int64_t rpb = cdiv(npix * cg.groups, 4096);
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
-        hipLaunchKernelGGL(bn_act_bwd_rows_kernel, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
+        hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
                            count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4);
         XV2_CHECK_LAUNCH();
@@ -743,31 +757,37 @@ static int bn_bwd_apply_impl(const float* dz, int lddz, const float* z, int ldz,
     }
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
-        hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+        hipLaunchKernelGGL((bn_act_bwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
                            y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C,
                            zbits);
     else
-        hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
+        hipLaunchKernelGGL((bn_act_bwd_kernel<false, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,
                            y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train, dy, lddy, dres, lddres, npix, C,
                            0);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 
-extern "C" int xv2_bn_act_backward_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+extern "C" int xv2_bn_act_backward_apply(const void* dz, int lddz, const void* z, int ldz, const void* y, int ldy,
                                          const float* mean, const float* invstd, const float* gamma,
                                          const float* scale, const float* shift, const double* sums2, double count,
-                                         int act, int train, float* dy, int lddy, float* dres, int lddres,
-                                         int64_t npix, int C, void* stream) {
-    return bn_bwd_apply_impl(dz, lddz, z, ldz, 0, y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, train,
-                             dy, lddy, dres, lddres, npix, C, stream);
+                                         int act, int train, void* dy, int lddy, void* dres, int lddres,
+                                         int64_t npix, int C, int dtype, void* stream) {
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_bwd_apply_impl<T>((const T*)dz, lddz, (const T*)z, ldz, 0, (const T*)y, ldy, mean,
+                                                         invstd, gamma, scale, shift, sums2, count, act, train, (T*)dy,
+                                                         lddy, (T*)dres, lddres, npix, C, stream));
 }
 
-extern "C" int xv2_bn_act_backward_apply_mask(const float* dz, int lddz, const uint8_t* zmask, const float* y, int ldy,
+extern "C" int xv2_bn_act_backward_apply_mask(const void* dz, int lddz, const uint8_t* zmask, const void* y, int ldy,
                                               const float* mean, const float* invstd, const float* gamma,
-                                              const double* sums2, double count, int act, int train, float* dy,
-                                              int lddy, float* dres, int lddres, int64_t npix, int C, void* stream) {
+                                              const double* sums2, double count, int act, int train, void* dy,
+                                              int lddy, void* dres, int lddres, int64_t npix, int C, int dtype,
+                                              void* stream) {
     XV2_CHECK_ARG(zmask, "bn_act_backward_apply_mask: mask is required");
-    return bn_bwd_apply_impl(dz, lddz, reinterpret_cast<const float*>(zmask), 4, 1, y, ldy, mean, invstd, gamma, nullptr,
-                             nullptr, sums2, count, act, train, dy, lddy, dres, lddres, npix, C, stream);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return bn_bwd_apply_impl<T>((const T*)dz, lddz, reinterpret_cast<const T*>(zmask), 4, 1,
+                                                         (const T*)y, ldy, mean, invstd, gamma, nullptr, nullptr, sums2,
+                                                         count, act, train, (T*)dy, lddy, (T*)dres, lddres, npix, C,
+                                                         stream));
 }

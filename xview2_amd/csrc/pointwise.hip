@@ -22,8 +22,8 @@ static inline int grid_for(int64_t total, int cap = 8192) {
 // of every 4*L chunk.  COUT <= 4.
 constexpr int HEAD_BLOCKS = 1024;
 
-template <int COUT>
-__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, int ldx, int64_t npix,
+template <int COUT, typename T>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, int ldx, int64_t npix,
                                                         int64_t hw, int Cin, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int nchw, int L) {
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
         for (int c = lane_in * 4; c < Cin; c += 4 * L) {
-            const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+            const float4 v = ld4(x + p * ldx + c);
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
                 const float4 ww = *reinterpret_cast<const float4*>(w + o * Cin + c);
@@ -63,11 +63,11 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
 }
 
 // dx[p][c] = sum_o dy[p][o] w[o][c];  per-block partial dw[o][c] = sum_p dy[p][o] x[p][c], db[o]
-template <int COUT>
-__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ x, int ldx,
+template <int COUT, typename T>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ dy, int64_t npix, int64_t hw,
                                                         int Cin, const float* __restrict__ w, int nchw,
-                                                        float* __restrict__ dx, int lddx, float* __restrict__ part,
+                                                        T* __restrict__ dx, int lddx, float* __restrict__ part,
                                                         int L) {
     extern __shared__ float sh[];  // [gpb][COUT][4*L chunk] reduced per chunk
     const int tid = threadIdx.x;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                     g[o] = dy[p * COUT + o];
                 }
             }
-            const float4 v = *reinterpret_cast<const float4*>(x + p * ldx + c);
+            const float4 v = ld4(x + p * ldx + c);
             float4 d = make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__
                 dwacc[o].x += g[o] * v.x; dwacc[o].y += g[o] * v.y; dwacc[o].z += g[o] * v.z; dwacc[o].w += g[o] * v.w;
                 if (cb == 0 && lane_in == 0) dbacc[o] += g[o];
             }
-            if (dx) *reinterpret_cast<float4*>(dx + p * lddx + c) = d;
+            if (dx) st4(dx + p * lddx + c, d);
         }
         // reduce dwacc over the groups of this block (fixed order)
 #pragma unroll
@@ -153,18 +153,18 @@ __global__ void __launch_bounds__(256) head_bwd_reduce_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------- elementwise
-__global__ void add_relu_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                    float4* __restrict__ r, int64_t n4) {
+template <typename T>
+__global__ void add_relu_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ r, int64_t n4) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 x = a[i], y = b[i];
-        r[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+        const float4 x = ld4(a + 4 * i), y = ld4(b + 4 * i);
+        st4(r + 4 * i, make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f)));
     }
 }
-__global__ void add_relu_bwd_kernel(const float4* __restrict__ r, const float4* __restrict__ dr,
-                                    float4* __restrict__ d, int64_t n4) {
+template <typename T>
+__global__ void add_relu_bwd_kernel(const T* __restrict__ r, const T* __restrict__ dr, T* __restrict__ d, int64_t n4) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 x = r[i], g = dr[i];
-        d[i] = make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f);
+        const float4 x = ld4(r + 4 * i), g = ld4(dr + 4 * i);
+        st4(d + 4 * i, make_float4(x.x > 0.f ? g.x : 0.f, x.y > 0.f ? g.y : 0.f, x.z > 0.f ? g.z : 0.f, x.w > 0.f ? g.w : 0.f));
     }
 }
 __global__ void axpby_kernel(float alpha, const float4* __restrict__ a, float beta, const float4* __restrict__ b,
@@ -178,33 +178,35 @@ __global__ void axpby_kernel(float alpha, const float4* __restrict__ a, float be
     }
 }
 
-__global__ void gate_mul_fwd_kernel(const float* __restrict__ skip, int lds, const float* __restrict__ gate,
-                                    float* __restrict__ out, int64_t npix, int C) {
+template <typename T>
+__global__ void gate_mul_fwd_kernel(const T* __restrict__ skip, int lds, const float* __restrict__ gate,
+                                    T* __restrict__ out, int64_t npix, int C) {
     const int C4 = C >> 2;
     const int64_t total = npix * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / C4;
         const int c = (int)(i - p * C4) * 4;
         const float g = gate[p];
-        const float4 v = *reinterpret_cast<const float4*>(skip + p * lds + c);
-        *reinterpret_cast<float4*>(out + p * C + c) = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
+        const float4 v = ld4(skip + p * lds + c);
+        st4(out + p * C + c, make_float4(v.x * g, v.y * g, v.z * g, v.w * g));
     }
 }
 // one wave per pixel group: dskip = dout*gate ; dgate[p] = sum_c dout*skip
-__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const float* __restrict__ skip, int lds,
+template <typename T>
+__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const T* __restrict__ skip, int lds,
                                                             const float* __restrict__ gate,
-                                                            const float* __restrict__ dout,
-                                                            float* __restrict__ dskip, float* __restrict__ dgate,
+                                                            const T* __restrict__ dout,
+                                                            T* __restrict__ dskip, float* __restrict__ dgate,
                                                             int64_t npix, int C, int L) {
     const int tid = threadIdx.x, lane_in = tid % L, gpb = 256 / L;
     for (int64_t p = (int64_t)blockIdx.x * gpb + tid / L; p < npix; p += (int64_t)gridDim.x * gpb) {
         const float g = gate[p];
         float acc = 0.f;
         for (int c = lane_in * 4; c < C; c += 4 * L) {
-            const float4 d = *reinterpret_cast<const float4*>(dout + p * C + c);
-            const float4 s = *reinterpret_cast<const float4*>(skip + p * lds + c);
+            const float4 d = ld4(dout + p * C + c);
+            const float4 s = ld4(skip + p * lds + c);
             acc += d.x * s.x + d.y * s.y + d.z * s.z + d.w * s.w;
-            *reinterpret_cast<float4*>(dskip + p * C + c) = make_float4(d.x * g, d.y * g, d.z * g, d.w * g);
+            st4(dskip + p * C + c, make_float4(d.x * g, d.y * g, d.z * g, d.w * g));
         }
         for (int s = L >> 1; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
         if (lane_in == 0) dgate[p] = acc;
@@ -231,14 +233,15 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, int N,
         y[i] = x[(n * hw + q) * ldx + c];
     }
 }
-__global__ void copy_channels_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
                                      int64_t npix, int C) {
     const int C4 = C >> 2;
     const int64_t total = npix * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / C4;
         const int c = (int)(i - p * C4) * 4;
-        *reinterpret_cast<float4*>(dst + p * ldd + c) = *reinterpret_cast<const float4*>(src + p * lds + c);
+        st4(dst + p * ldd + c, ld4(src + p * lds + c));
     }
 }
 
@@ -248,7 +251,8 @@ constexpr int SPLAT_CHUNKS = 256;
 // b: [N][hw][Cb] broadcast over the C2/Cb radix groups (column c of a pairs with column c % Cb of b).
 // grid (chunks, column groups, N); a block = (cgw/4 float4 lanes) x (256/(cgw/4) row lanes), cgw = min(C2, 256):
 // 16-byte loads, two rows in flight per lane, LDS fold of the row lanes.
-__global__ void __launch_bounds__(256) splat_colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>
+__global__ void __launch_bounds__(256) splat_colsum_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                             int64_t hw, int C2, int Cb, int cgw, int rows_per_chunk,
                                                             float* __restrict__ part) {
     __shared__ float4 sh[256];
@@ -258,13 +262,13 @@ __global__ void __launch_bounds__(256) splat_colsum_kernel(const float* __restri
     const int c = blockIdx.y * cgw + tx * 4;
     const int cb = b ? c % Cb : 0;
     const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
-    const float* pa = a + (size_t)n * hw * C2 + c;
-    const float* pb = b ? b + (size_t)n * hw * Cb + cb : nullptr;
+    const T* pa = a + (size_t)n * hw * C2 + c;
+    const T* pb = b ? b + (size_t)n * hw * Cb + cb : nullptr;
     float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
     auto term = [&](int64_t r, float4& s) {
-        float4 v = *reinterpret_cast<const float4*>(pa + r * C2);
+        float4 v = ld4(pa + r * C2);
         if (pb) {
-            const float4 w = *reinterpret_cast<const float4*>(pb + r * Cb);
+            const float4 w = ld4(pb + r * Cb);
             v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
         }
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -321,8 +325,9 @@ __global__ void __launch_bounds__(256) splat_datt_finish_kernel(const float* __r
     const float a = splat_fold(part + (size_t)n * SPLAT_CHUNKS * C2 + cc, (size_t)C2, chunks, sh);
     if (threadIdx.x < 64 && c < C2) datt[(size_t)n * C2 + c] = a;
 }
-__global__ void splat_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ att, int64_t hw,
-                                       int C, float* __restrict__ out, int64_t total4) {
+template <typename T>
+__global__ void splat_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ att, int64_t hw,
+                                       int C, T* __restrict__ out, int64_t total4) {
     const int C4 = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / C4;
@@ -330,16 +335,16 @@ __global__ void splat_apply_fwd_kernel(const float* __restrict__ x, const float*
         const int64_t n = p / hw;
         const float4 a0 = *reinterpret_cast<const float4*>(att + n * 2 * C + c);
         const float4 a1 = *reinterpret_cast<const float4*>(att + n * 2 * C + C + c);
-        const float4 x0 = *reinterpret_cast<const float4*>(x + p * 2 * C + c);
-        const float4 x1 = *reinterpret_cast<const float4*>(x + p * 2 * C + C + c);
-        *reinterpret_cast<float4*>(out + p * C + c) =
-            make_float4(a0.x * x0.x + a1.x * x1.x, a0.y * x0.y + a1.y * x1.y, a0.z * x0.z + a1.z * x1.z,
-                        a0.w * x0.w + a1.w * x1.w);
+        const float4 x0 = ld4(x + p * 2 * C + c);
+        const float4 x1 = ld4(x + p * 2 * C + C + c);
+        st4(out + p * C + c, make_float4(a0.x * x0.x + a1.x * x1.x, a0.y * x0.y + a1.y * x1.y, a0.z * x0.z + a1.z * x1.z,
+                                         a0.w * x0.w + a1.w * x1.w));
     }
 }
-__global__ void splat_apply_bwd_kernel(const float* __restrict__ att, const float* __restrict__ dout,
+template <typename T>
+__global__ void splat_apply_bwd_kernel(const float* __restrict__ att, const T* __restrict__ dout,
                                        const float* __restrict__ dgap, int64_t hw, int C, float inv_hw,
-                                       float* __restrict__ dx, int64_t total4) {
+                                       T* __restrict__ dx, int64_t total4) {
     const int C4 = C >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / C4;
@@ -347,16 +352,14 @@ __global__ void splat_apply_bwd_kernel(const float* __restrict__ att, const floa
         const int64_t n = p / hw;
         const float4 a0 = *reinterpret_cast<const float4*>(att + n * 2 * C + c);
         const float4 a1 = *reinterpret_cast<const float4*>(att + n * 2 * C + C + c);
-        const float4 d = *reinterpret_cast<const float4*>(dout + p * C + c);
+        const float4 d = ld4(dout + p * C + c);
         float4 g = make_float4(0, 0, 0, 0);
         if (dgap) {
             g = *reinterpret_cast<const float4*>(dgap + n * C + c);
             g.x *= inv_hw; g.y *= inv_hw; g.z *= inv_hw; g.w *= inv_hw;
         }
-        *reinterpret_cast<float4*>(dx + p * 2 * C + c) =
-            make_float4(d.x * a0.x + g.x, d.y * a0.y + g.y, d.z * a0.z + g.z, d.w * a0.w + g.w);
-        *reinterpret_cast<float4*>(dx + p * 2 * C + C + c) =
-            make_float4(d.x * a1.x + g.x, d.y * a1.y + g.y, d.z * a1.z + g.z, d.w * a1.w + g.w);
+        st4(dx + p * 2 * C + c, make_float4(d.x * a0.x + g.x, d.y * a0.y + g.y, d.z * a0.z + g.z, d.w * a0.w + g.w));
+        st4(dx + p * 2 * C + C + c, make_float4(d.x * a1.x + g.x, d.y * a1.y + g.y, d.z * a1.z + g.z, d.w * a1.w + g.w));
     }
 }
 
@@ -443,8 +446,9 @@ static int pick_L(int Cin) {
 
 using namespace xv2;
 
-extern "C" int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
-                                     const float* w, const float* bias, float* y, int nchw_out, void* stream) {
+template <typename T>
+static int head_conv_forward_impl(const T* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout, const float* w,
+                                  const float* bias, float* y, int nchw_out, void* stream) {
     XV2_CHECK_ARG(Cout >= 1 && Cout <= 4, "head_conv: Cout=%d must be in 1..4", Cout);
     XV2_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0, "head_conv: Cin=%d must be a multiple of 4", Cin);
     const int L = pick_L(Cin);
@@ -452,7 +456,7 @@ extern "C" int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int6
     const int grid = (int)std::min<int64_t>(cdiv(npix, 256 / L), 16384);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_HF(CO) \
-    hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, st, x, ldx, npix, hw, Cin, w, bias, y, nchw_out, L)
+    hipLaunchKernelGGL((head_fwd_kernel<CO, T>), dim3(grid), dim3(256), 0, st, x, ldx, npix, hw, Cin, w, bias, y, nchw_out, L)
     switch (Cout) {
         case 1: LAUNCH_HF(1); break;
         case 2: LAUNCH_HF(2); break;
@@ -463,15 +467,22 @@ extern "C" int xv2_head_conv_forward(const float* x, int ldx, int64_t npix, int6
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
+extern "C" int xv2_head_conv_forward(const void* x, int ldx, int64_t npix, int64_t hw, int Cin, int Cout,
+                                     const float* w, const float* bias, float* y, int nchw_out, int dtype,
+                                     void* stream) {
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return head_conv_forward_impl<T>((const T*)x, ldx, npix, hw, Cin, Cout, w, bias, y, nchw_out, stream));
+}
 
 extern "C" size_t xv2_head_conv_backward_workspace(int64_t npix, int Cin, int Cout) {
     (void)npix;
     return (size_t)HEAD_BLOCKS * Cout * (Cin + 1) * sizeof(float);
 }
 
-extern "C" int xv2_head_conv_backward(const float* x, int ldx, const float* dy, int64_t npix, int64_t hw, int Cin,
-                                      int Cout, const float* w, int nchw_dy, float* dx, int lddx, float* dw,
-                                      float* dbias, float* workspace, void* stream) {
+template <typename T>
+static int head_conv_backward_impl(const T* x, int ldx, const float* dy, int64_t npix, int64_t hw, int Cin, int Cout,
+                                   const float* w, int nchw_dy, T* dx, int lddx, float* dw, float* dbias,
+                                   float* workspace, void* stream) {
     XV2_CHECK_ARG(Cout >= 1 && Cout <= 4, "head_conv: Cout=%d must be in 1..4", Cout);
     XV2_CHECK_ARG(Cin % 4 == 0 && ldx % 4 == 0 && (!dx || lddx % 4 == 0), "head_conv: Cin=%d must be a multiple of 4", Cin);
     const int L = pick_L(Cin);
@@ -480,7 +491,7 @@ extern "C" int xv2_head_conv_backward(const float* x, int ldx, const float* dy, 
     hipStream_t st = (hipStream_t)stream;
     const size_t smem = (size_t)(256 / L) * Cout * L * 4 * sizeof(float);
 #define LAUNCH_HB(CO)                                                                                        \
-    hipLaunchKernelGGL(head_bwd_kernel<CO>, dim3(grid), dim3(256), smem, st, x, ldx, dy, npix, hw, Cin, w, \
+    hipLaunchKernelGGL((head_bwd_kernel<CO, T>), dim3(grid), dim3(256), smem, st, x, ldx, dy, npix, hw, Cin, w, \
                        nchw_dy, dx, lddx, workspace, L)
     switch (Cout) {
         case 1: LAUNCH_HB(1); break;
@@ -495,18 +506,27 @@ extern "C" int xv2_head_conv_backward(const float* x, int ldx, const float* dy, 
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
+extern "C" int xv2_head_conv_backward(const void* x, int ldx, const float* dy, int64_t npix, int64_t hw, int Cin,
+                                      int Cout, const float* w, int nchw_dy, void* dx, int lddx, float* dw,
+                                      float* dbias, float* workspace, int dtype, void* stream) {
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, return head_conv_backward_impl<T>((const T*)x, ldx, dy, npix, hw, Cin, Cout, w, nchw_dy,
+                                                               (T*)dx, lddx, dw, dbias, workspace, stream));
+}
 
-extern "C" int xv2_add_relu_forward(const float* a, const float* b, float* r, int64_t n, void* stream) {
+extern "C" int xv2_add_relu_forward(const void* a, const void* b, void* r, int64_t n, int dtype, void* stream) {
     XV2_CHECK_ARG(n % 4 == 0, "add_relu: n must be a multiple of 4");
-    hipLaunchKernelGGL(add_relu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)a, (const float4*)b, (float4*)r, n / 4);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_relu_fwd_kernel<T>, dim3(grid_for(n / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)a, (const T*)b, (T*)r, n / 4));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_add_relu_backward(const float* r, const float* dr, float* dab, int64_t n, void* stream) {
+extern "C" int xv2_add_relu_backward(const void* r, const void* dr, void* dab, int64_t n, int dtype, void* stream) {
     XV2_CHECK_ARG(n % 4 == 0, "add_relu: n must be a multiple of 4");
-    hipLaunchKernelGGL(add_relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)r, (const float4*)dr, (float4*)dab, n / 4);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(add_relu_bwd_kernel<T>, dim3(grid_for(n / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)r, (const T*)dr, (T*)dab, n / 4));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -521,20 +541,24 @@ extern "C" int xv2_axpby(float alpha, const float* a, float beta, const float* b
 extern "C" int xv2_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
     return xv2_axpby(1.f, a, 1.f, b, out, n, stream);
 }
-extern "C" int xv2_gate_mul_forward(const float* skip, int lds, const float* gate, float* out, int64_t npix, int C,
-                                    void* stream) {
+extern "C" int xv2_gate_mul_forward(const void* skip, int lds, const float* gate, void* out, int64_t npix, int C,
+                                    int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0, "gate_mul: C must be a multiple of 4");
-    hipLaunchKernelGGL(gate_mul_fwd_kernel, dim3(grid_for(npix * C / 4)), dim3(256), 0, (hipStream_t)stream, skip,
-                       lds, gate, out, npix, C);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gate_mul_fwd_kernel<T>, dim3(grid_for(npix * C / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)skip, lds, gate, (T*)out, npix, C));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_gate_mul_backward(const float* skip, int lds, const float* gate, const float* dout, float* dskip,
-                                     float* dgate, int64_t npix, int C, void* stream) {
+extern "C" int xv2_gate_mul_backward(const void* skip, int lds, const float* gate, const void* dout, void* dskip,
+                                     float* dgate, int64_t npix, int C, int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0, "gate_mul: C must be a multiple of 4");
+    XV2_CHECK_DTYPE(dtype);
     const int L = pick_L(C);
-    hipLaunchKernelGGL(gate_mul_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(npix, 256 / L), 16384)), dim3(256),
-                       0, (hipStream_t)stream, skip, lds, gate, dout, dskip, dgate, npix, C, L);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(gate_mul_bwd_kernel<T>,
+                                                 dim3((unsigned)std::min<int64_t>(cdiv(npix, 256 / L), 16384)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)skip, lds, gate, (const T*)dout,
+                                                 (T*)dskip, dgate, npix, C, L));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -553,10 +577,12 @@ extern "C" int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, in
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_copy_channels(const float* src, int lds, float* dst, int ldd, int64_t npix, int C, void* stream) {
+extern "C" int xv2_copy_channels(const void* src, int lds, void* dst, int ldd, int64_t npix, int C, int dtype,
+                                 void* stream) {
     XV2_CHECK_ARG(C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "copy_channels: multiples of 4 required");
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * C / 4)), dim3(256), 0, (hipStream_t)stream, src,
-                       lds, dst, ldd, npix, C);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid_for(npix * C / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)src, lds, (T*)dst, ldd, npix, C));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -578,40 +604,43 @@ static inline int splat_rows(int64_t hw, int C2, int N, int& chunks, int& cgw) {
     return (int)rpc;
 }
 static inline bool splat_vec_ok(int C) { return C % 4 == 0 && ((2 * C) % 256 == 0 || (2 * C <= 256 && 256 % (2 * C / 4) == 0)); }
-extern "C" int xv2_splat_gap_forward(const float* x, int N, int64_t hw, int C, float* gap, float* workspace,
-                                     void* stream) {
+extern "C" int xv2_splat_gap_forward(const void* x, int N, int64_t hw, int C, float* gap, float* workspace,
+                                     int dtype, void* stream) {
     XV2_CHECK_ARG(splat_vec_ok(C), "splat_gap: unsupported channel count %d", C);
+    XV2_CHECK_DTYPE(dtype);
     int chunks, cgw;
     const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, (const float*)nullptr, hw,
-                       2 * C, 0, cgw, rpc, workspace);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(splat_colsum_kernel<T>, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
+                                                 (const T*)x, (const T*)nullptr, hw, 2 * C, 0, cgw, rpc, workspace));
     XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, 64), N), dim3(256), 0, st, workspace, N, C,
                        chunks, 1.f / (float)hw, gap);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_splat_apply_forward(const float* x, const float* att, int N, int64_t hw, int C, float* out,
-                                       void* stream) {
+extern "C" int xv2_splat_apply_forward(const void* x, const float* att, int N, int64_t hw, int C, void* out,
+                                       int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "splat_apply: C must be a multiple of 4");
+    XV2_CHECK_DTYPE(dtype);
     const int64_t total4 = (int64_t)N * hw * C / 4;
-    hipLaunchKernelGGL(splat_apply_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, att, hw,
-                       C, out, total4);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(splat_apply_fwd_kernel<T>, dim3(grid_for(total4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)x, att, hw, C, (T*)out, total4));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_splat_apply_backward(const float* x, const float* att, const float* dout, const float* dgap,
-                                        int N, int64_t hw, int C, float* dx, float* datt, float* workspace,
-                                        void* stream) {
+extern "C" int xv2_splat_apply_backward(const void* x, const float* att, const void* dout, const float* dgap,
+                                        int N, int64_t hw, int C, void* dx, float* datt, float* workspace,
+                                        int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "splat_apply: C must be a multiple of 4");
+    XV2_CHECK_DTYPE(dtype);
     hipStream_t st = (hipStream_t)stream;
     if (datt) {
         XV2_CHECK_ARG(splat_vec_ok(C), "splat_apply: unsupported channel count %d", C);
         int chunks, cgw;
         const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
-        hipLaunchKernelGGL(splat_colsum_kernel, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st, x, dout, hw, 2 * C, C,
-                           cgw, rpc, workspace);
+        XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(splat_colsum_kernel<T>, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
+                                                     (const T*)x, (const T*)dout, hw, 2 * C, C, cgw, rpc, workspace));
         XV2_CHECK_LAUNCH();
         hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(2 * C, 64), N), dim3(256), 0, st,
                            workspace, N, 2 * C, chunks, datt);
@@ -619,8 +648,8 @@ extern "C" int xv2_splat_apply_backward(const float* x, const float* att, const 
     }
     if (dx) {
         const int64_t total4 = (int64_t)N * hw * C / 4;
-        hipLaunchKernelGGL(splat_apply_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, st, att, dout, dgap, hw, C,
-                           1.f / (float)hw, dx, total4);
+        XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(splat_apply_bwd_kernel<T>, dim3(grid_for(total4)), dim3(256), 0, st, att,
+                                                     (const T*)dout, dgap, hw, C, 1.f / (float)hw, (T*)dx, total4));
         XV2_CHECK_LAUNCH();
     }
     return XV2_OK;

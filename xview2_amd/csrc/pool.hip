@@ -10,14 +10,13 @@
 
 namespace xv2 {
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void add4(float4& a, const float4& b, float w) {
     a.x += b.x * w; a.y += b.y * w; a.z += b.z * w; a.w += b.w * w;
 }
 
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
-                                                           int OH, int OW, float* __restrict__ y,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C,
+                                                           int OH, int OW, T* __restrict__ y,
                                                            uint8_t* __restrict__ idx) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * OH * OW * C4;
@@ -55,9 +54,10 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dy,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dy,
                                                            const uint8_t* __restrict__ idx, int N, int H, int W,
-                                                           int C, int OH, int OW, float* __restrict__ dx) {
+                                                           int C, int OH, int OW, T* __restrict__ dx) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -102,9 +102,10 @@ __device__ __forceinline__ float avg_divisor(int o, int k, int s, int pad, int L
     return (float)(incl ? pool : (en - st));
 }
 
-__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C,
                                                            int k, int s, int pad, int incl, int OH, int OW,
-                                                           float* __restrict__ y) {
+                                                           T* __restrict__ y) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * OH * OW * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -124,9 +125,10 @@ __global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C,
+template <typename T>
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const T* __restrict__ dy, int N, int H, int W, int C,
                                                            int k, int s, int pad, int incl, int OH, int OW,
-                                                           float* __restrict__ dx) {
+                                                           T* __restrict__ dx) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -307,37 +309,43 @@ static inline int grid_for(int64_t total) {
 
 using namespace xv2;
 
-extern "C" int xv2_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, float* y, uint8_t* idx,
+extern "C" int xv2_maxpool3x3s2_forward(const void* x, int N, int H, int W, int C, void* y, uint8_t* idx, int dtype,
                                         void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
+    XV2_CHECK_DTYPE(dtype);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, N, H, W, C, OH, OW, y, idx);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for((int64_t)N * OH * OW * C / 4)), dim3(256),
+                                                 0, (hipStream_t)stream, (const T*)x, N, H, W, C, OH, OW, (T*)y, idx));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_maxpool3x3s2_backward(const float* dy, const uint8_t* idx, int N, int H, int W, int C, float* dx,
-                                         void* stream) {
+extern "C" int xv2_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, int N, int H, int W, int C, void* dx,
+                                         int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
+    XV2_CHECK_DTYPE(dtype);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, dy, idx, N, H, W, C, OH, OW, dx);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)dy, idx, N, H, W, C, OH, OW, (T*)dx));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_avgpool_forward(const float* x, int N, int H, int W, int C, int k, int s, int pad,
-                                   int count_include_pad, int OH, int OW, float* y, void* stream) {
+extern "C" int xv2_avgpool_forward(const void* x, int N, int H, int W, int C, int k, int s, int pad,
+                                   int count_include_pad, int OH, int OW, void* y, int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "avgpool: C=%d must be a multiple of 4", C);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((int64_t)N * OH * OW * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, N, H, W, C, k, s, pad, count_include_pad, OH, OW, y);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(grid_for((int64_t)N * OH * OW * C / 4)), dim3(256),
+                                                 0, (hipStream_t)stream, (const T*)x, N, H, W, C, k, s, pad,
+                                                 count_include_pad, OH, OW, (T*)y));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_avgpool_backward(const float* dy, int N, int H, int W, int C, int k, int s, int pad,
-                                    int count_include_pad, int OH, int OW, float* dx, void* stream) {
+extern "C" int xv2_avgpool_backward(const void* dy, int N, int H, int W, int C, int k, int s, int pad,
+                                    int count_include_pad, int OH, int OW, void* dx, int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "avgpool: C=%d must be a multiple of 4", C);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, dy, N, H, W, C, k, s, pad, count_include_pad, OH, OW, dx);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)dy, N, H, W, C, k, s, pad,
+                                                 count_include_pad, OH, OW, (T*)dx));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

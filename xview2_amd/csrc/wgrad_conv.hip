@@ -12,6 +12,7 @@
 // model/layers.py and of the encoder blocks.
 #include "xv2_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace xv2 {
 
@@ -41,8 +42,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // BF16 = true: XV2_MATH_BF16 - the fp32 LDS tiles are kept, each lane gathers 8 consecutive pixels of its channel,
 // rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16 (8x fewer matrix instructions, fp32 accumulate).
-template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false>
+// HS = true (XV2_MATH_BF16_STORE): dY and X are bf16 in HBM (the RGB image of the stem stays fp32); a 4-channel element is
+// one 8-byte load widened to fp32 on its way into the unchanged fp32 LDS tiles.
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false, bool HS = false>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+    typedef typename std::conditional<HS, bf16_t, float>::type DT;                 // dY element
+    typedef typename std::conditional<HS && !SMALLC, bf16_t, float>::type XT;      // X element
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
     constexpr int MR = BM / WGM / 32, NR = BN / WGN / 32;
     static_assert(WGM * WGN * WK == 4, "4 waves");
     constexpr int AF4 = BM / 4, ARPP = 256 / AF4, APASS = 32 / ARPP;  // float4 per row, rows per pass
@@ -123,13 +129,25 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         const int iw0 = ow0 * p.stride;
         const int dbase = mb * p.ldDY;
 #pragma unroll
-        for (int j = 0; j < APASS; ++j)
-            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (dbase + a_const[j]) << 2, 0, 0));
+        for (int j = 0; j < APASS; ++j) {
+            if constexpr (HS) {
+                const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsD, (dbase + a_const[j]) << 1, 0, 0);
+                ra[j] = bf16x4_to_f32((unsigned)v.x, (unsigned)v.y);
+            } else {
+                ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (dbase + a_const[j]) << 2, 0, 0));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             const bool ok = rowok && (unsigned)(iw0 + b_k[j]) < (unsigned)p.IW;
-            const int off = ok ? ((ubase + b_const[j]) << 2) : (int)0x80000000;
-            rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+            if constexpr (HS) {
+                const int off = ok ? ((ubase + b_const[j]) << 1) : (int)0x80000000;
+                const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsX, off, 0, 0);
+                rb[j] = bf16x4_to_f32((unsigned)v.x, (unsigned)v.y);
+            } else {
+                const int off = ok ? ((ubase + b_const[j]) << 2) : (int)0x80000000;
+                rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+            }
         }
     };
     auto gload = [&](int kt) {
@@ -144,7 +162,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < APASS; ++j) {
             const int m = mb + a_r + j * ARPP;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < p.M) v = *reinterpret_cast<const float4*>(p.DY + (size_t)m * p.ldDY + co0 + a_c4 * 4);
+            if (m < p.M) v = ld4(reinterpret_cast<const DT*>(p.DY) + (size_t)m * p.ldDY + co0 + a_c4 * 4);
             ra[j] = v;
         }
 #pragma unroll
@@ -162,7 +180,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
                     if constexpr (SMALLC)
                         v = *reinterpret_cast<const float4*>(p.X0 + pix * p.ldX0);
                     else
-                        v = *reinterpret_cast<const float4*>(xsrc + pix * ldx + xch + b_c4 * 4);
+                        v = ld4(reinterpret_cast<const XT*>(xsrc) + pix * ldx + xch + b_c4 * 4);
                 }
             }
             rb[j] = v;
@@ -277,8 +295,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // (5 or 4 accumulators), gathers 8 pixels of its channel per lane out of the fp32 LDS rows, rounds them to bf16 and
 // issues v_mfma_f32_32x32x16_bf16.  Pixel rows are padded to 36 floats so the two lane halves (8 pixels apart) fall
 // into different banks.
-template <bool BF16>
+template <bool BF16, bool HS = false>
 __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams p) {
+    typedef typename std::conditional<HS, bf16_t, float>::type ET;     // dY / X element in HBM
     constexpr int LDP = BF16 ? 36 : 32;
     __shared__ __attribute__((aligned(16))) float smem[(2 * 32 + 4 * 34) * LDP < 4096 ? 4096 : (2 * 32 + 4 * 34) * LDP];
     float* dYs = smem;                  // [2][32 px][LDP]
@@ -307,20 +326,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
     float4 rd, rx0, rx1;
     // per-thread element pointers at image row 0 of sample n; a row step is ONE uniform pitch away (the 64-bit
     // index arithmetic of three loads per row was a third of this kernel's vector instructions)
-    const float* dy0 = p.DY + ((size_t)n * p.OH * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4;
+    const ET* dy0 = reinterpret_cast<const ET*>(p.DY) + ((size_t)n * p.OH * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4;
     const size_t dy_pitch = (size_t)p.OW * p.ldDY;
     const int iw = ow0 - 1 + px;
-    const float* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c4 * 4;       // halo pixel px
+    const ET* xa0 = reinterpret_cast<const ET*>(xsrc) + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c4 * 4;   // halo pixel px
     const size_t x_pitch = (size_t)p.IW * ldx;
     const bool xa_ok = iw >= 0, xb_ok = tid < 16 && iw + 32 < p.IW;                        // halo pixels 32, 33
-    auto load_dy = [&](int r) { rd = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch); };
+    auto load_dy = [&](int r) { rd = ld4(dy0 + (size_t)r * dy_pitch); };
     auto load_x = [&](int ih) {      // input row ih, pixels ow0-1 .. ow0+32
         rx0 = zero4;
         rx1 = zero4;
         if ((unsigned)ih < (unsigned)p.IH) {
-            const float* row = xa0 + (size_t)ih * x_pitch;
-            if (xa_ok) rx0 = *reinterpret_cast<const float4*>(row);
-            if (xb_ok) rx1 = *reinterpret_cast<const float4*>(row + (size_t)32 * ldx);
+            const ET* row = xa0 + (size_t)ih * x_pitch;
+            if (xa_ok) rx0 = ld4(row);
+            if (xb_ok) rx1 = ld4(row + (size_t)32 * ldx);
         }
     };
     auto store_dy = [&](int buf) { *reinterpret_cast<float4*>(dYs + buf * (32 * LDP) + px * LDP + c4 * 4) = rd; };
@@ -599,20 +618,21 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
     return pl;
 }
 
-template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false>
+template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = false, bool HS = false>
 static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 32 * (BM + BN) * 4;
-    auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC, BF16>;
+    auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC, BF16, HS>;
     static int kid = -1;
     if (kid < 0) {
         char nm[96];
-        snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, WGM, WGN, WK,
-                 SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"));
+        snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s%s>", BM, BN, WGM, WGN, WK,
+                 SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"), HS ? ",bf16hbm" : "");
         kid = prof_register(nm);
     }
     const double creal = SMALLC ? 3.0 : (double)p.Ctot;
+    const double ex = (HS && !SMALLC) ? 2.0 : 4.0, ed = HS ? 2.0 : 4.0;
     prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * creal,
-               4.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * creal + (double)p.M * p.Cout + (double)p.Cout * p.T * creal),
+               ex * (double)p.M / (p.OH * p.OW) * p.IH * p.IW * creal + ed * (double)p.M * p.Cout + 4.0 * (double)p.Cout * p.T * creal,
                stream);
     hipLaunchKernelGGL(kern, dim3(pl.tiles, pl.splitk), dim3(256), smem, stream, p);
     prof_end(stream);
@@ -626,6 +646,7 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     XV2_CHECK_ARG(d->KH * d->KW <= 52, "too many taps");
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
     const WgradPlan pl = make_plan(d);
+    const bool hs = d->math == XV2_MATH_BF16_STORE;
     XV2_CHECK_ARG(pl.smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "backward_weight: C0=%d C1=%d must be multiples of 32", d->C0, d->C1);
     WgradParams p;
@@ -639,9 +660,10 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
     p.tiles_n = pl.smallc ? (int)cdiv(p.T * 4, pl.bn) : p.Ctot / pl.bn;
     const size_t total = (size_t)d->Cout * p.T * p.Ctot;
     {
-        const long long bx0 = (long long)d->N * d->IH * d->IW * ldx0 * 4;
-        const long long bx1 = x1 ? (long long)d->N * d->IH * d->IW * ldx1 * 4 : 0;
-        const long long bdy = (long long)p.M * lddy * 4;
+        const long long ed = hs ? 2 : 4, ex = (hs && !pl.smallc) ? 2 : 4;
+        const long long bx0 = (long long)d->N * d->IH * d->IW * ldx0 * ex;
+        const long long bx1 = x1 ? (long long)d->N * d->IH * d->IW * ldx1 * ex : 0;
+        const long long bdy = (long long)p.M * lddy * ed;
         p.fast = (d->OW % 32 == 0 && bx0 < (1ll << 31) && bx1 < (1ll << 31) && bdy < (1ll << 31)) ? 1 : 0;
         p.bytesX0 = (unsigned)std::min<long long>(bx0, 0x7fffffffll);
         p.bytesX1 = (unsigned)std::min<long long>(bx1, 0x7fffffffll);
@@ -654,14 +676,17 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         }
     int rc;
     if (pl.alltaps) {
-        static int kid = -1, kid16 = -1;
+        static int kid = -1, kid16 = -1, kid16s = -1;
         if (kid < 0) {
             kid = prof_register("wgrad_alltaps_kernel");
             kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
+            kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
         }
-        prof_begin(d->math ? kid16 : kid, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
-                   4.0 * ((double)p.M * p.Ctot + (double)p.M * p.Cout + (double)total), stream);
-        if (d->math)
+        prof_begin(hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+                   (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
+        if (hs)
+            hipLaunchKernelGGL((wgrad_alltaps_kernel<true, true>), dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        else if (d->math)
             hipLaunchKernelGGL(wgrad_alltaps_kernel<true>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else
             hipLaunchKernelGGL(wgrad_alltaps_kernel<false>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
@@ -669,8 +694,17 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         XV2_CHECK_LAUNCH();
         rc = XV2_OK;
     } else if (pl.smallc) {
-        if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
+        if (hs) {
+            if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true, false, true>(p, pl, stream);
+            else rc = launch_wgrad<32, 64, 1, 2, 2, true, false, true>(p, pl, stream);
+        } else if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
+    } else if (hs) {
+        if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false, true, true>(p, pl, stream);
+        else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false, true, true>(p, pl, stream);
+        else if (pl.bm == 64 && pl.bn == 32) rc = launch_wgrad<64, 32, 2, 1, 2, false, true, true>(p, pl, stream);
+        else if (pl.bm == 32 && pl.bn == 64) rc = launch_wgrad<32, 64, 1, 2, 2, false, true, true>(p, pl, stream);
+        else rc = launch_wgrad<32, 32, 1, 1, 4, false, false, true>(p, pl, stream);
     } else if (d->math == XV2_MATH_BF16 && !(pl.bm == 32 && pl.bn == 32)) {
         if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false, true>(p, pl, stream);
         else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false, true>(p, pl, stream);
@@ -714,16 +748,17 @@ extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d) {
     return (size_t)(pl.nslab + pl.groups) * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
 }
 
-extern "C" int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const float* x0, int ldx0,
-                                          const float* x1, int ldx1, const float* dy, int lddy,
+extern "C" int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
+                                          const void* x1, int ldx1, const void* dy, int lddy,
                                           float* dw_oihw, int cin_real, float* workspace, void* stream) {
-    return wgrad_impl(d, x0, ldx0, x1, ldx1, dy, lddy, dw_oihw, cin_real, workspace, (hipStream_t)stream);
+    return wgrad_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)dy, lddy, dw_oihw, cin_real, workspace,
+                      (hipStream_t)stream);
 }
 
 // conv_transpose: the equivalent conv `d` has input = the transposed conv's OUTPUT gradient (large
 // tensor, C0 channels) and output-gradient = the transposed conv's INPUT x (Cout channels).
-extern "C" int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const float* x, int ldx,
-                                                    const float* dy, int lddy, float* dw, float* workspace,
+extern "C" int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const void* x, int ldx,
+                                                    const void* dy, int lddy, float* dw, float* workspace,
                                                     void* stream) {
-    return wgrad_impl(d, dy, lddy, nullptr, 0, x, ldx, dw, d->C0, workspace, (hipStream_t)stream);
+    return wgrad_impl(d, (const float*)dy, lddy, nullptr, 0, (const float*)x, ldx, dw, d->C0, workspace, (hipStream_t)stream);
 }

@@ -61,6 +61,63 @@ __device__ __forceinline__ float act_grad_from_pre(float u, int act) {
     return 1.f;
 }
 
+// ---- activation storage types --------------------------------------------------------------------------------
+// Activations live in HBM either as fp32 or (XV2_BF16: the --precision 16 path) as bf16; every kernel computes in
+// fp32 registers.  bf16_t is the raw 16-bit pattern; conversion to fp32 is a shift, back is round-to-nearest-even.
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// the value a bf16 store will hold (statistics are taken on what is actually stored)
+__device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ float4 ld4(const bf16_t* p) {     // 4 channels = one 8-byte load
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, const float4& v) {
+        uint2 u;
+        u.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        u.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+    static __device__ __forceinline__ float round(float v) { return bf16_round(v); }
+};
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p) { return Elem<T>::ld4(p); }
+template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v) { Elem<T>::st4(p, v); }
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return Elem<T>::ld(p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { Elem<T>::st(p, v); }
+// 4 packed bf16 (8 bytes, as loaded by a b64 buffer load) -> fp32
+__device__ __forceinline__ float4 bf16x4_to_f32(unsigned lo, unsigned hi) {
+    return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                       __uint_as_float(hi & 0xffff0000u));
+}
+
+#define XV2_CHECK_DTYPE(dt) XV2_CHECK_ARG((dt) == XV2_F32 || (dt) == XV2_BF16, "unknown activation dtype %d", (int)(dt))
+// run `call` with T bound to the storage type named by dtype
+#define XV2_DISPATCH_DTYPE(dt, ...)             \
+    do {                                        \
+        if ((dt) == XV2_BF16) {                 \
+            typedef xv2::bf16_t T;              \
+            __VA_ARGS__;                        \
+        } else {                                \
+            typedef float T;                    \
+            __VA_ARGS__;                        \
+        }                                       \
+    } while (0)
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

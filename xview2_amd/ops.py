@@ -28,6 +28,35 @@ def _f32(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# Storage type of activation tensors (and of their gradients / the packed weight layouts): fp32, or bf16 for the
+# --precision 16 path (XV2_MATH_BF16_STORE).  Statistics, coefficients, logits, weight gradients and the master weights
+# are always fp32.  The kernels take the element type from the tensors they are handed (`_dt`), this switch only
+# decides what NEW activation tensors are made of.
+STORAGE = torch.float32
+XV2_F32, XV2_BF16 = 0, 1
+
+
+def set_storage_dtype(dtype):
+    """torch.bfloat16: bf16 activations in HBM (implies the bf16 MFMA); None / torch.float32: fp32 storage"""
+    global STORAGE
+    STORAGE = torch.bfloat16 if dtype == torch.bfloat16 else torch.float32
+    clear_pack_cache()
+
+
+def _act(shape, like, dtype=None):
+    """a new activation tensor: element type of `like` unless given"""
+    return torch.empty(shape, dtype=like.dtype if dtype is None else dtype, device=like.device)
+
+
+def _dt(t):
+    return XV2_BF16 if t.dtype == torch.bfloat16 else XV2_F32
+
+
+def _same(t, like):
+    """`t` in the element type of `like` (gradients arriving from fp32-only ops)"""
+    return t if t is None or t.dtype == like.dtype else t.to(like.dtype)
+
+
 def _ws(nbytes, like):
     return torch.empty(((int(nbytes) + 3) // 4 + 4,), dtype=torch.float32, device=like.device)
 
@@ -63,13 +92,17 @@ def _out_hw(IH, IW, g):
     return OH, OW
 
 
-MATH_F32, MATH_BF16 = 0, 1
-MATH_MODE = MATH_F32     # process-wide default (set from --precision by the trainer / bench)
+MATH_F32, MATH_BF16, MATH_BF16_STORE = 0, 1, 2
+MATH_MODE = MATH_F32     # process-wide default for fp32-stored tensors (set from --precision by the trainer / bench)
 
 
-def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW):
-    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW,
-                    getattr(g, "math", None) if getattr(g, "math", None) is not None else MATH_MODE)
+def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW, half=False):
+    """half: the activations of this convolution are bf16 in HBM (XV2_MATH_BF16_STORE)"""
+    if half:
+        math = MATH_BF16_STORE
+    else:
+        math = getattr(g, "math", None) if getattr(g, "math", None) is not None else MATH_MODE
+    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW, math)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -89,18 +122,21 @@ PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is
 
 
 class _PackEntry:
-    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner")
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype")
 
 
-def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
+def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
+    """half: bf16 layouts (XV2_MATH_BF16_STORE); the 4-channel RGB stem weights are always packed in fp32"""
     global _pack_table, _pack_tick
     Cout, Cin, KH, KW = w_oihw.shape
+    pdt = torch.bfloat16 if (half and cin_pad != 4) else torch.float32
+    code = XV2_BF16 if pdt == torch.bfloat16 else XV2_F32
     if not PACK_CACHE:
-        ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw) if want_ohwi else None
-        ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw) if want_ihwo else None
-        call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, ohwi, ihwo)
+        ohwi = _act((Cout, KH * KW, cin_pad), w_oihw, pdt) if want_ohwi else None
+        ihwo = _act((cin_pad, KH * KW, Cout), w_oihw, pdt) if want_ihwo else None
+        call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, ohwi, ihwo, code)
         return ohwi, ihwo
-    key = (w_oihw.data_ptr(), Cout, Cin, KH, KW, cin_pad)
+    key = (w_oihw.data_ptr(), Cout, Cin, KH, KW, cin_pad, code)
     e = _packs.get(key)
     fresh = e is not None and e.version == w_oihw._version and e.epoch == WEIGHT_EPOCH
     _pack_tick += 1
@@ -119,17 +155,18 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo):
         e.geom = (Cout, Cin, KH * KW, cin_pad)
         _packs[key] = e
         _pack_table = None
+    e.dtype = code
     if want_ohwi and e.ohwi is None:
-        e.ohwi = _f32((Cout, KH * KW, cin_pad), w_oihw)
+        e.ohwi = _act((Cout, KH * KW, cin_pad), w_oihw, pdt)
         _pack_table = None
     if want_ihwo and e.ihwo is None:
-        e.ihwo = _f32((cin_pad, KH * KW, Cout), w_oihw)
+        e.ihwo = _act((cin_pad, KH * KW, Cout), w_oihw, pdt)
         _pack_table = None
     e.w = w_oihw.detach()
     base = w_oihw._base if w_oihw._base is not None else w_oihw
     e.owner = weakref.ref(base)        # the parameter; once it is gone the entry only wastes memory
     e.tick = _pack_tick
-    call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo)
+    call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo, code)
     e.version, e.epoch = w_oihw._version, WEIGHT_EPOCH
     return e.ohwi, e.ihwo
 
@@ -169,7 +206,7 @@ def repack_all():
         for e in _packs.values():
             Cout, Cin, T, cin_pad = e.geom
             rows.append([e.w.data_ptr(), e.ohwi.data_ptr() if e.ohwi is not None else 0,
-                         e.ihwo.data_ptr() if e.ihwo is not None else 0, Cout, Cin, T, cin_pad, start])
+                         e.ihwo.data_ptr() if e.ihwo is not None else 0, Cout, Cin, T | (e.dtype << 16), cin_pad, start])
             start += query("xv2_pack_weights_tiles", Cout, T, 1, cin_pad)
         dev = next(iter(_packs.values())).w.device
         _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start)
@@ -197,7 +234,11 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     Cout_t = weight.shape[0]
     G = g.groups
     OH, OW = _out_hw(IH, IW, g)
-    y = _f32((N, OH, OW, Cout_t), x0)
+    rgb = C0t == 4 and x1 is None               # the fp32 image of a stem: its OUTPUT follows the storage switch
+    half = (STORAGE == torch.bfloat16) if rgb else x0.dtype == torch.bfloat16
+    if x1 is not None and x1.dtype != x0.dtype:
+        raise RuntimeError("convolution sources of different element types (%s, %s)" % (x0.dtype, x1.dtype))
+    y = _act((N, OH, OW, Cout_t), x0, torch.bfloat16 if half else torch.float32)
     sums = torch.empty((Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
     coeffs = None
     if want_stats and bn is not None and not _sync_group(bn):
@@ -210,10 +251,10 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     cin_w = w.shape[1]
     for gi in range(G):
         wg = w[gi * Coutg:(gi + 1) * Coutg]
-        ohwi, ihwo = _pack(wg, C0g + C1t, True, ihwo_out is not None)
+        ohwi, ihwo = _pack(wg, C0g + C1t, True, ihwo_out is not None, half)
         if ihwo_out is not None:
             ihwo_out.append(ihwo)
-        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         part = None
         if want_stats:
             tiles = query("xv2_conv2d_forward_stats_tiles", d)
@@ -253,19 +294,20 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
     w = weight.contiguous()
     C0g, Coutg = C0t // G, Cout_t // G
     if add_to0 is not None and not (add_to0.is_contiguous() and tuple(add_to0.shape) == (N, IH, IW, C0t)
-                                    and add_to0.dtype == torch.float32):
+                                    and add_to0.dtype == dy.dtype):
         raise RuntimeError("backward_data: accumulation target has the wrong layout")
-    dx0 = add_to0 if add_to0 is not None else _f32((N, IH, IW, C0t), dy)
-    dx1 = _f32((N, IH, IW, C1t), dy) if C1t else None
+    half = dy.dtype == torch.bfloat16
+    dx0 = add_to0 if add_to0 is not None else _act((N, IH, IW, C0t), dy)
+    dx1 = _act((N, IH, IW, C1t), dy) if C1t else None
     for gi in range(G):
         if ihwo_packs:
             ihwo = ihwo_packs[gi]
         else:
-            _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True)
-        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+            _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True, half)
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
         acc = 1 if add_to0 is not None else 0
-        if bnrec is not None and G == 1 and C1t == 0:
+        if bnrec is not None and G == 1 and C1t == 0 and not half:
             tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
             if tiles > 0:
                 part = _f32((tiles, C0t, 2), dy)
@@ -359,7 +401,7 @@ def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
     cin_real = weight.shape[1]
     dw = out if out is not None else _grad_like(weight if wparam is None else wparam)
     for gi in range(G):
-        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW)
+        d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, dy.dtype == torch.bfloat16)
         ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
         call("xv2_conv2d_backward_weight", d, Ptr(x0, gi * C0g), C0t, x1, C1t, Ptr(dy, gi * Coutg), Cout_t,
              Ptr(dw, gi * Coutg * cin_real * g.kh * g.kw), cin_real, ws)
@@ -476,6 +518,8 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
         count = float(npix)
     elif training:
         if sums is None:
+            if y.dtype != torch.float32:
+                raise RuntimeError("stand-alone BatchNorm statistics exist for fp32 tensors only")
             sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
             ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), y)
             call("xv2_bn_tensor_stats", y, C, npix, C, sums, ws)
@@ -484,15 +528,16 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
         mean, invstd, scale, shift = _bn_eval_coeffs(bn, y)
         count = float(npix)
     z = torch.empty_like(y)
+    residual = _same(residual, y)
     if want_mask:
         zmask = None
         if _mask_ok(C, act):
             zmask = torch.empty((npix * (C // 4),), dtype=torch.uint8, device=y.device)
-            call("xv2_bn_act_forward_mask", y, C, scale, shift, residual, C, act, z, C, npix, C, zmask)
+            call("xv2_bn_act_forward_mask", y, C, scale, shift, residual, C, act, z, C, npix, C, zmask, _dt(y))
         else:
-            call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
+            call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C, _dt(y))
         return z, (mean, invstd, count, scale, shift), zmask
-    call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C)
+    call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C, _dt(y))
     return z, (mean, invstd, count, scale, shift)
 
 
@@ -502,7 +547,8 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None):
     mean, invstd, count, scale, shift = stats
     C = y.shape[-1]
     npix = y.numel() // C
-    dz = dz.contiguous()
+    dz = _same(dz, y).contiguous()
+    dt = _dt(y)
     sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
     ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
@@ -517,20 +563,20 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None):
         scratch = torch.empty((64 * C * 2,), dtype=torch.float64, device=y.device)
         call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, scratch)
     elif masked:
-        call("xv2_bn_act_backward_reduce_mask", dz, C, z, y, C, mean, invstd, act, npix, C, sums2, dgamma, dbeta, ws)
+        call("xv2_bn_act_backward_reduce_mask", dz, C, z, y, C, mean, invstd, act, npix, C, sums2, dgamma, dbeta, ws, dt)
     else:
         call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
-             dbeta, ws)
+             dbeta, ws, dt)
     if training and _sync_group(bn):
         dist.all_reduce(sums2)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
     if masked:
         call("xv2_bn_act_backward_apply_mask", dz, C, z, y, C, mean, invstd, gamma, sums2, float(count), act,
-             1 if training else 0, dy, C, dres, C, npix, C)
+             1 if training else 0, dy, C, dres, C, npix, C, dt)
     else:
         call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, scale, shift, sums2, float(count),
-             act, 1 if training else 0, dy, C, dres, C, npix, C)
+             act, 1 if training else 0, dy, C, dres, C, npix, C, dt)
     return dy, dres, dgamma, dbeta
 
 
@@ -551,7 +597,9 @@ def conv_bn_act_infer(x0, x1, weight, residual, g, bn, act):
     _need_cuda(x0)
     x0 = x0.contiguous()
     x1 = x1.contiguous() if x1 is not None else None
-    residual = residual.contiguous() if residual is not None else None
+    if residual is not None:
+        half = (STORAGE == torch.bfloat16) if (x0.shape[-1] == 4 and x1 is None) else x0.dtype == torch.bfloat16
+        residual = residual.to(torch.bfloat16 if half else torch.float32).contiguous()
     scale, shift = _bn_eval_scale_shift(bn, x0)
     z, _ = _conv_forward(x0, x1, weight, g, None, want_stats=False, fused=(scale, shift, residual, act))
     return z
@@ -605,6 +653,7 @@ class ConvBnActFn(torch.autograd.Function):
         g = ctx.g
         if dz is None:
             dz = torch.zeros_like(y)
+        dpass = _same(dpass, y)
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
                                                ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec)
         ctx.rec = None
@@ -646,7 +695,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x0, x1, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _same(dy, x0 if x0.shape[-1] != 4 else dy).contiguous()
         g = ctx.g
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -661,7 +710,7 @@ class ConvFn(torch.autograd.Function):
             npix = dy.numel() // C
             sums = torch.empty((C, 2), dtype=torch.float64, device=dy.device)
             ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), dy)
-            call("xv2_bn_tensor_stats", dy, C, npix, C, sums, ws)
+            call("xv2_bn_tensor_stats", dy.float(), C, npix, C, sums, ws)     # column sums kernel: fp32 input
             db = sums[:, 0].to(torch.float32)
         return dx0, dx1, dw, db, None
 
@@ -677,9 +726,10 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         N, H, W, Cin = x.shape
         Cout = weight.shape[1]
         g = conv_cfg(2, 2, stride=2, pad=0)
-        d = _desc(N, 2 * H, 2 * W, Cout, 0, Cin, g, H, W)  # the equivalent 2x2/s2 convolution
-        _, ihwo = _pack(weight.contiguous(), Cout, False, True)
-        y = _f32((N, 2 * H, 2 * W, Cout), x)
+        half = x.dtype == torch.bfloat16
+        d = _desc(N, 2 * H, 2 * W, Cout, 0, Cin, g, H, W, half)  # the equivalent 2x2/s2 convolution
+        _, ihwo = _pack(weight.contiguous(), Cout, False, True, half)
+        y = _act((N, 2 * H, 2 * W, Cout), x)
         call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
         ctx.save_for_backward(x, weight)
         ctx.d = d
@@ -689,15 +739,15 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = _same(dy, x).contiguous()
         d = ctx.d
         Cin, Cout = weight.shape[0], weight.shape[1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            ohwi, _ = _pack(weight.contiguous(), Cout, True, False)
+            ohwi, _ = _pack(weight.contiguous(), Cout, True, False, x.dtype == torch.bfloat16)
             dx = torch.empty_like(x)
             rec, ctx.src_rec = ctx.src_rec, None
-            tiles = query("xv2_conv_transpose2d_backward_data_bn_tiles", d) if rec is not None else 0
+            tiles = query("xv2_conv_transpose2d_backward_data_bn_tiles", d) if (rec is not None and x.dtype == torch.float32) else 0
             if tiles > 0:      # the producer layer's BatchNorm-backward statistics ride along in the epilogue
                 part = _f32((tiles, Cin, 2), x)
                 call("xv2_conv_transpose2d_backward_data_bn", d, dy, Cout, ohwi, dx, Cin, rec.y, Cin, rec.mean,
@@ -723,7 +773,7 @@ class HeadConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         y = _f32((N, Cout, H, W) if nchw_out else (N, H, W, Cout), x)
         w2 = weight.reshape(Cout, Cin).contiguous()
-        call("xv2_head_conv_forward", x, Cin, N * H * W, H * W, Cin, Cout, w2, bias, y, 1 if nchw_out else 0)
+        call("xv2_head_conv_forward", x, Cin, N * H * W, H * W, Cin, Cout, w2, bias, y, 1 if nchw_out else 0, _dt(x))
         ctx.save_for_backward(x, w2)
         ctx.nchw, ctx.has_bias, ctx.wshape = nchw_out, bias is not None, weight.shape
         return y
@@ -731,7 +781,7 @@ class HeadConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = dy.float().contiguous()
         N, H, W, Cin = x.shape
         Cout = w2.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -739,7 +789,7 @@ class HeadConvFn(torch.autograd.Function):
         db = _f32((Cout,), x) if ctx.has_bias else None
         ws = _ws(query("xv2_head_conv_backward_workspace", N * H * W, Cin, Cout), x)
         call("xv2_head_conv_backward", x, Cin, dy, N * H * W, H * W, Cin, Cout, w2, 1 if ctx.nchw else 0, dx, Cin,
-             dw, db, ws)
+             dw, db, ws, _dt(x))
         return dx, dw.reshape(ctx.wshape), db, None
 
 
@@ -771,9 +821,9 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         x = x.contiguous()
         N, H, W, C = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = _f32((N, OH, OW, C), x)
+        y = _act((N, OH, OW, C), x)
         idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
-        call("xv2_maxpool3x3s2_forward", x, N, H, W, C, y, idx)
+        call("xv2_maxpool3x3s2_forward", x, N, H, W, C, y, idx, _dt(x))
         ctx.save_for_backward(idx)
         ctx.shape = (N, H, W, C)
         return y
@@ -782,8 +832,8 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         N, H, W, C = ctx.shape
-        dx = _f32(ctx.shape, dy)
-        call("xv2_maxpool3x3s2_backward", dy.contiguous(), idx, N, H, W, C, dx)
+        dx = _act(ctx.shape, dy)
+        call("xv2_maxpool3x3s2_backward", dy.contiguous(), idx, N, H, W, C, dx, _dt(dy))
         return dx
 
 
@@ -801,16 +851,16 @@ class AvgPoolFn(torch.autograd.Function):
                 o -= 1
             return o
         OH, OW = osz(H), osz(W)
-        y = _f32((N, OH, OW, C), x)
-        call("xv2_avgpool_forward", x, N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW, y)
+        y = _act((N, OH, OW, C), x)
+        call("xv2_avgpool_forward", x, N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW, y, _dt(x))
         ctx.cfg = (N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C, k, s, pad, inc, OH, OW = ctx.cfg
-        dx = _f32((N, H, W, C), dy)
-        call("xv2_avgpool_backward", dy.contiguous(), N, H, W, C, k, s, pad, inc, OH, OW, dx)
+        dx = _act((N, H, W, C), dy)
+        call("xv2_avgpool_backward", dy.contiguous(), N, H, W, C, k, s, pad, inc, OH, OW, dx, _dt(dy))
         return dx, None, None, None, None, None
 
 
@@ -818,19 +868,20 @@ class AdaptiveAvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bins):
         _need_cuda(x)
-        x = x.contiguous()
+        ctx.dtype = x.dtype
+        x = x.float().contiguous()          # PPM branch (not in any BASELINE configuration): fp32 kernels
         N, H, W, C = x.shape
         y = _f32((N, bins, bins, C), x)
         call("xv2_adaptive_avgpool_forward", x, C, N, H, W, C, bins, y)
         ctx.cfg = (N, H, W, C, bins)
-        return y
+        return y.to(ctx.dtype)
 
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C, bins = ctx.cfg
         dx = _f32((N, H, W, C), dy)
-        call("xv2_adaptive_avgpool_backward", dy.contiguous(), N, H, W, C, bins, dx, C, 0)
-        return dx, None
+        call("xv2_adaptive_avgpool_backward", dy.float().contiguous(), N, H, W, C, bins, dx, C, 0)
+        return dx.to(ctx.dtype), None
 
 
 class BilinearFn(torch.autograd.Function):
@@ -839,28 +890,29 @@ class BilinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, OH, OW):
         _need_cuda(x)
-        x = x.contiguous()
+        ctx.dtype = x.dtype
+        x = x.float().contiguous()          # PPM / --dec_interp / --interpolate paths: fp32 kernels
         N, IH, IW, C = x.shape
         y = _f32((N, OH, OW, C), x)
         call("xv2_bilinear_forward", x, N, IH, IW, C, OH, OW, y, C)
         ctx.cfg = (N, IH, IW, C, OH, OW)
-        return y
+        return y.to(ctx.dtype)
 
     @staticmethod
     def backward(ctx, dy):
         N, IH, IW, C, OH, OW = ctx.cfg
         dx = _f32((N, IH, IW, C), dy)
-        call("xv2_bilinear_backward", dy.contiguous(), C, N, IH, IW, C, OH, OW, dx)
-        return dx, None, None
+        call("xv2_bilinear_backward", dy.float().contiguous(), C, N, IH, IW, C, OH, OW, dx)
+        return dx.to(ctx.dtype), None, None
 
 
 class AddReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         _need_cuda(a)
-        a, b = a.contiguous(), b.contiguous()
+        a, b = a.contiguous(), _same(b, a).contiguous()
         r = torch.empty_like(a)
-        call("xv2_add_relu_forward", a, b, r, a.numel())
+        call("xv2_add_relu_forward", a, b, r, a.numel(), _dt(a))
         ctx.save_for_backward(r)
         return r
 
@@ -868,7 +920,7 @@ class AddReluFn(torch.autograd.Function):
     def backward(ctx, dr):
         (r,) = ctx.saved_tensors
         d = torch.empty_like(r)
-        call("xv2_add_relu_backward", r, dr.contiguous(), d, r.numel())
+        call("xv2_add_relu_backward", r, _same(dr, r).contiguous(), d, r.numel(), _dt(r))
         return d, d
 
 
@@ -878,10 +930,10 @@ class GateMulFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, skip, gate):
         _need_cuda(skip)
-        skip, gate = skip.contiguous(), gate.contiguous()
+        skip, gate = skip.contiguous(), gate.float().contiguous()
         C = skip.shape[-1]
         out = torch.empty_like(skip)
-        call("xv2_gate_mul_forward", skip, C, gate, out, skip.numel() // C, C)
+        call("xv2_gate_mul_forward", skip, C, gate, out, skip.numel() // C, C, _dt(skip))
         ctx.save_for_backward(skip, gate)
         return out
 
@@ -891,7 +943,8 @@ class GateMulFn(torch.autograd.Function):
         C = skip.shape[-1]
         dskip = torch.empty_like(skip)
         dgate = torch.empty_like(gate)
-        call("xv2_gate_mul_backward", skip, C, gate, dout.contiguous(), dskip, dgate, skip.numel() // C, C)
+        call("xv2_gate_mul_backward", skip, C, gate, _same(dout, skip).contiguous(), dskip, dgate, skip.numel() // C, C,
+             _dt(skip))
         return dskip, dgate
 
 
@@ -907,7 +960,7 @@ class SplitAttentionFn(torch.autograd.Function):
         C, hw = C2 // 2, H * W
         inter = w1.shape[0]
         gap = _f32((N, C), x)
-        call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x))
+        call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x), _dt(x))
         w1m, w2m = w1.reshape(inter, C).contiguous(), w2.reshape(C2, inter).contiguous()
         h1 = _f32((N, inter), x)
         call("xv2_linear_forward", gap, w1m, b1, h1, N, C, inter)
@@ -916,8 +969,8 @@ class SplitAttentionFn(torch.autograd.Function):
         call("xv2_linear_forward", a1, w2m, b2, logits, N, inter, C2)
         att = _f32((N, C2), x)
         call("xv2_rsoftmax_forward", logits, att, N, C)
-        out = _f32((N, H, W, C), x)
-        call("xv2_splat_apply_forward", x, att, N, hw, C, out)
+        out = _act((N, H, W, C), x)
+        call("xv2_splat_apply_forward", x, att, N, hw, C, out, _dt(x))
         ctx.save_for_backward(x, gap, w1m, h1, a1, g1, st[0], st[1], w2m, att, st[3], st[4])
         ctx.count, ctx.bn1, ctx.training = st[2], bn1, training
         ctx.shapes = (w1.shape, w2.shape)
@@ -927,13 +980,13 @@ class SplitAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att, scale1, shift1 = ctx.saved_tensors
-        dout = dout.contiguous()
+        dout = _same(dout, x).contiguous()
         N, H, W, C2 = x.shape
         C, hw = C2 // 2, H * W
         inter = w1m.shape[0]
         datt = _f32((N, C2), x)
         ws = _ws(query("xv2_splat_gap_workspace", N, hw, C), x)
-        call("xv2_splat_apply_backward", x, att, dout, None, N, hw, C, None, datt, ws)
+        call("xv2_splat_apply_backward", x, att, dout, None, N, hw, C, None, datt, ws, _dt(x))
         dlogits = _f32((N, C2), x)
         call("xv2_rsoftmax_backward", att, datt, dlogits, N, C)
         pw1, pb1, pw2, pb2 = ctx.params
@@ -947,7 +1000,7 @@ class SplitAttentionFn(torch.autograd.Function):
         db1 = _grad_like(pb1) if pb1 is not None else _f32((inter,), x)
         call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
         dx = torch.empty_like(x)
-        call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws)
+        call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws, _dt(x))
         s1, s2 = ctx.shapes
         return dx, dw1.reshape(s1), db1, dg1, dbe1, dw2.reshape(s2), db2, None, None
 
@@ -998,7 +1051,7 @@ def nchw_to_nhwc(x, c_pad=None):
 
 def nhwc_to_nchw(x):
     _need_cuda(x)
-    x = x.contiguous()
+    x = x.float().contiguous()
     N, H, W, C = x.shape
     y = _f32((N, C, H, W), x)
     call("xv2_nhwc_to_nchw", x, C, N, C, H, W, y)
@@ -1031,13 +1084,13 @@ class CatChannelsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
         _need_cuda(xs[0])
-        xs = [t.contiguous() for t in xs]
+        xs = [_same(t, xs[0]).contiguous() for t in xs]
         cs = [t.shape[-1] for t in xs]
-        out = _f32(tuple(xs[0].shape[:-1]) + (sum(cs),), xs[0])
+        out = _act(tuple(xs[0].shape[:-1]) + (sum(cs),), xs[0])
         npix = xs[0].numel() // cs[0]
         off = 0
         for t, c in zip(xs, cs):
-            call("xv2_copy_channels", t, c, Ptr(out, off), sum(cs), npix, c)
+            call("xv2_copy_channels", t, c, Ptr(out, off), sum(cs), npix, c, _dt(out))
             off += c
         ctx.cs = cs
         return out
@@ -1049,8 +1102,8 @@ class CatChannelsFn(torch.autograd.Function):
         npix = d.numel() // sum(cs)
         outs, off = [], 0
         for c in cs:
-            o = _f32(tuple(d.shape[:-1]) + (c,), d)
-            call("xv2_copy_channels", Ptr(d, off), sum(cs), o, c, npix, c)
+            o = _act(tuple(d.shape[:-1]) + (c,), d)
+            call("xv2_copy_channels", Ptr(d, off), sum(cs), o, c, npix, c, _dt(d))
             outs.append(o)
             off += c
         return tuple(outs)

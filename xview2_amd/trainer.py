@@ -3,7 +3,8 @@
 every epoch driving ``f1_score`` checkpointing (ModelCheckpoint(monitor="f1_score", mode="max", save_last=True)),
 resume.  Checkpoints keep PL's layout ``{"state_dict": ..., "hyper_parameters": {"args": ...}, "epoch": ...}`` with the
 reference's key names (``model.unet.enc_l1.0.weight`` ...), so files move between the two code bases.
-``precision=16`` (the reference's fp16 AMP) selects XV2_MATH_BF16: bf16 MFMA with fp32 accumulation/storage."""
+``precision=16`` (the reference's fp16 AMP) selects XV2_MATH_BF16_STORE: bf16 activations in HBM, bf16 MFMA with fp32
+accumulation, fp32 BatchNorm statistics and master weights."""
 import os
 
 import torch
@@ -21,9 +22,10 @@ class Trainer:
         self.checkpointing = bool(checkpoint_callback)
         self.log_every = log_every
         from . import ops
-        # the reference's --precision 16 is fp16 autocast (convs in half precision, fp32 accumulate, fp32 BN/master
-        # weights); here: bf16 MFMA on bf16-rounded operands with everything else in fp32
+        # the reference's --precision 16 is fp16 autocast (activations and convolutions in half precision, fp32
+        # accumulate, fp32 BN statistics / master weights); here the 16-bit type is bf16 (no loss scaling needed)
         ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.MATH_F32
+        ops.set_storage_dtype(torch.bfloat16 if precision == 16 else None)
         self.rank, self.local_rank, self.world = xdist.init_from_env()
         self.device = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.device)
