@@ -46,6 +46,8 @@ def prof_time(fn, iters=10):
 def main():
     if os.environ.get("XV2_MATH") == "1":
         ops.MATH_MODE = ops.MATH_BF16
+    half = os.environ.get("XV2_MATH") == "2"          # bf16 storage (XV2_MATH_BF16_STORE)
+    adt = torch.bfloat16 if half else torch.float32
     filt = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 20
     for i, a in enumerate(sys.argv):
@@ -73,11 +75,11 @@ def main():
         if filt and not any(f in name for f in filt):
             continue
         g = ops.conv_cfg(k, k, s, p)
-        x0 = torch.randn(N, H, W, C0, device=dev)
-        x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
+        x0 = torch.randn(N, H, W, C0, device=dev).to(adt)
+        x1 = torch.randn(N, H, W, C1, device=dev).to(adt) if C1 else None
         w = torch.randn(Co, C0 + C1, k, k, device=dev) * 0.05
         OH, OW = ops._out_hw(H, W, g)
-        dy = torch.randn(N, OH, OW, Co, device=dev)
+        dy = torch.randn(N, OH, OW, Co, device=dev).to(adt)
         gf = 2.0 * N * OH * OW * Co * (C0 + C1) * k * k / 1e9
         tf = prof_time(lambda: ops._conv_forward(x0, x1, w, g, None, True))
         td = prof_time(lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))

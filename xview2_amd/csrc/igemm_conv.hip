@@ -39,6 +39,14 @@ namespace xv2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_LD = BK + 4;
+constexpr int LDS_LD_H_ = BK + 8;
+// floats of LDS shared by the main-loop operand buffers and the epilogue staging tile
+template <int BM, int BN, bool HIN, int NH>
+constexpr int igemm_main_floats() {
+    if (!HIN) return 2 * (BM + BN) * LDS_LD;
+    const int loop = 2 * (BM + BN) * LDS_LD_H_ / 2, epi = (BM / NH) * (BN + 4);
+    return loop > epi ? loop : epi;
+}
 
 // bf16-compute variant ("--precision 16"): operands stay fp32 in HBM, are rounded to bf16 (RNE) while being staged
 // into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything outside the MFMA is unchanged.
@@ -66,10 +74,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     static_assert(!HIN || BF16, "bf16 operands imply the bf16 MFMA");
     typedef typename std::conditional<HS, bf16_t, float>::type OT;   // output / residual element type
 
+    // bf16 operands: the LDS image is half as large, and with the epilogue staged in two row halves a block needs
+    // ~45 KB instead of 74 KB - three blocks per CU instead of two hide more of the global-load latency
+    constexpr int NH = (HIN && WGM >= 2) ? 2 : 1;       // epilogue staging passes
+    constexpr int MAIN_FLOATS = igemm_main_floats<BM, BN, HIN, NH>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
-    int* rowoff = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LDS_LD);  // [BM]
+    int* rowoff = reinterpret_cast<int*>(smem + MAIN_FLOATS);             // [BM]
     float* red = reinterpret_cast<float*>(rowoff + BM);                   // [WGM][BN][2]
 
     const int tid = threadIdx.x;
@@ -354,29 +366,44 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     // and cover whole 128..512-byte output rows: for the K<=256 1x1 convolutions the dword-store epilogue was
     // two thirds of the kernel.  BatchNorm partial sums are taken from the registers on the way.
     constexpr int CLD = BN + 4;
+    constexpr int HROWS = BM / NH;          // rows staged per pass
     float* Cs = smem;
     const bool do_stats = p.stats && p.ksplit == 1 && !p.bnb_y;
+    if (do_stats) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int cl = wn * WTN + j * 32 + l31;
-        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < NR; ++j) {
+            const int cl = wn * WTN + j * 32 + l31;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
+            for (int i = 0; i < MR; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Cs[row * CLD + cl] = acc[i][j][r];
-                const float sv = (HS && do_stats) ? bf16_round(acc[i][j][r]) : acc[i][j][r];
-                s1 += sv;
-                s2 += sv * sv;
+                for (int r = 0; r < 16; ++r) {
+                    const float sv = HS ? bf16_round(acc[i][j][r]) : acc[i][j][r];
+                    s1 += sv;
+                    s2 += sv * sv;
+                }
             }
-        }
-        if (do_stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) {
                 red[(wm * BN + cl) * 2 + 0] = s1;
                 red[(wm * BN + cl) * 2 + 1] = s2;
+            }
+        }
+    }
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) {
+    if (NH == 1 || (wm * WTM) / HROWS == hh) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int cl = wn * WTN + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h - hh * HROWS;
+                    Cs[row * CLD + cl] = acc[i][j][r];
+                }
             }
         }
     }
@@ -396,11 +423,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             bsf = *reinterpret_cast<const float4*>(p.bnb_shift + bc);
         }
 #pragma unroll 4
-        for (int e = tid; e < BM * F4R; e += 256) {
-            const int row = e / F4R, c = (e % F4R) * 4;
+        for (int e = tid; e < HROWS * F4R; e += 256) {
+            const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
             const int off = rowoff[row];
             if (off < 0) continue;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + c);
+            float4 v = *reinterpret_cast<const float4*>(Cs + (row - hh * HROWS) * CLD + c);
             const int col = n0 + c;
             if (slab) {
                 *reinterpret_cast<float4*>(slab + (size_t)off * p.Nout + col) = v;
@@ -461,6 +488,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             }
         }
     }
+    if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
+  }
     if (do_stats && tid < BN) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -548,15 +577,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool HIN, int WGM>
 constexpr size_t igemm_smem_bytes() {
-    return (size_t)(2 * (BM + BN) * LDS_LD) * 4 + BM * 4 + 4 * BN * 2 * 4;
+    return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1>() * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
-    constexpr size_t smem = igemm_smem_bytes<BM, BN>();
+    constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
     auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS>;
     if (!attr_set) {
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

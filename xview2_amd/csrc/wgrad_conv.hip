@@ -284,6 +284,153 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf16-native weight gradient (XV2_MATH_BF16_STORE, shapes with OW % 32 == 0): the tiles stay bf16 all the way.
+// dY and X arrive pixel-major / channel-minor, and the MFMA wants, per lane, 8 consecutive PIXELS of one channel; the
+// fp32-LDS variant above gathers them with 8 ds_read_b32 + 8 conversions per fragment.  Here the 16-byte global loads
+// (8 channels of a pixel) are stored to LDS as they are and the fragments come out of ds_read_b64_tr_b16 - the gfx950
+// transpose read: a 16-lane group fetches a [4 pixels][16 channels] block (each lane 4 consecutive channels of one
+// pixel) and every lane receives the 4 pixels of ITS channel - two reads per 32x16 operand, no VALU.
+// Row stride = tile width + 32 elements (64 bytes: BM = 128 -> 320 B, BM = 64 -> 192 B), i.e. 64 or 192 mod 256:
+// the 4 pixel rows x 2 channel groups a 32-lane half touches fall into 8 different 32-byte bank groups.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
+    constexpr int MR = BM / 64, NR = BN / 64;              // 4 waves as 2 x 2, wave tile (BM/2) x (BN/2)
+    constexpr int SA = BM + 32, SB = BN + 32;              // LDS row strides in bf16 elements
+    constexpr int ALPR = BM / 8, ARPP = 256 / ALPR, APASS = 32 / ARPP;   // 16-byte lanes per row, rows per pass
+    constexpr int BLPR = BN / 8, BRPP = 256 / BLPR, BPASS = 32 / BRPP;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);          // [2][32 px][SA]   dY tile
+    bf16_t* Bs = As + 2 * 32 * SA;                         // [2][32 px][SB]   X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b = blockIdx.x;
+    const int tn = b % p.tiles_n;
+    b /= p.tiles_n;
+    const int tap = b % p.T;
+    const int co0 = (b / p.T) * BM, cn0 = tn * BN;
+    const bool first = cn0 < p.C0;
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+    const int dh = p.taps[tap].dh, dw = p.taps[tap].dw;
+    const int ohw = p.OH * p.OW;
+    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? p.X0 : p.X1), 0,
+                                                                   first ? p.bytesX0 : p.bytesX1, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.bytesDY, 0x00020000);
+    const int a_c8 = tid % ALPR, a_r = tid / ALPR, b_c8 = tid % BLPR, b_r = tid / BLPR;
+    int a_const[APASS], b_const[BPASS], b_k[BPASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) a_const[j] = (a_r + j * ARPP) * p.ldDY + co0 + a_c8 * 8;
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        b_k[j] = (b_r + j * BRPP) * p.stride + dw;
+        b_const[j] = b_k[j] * ldx + xch + b_c8 * 8;
+    }
+    i32x4 ra[APASS], rb[BPASS];
+    auto gload = [&](int kt) {      // a 32-pixel reduction tile lies inside one output row (OW % 32 == 0)
+        const int mb = kt * 32;
+        const int n = mb / ohw;
+        const int rem = mb - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow0 = rem - oh * p.OW;
+        const int ih = oh * p.stride + dh;
+        const bool rowok = (unsigned)ih < (unsigned)p.IH;
+        const int iw0 = ow0 * p.stride;
+        const int ubase = ((n * p.IH + ih) * p.IW + iw0) * ldx;
+        const int dbase = mb * p.ldDY;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsD, (dbase + a_const[j]) << 1, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const bool ok = rowok && (unsigned)(iw0 + b_k[j]) < (unsigned)p.IW;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((ubase + b_const[j]) << 1) : (int)0x80000000, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            *reinterpret_cast<i32x4*>(As + (buf * 32 + a_r + j * ARPP) * SA + a_c8 * 8) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j)
+            *reinterpret_cast<i32x4*>(Bs + (buf * 32 + b_r + j * BRPP) * SB + b_c8 * 8) = rb[j];
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transpose-read addressing: 16-lane group g = lane >> 4 serves channels 16 * (g & 1) .. + 15 of the 32-wide
+    // operand and pixels 8 * (g >> 1) .. + 7 of the 16-pixel k-step; lane i of the group fetches pixel (i >> 2),
+    // channels 4 * (i & 3) .. + 3 of the 4 x 16 block and receives the 4 pixels of channel i
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int frow = 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+        if (kt0 + 1 < kt1) gload(kt0 + 1);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            lstore(buf ^ 1);
+            if (kt + 2 < kt1) gload(kt + 2);
+        }
+        const bf16_t* a = As + (buf * 32 + frow) * SA + wm * (BM / 2) + fcol;
+        const bf16_t* bb = Bs + (buf * 32 + frow) * SB + wn * (BN / 2) + fcol;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MR], bf[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + (16 * ks) * SA + i * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + (16 * ks + 4) * SA + i * 32));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bb + (16 * ks) * SB + j * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(bb + (16 * ks + 4) * SB + j * 32));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // slab: part[split][co][T][Ctot]
+    const size_t rowlen = (size_t)p.T * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const size_t coloff = (size_t)tap * p.Ctot + cn0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)row * rowlen + coloff] = acc[i][j][r];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // All-taps variant for 3x3 / stride 1 / pad 1 layers with few channels (the 1024x1024 decoder level, 32 -> 32).
 // The per-tap kernel above re-reads the dY tile and a shifted X tile for every tap: 8 KB of L2->LDS traffic per
 // 16 MFMAs per wave set, which is what bounds it at ~58 TFLOP/s for a 32x32 tile.  Here one block owns a
@@ -527,6 +674,15 @@ struct WgradPlan {
     int groups;        // > 0: two-level slab sum with this many intermediate slabs
 };
 
+static bool use_tr_wgrad() {      // XV2_WGRAD_TR=0: fall back to the fp32-LDS gather variant (A/B measurements)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("XV2_WGRAD_TR");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 static int alltaps_max_tiles() {
     static int v = -1;
     if (v < 0) {
@@ -699,6 +855,21 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
             else rc = launch_wgrad<32, 64, 1, 2, 2, true, false, true>(p, pl, stream);
         } else if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
+    } else if (hs && p.fast && use_tr_wgrad() && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
+        static int kid128 = -1, kid64 = -1;
+        if (kid128 < 0) {
+            kid128 = prof_register("wgrad_tr_kernel<128,128,bf16hbm>");
+            kid64 = prof_register("wgrad_tr_kernel<64,64,bf16hbm>");
+        }
+        prof_begin(pl.bm == 128 ? kid128 : kid64, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+                   2.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
+        if (pl.bm == 128)
+            hipLaunchKernelGGL((wgrad_tr_kernel<128, 128>), dim3(pl.tiles, pl.splitk), dim3(256), 2 * 32 * (160 + 160) * 2, stream, p);
+        else
+            hipLaunchKernelGGL((wgrad_tr_kernel<64, 64>), dim3(pl.tiles, pl.splitk), dim3(256), 2 * 32 * (96 + 96) * 2, stream, p);
+        prof_end(stream);
+        XV2_CHECK_LAUNCH();
+        rc = XV2_OK;
     } else if (hs) {
         if (pl.bm == 128) rc = launch_wgrad<128, 128, 2, 2, 1, false, true, true>(p, pl, stream);
         else if (pl.bm == 64 && pl.bn == 64) rc = launch_wgrad<64, 64, 2, 2, 1, false, true, true>(p, pl, stream);
