@@ -23,6 +23,10 @@ constexpr int D_TH = 4, D_TW = 32, D_HW = D_TW + 2, D_HH = D_TH + 2, D_LD = 36;
 constexpr int D_HALO = D_HH * D_HW;                       // 204 pixels
 constexpr int D_HLOADS = (D_HALO * 8 + 255) / 256;        // float4 per thread per halo (7)
 constexpr size_t D_SMEM = (size_t)(D_HALO * D_LD + 9 * 32 * D_LD) * 4 + 4 * 32 * 2 * 4;
+// bf16 storage: halo and weights stay bf16 in LDS ([row][32 ch + 8 pad], 80-byte rows: conflict-free 16-byte reads)
+constexpr int D_LDH = 40;
+constexpr int D_HLOADS_H = (D_HALO * 4 + 255) / 256;      // 16-byte loads (8 channels) per thread per halo (4)
+constexpr size_t D_SMEM_H = (size_t)(D_HALO + 9 * 32) * D_LDH * 2 + 4 * 32 * 2 * 4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -36,11 +40,12 @@ template <bool BF16, bool HS = false>
 __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
     constexpr int ESH = HS ? 1 : 2;
     typedef typename std::conditional<HS, bf16_t, float>::type OT;
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
     float* wts = smem + D_HALO * D_LD;          // [9][32][36]
-    float* red = wts + 9 * 32 * D_LD;           // [4][32][2]
+    float* red = HS ? smem + (D_HALO + 9 * 32) * D_LDH / 2 : wts + 9 * 32 * D_LD;           // [4][32][2]
+    __bf16* halo_h = reinterpret_cast<__bf16*>(smem);         // HS: [204][40] bf16
+    __bf16* wts_h = halo_h + D_HALO * D_LDH;                   // HS: [9][32][40] bf16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -58,13 +63,16 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     if (p0 >= p1) return;
 
     // weights, once: [tap][n][32 channels]
-    for (int e = tid; e < 9 * 32 * 8; e += 256) {
-        const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
-        const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << ESH;
-        if constexpr (HS) {
-            const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsB, off, 0, 0);
-            *reinterpret_cast<float4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = bf16x4_to_f32((unsigned)v.x, (unsigned)v.y);
-        } else {
+    if constexpr (HS) {
+        for (int e = tid; e < 9 * 32 * 4; e += 256) {
+            const int c8 = e & 3, nn = (e >> 2) & 31, t = e >> 7;
+            const int off = ((nn * p.T + p.taps[t].slot) * 32 + c8 * 8) << 1;
+            *reinterpret_cast<i32x4*>(wts_h + (t * 32 + nn) * D_LDH + c8 * 8) = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+        }
+    } else {
+        for (int e = tid; e < 9 * 32 * 8; e += 256) {
+            const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
+            const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
             *reinterpret_cast<i32x4*>(wts + (t * 32 + nn) * D_LD + c4 * 4) = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
         }
     }
@@ -73,14 +81,16 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     // this thread's D_HLOADS halo elements: (row, column) inside the 6 x 34 halo and the byte offset relative to the
     // patch origin - fixed for the whole kernel
     int hrow[D_HLOADS], hcol[D_HLOADS], hrel[D_HLOADS];
+    constexpr int LPP = HS ? 4 : 8;              // 16-byte lanes per halo pixel
+    constexpr int NHL = HS ? D_HLOADS_H : D_HLOADS;
 #pragma unroll
     for (int j = 0; j < D_HLOADS; ++j) {
         const int e = tid + j * 256;
-        const int px = e >> 3, c4 = e & 7;
+        const int px = e / LPP, c4 = e % LPP;
         hrow[j] = px / D_HW;
         hcol[j] = px - hrow[j] * D_HW;
-        hrel[j] = e < D_HALO * 8 ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * 4) << ESH : 0;
-        if (e >= D_HALO * 8) hrow[j] = -(1 << 20);      // never valid
+        hrel[j] = e < D_HALO * LPP ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * (32 / LPP)) << ESH : 0;
+        if (e >= D_HALO * LPP) hrow[j] = -(1 << 20);      // never valid
     }
     auto hload = [&](int patch) {
         const int tw = patch % tiles_w;
@@ -89,25 +99,19 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int oh0 = th * D_TH, ow0 = tw * D_TW;
         const int base = (((n * p.IH + oh0) * p.IW + ow0) * p.ldA0) << ESH;
 #pragma unroll
-        for (int j = 0; j < D_HLOADS; ++j) {
+        for (int j = 0; j < NHL; ++j) {
             const int ih = oh0 - 1 + hrow[j], iw = ow0 - 1 + hcol[j];
             const bool ok = (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            if constexpr (HS) {
-                const i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
-                hr[j].x = v.x;
-                hr[j].y = v.y;
-            } else {
-                hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
-            }
+            hr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? base + hrel[j] : (int)0x80000000, 0, 0);
         }
     };
     auto hstore = [&]() {
 #pragma unroll
-        for (int j = 0; j < D_HLOADS; ++j) {
+        for (int j = 0; j < NHL; ++j) {
             const int e = tid + j * 256;
-            if (e < D_HALO * 8) {
+            if (e < D_HALO * LPP) {
                 if constexpr (HS)
-                    *reinterpret_cast<float4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = bf16x4_to_f32((unsigned)hr[j].x, (unsigned)hr[j].y);
+                    *reinterpret_cast<i32x4*>(halo_h + (e >> 2) * D_LDH + (e & 3) * 8) = hr[j];
                 else
                     *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
             }
@@ -133,6 +137,15 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dh = p.taps[t].dh, dw = p.taps[t].dw;
+            if constexpr (HS) {      // bf16 image in LDS: a 16-byte read IS the 8-channel MFMA operand
+                const __bf16* a = halo_h + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LDH + 8 * h;
+                const __bf16* b = wts_h + (t * 32 + l31) * D_LDH + 8 * h;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a + kk * 16),
+                                                                  *reinterpret_cast<const bf16x8*>(b + kk * 16), acc, 0, 0, 0);
+                continue;
+            }
             if constexpr (BF16) {
                 const float* a = halo + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LD + 8 * h;
                 const float* b = wts + (t * 32 + l31) * D_LD + 8 * h;
@@ -231,7 +244,7 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
         XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_H));
         attr_set = true;
         kid = prof_register("direct3x3_n32_kernel");
         kid16 = prof_register("direct3x3_n32_kernel<bf16>");
@@ -239,13 +252,14 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     }
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / (D_TH * D_TW);
-    const int grid = std::min(npatches, 512);      // persistent: 2 blocks per CU, each walks a run of patches
+    // persistent: 2 blocks per CU (fp32 LDS image, 71 KB), 4 per CU with the bf16 image (40 KB); each walks a run of patches
+    const int grid = std::min(npatches, p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
     prof_begin(p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
     if (p.math == XV2_MATH_BF16_STORE)
-        hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, p, npatches);
     else if (p.math)
         hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
     else

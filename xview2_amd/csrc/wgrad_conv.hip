@@ -595,6 +595,120 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
     }
 }
 
+// bf16-native all-taps variant (XV2_MATH_BF16_STORE): same block / strip / ring organisation as above, but the dY row and
+// the 4-row X ring live in LDS as bf16 exactly as loaded (16-byte loads, [pixel][32 channels], 64-byte rows: four
+// consecutive pixel rows fill one 256-byte bank row) and every MFMA operand is two ds_read_b64_tr_b16 transpose reads
+// instead of 8-10 ds_read_b32 + as many conversions - the fp32-LDS bf16 variant spent twice the MFMA time in the LDS.
+// Wave wk takes the 16-pixel k-group (wk & 1) and the taps of parity (wk >> 1), as in the BF16 branch above.
+__global__ void __launch_bounds__(256, 4) wgrad_alltaps_tr_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[4096];     // 16 KB: operand image (12.9 KB) / epilogue fold
+    bf16_t* dYs = reinterpret_cast<bf16_t*>(smem);                // [2][32 px][32 co]
+    bf16_t* Xs = dYs + 2 * 32 * 32;                               // [4 ring rows][34 px][32 ci]
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int co0 = tm * 32, cn0 = tn * 32;
+    const int chunks = p.ktiles, rows_per = p.kt_per_split;
+    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int tilesW = p.OW / 32;
+    const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
+    const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
+    const bool first = cn0 < p.C0;
+    const bf16_t* xsrc = reinterpret_cast<const bf16_t*>(first ? p.X0 : p.X1);
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+
+    // loads: 4 lanes x 16 bytes per pixel; threads 0..127 the dY row (32 px), threads 0..135 the X row (34 px)
+    const int px = tid >> 2, c8 = tid & 3;
+    const bf16_t* dy0 = reinterpret_cast<const bf16_t*>(p.DY) + ((size_t)n * p.OH * p.OW + ow0 + (px & 31)) * p.ldDY + co0 + c8 * 8;
+    const size_t dy_pitch = (size_t)p.OW * p.ldDY;
+    const int iw = ow0 - 1 + px;
+    const bf16_t* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c8 * 8;
+    const size_t x_pitch = (size_t)p.IW * ldx;
+    const bool do_dy = tid < 128, do_x = tid < 136 && iw >= 0 && iw < p.IW;
+    const i32x4 zero = {0, 0, 0, 0};
+    i32x4 rd = zero, rx = zero;
+    auto load_dy = [&](int r) { if (do_dy) rd = *reinterpret_cast<const i32x4*>(dy0 + (size_t)r * dy_pitch); };
+    auto load_x = [&](int ih) {
+        rx = zero;
+        if (do_x && (unsigned)ih < (unsigned)p.IH) rx = *reinterpret_cast<const i32x4*>(xa0 + (size_t)ih * x_pitch);
+    };
+    auto store_dy = [&](int buf) { if (do_dy) *reinterpret_cast<i32x4*>(dYs + (buf * 32 + px) * 32 + c8 * 8) = rd; };
+    auto store_x = [&](int ih) { if (tid < 136) *reinterpret_cast<i32x4*>(Xs + (((ih + 4) & 3) * 34 + px) * 32 + c8 * 8) = rx; };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int q0 = 16 * (wk & 1), odd = wk >> 1;
+    const int frow = q0 + 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    auto frag = [&](const bf16_t* base) {       // base -> pixel row `frow` of the operand, channel fcol
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    load_x(r0 - 1);
+    store_x(r0 - 1);
+    load_x(r0);
+    store_x(r0);
+    load_x(r0 + 1);
+    store_x(r0 + 1);
+    load_dy(r0);
+    store_dy(0);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            load_dy(r + 1);
+            load_x(r + 2);
+        }
+        const bf16x8 af = frag(dYs + (buf * 32 + frow) * 32 + fcol);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const bf16_t* row = Xs + (((r - 1 + kh + 4) & 3) * 34 + frow) * 32 + fcol;     // input row r-1+kh
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = kh * 3 + kw;
+                if ((t & 1) != odd) continue;          // wave-uniform
+                const bf16x8 bf = frag(row + kw * 32);  // halo pixel = output pixel + kw
+                acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t >> 1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_dy(buf ^ 1);    // last read in step r-1 (all waves are past its barrier)
+            store_x(r + 2);       // ring slot of row r-2, idem
+        }
+        __syncthreads();
+    }
+
+    // fold the two k-groups of every tap through LDS and write the block's slab part[y][co][T][Ctot]
+    const size_t rowlen = (size_t)9 * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool mine = (wk >> 1) == (t & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = mine ? acc[t >> 1][r] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            const float v = (smem[e] + smem[1024 + e]) + (smem[2048 + e] + smem[3072 + e]);
+            const int r = e >> 6, ln = e & 63;
+            const int row = co0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + (ln & 31)] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // first stage of a two-level slab sum (many slabs, few elements): out2[g][i] = sum over the g-th group of slabs
 __global__ void wgrad_reduce_stage1_kernel(const float* __restrict__ part, int nslab, int per, size_t total,
                                            float* __restrict__ out2) {
@@ -840,7 +954,9 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         }
         prof_begin(hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
-        if (hs)
+        if (hs && use_tr_wgrad())
+            hipLaunchKernelGGL(wgrad_alltaps_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        else if (hs)
             hipLaunchKernelGGL((wgrad_alltaps_kernel<true, true>), dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (d->math)
             hipLaunchKernelGGL(wgrad_alltaps_kernel<true>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
