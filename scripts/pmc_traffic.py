@@ -22,19 +22,29 @@ def per_kernel(db, counter):
 
 
 def pretty(mangled):
+    """mangled kernel symbol -> the name bench.py's in-library profiler registers (roofline.kernel)"""
+    if "wgrad_alltaps_tr_kernel" in mangled:
+        return "wgrad_alltaps_kernel<bf16hbm>"
     if "wgrad_alltaps_kernel" in mangled:
-        return "wgrad_alltaps_kernel"
+        return "wgrad_alltaps_kernel<bf16>" if "ILb1E" in mangled else "wgrad_alltaps_kernel"
     if "direct3x3_n32_kernel" in mangled:
-        return "direct3x3_n32_kernel"
+        if "ILb1ELb1E" in mangled:
+            return "direct3x3_n32_kernel<bf16hbm>"
+        return "direct3x3_n32_kernel<bf16>" if "ILb1E" in mangled else "direct3x3_n32_kernel"
+    m = re.match(r"_ZN3xv2\d+wgrad_tr_kernelILi(\d+)ELi(\d+)E", mangled)
+    if m:
+        return "wgrad_tr_kernel<%s,%s,bf16hbm>" % (m.group(1), m.group(2))
     m = re.match(r"_ZN3xv2\d+(igemm|wgrad)_kernelI(.*?)EEv", mangled)
     if not m:
         return None
     args = re.findall(r"L([ib])(\d+)E", m.group(2))
-    vals = [int(v) for _, v in args]
+    vals = [int(v) for _, v in args] + [0, 0, 0]
     if m.group(1) == "igemm":
-        tag = "rgb" if vals[4] else ("c32,bf16" if len(vals) > 5 and vals[5] else "c32")
+        smallc, bf16, hs = vals[4], vals[5], vals[6]
+        tag = ("rgb,bf16out" if hs else "rgb") if smallc else ("c32,bf16hbm" if hs else ("c32,bf16" if bf16 else "c32"))
         return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], tag)
-    tag = "rgb" if vals[5] else ("c32,bf16" if len(vals) > 6 and vals[6] else "c32")
+    smallc, bf16, hs = vals[5], vals[6], vals[7]
+    tag = ("rgb" if smallc else ("c32,bf16" if bf16 else "c32")) + (",bf16hbm" if hs else "")
     return "wgrad_kernel<%d,%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], vals[4], tag)
 
 

@@ -89,7 +89,14 @@ def _conv(a):
     return a
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_handle():
+    """hipStream_t of torch's current stream (the raw-handle query is ~10x cheaper than building a Stream object, and
+    this runs once per launch: ~1000 times per training step)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -101,6 +108,17 @@ def call(name, *args):
         raise RuntimeError("%s: %s" % (name, _lib.lib().xv2_last_error().decode()))
 
 
+_query_cache = {}
+
+
 def query(name, *args):
-    """Value-returning helper (workspace sizes, tile counts): no stream argument."""
+    """Value-returning helper (workspace sizes, tile counts): no stream argument.  Pure functions of a convolution
+    descriptor are memoised (the same ~100 geometries recur every step)."""
+    if len(args) >= 1 and isinstance(args[0], ConvDesc) and all(isinstance(a, int) for a in args[1:]):
+        key = (name, args[0].key()) + tuple(args[1:])
+        v = _query_cache.get(key)
+        if v is None:
+            v = _func(name)(*[_conv(a) for a in args])
+            _query_cache[key] = v
+        return v
     return _func(name)(*[_conv(a) for a in args])
