@@ -24,16 +24,17 @@ struct ChunkGeom {
 // Vector path: a block covers `cgw` channels (cgw/4 float4 lanes x 256/(cgw/4) row lanes) and `rpb` rows; wide
 // tensors (C a multiple of 256) are cut into 256-channel groups along grid.y so that a block keeps 4 row lanes and
 // the number of row chunks - hence the partial-sum traffic - stays a small fraction of the tensor.
-static ChunkGeom chunk_geom(int64_t npix, int C) {
+// W = channels per lane of the vector path: 4 (fp32, 16-byte accesses) or 8 (bf16, 16-byte accesses)
+static ChunkGeom chunk_geom(int64_t npix, int C, int W = 4) {
     ChunkGeom g;
     g.cgw = 0;
     g.groups = 1;
-    if (C % 4 == 0) {
+    if (C % W == 0) {
         if (C > 256 && C % 256 == 0) g.cgw = 256;
-        else if (C / 4 <= 256 && 256 % (C / 4) == 0) g.cgw = C;
+        else if (C / W <= 256 && 256 % (C / W) == 0) g.cgw = C;
     }
     if (g.cgw) g.groups = C / g.cgw;
-    const int64_t rows_per_pass = g.cgw ? 256 / (g.cgw / 4) : 4;
+    const int64_t rows_per_pass = g.cgw ? 256 / (g.cgw / W) : 4;
     int64_t rpb = cdiv(npix * g.groups, 2048);
     rpb = cdiv(rpb, rows_per_pass) * rows_per_pass;
     if (rpb < rows_per_pass * 8) rpb = rows_per_pass * 8;
@@ -72,36 +73,51 @@ struct ColOp {
             f1 += g * xh;
         }
     }
-    __device__ __forceinline__ void apply4(int64_t row, int c, float4& f0, float4& f1, const float4& mu,
-                                           const float4& is) const {
+    // one 16-byte access per tensor: NV float4 groups = 4 (fp32) or 8 (bf16) consecutive channels starting at c
+    __device__ __forceinline__ void applyv(int64_t row, int c, float4 (&f0)[Vec16<T>::NV], float4 (&f1)[Vec16<T>::NV],
+                                           const float4 (&mu)[Vec16<T>::NV], const float4 (&is)[Vec16<T>::NV],
+                                           const float4 (&sc)[Vec16<T>::NV], const float4 (&sf)[Vec16<T>::NV]) const {
+        constexpr int NV = Vec16<T>::NV;
         if constexpr (MODE == 0) {
-            float4 v = ld4(a + row * lda + c);
-            v.x -= mu.x; v.y -= mu.y; v.z -= mu.z; v.w -= mu.w;   // mu = first row (shift)
-            f0.x += v.x; f0.y += v.y; f0.z += v.z; f0.w += v.w;
-            f1.x += v.x * v.x; f1.y += v.y * v.y; f1.z += v.z * v.z; f1.w += v.w * v.w;
-        } else {
-            const float4 d = ld4(a + row * lda + c);
-            const float4 yy = ld4(y + row * ldy + c);
-            float gx, gy, gz, gw;
-            if (z && zbits) {
-                const unsigned m = reinterpret_cast<const uint8_t*>(z)[row * c4tot + (c >> 2)];
-                gx = d.x * act_grad_from_output((m & 1u) ? 1.f : -1.f, act); gy = d.y * act_grad_from_output((m & 2u) ? 1.f : -1.f, act);
-                gz = d.z * act_grad_from_output((m & 4u) ? 1.f : -1.f, act); gw = d.w * act_grad_from_output((m & 8u) ? 1.f : -1.f, act);
-            } else if (z) {
-                const float4 zz = ld4(z + row * ldz + c);
-                gx = d.x * act_grad_from_output(zz.x, act); gy = d.y * act_grad_from_output(zz.y, act);
-                gz = d.z * act_grad_from_output(zz.z, act); gw = d.w * act_grad_from_output(zz.w, act);
-            } else {
-                const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-                const float4 sf = *reinterpret_cast<const float4*>(shift + c);
-                gx = d.x * act_grad_from_pre(__fmaf_rn(yy.x, sc.x, sf.x), act);
-                gy = d.y * act_grad_from_pre(__fmaf_rn(yy.y, sc.y, sf.y), act);
-                gz = d.z * act_grad_from_pre(__fmaf_rn(yy.z, sc.z, sf.z), act);
-                gw = d.w * act_grad_from_pre(__fmaf_rn(yy.w, sc.w, sf.w), act);
+            float4 v[NV];
+            Vec16<T>::ld(a + row * lda + c, v);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                v[q].x -= mu[q].x; v[q].y -= mu[q].y; v[q].z -= mu[q].z; v[q].w -= mu[q].w;   // mu = first row (shift)
+                f0[q].x += v[q].x; f0[q].y += v[q].y; f0[q].z += v[q].z; f0[q].w += v[q].w;
+                f1[q].x += v[q].x * v[q].x; f1[q].y += v[q].y * v[q].y; f1[q].z += v[q].z * v[q].z; f1[q].w += v[q].w * v[q].w;
             }
-            f0.x += gx; f0.y += gy; f0.z += gz; f0.w += gw;
-            f1.x += gx * ((yy.x - mu.x) * is.x); f1.y += gy * ((yy.y - mu.y) * is.y);
-            f1.z += gz * ((yy.z - mu.z) * is.z); f1.w += gw * ((yy.w - mu.w) * is.w);
+        } else {
+            float4 d[NV], yy[NV], zz[NV];
+            Vec16<T>::ld(a + row * lda + c, d);
+            Vec16<T>::ld(y + row * ldy + c, yy);
+            unsigned m = 0;
+            if (z && zbits) {
+                const uint8_t* mp = reinterpret_cast<const uint8_t*>(z) + row * c4tot + (c >> 2);
+                m = NV == 2 ? *reinterpret_cast<const unsigned short*>(mp) : *mp;
+            } else if (z) {
+                Vec16<T>::ld(z + row * ldz + c, zz);
+            }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                float gx, gy, gz, gw;
+                if (z && zbits) {
+                    const unsigned mq = m >> (8 * q);
+                    gx = d[q].x * act_grad_from_output((mq & 1u) ? 1.f : -1.f, act); gy = d[q].y * act_grad_from_output((mq & 2u) ? 1.f : -1.f, act);
+                    gz = d[q].z * act_grad_from_output((mq & 4u) ? 1.f : -1.f, act); gw = d[q].w * act_grad_from_output((mq & 8u) ? 1.f : -1.f, act);
+                } else if (z) {
+                    gx = d[q].x * act_grad_from_output(zz[q].x, act); gy = d[q].y * act_grad_from_output(zz[q].y, act);
+                    gz = d[q].z * act_grad_from_output(zz[q].z, act); gw = d[q].w * act_grad_from_output(zz[q].w, act);
+                } else {
+                    gx = d[q].x * act_grad_from_pre(__fmaf_rn(yy[q].x, sc[q].x, sf[q].x), act);
+                    gy = d[q].y * act_grad_from_pre(__fmaf_rn(yy[q].y, sc[q].y, sf[q].y), act);
+                    gz = d[q].z * act_grad_from_pre(__fmaf_rn(yy[q].z, sc[q].z, sf[q].z), act);
+                    gw = d[q].w * act_grad_from_pre(__fmaf_rn(yy[q].w, sc[q].w, sf[q].w), act);
+                }
+                f0[q].x += gx; f0[q].y += gy; f0[q].z += gz; f0[q].w += gw;
+                f1[q].x += gx * ((yy[q].x - mu[q].x) * is[q].x); f1[q].y += gy * ((yy[q].y - mu[q].y) * is[q].y);
+                f1[q].z += gz * ((yy[q].z - mu[q].z) * is[q].z); f1[q].w += gw * ((yy[q].w - mu[q].w) * is[q].w);
+            }
         }
     }
 };
@@ -109,42 +125,54 @@ struct ColOp {
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op, int64_t npix, int C, int rpb, int cgw,
                                                               double* __restrict__ part) {
-    __shared__ float sh[256 * 8];
+    __shared__ float sh[256 * 8 * Vec16<T>::NV];
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rpb;
     const int64_t r1 = min(r0 + (int64_t)rpb, npix);
     double* out = part + (size_t)blockIdx.x * C * 2;
     if (cgw) {
-        const int C4 = cgw / 4;
-        const int rpp = 256 / C4;
-        const int tx = tid % C4, ty = tid / C4;
-        const int cb = blockIdx.y * cgw + tx * 4;     // first of this thread's 4 channels
-        float4 f0 = make_float4(0, 0, 0, 0), f1 = make_float4(0, 0, 0, 0);
-        float4 mu = make_float4(0, 0, 0, 0), is = make_float4(0, 0, 0, 0);
-        if constexpr (MODE == 1) {
-            mu = *reinterpret_cast<const float4*>(op.mean + cb);
-            is = *reinterpret_cast<const float4*>(op.invstd + cb);
-        } else {
-            mu = ld4(op.a + cb);
+        constexpr int NV = Vec16<T>::NV, W = 4 * NV;
+        const int CW = cgw / W;
+        const int rpp = 256 / CW;
+        const int tx = tid % CW, ty = tid / CW;
+        const int cb = blockIdx.y * cgw + tx * W;     // first of this thread's W channels
+        float4 f0[NV], f1[NV], g0[NV], g1[NV], mu[NV], is[NV], sc[NV], sf[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            f0[q] = f1[q] = g0[q] = g1[q] = mu[q] = is[q] = sc[q] = sf[q] = make_float4(0, 0, 0, 0);
+            if constexpr (MODE == 1) {
+                mu[q] = *reinterpret_cast<const float4*>(op.mean + cb + 4 * q);
+                is[q] = *reinterpret_cast<const float4*>(op.invstd + cb + 4 * q);
+                if (!op.z) {
+                    sc[q] = *reinterpret_cast<const float4*>(op.scale + cb + 4 * q);
+                    sf[q] = *reinterpret_cast<const float4*>(op.shift + cb + 4 * q);
+                }
+            } else {
+                mu[q] = ld4(op.a + cb + 4 * q);
+            }
         }
         // two rows in flight per iteration (independent accumulators): more bytes outstanding per lane
-        float4 g0 = make_float4(0, 0, 0, 0), g1 = make_float4(0, 0, 0, 0);
         int64_t r = r0 + ty;
         for (; r + rpp < r1; r += 2 * rpp) {
-            op.apply4(r, cb, f0, f1, mu, is);
-            op.apply4(r + rpp, cb, g0, g1, mu, is);
+            op.applyv(r, cb, f0, f1, mu, is, sc, sf);
+            op.applyv(r + rpp, cb, g0, g1, mu, is, sc, sf);
         }
-        if (r < r1) op.apply4(r, cb, f0, f1, mu, is);
-        f0.x += g0.x; f0.y += g0.y; f0.z += g0.z; f0.w += g0.w;
-        f1.x += g1.x; f1.y += g1.y; f1.z += g1.z; f1.w += g1.w;
-        float* s = sh + tid * 8;
-        s[0] = f0.x; s[1] = f0.y; s[2] = f0.z; s[3] = f0.w;
-        s[4] = f1.x; s[5] = f1.y; s[6] = f1.z; s[7] = f1.w;
+        if (r < r1) op.applyv(r, cb, f0, f1, mu, is, sc, sf);
+        // per 4-channel group q: the fold below is the one the 4-wide layout performs (same order, same result)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            f0[q].x += g0[q].x; f0[q].y += g0[q].y; f0[q].z += g0[q].z; f0[q].w += g0[q].w;
+            f1[q].x += g1[q].x; f1[q].y += g1[q].y; f1[q].z += g1[q].z; f1[q].w += g1[q].w;
+            float* s = sh + (tid * NV + q) * 8;
+            s[0] = f0[q].x; s[1] = f0[q].y; s[2] = f0[q].z; s[3] = f0[q].w;
+            s[4] = f1[q].x; s[5] = f1[q].y; s[6] = f1[q].z; s[7] = f1[q].w;
+        }
         __syncthreads();
-        if (tid < C4) {
+        if (tid < CW * NV) {          // one thread per 4-channel group of the block's cgw channels
+            const int lane = tid / NV, q = tid % NV;
             double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-            for (int q = 0; q < rpp; ++q) {
-                const float* t = sh + (q * C4 + tid) * 8;
+            for (int rr = 0; rr < rpp; ++rr) {
+                const float* t = sh + ((rr * CW + lane) * NV + q) * 8;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     a0[k] += t[k];
@@ -404,24 +432,34 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
                                                           T* __restrict__ z, int ldz, int64_t npix, int C,
                                                           uint8_t* __restrict__ zmask) {
     if constexpr (VEC) {
-        const int C4 = C >> 2;
-        const int64_t total = npix * C4;
+        constexpr int NV = Vec16<T>::NV, W = 4 * NV;     // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
+        const int CW = C / W;
+        const int64_t total = npix * CW;
         for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t row = i / C4;
-            const int c = (int)(i - row * C4) * 4;
-            const float4 v = ld4(y + row * ldy + c);
-            const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-            const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-            float4 o;
-            o.x = __fmaf_rn(v.x, sc.x, sh.x); o.y = __fmaf_rn(v.y, sc.y, sh.y);
-            o.z = __fmaf_rn(v.z, sc.z, sh.z); o.w = __fmaf_rn(v.w, sc.w, sh.w);
-            if (res) {
-                const float4 r = ld4(res + row * ldr + c);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            const int64_t row = i / CW;
+            const int c = (int)(i - row * CW) * W;
+            float4 v[NV], r[NV], o[NV];
+            Vec16<T>::ld(y + row * ldy + c, v);
+            if (res) Vec16<T>::ld(res + row * ldr + c, r);
+            unsigned mbits = 0;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const float4 sc = *reinterpret_cast<const float4*>(scale + c + 4 * q);
+                const float4 sh = *reinterpret_cast<const float4*>(shift + c + 4 * q);
+                o[q].x = __fmaf_rn(v[q].x, sc.x, sh.x); o[q].y = __fmaf_rn(v[q].y, sc.y, sh.y);
+                o[q].z = __fmaf_rn(v[q].z, sc.z, sh.z); o[q].w = __fmaf_rn(v[q].w, sc.w, sh.w);
+                if (res) {
+                    o[q].x += r[q].x; o[q].y += r[q].y; o[q].z += r[q].z; o[q].w += r[q].w;
+                }
+                o[q].x = apply_act(o[q].x, act); o[q].y = apply_act(o[q].y, act);
+                o[q].z = apply_act(o[q].z, act); o[q].w = apply_act(o[q].w, act);
+                mbits |= (unsigned)((o[q].x > 0.f) | ((o[q].y > 0.f) << 1) | ((o[q].z > 0.f) << 2) | ((o[q].w > 0.f) << 3)) << (8 * q);
             }
-            o.x = apply_act(o.x, act); o.y = apply_act(o.y, act); o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
-            st4(z + row * ldz + c, o);
-            if (zmask) zmask[i] = (uint8_t)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
+            Vec16<T>::st(z + row * ldz + c, o);
+            if (zmask) {      // one byte per 4 channels, dense rows: byte index = row * C/4 + c/4
+                if constexpr (NV == 2) reinterpret_cast<unsigned short*>(zmask)[i] = (unsigned short)mbits;
+                else zmask[i] = (uint8_t)mbits;
+            }
         }
     } else {
         const int64_t total = npix * C;
@@ -512,13 +550,14 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
                                                                int train, T* __restrict__ dy, int lddy,
                                                                T* __restrict__ dres, int lddres, int64_t npix, int cgw,
                                                                int rows_per_block, int zbits, int c4tot) {
-    const int C4 = cgw >> 2, rpp = 256 / C4;
-    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
-    const int c = blockIdx.y * cgw + tx * 4;
+    constexpr int NV = Vec16<T>::NV, W = 4 * NV;      // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
+    const int CW = cgw / W, rpp = 256 / CW;
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int c = blockIdx.y * cgw + tx * W;
     const float inv_count = (float)(1.0 / count);
-    float gi[4], mu[4], is[4], sg[4], sgx[4], sc[4], sf[4];
+    float gi[W], mu[W], is[W], sg[W], sgx[W], sc[W], sf[W];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < W; ++k) {
         is[k] = invstd[c + k];
         mu[k] = mean[c + k];
         gi[k] = (gamma ? gamma[c + k] : 1.f) * is[k];
@@ -531,19 +570,27 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
     const int64_t r1 = min(r0 + (int64_t)rows_per_block, npix);
     const bool need_y = train || !z;
     for (int64_t r = r0 + ty; r < r1; r += rpp) {
-        float d[4], zz[4], yy[4], o[4], g[4];
-        *reinterpret_cast<float4*>(d) = ld4(dz + r * lddz + c);
+        float4 dv[NV], zv[NV], yv[NV], ov[NV], gv[NV];
+        Vec16<T>::ld(dz + r * lddz + c, dv);
+        unsigned m = 0;
         if (z && zbits) {
-            const unsigned m = reinterpret_cast<const uint8_t*>(z)[r * c4tot + (c >> 2)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) zz[k] = ((m >> k) & 1u) ? 1.f : -1.f;
+            const uint8_t* mp = reinterpret_cast<const uint8_t*>(z) + r * c4tot + (c >> 2);
+            m = NV == 2 ? *reinterpret_cast<const unsigned short*>(mp) : *mp;
         } else if (z) {
-            *reinterpret_cast<float4*>(zz) = ld4(z + r * ldz + c);
+            Vec16<T>::ld(z + r * ldz + c, zv);
         }
-        if (need_y) *reinterpret_cast<float4*>(yy) = ld4(y + r * ldy + c);
+        if (need_y) Vec16<T>::ld(y + r * ldy + c, yv);
+        const float* d = reinterpret_cast<const float*>(dv);
+        const float* yy = reinterpret_cast<const float*>(yv);
+        float* o = reinterpret_cast<float*>(ov);
+        float* g = reinterpret_cast<float*>(gv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            g[k] = d[k] * (z ? act_grad_from_output(zz[k], act) : act_grad_from_pre(__fmaf_rn(yy[k], sc[k], sf[k]), act));
+        for (int k = 0; k < W; ++k) {
+            float zz;
+            if (z && zbits) zz = ((m >> (8 * (k >> 2) + (k & 3))) & 1u) ? 1.f : -1.f;
+            else if (z) zz = reinterpret_cast<const float*>(zv)[k];
+            else zz = 0.f;
+            g[k] = d[k] * (z ? act_grad_from_output(zz, act) : act_grad_from_pre(__fmaf_rn(yy[k], sc[k], sf[k]), act));
             if (train) {
                 const float xh = (yy[k] - mu[k]) * is[k];
                 o[k] = gi[k] * (g[k] - sg[k] - xh * sgx[k]);
@@ -551,8 +598,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
                 o[k] = gi[k] * g[k];
             }
         }
-        st4(dy + r * lddy + c, *reinterpret_cast<float4*>(o));
-        if (dres) st4(dres + r * lddres + c, *reinterpret_cast<float4*>(g));
+        Vec16<T>::st(dy + r * lddy + c, ov);
+        if (dres) Vec16<T>::st(dres + r * lddres + c, gv);
     }
 }
 
@@ -593,8 +640,8 @@ extern "C" int xv2_bn_backward_reduce_partials(const float* partial, int64_t til
 }
 
 extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
-    const ChunkGeom g = chunk_geom(npix, C);
-    size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
+    const ChunkGeom g4 = chunk_geom(npix, C, 4), g8 = chunk_geom(npix, C, 8);    // fp32 / bf16 lane layouts
+    size_t part = (size_t)std::max(g4.chunks, g8.chunks) * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
     return part + (size_t)XV2_BN_SCRATCH_ROWS * C * 2 * sizeof(double);
 }
@@ -603,7 +650,7 @@ extern "C" size_t xv2_bn_backward_workspace(int64_t npix, int C) { return xv2_bn
 template <int MODE, typename T>
 static int column_sums(const ColOp<MODE, T>& op, int64_t npix, int C, double* sums, float* workspace, hipStream_t st,
                        float* f0 = nullptr, float* f1 = nullptr) {
-    const ChunkGeom g = chunk_geom(npix, C);
+    const ChunkGeom g = chunk_geom(npix, C, 4 * Vec16<T>::NV);
     size_t part = (size_t)g.chunks * C * 2 * sizeof(double);
     part = (part + 15) & ~(size_t)15;
     double* dpart = reinterpret_cast<double*>(workspace);
@@ -650,13 +697,14 @@ extern "C" int xv2_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return XV2_OK;
 }
 
-// 4-channel vector accesses: 16 bytes in fp32, 8 bytes in bf16
-static inline bool vec_ok(int C, size_t esz, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
-    if (C % 4) return false;
+// W-channel vector accesses of `esz`-byte elements (W * esz bytes, aligned)
+static inline bool vec_ok(int C, size_t esz, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs,
+                          int W = 4) {
+    if (C % W) return false;
     for (int l : lds)
-        if (l % 4) return false;
+        if (l % W) return false;
     for (const void* p : ptrs)
-        if (p && (reinterpret_cast<uintptr_t>(p) & (4 * esz - 1))) return false;
+        if (p && (reinterpret_cast<uintptr_t>(p) & (W * esz - 1))) return false;
     return true;
 }
 
@@ -664,10 +712,11 @@ template <typename T>
 static int bn_act_forward_impl(const T* y, int ldy, const float* scale, const float* shift, const T* residual,
                                int ldr, int act, T* z, int ldz, int64_t npix, int C, uint8_t* zmask, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_forward: empty");
-    const bool vec = vec_ok(C, sizeof(T), {ldy, ldz, residual ? ldr : 0}, {y, z, residual}) &&
+    constexpr int W = 4 * Vec16<T>::NV;
+    const bool vec = vec_ok(C, sizeof(T), {ldy, ldz, residual ? ldr : 0}, {y, z, residual}, W) &&
                      vec_ok(C, 4, {}, {scale, shift});
-    XV2_CHECK_ARG(!zmask || (vec && act != XV2_ACT_SIGMOID), "bn_act_forward_mask: needs C %% 4 == 0, aligned rows, ReLU-type activation");
-    const int grid = ew_grid(npix * (vec ? C / 4 : C));
+    XV2_CHECK_ARG(!zmask || (vec && act != XV2_ACT_SIGMOID), "bn_act_forward_mask: needs C %% %d == 0, aligned rows, ReLU-type activation", W);
+    const int grid = ew_grid(npix * (vec ? C / W : C));
     if (vec)
         hipLaunchKernelGGL((bn_act_fwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
                            shift, residual, ldr, act, z, ldz, npix, C, zmask);
@@ -701,7 +750,7 @@ static int bn_bwd_reduce_impl(const T* dz, int lddz, const T* z, int ldz, int zb
                               int64_t npix, int C, double* sums2, float* dgamma, float* dbeta, float* workspace,
                               void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_reduce: empty");
-    XV2_CHECK_ARG(!zbits || (C % 4 == 0 && chunk_geom(npix, C).cgw && act != XV2_ACT_SIGMOID),
+    XV2_CHECK_ARG(!zbits || (C % 4 == 0 && chunk_geom(npix, C, 4 * Vec16<T>::NV).cgw && act != XV2_ACT_SIGMOID),
                   "bn backward (mask form): unsupported channel count %d / activation", C);
     XV2_CHECK_ARG(C % 4 != 0 || (lddz % 4 == 0 && (!z || ldz % 4 == 0) && ldy % 4 == 0), "bn backward: strides must be multiples of 4");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
@@ -741,12 +790,15 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
                              int lddy, T* dres, int lddres, int64_t npix, int C, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
-    const bool vec = vec_ok(C, sizeof(T), {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
-                            {dz, zbits ? nullptr : z, y, dy, dres});
+    constexpr int W = 4 * Vec16<T>::NV;
+    const bool vecw = vec_ok(C, sizeof(T), {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
+                             {dz, zbits ? nullptr : z, y, dy, dres}, W);
+    const bool vec = vecw || vec_ok(C, sizeof(T), {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
+                                    {dz, zbits ? nullptr : z, y, dy, dres}, 4);
     XV2_CHECK_ARG(!zbits || (vec && act != XV2_ACT_SIGMOID), "bn backward (mask form): needs C %% 4 == 0, aligned rows, ReLU-type activation");
-    const ChunkGeom cg = chunk_geom(npix, C);
-    if (vec && cg.cgw) {
-        const int rpp = 256 / (cg.cgw / 4);
+    const ChunkGeom cg = chunk_geom(npix, C, W);
+    if (vecw && cg.cgw) {
+        const int rpp = 256 / (cg.cgw / W);
         int64_t rpb = cdiv(npix * cg.groups, 4096);
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,

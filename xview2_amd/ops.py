@@ -501,10 +501,12 @@ def _bn_rec_of(x, C):
     return rec if rec is not None and rec.C == C else None
 
 
-def _mask_ok(C, act):
-    """layers whose activation follows a residual add can hand the backward pass a byte mask instead of z"""
-    return (ZMASK and act in (ACT_RELU, ACT_LEAKY) and C % 4 == 0 and
-            (C % 256 == 0 or (C // 4 <= 256 and 256 % (C // 4) == 0)))
+def _mask_ok(C, act, half=False):
+    """layers whose activation follows a residual add can hand the backward pass a byte mask instead of z
+    (W = channels per 16-byte lane of the BatchNorm kernels: 4 in fp32, 8 in bf16)"""
+    W = 8 if half else 4
+    return (ZMASK and act in (ACT_RELU, ACT_LEAKY) and C % W == 0 and
+            (C % 256 == 0 or (C // W <= 256 and 256 % (C // W) == 0)))
 
 
 def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False):
@@ -531,7 +533,7 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
     residual = _same(residual, y)
     if want_mask:
         zmask = None
-        if _mask_ok(C, act):
+        if _mask_ok(C, act, y.dtype == torch.bfloat16):
             zmask = torch.empty((npix * (C // 4),), dtype=torch.uint8, device=y.device)
             call("xv2_bn_act_forward_mask", y, C, scale, shift, residual, C, act, z, C, npix, C, zmask, _dt(y))
         else:
