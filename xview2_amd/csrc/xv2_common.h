@@ -95,30 +95,20 @@ template <> struct Elem<bf16_t> {
     }
     static __device__ __forceinline__ float round(float v) { return bf16_round(v); }
 };
-// 16-byte accesses: NV float4 groups per lane (fp32: 1 group = 4 channels, bf16: 2 groups = 8 channels)
+// vector accesses of the streaming kernels: NV float4 groups (4 * NV channels) per lane
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int NV = 1;
     static __device__ __forceinline__ void ld(const float* p, float4 (&v)[1]) { v[0] = *reinterpret_cast<const float4*>(p); }
     static __device__ __forceinline__ void st(float* p, const float4 (&v)[1]) { *reinterpret_cast<float4*>(p) = v[0]; }
 };
+// bf16: measured on MI355X, 8 channels (one 16-byte access) per lane LOSES against 4 channels (8 bytes) in the streaming
+// BatchNorm kernels - the per-lane coefficient registers double (110-138 VGPRs, occupancy 3-4 instead of 7-8) and with
+// them the bytes in flight per CU drop.  So the bf16 lane also owns 4 channels; the NV-generic kernel bodies stay.
 template <> struct Vec16<bf16_t> {
-    static constexpr int NV = 2;
-    static __device__ __forceinline__ void ld(const bf16_t* p, float4 (&v)[2]) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p);
-        v[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                           __uint_as_float(u.y & 0xffff0000u));
-        v[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
-                           __uint_as_float(u.w & 0xffff0000u));
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, const float4 (&v)[2]) {
-        uint4 u;
-        u.x = (unsigned)f32_to_bf16(v[0].x) | ((unsigned)f32_to_bf16(v[0].y) << 16);
-        u.y = (unsigned)f32_to_bf16(v[0].z) | ((unsigned)f32_to_bf16(v[0].w) << 16);
-        u.z = (unsigned)f32_to_bf16(v[1].x) | ((unsigned)f32_to_bf16(v[1].y) << 16);
-        u.w = (unsigned)f32_to_bf16(v[1].z) | ((unsigned)f32_to_bf16(v[1].w) << 16);
-        *reinterpret_cast<uint4*>(p) = u;
-    }
+    static constexpr int NV = 1;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float4 (&v)[1]) { v[0] = Elem<bf16_t>::ld4(p); }
+    static __device__ __forceinline__ void st(bf16_t* p, const float4 (&v)[1]) { Elem<bf16_t>::st4(p, v[0]); }
 };
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p) { return Elem<T>::ld4(p); }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float4& v) { Elem<T>::st4(p, v); }

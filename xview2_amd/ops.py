@@ -504,7 +504,7 @@ def _bn_rec_of(x, C):
 def _mask_ok(C, act, half=False):
     """layers whose activation follows a residual add can hand the backward pass a byte mask instead of z
     (W = channels per 16-byte lane of the BatchNorm kernels: 4 in fp32, 8 in bf16)"""
-    W = 8 if half else 4
+    W = 4          # channels per lane of the BatchNorm kernels (csrc/xv2_common.h Vec16: 4 for both storage types)
     return (ZMASK and act in (ACT_RELU, ACT_LEAKY) and C % W == 0 and
             (C % 256 == 0 or (C // W <= 256 and 256 % (C // W) == 0)))
 
