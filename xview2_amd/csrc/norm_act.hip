@@ -11,6 +11,17 @@
 
 namespace xv2 {
 
+// experiment hook (XV2_BN_BLOCKS): cap on the grid of the streaming BatchNorm kernels - smaller grids leave wave slots
+// to weight-gradient kernels co-scheduled from the side stream
+static int bn_blocks(int dflt) {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("XV2_BN_BLOCKS");
+        v = e ? atoi(e) : -1;
+    }
+    return v > 0 ? v : dflt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // column partials: for every chunk of `rpb` rows, part[chunk][C][2] = (sum f0, sum f1) per channel.
 // F(row, c4 or c, vec) returns the two quantities to accumulate.
@@ -35,7 +46,7 @@ static ChunkGeom chunk_geom(int64_t npix, int C, int W = 4) {
     }
     if (g.cgw) g.groups = C / g.cgw;
     const int64_t rows_per_pass = g.cgw ? 256 / (g.cgw / W) : 4;
-    int64_t rpb = cdiv(npix * g.groups, 2048);
+    int64_t rpb = cdiv(npix * g.groups, bn_blocks(2048));
     rpb = cdiv(rpb, rows_per_pass) * rows_per_pass;
     if (rpb < rows_per_pass * 8) rpb = rows_per_pass * 8;
     g.rpb = (int)rpb;
@@ -615,7 +626,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
 
 static inline int ew_grid(int64_t total) {
     int64_t b = cdiv(total, 256);
-    if (b > 256 * 16) b = 256 * 16;
+    if (b > bn_blocks(256 * 16)) b = bn_blocks(256 * 16);
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -809,7 +820,7 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
     const ChunkGeom cg = chunk_geom(npix, C, W);
     if (vecw && cg.cgw) {
         const int rpp = 256 / (cg.cgw / W);
-        int64_t rpb = cdiv(npix * cg.groups, 4096);
+        int64_t rpb = cdiv(npix * cg.groups, bn_blocks(4096));
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
