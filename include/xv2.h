@@ -260,6 +260,26 @@ int xv2_splat_apply_backward(const void* x, const float* att, const void* dout,
                              const float* dgap, int N, int64_t hw, int C, void* dx, float* datt,
                              float* workspace, int dtype, void* stream);
 
+/* The whole [N, C]-vector tail of SplAtConv2d in two calls (three / four launches instead of ~10 / ~12): GAP partial
+ * sums + fold, fc1, bn1 (training: batch statistics over the N samples of THIS process + running-statistics update;
+ * eval: running statistics) + ReLU, fc2, rSoftMax -> att; and the backward of that chain from dout.  Only without a
+ * cross-rank SyncBatchNorm exchange between fc1 and bn1 (otherwise use the op-by-op entry points above).
+ * xv2_splat_att_supported: N * inter <= 8192 and the channel constraints of xv2_splat_gap_forward. */
+int xv2_splat_att_supported(int N, int C, int inter);
+size_t xv2_splat_att_workspace(int N, int64_t hw, int C, int inter);
+int xv2_splat_att_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1, const float* b1,
+                          const float* gamma1, const float* beta1, float eps, float momentum, float* running_mean,
+                          float* running_var, int train, const float* w2, const float* b2, float* gap, float* h1,
+                          float* a1, float* mean1, float* invstd1, float* att, float* workspace, int dtype,
+                          void* stream);
+/* dw2 [2C][inter], db2 [2C], dgamma1 / dbeta1 / db1 [inter], dw1 [inter][C], dgap [N][C] (feed dgap to
+ * xv2_splat_apply_backward for dx) */
+int xv2_splat_att_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter, const float* gap,
+                           const float* h1, const float* a1, const float* mean1, const float* invstd1,
+                           const float* gamma1, const float* w1, const float* w2, const float* att, int train,
+                           float* dw2, float* db2, float* dgamma1, float* dbeta1, float* dw1, float* db1, float* dgap,
+                           float* workspace, int dtype, void* stream);
+
 /* ---- attention gate glue (model/layers.py:161-166) ---------------------------------------- */
 /* r = relu(a + b) */
 int xv2_add_relu_forward(const void* a, const void* b, void* r, int64_t n, int dtype, void* stream);

@@ -710,3 +710,45 @@ def test_bf16_storage_stem_residual_convt_pool_head():
     close(y.cpu(), yr, 1e-5, "head y bf16-in")
     bf16_close(nchw(ah.grad.float()), xr.grad, 1e-2, "head dx")
     close(wgh.grad, whr.grad, 1e-4, "head dw")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 12, 64, 32), (8, 6, 6, 128, 64), (2, 4, 4, 512, 256), (3, 8, 8, 256, 128)])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_split_attention_tail_equals_the_op_by_op_chain(shape, training):
+    """xv2_splat_att_forward / _backward (GAP fold + fc1 + bn1 + ReLU + fc2 + rSoftMax in two launches) against the
+    op-by-op entry points it replaces (which are themselves checked against PyTorch above and stay in use under
+    SyncBatchNorm): same outputs, gradients and running statistics to fp32 rounding."""
+    from xview2_amd import ops
+    N, H, W, C, inter = shape
+    torch.manual_seed(N + C)
+    x = torch.randn(N, H, W, 2 * C, device=dev()).relu_()
+    fc1 = torch.nn.Conv2d(C, inter, 1).to(dev())
+    fc2 = torch.nn.Conv2d(inter, 2 * C, 1).to(dev())
+    dout = torch.randn(N, H, W, C, device=dev())
+    res = {}
+    for fused in (False, True):
+        ops.FUSED_SPLAT = fused
+        try:
+            bn1 = torch.nn.BatchNorm2d(inter).to(dev())
+            with torch.no_grad():
+                bn1.weight.uniform_(0.5, 1.5)
+                bn1.bias.normal_(0, 0.1)
+                bn1.running_mean.normal_(0, 0.1)
+                bn1.running_var.uniform_(0.5, 1.5)
+            torch.manual_seed(7)
+            with torch.no_grad():
+                bn1.weight.copy_(torch.rand(inter) + 0.5)
+                bn1.bias.copy_(torch.randn(inter) * 0.1)
+                bn1.running_mean.copy_(torch.randn(inter) * 0.1)
+                bn1.running_var.copy_(torch.rand(inter) + 0.5)
+            xx = x.clone().requires_grad_(True)
+            ps = [p.detach().clone().requires_grad_(True) for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+            out = ops.SplitAttentionFn.apply(xx, ps[0], ps[1], bn1.weight, bn1.bias, ps[2], ps[3], ops.BnState(bn1), training)
+            out.backward(dout)
+            res[fused] = [out.detach(), xx.grad] + [p.grad for p in ps] + [bn1.weight.grad, bn1.bias.grad,
+                                                                           bn1.running_mean.clone(), bn1.running_var.clone()]
+        finally:
+            ops.FUSED_SPLAT = True
+    names = ["out", "dx", "dw1", "db1", "dw2", "db2", "dgamma1", "dbeta1", "running_mean", "running_var"]
+    for nm, a, b in zip(names, res[True], res[False]):
+        close(a, b, 2e-5, "fused split attention " + nm)

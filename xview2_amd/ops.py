@@ -950,9 +950,14 @@ class GateMulFn(torch.autograd.Function):
         return dskip, dgate
 
 
+FUSED_SPLAT = os.environ.get("XV2_FUSED_SPLAT", "1") != "0"
+
+
 class SplitAttentionFn(torch.autograd.Function):
     """ResNeSt radix-2 split attention on top of the (already BN+ReLU'd) grouped-conv output x
-    [N,H,W,2C]: gap -> fc1 -> BN1 -> ReLU -> fc2 -> rSoftMax -> sum_r att_r * x_r."""
+    [N,H,W,2C]: gap -> fc1 -> BN1 -> ReLU -> fc2 -> rSoftMax -> sum_r att_r * x_r.
+    Without a SyncBatchNorm exchange the [N, C]-vector chain runs as xv2_splat_att_forward / _backward (3 + 4 launches
+    instead of ~10 + ~12 tiny ones); with it, op by op around the all-reduce of bn1's statistics."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, bn1, training):
@@ -961,15 +966,32 @@ class SplitAttentionFn(torch.autograd.Function):
         N, H, W, C2 = x.shape
         C, hw = C2 // 2, H * W
         inter = w1.shape[0]
-        gap = _f32((N, C), x)
-        call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x), _dt(x))
         w1m, w2m = w1.reshape(inter, C).contiguous(), w2.reshape(C2, inter).contiguous()
+        gap, att = _f32((N, C), x), _f32((N, C2), x)
+        ctx.fused = (FUSED_SPLAT and not (training and _sync_group(bn1)) and b1 is not None and
+                     query("xv2_splat_att_supported", N, C, inter) == 1)
+        if ctx.fused:
+            h1, a1 = _f32((N, inter), x), _f32((N, inter), x)
+            mean1, invstd1 = _f32((inter,), x), _f32((inter,), x)
+            ws = _ws(query("xv2_splat_att_workspace", N, hw, C, inter), x)
+            if training:
+                bn_stats_changed()
+            call("xv2_splat_att_forward", x, N, hw, C, inter, w1m, b1, bn1.weight, bn1.bias, float(bn1.eps),
+                 float(bn1.momentum), bn1.running_mean, bn1.running_var, 1 if training else 0, w2m, b2, gap, h1, a1,
+                 mean1, invstd1, att, ws, _dt(x))
+            out = _act((N, H, W, C), x)
+            call("xv2_splat_apply_forward", x, att, N, hw, C, out, _dt(x))
+            ctx.save_for_backward(x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att)
+            ctx.training = training
+            ctx.shapes = (w1.shape, w2.shape)
+            ctx.params = (w1, b1, w2, b2, bn1.weight, bn1.bias)
+            return out
+        call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x), _dt(x))
         h1 = _f32((N, inter), x)
         call("xv2_linear_forward", gap, w1m, b1, h1, N, C, inter)
         a1, st = _bn_forward(h1, None, ACT_RELU, bn1, None, training)
         logits = _f32((N, C2), x)
         call("xv2_linear_forward", a1, w2m, b2, logits, N, inter, C2)
-        att = _f32((N, C2), x)
         call("xv2_rsoftmax_forward", logits, att, N, C)
         out = _act((N, H, W, C), x)
         call("xv2_splat_apply_forward", x, att, N, hw, C, out, _dt(x))
@@ -981,6 +1003,24 @@ class SplitAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.fused:
+            x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
+            dout = _same(dout, x).contiguous()
+            N, H, W, C2 = x.shape
+            C, hw = C2 // 2, H * W
+            inter = w1m.shape[0]
+            pw1, pb1, pw2, pb2, pg1, pbe1 = ctx.params
+            ctx.params = None
+            dw1, db1, dw2, db2 = _grad_like(pw1), _grad_like(pb1), _grad_like(pw2), _grad_like(pb2)
+            dg1, dbe1 = _grad_like(pg1), _grad_like(pbe1)
+            dgap = _f32((N, C), x)
+            ws = _ws(query("xv2_splat_att_workspace", N, hw, C, inter), x)
+            call("xv2_splat_att_backward", x, dout, N, hw, C, inter, gap, h1, a1, mean1, invstd1, g1, w1m, w2m, att,
+                 1 if ctx.training else 0, dw2, db2, dg1, dbe1, dw1, db1, dgap, ws, _dt(x))
+            dx = torch.empty_like(x)
+            call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws, _dt(x))
+            s1, s2 = ctx.shapes
+            return dx, dw1.reshape(s1), db1, dg1, dbe1, dw2.reshape(s2), db2, None, None
         x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att, scale1, shift1 = ctx.saved_tensors
         dout = _same(dout, x).contiguous()
         N, H, W, C2 = x.shape
