@@ -440,38 +440,19 @@ __global__ void rsoftmax_bwd_kernel(const float* __restrict__ a, const float* __
 // The [N, C]-vector part of SplAtConv2d - GAP fold, fc1, bn1 (+ReLU), fc2, rSoftMax - is ~10 tiny launches when
 // written op by op (4-5 us of GPU time and ~13 us of host time each, 16/33/66 blocks per resnest50/101/200 pass, once
 // more in backward).  Without a cross-rank statistics exchange between fc1 and bn1 the whole chain is two launches.
-//   splat_fc1_kernel   grid (ceil(inter/64), N): folds the GAP partials of sample n (every block, redundantly; block
-//                      x == 0 stores gap[n]) and computes 64 outputs of h1[n] = fc1(gap[n]).
+//   (splat_colsum_kernel + splat_gap_finish_kernel: the GAP itself, chip-wide)
+//   splat_fc1_kernel   grid (ceil(inter/64), N): 64 outputs of h1[n] = fc1(gap[n]) per block.
 //   splat_att_kernel   grid (C/64): every block rebuilds bn1 for ALL `inter` channels from h1 [N][inter] (two-pass
 //                      fp64 statistics over the N samples; block 0 stores them and updates the running statistics),
 //                      a1 = relu(bn1(h1)) in LDS, then fc2 + rSoftMax for its 64 channel pairs (c, C + c).
 constexpr int SPLAT_MAX_NI = 8192;      // N * inter floats of LDS per matrix (h1 / a1)
 
-__global__ void __launch_bounds__(256) splat_fc1_kernel(const float* __restrict__ part, int chunks, int N, int C,
-                                                         int inter, float inv_hw, const float* __restrict__ w1,
-                                                         const float* __restrict__ b1, float* __restrict__ gap,
+__global__ void __launch_bounds__(256) splat_fc1_kernel(const float* __restrict__ gap, int N, int C, int inter,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                          float* __restrict__ h1) {
     extern __shared__ float sg[];       // [C] gap of sample n
     const int n = blockIdx.y, tid = threadIdx.x;
-    const float* p = part + (size_t)n * SPLAT_CHUNKS * 2 * C;
-    for (int c = tid; c < C; c += 256) {
-        // same fold order as splat_gap_finish_kernel would use per column is not required: fixed order per column
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1v = 0.f;
-        int k = 0;
-        for (; k + 1 < chunks; k += 2) {
-            a0 += p[(size_t)k * 2 * C + c];
-            a1 += p[(size_t)(k + 1) * 2 * C + c];
-            b0 += p[(size_t)k * 2 * C + C + c];
-            b1v += p[(size_t)(k + 1) * 2 * C + C + c];
-        }
-        if (k < chunks) {
-            a0 += p[(size_t)k * 2 * C + c];
-            b0 += p[(size_t)k * 2 * C + C + c];
-        }
-        const float g = ((a0 + a1) + (b0 + b1v)) * inv_hw;
-        sg[c] = g;
-        if (blockIdx.x == 0) gap[(size_t)n * C + c] = g;
-    }
+    for (int c = tid; c < C; c += 256) sg[c] = gap[(size_t)n * C + c];
     __syncthreads();
     // 4 lanes per output, 64 outputs per block
     const int j = blockIdx.x * 64 + (tid >> 2), q = tid & 3;
@@ -566,10 +547,10 @@ __global__ void __launch_bounds__(256) splat_att_kernel(const float* __restrict_
     }
 }
 
-// backward, first half.  grid (C/64): block = the channel pairs (c, C + c), c in [c0, c0 + 64): folds the datt partials
-// of its columns, rSoftMax backward -> dlogits [N][128] (LDS), dw2 / db2 rows of its 128 outputs, and its
+// backward, first half (after splat_colsum_kernel + splat_datt_finish_kernel produced datt).  grid (C/64): block = the
+// channel pairs (c, C + c), c in [c0, c0 + 64): rSoftMax backward -> dlogits [N][128] (LDS), dw2 / db2 rows of its 128 outputs, and its
 // contribution to da1: pda1[block][N][inter] = sum_{k in block} dlogits[n][k] * w2[k][j].
-__global__ void __launch_bounds__(256) splat_att_bwd1_kernel(const float* __restrict__ part, int chunks, int N, int C,
+__global__ void __launch_bounds__(256) splat_att_bwd1_kernel(const float* __restrict__ datt, int N, int C,
                                                               int inter, const float* __restrict__ att,
                                                               const float* __restrict__ a1,
                                                               const float* __restrict__ w2, float* __restrict__ dw2,
@@ -583,21 +564,7 @@ __global__ void __launch_bounds__(256) splat_att_bwd1_kernel(const float* __rest
         const int n = i >> 6, cc = i & 63;
         float dl0 = 0.f, dl1 = 0.f;
         if (c0 + cc < C) {
-            const float* p = part + (size_t)n * SPLAT_CHUNKS * 2 * C;
-            float d0 = 0.f, d1 = 0.f, e0 = 0.f, e1 = 0.f;      // datt[n][c], datt[n][C + c]: fixed-order chunk fold
-            int k = 0;
-            for (; k + 1 < chunks; k += 2) {
-                d0 += p[(size_t)k * 2 * C + c0 + cc];
-                e0 += p[(size_t)(k + 1) * 2 * C + c0 + cc];
-                d1 += p[(size_t)k * 2 * C + C + c0 + cc];
-                e1 += p[(size_t)(k + 1) * 2 * C + C + c0 + cc];
-            }
-            if (k < chunks) {
-                d0 += p[(size_t)k * 2 * C + c0 + cc];
-                d1 += p[(size_t)k * 2 * C + C + c0 + cc];
-            }
-            d0 += e0;
-            d1 += e1;
+            const float d0 = datt[(size_t)n * 2 * C + c0 + cc], d1 = datt[(size_t)n * 2 * C + C + c0 + cc];
             const float a0 = att[(size_t)n * 2 * C + c0 + cc], a1v = att[(size_t)n * 2 * C + C + c0 + cc];
             const float dot = a0 * d0 + a1v * d1;
             dl0 = a0 * (d0 - dot);
@@ -964,7 +931,8 @@ extern "C" int xv2_splat_att_supported(int N, int C, int inter) {
 }
 extern "C" size_t xv2_splat_att_workspace(int N, int64_t hw, int C, int inter) {
     (void)hw;
-    return (size_t)N * SPLAT_CHUNKS * 2 * C * sizeof(float) + (size_t)cdiv(C, 64) * N * inter * sizeof(float);
+    return (size_t)N * SPLAT_CHUNKS * 2 * C * sizeof(float) + (size_t)cdiv(C, 64) * N * inter * sizeof(float) +
+           (size_t)N * 2 * C * sizeof(float);
 }
 extern "C" int xv2_splat_att_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1,
                                      const float* b1, const float* gamma1, const float* beta1, float eps,
@@ -981,8 +949,11 @@ extern "C" int xv2_splat_att_forward(const void* x, int N, int64_t hw, int C, in
     XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(splat_colsum_kernel<T>, dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
                                                  (const T*)x, (const T*)nullptr, hw, 2 * C, 0, cgw, rpc, workspace));
     XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, 64), N), dim3(256), 0, st, workspace, N, C,
+                       chunks, 1.f / (float)hw, gap);
+    XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_fc1_kernel, dim3((unsigned)cdiv(inter, 64), N), dim3(256), (size_t)C * sizeof(float), st,
-                       workspace, chunks, N, C, inter, 1.f / (float)hw, w1, b1, gap, h1);
+                       gap, N, C, inter, w1, b1, h1);
     XV2_CHECK_LAUNCH();
     SplatBn bn{gamma1, beta1, running_mean, running_var, eps, momentum, train};
     hipLaunchKernelGGL(splat_att_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), (size_t)(N * inter + N * 128) * sizeof(float),
@@ -1007,8 +978,12 @@ extern "C" int xv2_splat_att_backward(const void* x, const void* dout, int N, in
     XV2_CHECK_LAUNCH();
     float* pda1 = workspace + (size_t)N * SPLAT_CHUNKS * 2 * C;
     const int nb = (int)cdiv(C, 64);
+    float* datt = pda1 + (size_t)nb * N * inter;
+    hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(2 * C, 64), N), dim3(256), 0, st, workspace, N, 2 * C,
+                       chunks, datt);
+    XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_att_bwd1_kernel, dim3(nb), dim3(256), (size_t)(N * inter + N * 128) * sizeof(float), st,
-                       workspace, chunks, N, C, inter, att, a1, w2, dw2, db2, pda1);
+                       datt, N, C, inter, att, a1, w2, dw2, db2, pda1);
     XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_att_bwd2_kernel, dim3(nb), dim3(256), (size_t)(N * inter + N * 64) * sizeof(float), st, pda1,
                        nb, N, C, inter, gap, h1, a1, mean1, invstd1, gamma1, train, w1, dgamma1, dbeta1, dw1, db1, dgap);
