@@ -748,7 +748,7 @@ def test_fused_split_attention_tail_equals_the_op_by_op_chain(shape, training):
             res[fused] = [out.detach(), xx.grad] + [p.grad for p in ps] + [bn1.weight.grad, bn1.bias.grad,
                                                                            bn1.running_mean.clone(), bn1.running_var.clone()]
         finally:
-            ops.FUSED_SPLAT = True
+            ops.FUSED_SPLAT = False
     names = ["out", "dx", "dw1", "db1", "dw2", "db2", "dgamma1", "dbeta1", "running_mean", "running_var"]
     for nm, a, b in zip(names, res[True], res[False]):
         if nm == "db1" and training:

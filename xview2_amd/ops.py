@@ -950,7 +950,11 @@ class GateMulFn(torch.autograd.Function):
         return dskip, dgate
 
 
-FUSED_SPLAT = os.environ.get("XV2_FUSED_SPLAT", "1") != "0"
+# Fused [N, C]-vector tail of split attention (xv2_splat_att_forward / _backward: 4 + 5 launches instead of 11 + 12):
+# exact, tested, but measured SLOWER on MI355X (resnest50 step 43.7 -> 44.5 ms fp32, 19.9 -> 20.8 ms bf16) - its few
+# fat blocks walk 128..256-long dependent load chains where the op-by-op kernels spread the same work over the chip -
+# so it stays opt-in (XV2_FUSED_SPLAT=1).
+FUSED_SPLAT = os.environ.get("XV2_FUSED_SPLAT", "0") != "0"
 
 
 class SplitAttentionFn(torch.autograd.Function):
