@@ -459,3 +459,40 @@ def test_fused_inference_path_is_bit_identical_to_the_unfused_eval_forward(name)
         assert not torch.equal(r1, r0)          # the step really changed the network
     finally:
         xnn.FUSED_INFERENCE = True
+
+
+@pytest.mark.parametrize("name", ["post_siamese_resnest50_ds", "post_siamese_coral"])
+def test_batched_siamese_passes_equal_two_sequential_passes(name):
+    """SiameseUNet runs its shared-weight U-Net on the pre and the post image (model/unet.py:232-233).  The default
+    here sends both through as ONE batch of 2B with per-part BatchNorm statistics (ops.BN_SPLIT); it must reproduce
+    the two sequential passes: logits, loss, every gradient, running statistics (updated pre then post) and
+    num_batches_tracked (+2)."""
+    from xview2_amd import criterion, networks
+    a = ARGS(**MODEL_CASES[name])
+    B = 4
+    x, y = model_input(a, batch=B).to(DEV), labels(a, batch=B).to(DEV)
+    res = {}
+    for batched in (False, True):
+        networks.BATCH_SIAMESE = batched
+        try:
+            _, hip = build_pair(a)
+            hip.train()
+            p = hip(x)
+            loss = criterion.compute_loss(criterion.Loss(a), p, y, a.deep_supervision)
+            loss.backward()
+            p0 = p[0] if isinstance(p, list) else p
+            res[batched] = (p0.detach(), float(loss), {k: v.grad.detach().clone() for k, v in hip.named_parameters()
+                                                       if v.grad is not None}, {k: v.clone() for k, v in hip.state_dict().items()})
+        finally:
+            networks.BATCH_SIAMESE = True
+    (pa, la, ga, sa), (pb, lb, gb, sb) = res[False], res[True]
+    assert rel(pb, pa) <= 2e-4 and abs(la - lb) <= 1e-5 * max(1.0, abs(la))
+    assert set(ga) == set(gb)
+    num = sum(float((gb[k].double() - ga[k].double()).pow(2).sum()) for k in ga)
+    den = sum(float(ga[k].double().pow(2).sum()) for k in ga)
+    assert (num / den) ** 0.5 <= 5e-3, (num / den) ** 0.5
+    for k in sa:
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 2, k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(sb[k], sa[k]) <= 1e-4, k

@@ -8,6 +8,8 @@ observable quirks are preserved on purpose: FusedUNet/
 and read --dec_interp as "no skip"; ParallelUNet evaluates ``unet_pre`` on the pre image twice; CatUNet
 raises TypeError at construction.
 """
+import os
+
 from torch import nn
 
 from . import nn as xnn
@@ -16,6 +18,7 @@ from .decoder import ASPP, PPM, FusionBlock, OutputBlock, UpsampleBlock
 from .encoders import get_encoder  # noqa: F401  (re-exported, same contract as unet.py:45)
 
 DECF = [512, 256, 128, 64, 32]
+BATCH_SIAMESE = os.environ.get("XV2_BATCH_SIAMESE", "1") != "0"   # SiameseUNet: pre + post as one split batch
 _FIRST_LEVEL = {1: 0, 2: 1, 4: 2}
 
 
@@ -142,8 +145,17 @@ class SiameseUNet(nn.Module):  # unet.py:218-236 (shared weights, BN statistics 
                                            self.unet.enc_chn[-1])
 
     def forward(self, data):
-        a, b = self.unet(_pre(data)), self.unet(_post(data))
-        return self.output_block(*[concat(x, y) for x, y in zip(a, b)])
+        if not BATCH_SIAMESE or not data.is_cuda:
+            a, b = self.unet(_pre(data)), self.unet(_post(data))
+            return self.output_block(*[concat(x, y) for x, y in zip(a, b)])
+        # Both shared-weight passes (unet.py:232-233) as ONE batch of 2B: [pre_0..pre_B-1, post_0..post_B-1].  Every
+        # convolution / pooling / transposed convolution launches once instead of twice on twice the rows, the weight
+        # gradient of the shared parameters is one launch instead of two plus an accumulation, and (data parallel)
+        # each SyncBatchNorm exchange carries the statistics of both passes in one collective.  BatchNorm keeps the
+        # reference's semantics: statistics per pass, running statistics updated pre then post (ops.BN_SPLIT).
+        with xnn.bn_split(2):
+            outs = self.unet(ops.nchw_pair_to_nhwc(data, 4))
+        return self.output_block(*[None if t is None else ops.PairCatFn.apply(t) for t in outs])
 
 
 class SiameseEncUNet(nn.Module, _EncoderMixin):  # unet.py:239-317

@@ -40,7 +40,21 @@ def bump_bn_counter(bn):
     if not hasattr(bn, "_xv2_pending"):
         bn._xv2_pending = 0
         bn.register_state_dict_pre_hook(_flush_bn_counter)
-    bn._xv2_pending += 1
+    bn._xv2_pending += ops.BN_SPLIT          # a split batch counts as BN_SPLIT consecutive batches
+
+
+class bn_split:
+    """`with bn_split(2):` - the batch entering the network holds 2 independent BatchNorm batches back to back
+    (ops.BN_SPLIT): SiameseUNet's shared-weight passes over the pre and the post image as ONE batch."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def __enter__(self):
+        self.old, ops.BN_SPLIT = ops.BN_SPLIT, self.parts
+
+    def __exit__(self, *exc):
+        ops.BN_SPLIT = self.old
 
 
 FUSED_INFERENCE = True     # eval + no_grad: one launch per conv layer (tests switch it off to compare both forms)

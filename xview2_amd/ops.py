@@ -239,11 +239,13 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     if x1 is not None and x1.dtype != x0.dtype:
         raise RuntimeError("convolution sources of different element types (%s, %s)" % (x0.dtype, x1.dtype))
     y = _act((N, OH, OW, Cout_t), x0, torch.bfloat16 if half else torch.float32)
-    sums = torch.empty((Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
+    S = BN_SPLIT if (want_stats and N % BN_SPLIT == 0) else 1
+    sums = torch.empty((S, Cout_t, 2) if S > 1 else (Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
     coeffs = None
     if want_stats and bn is not None and not _sync_group(bn):
-        coeffs = tuple(_f32((Cout_t,), x0) for _ in range(4))
+        coeffs = tuple(_f32((S, Cout_t) if S > 1 else (Cout_t,), x0) for _ in range(4))
         bn_stats_changed()
+    stats_ok = True        # False: the M tiles do not split evenly over the S parts -> statistics taken from y afterwards
     w = weight.contiguous()
     if G > 1 and x1 is not None:
         raise RuntimeError("grouped convolution over a virtual concat is not supported")
@@ -269,16 +271,24 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
              None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part,
              _ws(wsb, x0) if wsb else None)
-        if want_stats:
+        if want_stats and S > 1 and ((N * OH * OW) % tiles != 0 or tiles % S != 0):
+            stats_ok = False
+        elif want_stats:
             scratch = torch.empty((64 * Coutg * 2,), dtype=torch.float64, device=x0.device)
-            if coeffs is None:
-                call("xv2_bn_reduce_stats", part, tiles, Coutg, Ptr(sums, gi * Coutg * 2), scratch)
-            else:
-                o = gi * Coutg
-                call("xv2_bn_reduce_finalize", part, tiles, Coutg, Ptr(sums, o * 2), scratch, float(N * OH * OW),
-                     _off(bn.weight, o), _off(bn.bias, o), float(bn.eps), float(bn.momentum),
-                     _off(bn.running_mean, o), _off(bn.running_var, o), *(Ptr(t, o) for t in coeffs))
+            tp = tiles // S
+            for h in range(S):                   # part h = rows [h*M/S, (h+1)*M/S) = tiles [h*tp, (h+1)*tp)
+                ph = Ptr(part, h * tp * Coutg * 2)
+                o = h * Cout_t + gi * Coutg
+                if coeffs is None:
+                    call("xv2_bn_reduce_stats", ph, tp, Coutg, Ptr(sums, o * 2), scratch)
+                else:
+                    og = gi * Coutg
+                    call("xv2_bn_reduce_finalize", ph, tp, Coutg, Ptr(sums, o * 2), scratch, float(N * OH * OW // S),
+                         _off(bn.weight, og), _off(bn.bias, og), float(bn.eps), float(bn.momentum),
+                         _off(bn.running_mean, og), _off(bn.running_var, og), *(Ptr(t, o) for t in coeffs))
     assert cin_w <= C0g + C1t
+    if want_stats and not stats_ok:
+        sums, coeffs = None, None           # _bn_forward takes the statistics of each part from y
     if bn is not None:
         return y, sums, coeffs
     return y, sums
@@ -412,24 +422,36 @@ def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
 # batch-norm pieces
 FORCE_COLLECTIVES = False   # tests: exercise the collective code paths on a single-rank process group
 
+# BN_SPLIT = S > 1: the batch dimension holds S independent BatchNorm batches of equal size, back to back (the
+# Siamese U-Net runs its shared-weight network on the pre and the post image: model/unet.py:231-236 calls it twice,
+# here both images travel as ONE batch of 2B).  Convolutions, pooling, heads see one big batch (half the launches,
+# twice the rows per launch, shared-weight gradients summed inside one weight-gradient launch); every training-mode
+# BatchNorm keeps per-part statistics - reduced, (all-reduced: ONE collective for the S parts,) finalised and applied
+# part by part, running statistics updated in part order - so the result equals S sequential passes.
+BN_SPLIT = 1
+
 
 def _sync_group(bn):
     return bn.sync and dist.is_available() and dist.is_initialized() and (
         dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
-def _bn_train_coeffs(sums, count, bn, like):
-    """sums: double [C,2] local; returns mean, invstd, scale, shift, global count"""
-    C = sums.shape[0]
+def _bn_train_coeffs(sums, count, bn, like, S=1):
+    """sums: double [C,2] (or [S,C,2]: S independent parts, `count` elements each) local; returns mean, invstd, scale,
+    shift ([C] or [S,C]) and the global count per part"""
+    C = sums.shape[-2]
     bn_stats_changed()
     if _sync_group(bn):
         # every rank holds the same per-GPU batch (weak scaling), so the global count is local*world and the
-        # exchange is ONE in-place all-reduce of the fp64 (sum, sum-of-squares) vector - no host round trip
+        # exchange is ONE in-place all-reduce of the fp64 (sum, sum-of-squares) vector - no host round trip; the S
+        # parts of a split batch travel in the same collective
         dist.all_reduce(sums)
         count = float(count) * dist.get_world_size()
-    mean, invstd, scale, shift = (_f32((C,), like) for _ in range(4))
-    call("xv2_bn_finalize", sums, float(count), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
-         bn.running_mean, bn.running_var, mean, invstd, scale, shift, C)
+    shape = (S, C) if S > 1 else (C,)
+    mean, invstd, scale, shift = (_f32(shape, like) for _ in range(4))
+    for h in range(S):           # in part order: the running statistics see the parts as consecutive batches
+        call("xv2_bn_finalize", Ptr(sums, h * C * 2), float(count), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
+             bn.running_mean, bn.running_var, Ptr(mean, h * C), Ptr(invstd, h * C), Ptr(scale, h * C), Ptr(shift, h * C), C)
     return mean, invstd, scale, shift, float(count)
 
 
@@ -509,76 +531,103 @@ def _mask_ok(C, act, half=False):
             (C % 256 == 0 or (C // W <= 256 and 256 % (C // W) == 0)))
 
 
-def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False):
+def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False, split=1):
     """y raw [.., C]; returns z and the context needed by _bn_backward.  `coeffs`: (mean, invstd, scale, shift)
     when the statistics reduction already derived them (xv2_bn_reduce_finalize).  want_mask: also return the
-    1-bit-per-element sign mask of z (a byte per 4 channels) as a third value, or None if the shape has no mask form."""
+    1-bit-per-element sign mask of z (a byte per 4 channels) as a third value, or None if the shape has no mask form.
+    split = S > 1: S independent BatchNorm batches back to back along the rows (BN_SPLIT); sums / coeffs are [S, ...]."""
     C = y.shape[-1]
     npix = y.numel() // C
+    S = split if training else 1
+    rows = npix // S
     if training and coeffs is not None:
         mean, invstd, scale, shift = coeffs
-        count = float(npix)
+        count = float(rows)
     elif training:
         if sums is None:
-            if y.dtype != torch.float32:
-                raise RuntimeError("stand-alone BatchNorm statistics exist for fp32 tensors only")
-            sums = torch.empty((C, 2), dtype=torch.float64, device=y.device)
-            ws = _ws(query("xv2_bn_tensor_stats_workspace", npix, C), y)
-            call("xv2_bn_tensor_stats", y, C, npix, C, sums, ws)
-        mean, invstd, scale, shift, count = _bn_train_coeffs(sums, npix, bn, y)
+            ysrc = y if y.dtype == torch.float32 else y.float()     # column-sum kernel: fp32 input (small / odd shapes only)
+            sums = torch.empty((S, C, 2) if S > 1 else (C, 2), dtype=torch.float64, device=y.device)
+            ws = _ws(query("xv2_bn_tensor_stats_workspace", rows, C), y)
+            for h in range(S):
+                call("xv2_bn_tensor_stats", Ptr(ysrc, h * rows * C), C, rows, C, Ptr(sums, h * C * 2), ws)
+        mean, invstd, scale, shift, count = _bn_train_coeffs(sums, rows, bn, y, S)
     else:
         mean, invstd, scale, shift = _bn_eval_coeffs(bn, y)
         count = float(npix)
     z = torch.empty_like(y)
     residual = _same(residual, y)
-    if want_mask:
-        zmask = None
-        if _mask_ok(C, act, y.dtype == torch.bfloat16):
-            zmask = torch.empty((npix * (C // 4),), dtype=torch.uint8, device=y.device)
-            call("xv2_bn_act_forward_mask", y, C, scale, shift, residual, C, act, z, C, npix, C, zmask, _dt(y))
+    zmask = None
+    if want_mask and _mask_ok(C, act, y.dtype == torch.bfloat16):
+        zmask = torch.empty((npix * (C // 4),), dtype=torch.uint8, device=y.device)
+    for h in range(S):
+        o, oc = h * rows * C, h * C
+        yh, zh = Ptr(y, o), Ptr(z, o)
+        rh = None if residual is None else Ptr(residual, o)
+        if zmask is not None:
+            call("xv2_bn_act_forward_mask", yh, C, Ptr(scale, oc), Ptr(shift, oc), rh, C, act, zh, C, rows, C,
+                 Ptr(zmask, h * rows * (C // 4)), _dt(y))
         else:
-            call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C, _dt(y))
+            call("xv2_bn_act_forward", yh, C, Ptr(scale, oc), Ptr(shift, oc), rh, C, act, zh, C, rows, C, _dt(y))
+    if want_mask:
         return z, (mean, invstd, count, scale, shift), zmask
-    call("xv2_bn_act_forward", y, C, scale, shift, residual, C, act, z, C, npix, C, _dt(y))
     return z, (mean, invstd, count, scale, shift)
 
 
-def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None):
+def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, split=1):
     """z may be None (layers without a residual input): the activation mask is then recomputed from y; a uint8 `z` is
-    the byte mask written by xv2_bn_act_forward_mask"""
+    the byte mask written by xv2_bn_act_forward_mask.  split: see _bn_forward (the per-part coefficients are [S, C])."""
     mean, invstd, count, scale, shift = stats
     C = y.shape[-1]
     npix = y.numel() // C
+    S = split if training else 1
+    rows = npix // S
     dz = _same(dz, y).contiguous()
     dt = _dt(y)
-    sums2 = torch.empty((C, 2), dtype=torch.float64, device=y.device)
+    sums2 = torch.empty((S, C, 2) if S > 1 else (C, 2), dtype=torch.float64, device=y.device)
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
-    ws = _ws(query("xv2_bn_backward_workspace", npix, C), y)
+    ws = _ws(query("xv2_bn_backward_workspace", rows, C), y)
     masked = z is not None and z.dtype == torch.uint8
     pre = None
     if rec is not None and rec.part is not None:
         # statistics already taken by the consumer's backward-data epilogue - valid only for that very tensor
-        if z is None and rec.token == (dz.data_ptr(), dz._version):
+        if z is None and S == 1 and rec.token == (dz.data_ptr(), dz._version):
             pre = (rec.part, rec.tiles)
         rec.part, rec.token = None, None
-    if pre is not None:
-        scratch = torch.empty((64 * C * 2,), dtype=torch.float64, device=y.device)
-        call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, scratch)
-    elif masked:
-        call("xv2_bn_act_backward_reduce_mask", dz, C, z, y, C, mean, invstd, act, npix, C, sums2, dgamma, dbeta, ws, dt)
-    else:
-        call("xv2_bn_act_backward_reduce", dz, C, z, C, y, C, mean, invstd, scale, shift, act, npix, C, sums2, dgamma,
-             dbeta, ws, dt)
+    tmp = (_f32((C,), y), _f32((C,), y)) if S > 1 else None
+    for h in range(S):
+        o, oc = h * rows * C, h * C
+        dg, db = (dgamma, dbeta) if h == 0 else tmp      # the parameter gradients are the LOCAL sums over all parts
+        s2 = Ptr(sums2, oc * 2)
+        if pre is not None:
+            scratch = torch.empty((64 * C * 2,), dtype=torch.float64, device=y.device)
+            call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, scratch)
+        elif masked:
+            call("xv2_bn_act_backward_reduce_mask", Ptr(dz, o), C, Ptr(z, h * rows * (C // 4)), Ptr(y, o), C,
+                 Ptr(mean, oc), Ptr(invstd, oc), act, rows, C, s2, dg, db, ws, dt)
+        else:
+            call("xv2_bn_act_backward_reduce", Ptr(dz, o), C, None if z is None else Ptr(z, o), C, Ptr(y, o), C,
+                 Ptr(mean, oc), Ptr(invstd, oc), Ptr(scale, oc), Ptr(shift, oc), act, rows, C, s2, dg, db, ws, dt)
+        if h > 0 and C % 4 == 0:
+            call("xv2_axpby", 1.0, dgamma, 1.0, tmp[0], dgamma, C)
+            call("xv2_axpby", 1.0, dbeta, 1.0, tmp[1], dbeta, C)
+        elif h > 0:                      # the 1-channel psi BatchNorm of the attention gate
+            dgamma.add_(tmp[0])
+            dbeta.add_(tmp[1])
     if training and _sync_group(bn):
         dist.all_reduce(sums2)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    if masked:
-        call("xv2_bn_act_backward_apply_mask", dz, C, z, y, C, mean, invstd, gamma, sums2, float(count), act,
-             1 if training else 0, dy, C, dres, C, npix, C, dt)
-    else:
-        call("xv2_bn_act_backward_apply", dz, C, z, C, y, C, mean, invstd, gamma, scale, shift, sums2, float(count),
-             act, 1 if training else 0, dy, C, dres, C, npix, C, dt)
+    for h in range(S):
+        o, oc = h * rows * C, h * C
+        drh = None if dres is None else Ptr(dres, o)
+        if masked:
+            call("xv2_bn_act_backward_apply_mask", Ptr(dz, o), C, Ptr(z, h * rows * (C // 4)), Ptr(y, o), C,
+                 Ptr(mean, oc), Ptr(invstd, oc), gamma, Ptr(sums2, oc * 2), float(count), act,
+                 1 if training else 0, Ptr(dy, o), C, drh, C, rows, C, dt)
+        else:
+            call("xv2_bn_act_backward_apply", Ptr(dz, o), C, None if z is None else Ptr(z, o), C, Ptr(y, o), C,
+                 Ptr(mean, oc), Ptr(invstd, oc), gamma, Ptr(scale, oc), Ptr(shift, oc), Ptr(sums2, oc * 2),
+                 float(count), act, 1 if training else 0, Ptr(dy, o), C, drh, C, rows, C, dt)
     return dy, dres, dgamma, dbeta
 
 
@@ -627,12 +676,13 @@ class ConvBnActFn(torch.autograd.Function):
         residual = residual.contiguous() if residual is not None else None
         need_dx = x0.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.ihwo = [] if need_dx else None
+        ctx.split = BN_SPLIT if (training and x0.shape[0] % BN_SPLIT == 0) else 1
         y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
         ctx.has_res = residual is not None
         if ctx.has_res:
-            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True)
+            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split)
         else:
-            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs)
+            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split)
             zmask = None
         # the activation mask of the backward pass is recomputed from y unless a residual entered before it; then it
         # comes from the byte mask written next to z (or from z itself for shapes without a mask form)
@@ -657,7 +707,8 @@ class ConvBnActFn(torch.autograd.Function):
             dz = torch.zeros_like(y)
         dpass = _same(dpass, y)
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
-                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec)
+                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec,
+                                               ctx.split)
         ctx.rec = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -802,7 +853,8 @@ class BnActFn(torch.autograd.Function):
     def forward(ctx, y, gamma, beta, residual, bn, act, training):
         _need_cuda(y)
         y = y.contiguous()
-        z, stats = _bn_forward(y, residual, act, bn, None, training)
+        ctx.split = BN_SPLIT if (training and y.shape[0] % BN_SPLIT == 0) else 1
+        z, stats = _bn_forward(y, residual, act, bn, None, training, split=ctx.split)
         ctx.has_res = residual is not None
         ctx.save_for_backward(y, z if ctx.has_res else None, gamma, stats[0], stats[1], stats[3], stats[4])
         ctx.count, ctx.bn, ctx.act, ctx.training = stats[2], bn, act, training
@@ -812,7 +864,7 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, dz):
         y, z, gamma, mean, invstd, scale, shift = ctx.saved_tensors
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
-                                               ctx.bn, ctx.training, ctx.has_res)
+                                               ctx.bn, ctx.training, ctx.has_res, None, ctx.split)
         return dy, dgamma, dbeta, dres, None, None, None
 
 
@@ -972,7 +1024,7 @@ class SplitAttentionFn(torch.autograd.Function):
         inter = w1.shape[0]
         w1m, w2m = w1.reshape(inter, C).contiguous(), w2.reshape(C2, inter).contiguous()
         gap, att = _f32((N, C), x), _f32((N, C2), x)
-        ctx.fused = (FUSED_SPLAT and not (training and _sync_group(bn1)) and b1 is not None and
+        ctx.fused = (FUSED_SPLAT and not (training and (_sync_group(bn1) or BN_SPLIT > 1)) and b1 is not None and
                      query("xv2_splat_att_supported", N, C, inter) == 1)
         if ctx.fused:
             h1, a1 = _f32((N, inter), x), _f32((N, inter), x)
@@ -993,7 +1045,8 @@ class SplitAttentionFn(torch.autograd.Function):
         call("xv2_splat_gap_forward", x, N, hw, C, gap, _ws(query("xv2_splat_gap_workspace", N, hw, C), x), _dt(x))
         h1 = _f32((N, inter), x)
         call("xv2_linear_forward", gap, w1m, b1, h1, N, C, inter)
-        a1, st = _bn_forward(h1, None, ACT_RELU, bn1, None, training)
+        ctx.split = BN_SPLIT if (training and N % BN_SPLIT == 0) else 1
+        a1, st = _bn_forward(h1, None, ACT_RELU, bn1, None, training, split=ctx.split)
         logits = _f32((N, C2), x)
         call("xv2_linear_forward", a1, w2m, b2, logits, N, inter, C2)
         call("xv2_rsoftmax_forward", logits, att, N, C)
@@ -1041,7 +1094,7 @@ class SplitAttentionFn(torch.autograd.Function):
         db2 = _grad_like(pb2) if pb2 is not None else _f32((C2,), x)
         call("xv2_linear_backward", a1, w2m, dlogits, da1, dw2, db2, N, inter, C2)
         dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count, scale1, shift1), g1, ACT_RELU,
-                                         ctx.bn1, ctx.training, False)
+                                         ctx.bn1, ctx.training, False, None, ctx.split)
         dgap, dw1 = _f32((N, C), x), _grad_like(pw1)
         db1 = _grad_like(pb1) if pb1 is not None else _f32((inter,), x)
         call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
@@ -1093,6 +1146,47 @@ def nchw_to_nhwc(x, c_pad=None):
     y = _f32((N, H, W, Cp), x)
     call("xv2_nchw_to_nhwc", x, x.stride(0), N, C, H, W, y, Cp)
     return y
+
+
+def nchw_pair_to_nhwc(x, c_pad=4):
+    """[B, 6, H, W] pre/post pair (model/unet.py:232-233 slices it) -> ONE NHWC batch [2B, H, W, c_pad]:
+    rows 0..B-1 the pre images (channels 0..2), rows B..2B-1 the post images (channels 3..5)"""
+    _need_cuda(x)
+    B, C6, H, W = x.shape
+    if C6 != 6:
+        raise RuntimeError("pre/post pair expected (6 channels), got %d" % C6)
+    x = x.contiguous()
+    y = _f32((2 * B, H, W, c_pad), x)
+    call("xv2_nchw_to_nhwc", x, x.stride(0), B, 3, H, W, y, c_pad)
+    call("xv2_nchw_to_nhwc", Ptr(x, 3 * H * W), x.stride(0), B, 3, H, W, Ptr(y, B * H * W * c_pad), c_pad)
+    return y
+
+
+class PairCatFn(torch.autograd.Function):
+    """[2B, H, W, C] (B pre rows then B post rows) -> [B, H, W, 2C] = cat(pre, post) along channels: `concat` of
+    model/unet.py:17-18 for the batched Siamese passes, forward and backward as two strided channel copies each."""
+
+    @staticmethod
+    def forward(ctx, t):
+        _need_cuda(t)
+        t = t.contiguous()
+        N2, H, W, C = t.shape
+        B = N2 // 2
+        npix = B * H * W
+        out = _act((B, H, W, 2 * C), t)
+        call("xv2_copy_channels", t, C, out, 2 * C, npix, C, _dt(t))
+        call("xv2_copy_channels", Ptr(t, npix * C), C, Ptr(out, C), 2 * C, npix, C, _dt(t))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        B, H, W, C2 = d.shape
+        C, npix = C2 // 2, B * H * W
+        dt = _act((2 * B, H, W, C), d)
+        call("xv2_copy_channels", d, C2, dt, C, npix, C, _dt(d))
+        call("xv2_copy_channels", Ptr(d, C), C2, Ptr(dt, npix * C), C, npix, C, _dt(d))
+        return dt
 
 
 def nhwc_to_nchw(x):
