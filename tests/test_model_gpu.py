@@ -461,7 +461,7 @@ def test_fused_inference_path_is_bit_identical_to_the_unfused_eval_forward(name)
         xnn.FUSED_INFERENCE = True
 
 
-@pytest.mark.parametrize("name", ["post_siamese_resnest50_ds", "post_siamese_coral"])
+@pytest.mark.parametrize("name", ["post_siamese_resnest50_ds", "post_siamese_coral", "post_siameseEnc_resnet50"])
 def test_batched_siamese_passes_equal_two_sequential_passes(name):
     """SiameseUNet runs its shared-weight U-Net on the pre and the post image (model/unet.py:232-233).  The default
     here sends both through as ONE batch of 2B with per-part BatchNorm statistics (ops.BN_SPLIT); it must reproduce

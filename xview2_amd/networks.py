@@ -184,8 +184,13 @@ class SiameseEncUNet(nn.Module, _EncoderMixin):  # unet.py:239-317
         return encs
 
     def forward(self, data):
-        pre, post = self.forward_enc(_pre(data)), self.forward_enc(_post(data))
-        encs = [concat(a, b) for a, b in zip(pre, post)]
+        if BATCH_SIAMESE and data.is_cuda:      # shared encoder over the pre/post pair as one split batch (see SiameseUNet)
+            with xnn.bn_split(2):
+                both = self.forward_enc(ops.nchw_pair_to_nhwc(data, 4))
+            encs = [ops.PairCatFn.apply(t) for t in both]
+        else:
+            pre, post = self.forward_enc(_pre(data)), self.forward_enc(_post(data))
+            encs = [concat(a, b) for a, b in zip(pre, post)]
         return self.output_block(*_decode(self, self.dilation, self.no_skip, encs))
 
 
