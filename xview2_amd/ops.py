@@ -222,6 +222,21 @@ def clear_pack_cache():
     _pack_table = None
 
 
+_scratch = {}
+
+
+def _stats_scratch(C, device):
+    """inter-block scratch of the statistics reduction (XV2_BN_SCRATCH_ROWS x C x 2 doubles).  Only ever used by
+    launches on the compute stream, which orders them, so one buffer per device is reused instead of ~60 allocations
+    per step."""
+    key = device.index
+    t = _scratch.get(key)
+    if t is None or t.numel() < 64 * C * 2:
+        t = torch.empty((64 * max(C, 4096) * 2,), dtype=torch.float64, device=device)
+        _scratch[key] = t
+    return t
+
+
 def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.  If `ihwo_out` is a list, the backward-data weight
     packs are produced by the same repack launch and appended to it (one per group).  With `bn` (a BnState that
@@ -243,7 +258,8 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     sums = torch.empty((S, Cout_t, 2) if S > 1 else (Cout_t, 2), dtype=torch.float64, device=x0.device) if want_stats else None
     coeffs = None
     if want_stats and bn is not None and not _sync_group(bn):
-        coeffs = tuple(_f32((S, Cout_t) if S > 1 else (Cout_t,), x0) for _ in range(4))
+        blob = _f32((4, S, Cout_t) if S > 1 else (4, Cout_t), x0)      # mean, invstd, scale, shift: one allocation
+        coeffs = (blob[0], blob[1], blob[2], blob[3])
         bn_stats_changed()
     stats_ok = True        # False: the M tiles do not split evenly over the S parts -> statistics taken from y afterwards
     w = weight.contiguous()
@@ -274,7 +290,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         if want_stats and S > 1 and ((N * OH * OW) % tiles != 0 or tiles % S != 0):
             stats_ok = False
         elif want_stats:
-            scratch = torch.empty((64 * Coutg * 2,), dtype=torch.float64, device=x0.device)
+            scratch = _stats_scratch(Coutg, x0.device)
             tp = tiles // S
             for h in range(S):                   # part h = rows [h*M/S, (h+1)*M/S) = tiles [h*tp, (h+1)*tp)
                 ph = Ptr(part, h * tp * Coutg * 2)
