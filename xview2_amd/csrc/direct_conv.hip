@@ -236,20 +236,21 @@ bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
 }
 
 int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    static int kid = -1, kid16 = -1, kid16s = -1;
-    if (!attr_set) {
-        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
-        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM));
-        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_H));
-        attr_set = true;
-        kid = prof_register("direct3x3_n32_kernel");
-        kid16 = prof_register("direct3x3_n32_kernel<bf16>");
-        kid16s = prof_register("direct3x3_n32_kernel<bf16hbm>");
-    }
+    static const hipError_t attr_rc = [] {      // thread-safe one-time setup (function-local static)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_H);
+        return e;
+    }();
+    XV2_CHECK_HIP(attr_rc);
+    static const int kid = prof_register("direct3x3_n32_kernel");
+    static const int kid16 = prof_register("direct3x3_n32_kernel<bf16>");
+    static const int kid16s = prof_register("direct3x3_n32_kernel<bf16hbm>");
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / (D_TH * D_TW);
     // persistent: 2 blocks per CU (fp32 LDS image, 71 KB), 4 per CU with the bf16 image (40 KB); each walks a run of patches

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/xv2.h"
@@ -37,7 +38,9 @@ static hipEvent_t prof_event() {
     }
     return g_prof_pool[g_prof_pool_next++];
 }
+static std::mutex g_prof_mu;
 int prof_register(const char* name) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_names.emplace_back(name);
     return (int)g_prof_names.size() - 1;
 }

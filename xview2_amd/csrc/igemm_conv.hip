@@ -584,21 +584,19 @@ constexpr size_t igemm_smem_bytes() {
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
     auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS>;
-    if (!attr_set) {
-        XV2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
-    static int kid = -1;
-    if (kid < 0) {
+    // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
+    // even with concurrent callers (the library may be driven from several host threads, one stream each)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    XV2_CHECK_HIP(attr_rc);
+    static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
                  SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (BF16 ? "c32,bf16" : "c32")));
-        kid = prof_register(nm);
-    }
+        return prof_register(nm);
+    }();
     IgemmParams q = p;
     int maxtiles = 0;
     double flops = 0.0;

@@ -892,13 +892,12 @@ template <int BM, int BN, int WGM, int WGN, int WK, bool SMALLC, bool BF16 = fal
 static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t stream) {
     constexpr size_t smem = (size_t)2 * 32 * (BM + BN) * 4;
     auto kern = wgrad_kernel<BM, BN, WGM, WGN, WK, SMALLC, BF16, HS>;
-    static int kid = -1;
-    if (kid < 0) {
+    static const int kid = [] {      // thread-safe one-time registration (function-local static)
         char nm[96];
         snprintf(nm, sizeof(nm), "wgrad_kernel<%d,%d,%d,%d,%d,%s%s>", BM, BN, WGM, WGN, WK,
                  SMALLC ? "rgb" : (BF16 ? "c32,bf16" : "c32"), HS ? ",bf16hbm" : "");
-        kid = prof_register(nm);
-    }
+        return prof_register(nm);
+    }();
     const double creal = SMALLC ? 3.0 : (double)p.Ctot;
     const double ex = (HS && !SMALLC) ? 2.0 : 4.0, ed = HS ? 2.0 : 4.0;
     prof_begin(kid, 2.0 * (double)p.M * p.Cout * p.T * creal,
@@ -946,12 +945,9 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         }
     int rc;
     if (pl.alltaps) {
-        static int kid = -1, kid16 = -1, kid16s = -1;
-        if (kid < 0) {
-            kid = prof_register("wgrad_alltaps_kernel");
-            kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
-            kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
-        }
+        static const int kid = prof_register("wgrad_alltaps_kernel");
+        static const int kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
+        static const int kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
         prof_begin(hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
         if (hs && use_tr_wgrad())
@@ -972,11 +968,8 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
         } else if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
     } else if (hs && p.fast && use_tr_wgrad() && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
-        static int kid128 = -1, kid64 = -1;
-        if (kid128 < 0) {
-            kid128 = prof_register("wgrad_tr_kernel<128,128,bf16hbm>");
-            kid64 = prof_register("wgrad_tr_kernel<64,64,bf16hbm>");
-        }
+        static const int kid128 = prof_register("wgrad_tr_kernel<128,128,bf16hbm>");
+        static const int kid64 = prof_register("wgrad_tr_kernel<64,64,bf16hbm>");
         prof_begin(pl.bm == 128 ? kid128 : kid64, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    2.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
         if (pl.bm == 128)
