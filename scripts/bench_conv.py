@@ -20,6 +20,9 @@ SHAPES = [
     ("l3.conv1 1024->256 1x1 @64", 2, 64, 64, 1024, 0, 256, 1, 1, 0),
     ("l1.conv3   64->256 1x1 @256", 2, 256, 256, 64, 0, 256, 1, 1, 0),
     ("l4.conv1 2048->512 1x1 @32", 2, 32, 32, 2048, 0, 512, 1, 1, 0),
+    ("l1.conv1  256->64  1x1 @256", 2, 256, 256, 256, 0, 64, 1, 1, 0),
+    ("l2.conv3  128->512 1x1 @128", 2, 128, 128, 128, 0, 512, 1, 1, 0),
+    ("l2.conv1  512->128 1x1 @128", 2, 128, 128, 512, 0, 128, 1, 1, 0),
     ("l2.0.conv2 128->128 s2 @256", 2, 256, 256, 128, 0, 128, 3, 2, 1),
     ("l4.0.conv2 512->512 s2 @64", 2, 64, 64, 512, 0, 512, 3, 2, 1),
 ]
