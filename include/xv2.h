@@ -58,6 +58,14 @@ typedef struct xv2_conv_desc {
  * master weights stay fp32.  The 4-channel RGB source of the stems stays an fp32 image with fp32 packed weights. */
 #define XV2_MATH_BF16_STORE 2
 
+/* fp32 tensors, fp32-grade arithmetic on the bf16 matrix pipe: each fp32 operand is split into three bf16 terms
+ * (x = hi + mid + lo, exact to 24 bits) while it is staged in LDS and the product is formed from the six significant
+ * cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid with v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped
+ * terms are below 2^-24 relative).  6 bf16 MFMAs of 16 k each replace 8 exact-fp32 MFMAs of 2 k each: 0.375x the
+ * matrix-pipe time for fp32-level accuracy.  Implicit-GEMM forward / backward-data only; the weight-gradient and direct
+ * 3x3 kernels and the RGB stem run their exact-fp32 forms under this mode. */
+#define XV2_MATH_F32X3 3
+
 /* element type of activation tensors for the non-convolution entry points (`dtype` arguments) */
 #define XV2_F32 0
 #define XV2_BF16 1

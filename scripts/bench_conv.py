@@ -49,6 +49,8 @@ def prof_time(fn, iters=10):
 def main():
     if os.environ.get("XV2_MATH") == "1":
         ops.MATH_MODE = ops.MATH_BF16
+    if os.environ.get("XV2_MATH") == "3":
+        ops.MATH_MODE = ops.MATH_F32X3
     half = os.environ.get("XV2_MATH") == "2"          # bf16 storage (XV2_MATH_BF16_STORE)
     adt = torch.bfloat16 if half else torch.float32
     filt = [a for a in sys.argv[1:] if not a.startswith("--")]

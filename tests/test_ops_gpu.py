@@ -756,3 +756,41 @@ def test_fused_split_attention_tail_equals_the_op_by_op_chain(shape, training):
             assert float(a.abs().max()) <= 1e-4 * float(res[True][2].abs().max()) + 1e-6
             continue
         close(a, b, 1e-4, "fused split attention " + nm)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_f32x3_split_bf16_conv_keeps_the_fp32_tolerances(case):
+    """XV2_MATH_F32X3: fp32 tensors, every operand split into three bf16 terms in LDS, six bf16 MFMAs per product
+    (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid).  The result must satisfy the SAME tolerances as the exact-fp32 MFMA
+    path (2e-4 outputs / 5e-4 gradients of the tensor maximum) against fp32 PyTorch - and stay within 2e-6 of the
+    exact-fp32 HIP result itself (the dropped cross terms are < 2^-24 relative per product)."""
+    from xview2_amd import ops
+    N, H, W, C0, C1, Cout, k, s, p, d, G = case
+    torch.manual_seed(sum(case) + 3)
+    x0 = torch.randn(N, C0, H, W)
+    x1 = torch.randn(N, C1, H, W) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, k, k) * (2.0 / (k * k * (C0 + C1) / G)) ** 0.5
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    xr, wr = xin.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p, d, G)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    outs = {}
+    for mode in (ops.MATH_F32, ops.MATH_F32X3):
+        ops.MATH_MODE = mode
+        try:
+            wg = w.to(dev()).requires_grad_(True)
+            a0 = nhwc(x0).requires_grad_(True)
+            a1 = nhwc(x1).requires_grad_(True) if C1 else None
+            y = ops.ConvFn.apply(a0, a1, wg, None, ops.conv_cfg(k, k, s, p, d, G))
+            y.backward(nhwc(dy))
+            dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
+            outs[mode] = (nchw(y), dx, wg.grad.detach().cpu())
+        finally:
+            ops.MATH_MODE = ops.MATH_F32
+    y3, dx3, dw3 = outs[ops.MATH_F32X3]
+    close(y3, yr, 2e-4, "f32x3 y")
+    close(dx3, xr.grad, 5e-4, "f32x3 dx")
+    close(dw3, wr.grad, 5e-4, "f32x3 dw")
+    close(y3, outs[ops.MATH_F32][0], 2e-6, "f32x3 vs exact fp32 MFMA, y")
+    close(dx3, outs[ops.MATH_F32][1], 2e-6, "f32x3 vs exact fp32 MFMA, dx")

@@ -59,8 +59,21 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // image as they are (no conversion anywhere on the operand path); the output tile is rounded to bf16 in the epilogue
 // and the BatchNorm statistics are taken on the ROUNDED values (what the next kernel will read).  The 4-channel RGB
 // source (SMALLC) stays an fp32 image with fp32 weights and exact-fp32 MFMA; only its output is bf16.
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
+// X3 = true (XV2_MATH_F32X3): fp32 tensors, each operand element split into three bf16 terms on its way into LDS (three
+// bf16 planes per operand, single-buffered: 61 KB for the 128x128 tile), six bf16 MFMAs per fp32-grade product.
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const bf16_t bh = f32_to_bf16(x);
+    const float r1 = x - bf16_to_f32(bh);              // exact
+    const bf16_t bm = f32_to_bf16(r1);
+    const float r2 = r1 - bf16_to_f32(bm);             // exact
+    h = bh;
+    m = bm;
+    l = f32_to_bf16(r2);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+    static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
     constexpr bool HIN = HS && !SMALLC;                 // bf16 operands in HBM
@@ -274,6 +287,64 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (X3) {
+        // planes: [hi | mid | lo] x ([A rows | B rows] x LDS_LD_H bf16); one buffer, two barriers per K-tile; the global
+        // loads of tile kt+1 are in flight while tile kt is multiplied
+        __bf16* pl0 = reinterpret_cast<__bf16*>(smem);
+        constexpr int PLANE = (BM + BN) * LDS_LD_H;
+        auto lstore3 = [&]() {
+#pragma unroll
+            for (int j = 0; j < AROWS + BROWS; ++j) {
+                const float4 v = j < AROWS ? ra[j < AROWS ? j : 0] : rb[j >= AROWS ? j - AROWS : 0];
+                const int row = j < AROWS ? r0 + 32 * j : BM + r0 + 32 * (j - AROWS);
+                unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+                split3(v.x, h0, m0_, l0);
+                split3(v.y, h1, m1, l1);
+                split3(v.z, h2, m2, l2);
+                split3(v.w, h3, m3, l3);
+                __bf16* d = pl0 + row * LDS_LD_H + c4 * 4;
+                *reinterpret_cast<uint2*>(d) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m0_ | (m1 << 16), m2 | (m3 << 16));
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+            }
+        };
+        gload(kt_begin);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            lstore3();
+            if (kt + 1 < kt_end) gload(kt + 1);
+            __syncthreads();
+            const __bf16* a = pl0 + (wm * WTM + l31) * LDS_LD_H + 8 * h;
+            const __bf16* b = pl0 + (BM + wn * WTN + l31) * LDS_LD_H + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[MR], am[MR], al[MR], bh[NR], bm_[NR], bl[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_LD_H + ks * 16);
+                    am[i] = *reinterpret_cast<const bf16x8*>(a + PLANE + i * 32 * LDS_LD_H + ks * 16);
+                    al[i] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE + i * 32 * LDS_LD_H + ks * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_LD_H + ks * 16);
+                    bm_[j] = *reinterpret_cast<const bf16x8*>(b + PLANE + j * 32 * LDS_LD_H + ks * 16);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(b + 2 * PLANE + j * 32 * LDS_LD_H + ks * 16);
+                }
+                // smallest terms first; the four accumulator tiles interleave, so dependent MFMAs are 4 issues apart
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j) {
+                            const bf16x8 x = t == 0 ? al[i] : t == 1 ? ah[i] : t == 2 ? am[i] : t == 3 ? am[i] : ah[i];
+                            const bf16x8 y = t == 0 ? bh[j] : t == 1 ? bl[j] : t == 2 ? bm_[j] : t == 3 ? bh[j] : t == 4 ? bm_[j] : bh[j];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
+                        }
+            }
+            __syncthreads();
+        }
+    } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
     // (tile kt).  The LDS store of the next tile sits at the START of an iteration, so nothing but the MFMA
     // tail stands between the last fragment read and the barrier.
@@ -357,6 +428,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         __syncthreads();
     }
 
+    }      // !X3
 #if XV2_ABL & 8
     if (acc[0][0][0] == 123.456f) p.Out0[0] = 1.f;
     return;
@@ -582,10 +654,11 @@ constexpr size_t igemm_smem_bytes() {
     return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1>() * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false>
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS>;
+    static_assert(!X3 || (size_t)3 * (BM + BN) * LDS_LD_H_ * 2 <= (size_t)2 * (BM + BN) * LDS_LD * 4, "X3 planes fit the fp32 buffers");
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -594,7 +667,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (BF16 ? "c32,bf16" : "c32")));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? "c32,f32x3" : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -696,7 +769,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (ks == 1 && bn >= 64) *p.plan_tiles = cdiv(maxM, bm);
         return XV2_OK;
     }
-    if (direct3x3_eligible(p, smallc)) return direct3x3_launch(p, stream);
+    if (direct3x3_eligible(p, smallc)) {
+        if (p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32;       // exact fp32 form of the direct kernel
+        return direct3x3_launch(p, stream);
+    }
+    if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
     pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
     if (getenv("XV2_DEBUG_TILE"))
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
@@ -711,6 +788,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
         int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                 : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                  : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
                                                : launch_one<128, 128, 2, 2, false>(p, stream);
         if (rc) return rc;
@@ -747,6 +825,17 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             return launch_one<64, 64, 2, 2, false, true, true>(p, stream);
         }
         return launch_one<128, 32, 4, 1, false, true, true>(p, stream);
+    }
+    if (p.math == XV2_MATH_F32X3) {
+        if (bn == 128) {
+            if (bm == 128) return launch_one<128, 128, 2, 2, false, true, false, true>(p, stream);
+            return launch_one<64, 128, 2, 2, false, true, false, true>(p, stream);
+        }
+        if (bn == 64) {
+            if (bm == 128) return launch_one<128, 64, 2, 2, false, true, false, true>(p, stream);
+            return launch_one<64, 64, 2, 2, false, true, false, true>(p, stream);
+        }
+        return launch_one<128, 32, 4, 1, false, true, false, true>(p, stream);
     }
     if (p.math) {
         if (bn == 128) {
@@ -790,7 +879,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
     p.bnb_ldy = p.bnb_act = 0;
     p.plan_tiles = nullptr;
-    XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_BF16_STORE, "conv: unknown math mode %d", d->math);
+    XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_F32X3, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
     p.ncls = 1;

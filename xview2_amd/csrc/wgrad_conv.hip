@@ -909,9 +909,12 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t s
     return XV2_OK;
 }
 
-static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
+static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, const float* x1, int ldx1,
                       const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                       hipStream_t stream) {
+    xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3 covers forward / backward-data only: exact fp32 here
+    if (dcopy.math == XV2_MATH_F32X3) dcopy.math = XV2_MATH_F32;
+    const xv2_conv_desc* d = &dcopy;
     XV2_CHECK_ARG(d->KH * d->KW <= 52, "too many taps");
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
     const WgradPlan pl = make_plan(d);
@@ -1023,7 +1026,10 @@ static int wgrad_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const f
 
 using namespace xv2;
 
-extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d) {
+extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d_in) {
+    xv2_conv_desc dcopy = *d_in;
+    if (dcopy.math == XV2_MATH_F32X3) dcopy.math = XV2_MATH_F32;
+    const xv2_conv_desc* d = &dcopy;
     const WgradPlan pl = make_plan(d);
     return (size_t)(pl.nslab + pl.groups) * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
 }

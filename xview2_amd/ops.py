@@ -92,7 +92,7 @@ def _out_hw(IH, IW, g):
     return OH, OW
 
 
-MATH_F32, MATH_BF16, MATH_BF16_STORE = 0, 1, 2
+MATH_F32, MATH_BF16, MATH_BF16_STORE, MATH_F32X3 = 0, 1, 2, 3
 MATH_MODE = MATH_F32     # process-wide default for fp32-stored tensors (set from --precision by the trainer / bench)
 
 
