@@ -292,27 +292,42 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         // loads of tile kt+1 are in flight while tile kt is multiplied
         __bf16* pl0 = reinterpret_cast<__bf16*>(smem);
         constexpr int PLANE = (BM + BN) * LDS_LD_H;
-        auto lstore3 = [&]() {
+        // software pipeline: the split of tile kt+1 (pure VALU on the registers the global loads filled) is issued in the
+        // shadow of tile kt's MFMAs (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles, a VALU op issues in 4), the
+        // LDS store of the packed terms and the next global loads sit between the two barriers
+        uint2 pk[AROWS + BROWS][3];
+        auto split_regs = [&]() {
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
                 const float4 v = j < AROWS ? ra[j < AROWS ? j : 0] : rb[j >= AROWS ? j - AROWS : 0];
-                const int row = j < AROWS ? r0 + 32 * j : BM + r0 + 32 * (j - AROWS);
                 unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
                 split3(v.x, h0, m0_, l0);
                 split3(v.y, h1, m1, l1);
                 split3(v.z, h2, m2, l2);
                 split3(v.w, h3, m3, l3);
+                pk[j][0] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                pk[j][1] = make_uint2(m0_ | (m1 << 16), m2 | (m3 << 16));
+                pk[j][2] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+            }
+        };
+        auto store_planes = [&]() {
+#pragma unroll
+            for (int j = 0; j < AROWS + BROWS; ++j) {
+                const int row = j < AROWS ? r0 + 32 * j : BM + r0 + 32 * (j - AROWS);
                 __bf16* d = pl0 + row * LDS_LD_H + c4 * 4;
-                *reinterpret_cast<uint2*>(d) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(m0_ | (m1 << 16), m2 | (m3 << 16));
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                *reinterpret_cast<uint2*>(d) = pk[j][0];
+                *reinterpret_cast<uint2*>(d + PLANE) = pk[j][1];
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = pk[j][2];
             }
         };
         gload(kt_begin);
+        split_regs();
+        store_planes();
+        if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
+        __syncthreads();
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            lstore3();
-            if (kt + 1 < kt_end) gload(kt + 1);
-            __syncthreads();
+            const bool more = kt + 1 < kt_end;
+            if (more) split_regs();              // tile kt+1: VALU only, overlaps the MFMAs below
             const __bf16* a = pl0 + (wm * WTM + l31) * LDS_LD_H + 8 * h;
             const __bf16* b = pl0 + (BM + wn * WTN + l31) * LDS_LD_H + 8 * h;
 #pragma unroll
@@ -330,7 +345,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                     bm_[j] = *reinterpret_cast<const bf16x8*>(b + PLANE + j * 32 * LDS_LD_H + ks * 16);
                     bl[j] = *reinterpret_cast<const bf16x8*>(b + 2 * PLANE + j * 32 * LDS_LD_H + ks * 16);
                 }
-                // smallest terms first; the four accumulator tiles interleave, so dependent MFMAs are 4 issues apart
+                // smallest terms first; the accumulator tiles interleave, so dependent MFMAs are MR*NR issues apart
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -342,7 +357,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
                         }
             }
-            __syncthreads();
+            if (more) {
+                // spread the split's VALU instructions between the MFMAs: ~6 VALU per 32-cycle MFMA slot
+                constexpr int NMFMA = 2 * 6 * MR * NR;
+#pragma unroll
+                for (int g = 0; g < NMFMA; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 40 / NMFMA + 1, 0);
+                }
+            }
+            __syncthreads();                     // every wave is done reading tile kt
+            if (more) {
+                store_planes();
+                if (kt + 2 < kt_end) gload(kt + 2);
+            }
+            __syncthreads();                     // tile kt+1 is in LDS
         }
     } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
