@@ -250,7 +250,7 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
 
 def set_precision(precision):
     from xview2_amd import ops
-    ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.MATH_F32
+    ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.fp32_math()
     if hasattr(ops, "set_storage_dtype"):
         ops.set_storage_dtype(torch.bfloat16 if precision == 16 else None)
 
@@ -464,6 +464,9 @@ def main():
     ms = dt / opt.steps * 1e3
     value = world * opt.batch * opt.steps / dt
 
+    x3 = opt.precision == 32 and _xops.fp32_math() == _xops.MATH_F32X3
+    step_peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else
+                 PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS)
     roof = None
     if prof and rows:
         # dominant kernel: its launches inside the TIMED region; the per-kernel table: the extra bracketed pass
@@ -475,7 +478,7 @@ def main():
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
             traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
         iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
-        peak = PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS
+        peak = step_peak
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -510,13 +513,14 @@ def main():
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
-                                   "fp32" if opt.precision == 32 else
+                                   "fp32 tensors, products as 3-way bf16 splits on the bf16 MFMA (XV2_F32X3=1; peak = bf16 "
+                                   "peak / 6 products)" if x3 else "fp32" if opt.precision == 32 else
                                    "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(model_tf, 2),
         "conv_roofline_frac_whole_step": round(
-            model_tf / world / (PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS), 4),
+            model_tf / world / step_peak, 4),
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not opt.no_encoder_probe:

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 
     float4 ra[AROWS], rb[BROWS];
 
-    auto gload = [&](int kt) {
+    auto gload_into = [&](int kt, float4 (&ra)[AROWS], float4 (&rb)[BROWS]) {
 #if XV2_ABL & 1
         return;
 #endif
@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             }
         }
     };
+    auto gload = [&](int kt) { gload_into(kt, ra, rb); };
     auto lstore = [&](int buf) {
 #if XV2_ABL & 2
         return;
@@ -295,11 +296,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         // software pipeline: the split of tile kt+1 (pure VALU on the registers the global loads filled) is issued in the
         // shadow of tile kt's MFMAs (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles, a VALU op issues in 4), the
         // LDS store of the packed terms and the next global loads sit between the two barriers
+        // Two raw register sets: while tile kt is multiplied out of LDS, tile kt+1 (loaded two iterations ago, long
+        // landed) is split on the VALU in the shadow of the MFMAs, and tile kt+2 is in flight into the other set.
         uint2 pk[AROWS + BROWS][3];
-        auto split_regs = [&]() {
+        float4 ra1[AROWS], rb1[BROWS];
+        auto split_regs = [&](const float4 (&xa)[AROWS], const float4 (&xb)[BROWS]) {
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
-                const float4 v = j < AROWS ? ra[j < AROWS ? j : 0] : rb[j >= AROWS ? j - AROWS : 0];
+                const float4 v = j < AROWS ? xa[j < AROWS ? j : 0] : xb[j >= AROWS ? j - AROWS : 0];
                 unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
                 split3(v.x, h0, m0_, l0);
                 split3(v.y, h1, m1, l1);
@@ -320,14 +324,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 *reinterpret_cast<uint2*>(d + 2 * PLANE) = pk[j][2];
             }
         };
-        gload(kt_begin);
-        split_regs();
-        store_planes();
-        if (kt_begin + 1 < kt_end) gload(kt_begin + 1);
-        __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const bool more = kt + 1 < kt_end;
-            if (more) split_regs();              // tile kt+1: VALU only, overlaps the MFMAs below
+        auto mfma_tile = [&]() {
             const __bf16* a = pl0 + (wm * WTM + l31) * LDS_LD_H + 8 * h;
             const __bf16* b = pl0 + (BM + wn * WTN + l31) * LDS_LD_H + 8 * h;
 #pragma unroll
@@ -357,21 +354,41 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
                         }
             }
-            if (more) {
-                // spread the split's VALU instructions between the MFMAs: ~6 VALU per 32-cycle MFMA slot
-                constexpr int NMFMA = 2 * 6 * MR * NR;
+            // pin the split results here: the instruction selector otherwise sinks the whole split below the barrier
+            // to its consumer (the LDS stores), out of reach of the scheduling groups that follow
 #pragma unroll
-                for (int g = 0; g < NMFMA; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 40 / NMFMA + 1, 0);
-                }
+            for (int j = 0; j < AROWS + BROWS; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
+            // spread the split's VALU instructions between the MFMAs: ~7 VALU per 32-cycle MFMA slot
+            constexpr int NMFMA = 2 * 6 * MR * NR;
+#pragma unroll
+            for (int g = 0; g < NMFMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 40 / NMFMA + 1, 0);
             }
+        };
+        // one pipeline step: multiply tile kt (in LDS) while splitting tile kt+1 (in `xa/xb`), then store tile kt+1 and
+        // refill the same registers with tile kt+3
+        auto step = [&](int kt, float4 (&xa)[AROWS], float4 (&xb)[BROWS]) {
+            split_regs(xa, xb);
+            mfma_tile();
             __syncthreads();                     // every wave is done reading tile kt
-            if (more) {
+            if (kt + 1 < kt_end) {
                 store_planes();
-                if (kt + 2 < kt_end) gload(kt + 2);
+                if (kt + 3 < kt_end) gload_into(kt + 3, xa, xb);
             }
             __syncthreads();                     // tile kt+1 is in LDS
+        };
+        gload_into(kt_begin, ra, rb);
+        split_regs(ra, rb);
+        store_planes();
+        if (kt_begin + 1 < kt_end) gload_into(kt_begin + 1, ra1, rb1);
+        if (kt_begin + 2 < kt_end) gload_into(kt_begin + 2, ra, rb);
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            step(kt, ra1, rb1);
+            if (kt + 1 < kt_end) step(kt + 1, ra, rb);
         }
     } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]

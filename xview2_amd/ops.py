@@ -96,6 +96,12 @@ MATH_F32, MATH_BF16, MATH_BF16_STORE, MATH_F32X3 = 0, 1, 2, 3
 MATH_MODE = MATH_F32     # process-wide default for fp32-stored tensors (set from --precision by the trainer / bench)
 
 
+def fp32_math():
+    """math mode of fp32-stored tensors: the exact-fp32 MFMA, or (opt-in, XV2_F32X3=1) the 3-way bf16 split with six
+    bf16 MFMAs per product (fp32-grade products, include/xv2.h XV2_MATH_F32X3)"""
+    return MATH_F32X3 if os.environ.get("XV2_F32X3", "0") == "1" else MATH_F32
+
+
 def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW, half=False):
     """half: the activations of this convolution are bf16 in HBM (XV2_MATH_BF16_STORE)"""
     if half:

@@ -24,7 +24,7 @@ class Trainer:
         from . import ops
         # the reference's --precision 16 is fp16 autocast (activations and convolutions in half precision, fp32
         # accumulate, fp32 BN statistics / master weights); here the 16-bit type is bf16 (no loss scaling needed)
-        ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.MATH_F32
+        ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.fp32_math()
         ops.set_storage_dtype(torch.bfloat16 if precision == 16 else None)
         self.rank, self.local_rank, self.world = xdist.init_from_env()
         self.device = torch.device("cuda", self.local_rank)
