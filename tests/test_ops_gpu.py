@@ -794,3 +794,4 @@ def test_f32x3_split_bf16_conv_keeps_the_fp32_tolerances(case):
     close(dw3, wr.grad, 5e-4, "f32x3 dw")
     close(y3, outs[ops.MATH_F32][0], 2e-6, "f32x3 vs exact fp32 MFMA, y")
     close(dx3, outs[ops.MATH_F32][1], 2e-6, "f32x3 vs exact fp32 MFMA, dx")
+    close(dw3, outs[ops.MATH_F32][2], 2e-6, "f32x3 vs exact fp32 MFMA, dw")

@@ -61,16 +61,6 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // source (SMALLC) stays an fp32 image with fp32 weights and exact-fp32 MFMA; only its output is bf16.
 // X3 = true (XV2_MATH_F32X3): fp32 tensors, each operand element split into three bf16 terms on its way into LDS (three
 // bf16 planes per operand, single-buffered: 61 KB for the 128x128 tile), six bf16 MFMAs per fp32-grade product.
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    const bf16_t bh = f32_to_bf16(x);
-    const float r1 = x - bf16_to_f32(bh);              // exact
-    const bf16_t bm = f32_to_bf16(r1);
-    const float r2 = r1 - bf16_to_f32(bm);             // exact
-    h = bh;
-    m = bm;
-    l = f32_to_bf16(r2);
-}
-
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
@@ -304,14 +294,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
                 const float4 v = j < AROWS ? xa[j < AROWS ? j : 0] : xb[j >= AROWS ? j - AROWS : 0];
-                unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-                split3(v.x, h0, m0_, l0);
-                split3(v.y, h1, m1, l1);
-                split3(v.z, h2, m2, l2);
-                split3(v.w, h3, m3, l3);
-                pk[j][0] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                pk[j][1] = make_uint2(m0_ | (m1 << 16), m2 | (m3 << 16));
-                pk[j][2] = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+                split3x4(v, pk[j][0], pk[j][1], pk[j][2]);
             }
         };
         auto store_planes = [&]() {
@@ -360,12 +343,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             for (int j = 0; j < AROWS + BROWS; ++j)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
-            // spread the split's VALU instructions between the MFMAs: ~7 VALU per 32-cycle MFMA slot
+            // spread the split's VALU instructions between the MFMAs: ~4 VALU per 32-cycle MFMA slot
             constexpr int NMFMA = 2 * 6 * MR * NR;
 #pragma unroll
             for (int g = 0; g < NMFMA; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 40 / NMFMA + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 18 / NMFMA + 1, 0);
             }
         };
         // one pipeline step: multiply tile kt (in LDS) while splitting tile kt+1 (in `xa/xb`), then store tile kt+1 and

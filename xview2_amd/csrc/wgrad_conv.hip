@@ -709,6 +709,144 @@ __global__ void __launch_bounds__(256, 4) wgrad_alltaps_tr_kernel(const WgradPar
     }
 }
 
+// XV2_MATH_F32X3 all-taps variant: fp32 dY / X in HBM, every element split into three bf16 terms (split3x4) on its way
+// into LDS - three bf16 planes of the operand image the kernel above uses, 38 KB - and every tap product issued as the
+// six significant bf16 cross products (hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll terms are below 2^-23 of |x||dy|).
+// 24-30 MFMAs per wave per row step instead of 4-5: the kernel is MFMA-bound where the bf16 one is latency-bound.
+// Wave wk takes the 16-pixel k-group (wk & 1) and the taps of one parity; which parity gets the 5-tap share alternates
+// pseudo-randomly between blocks so that the SIMDs of a CU are loaded evenly.
+__global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradParams p) {
+    constexpr int PL = 2 * 32 * 32 + 4 * 34 * 32;                 // bf16 elements per plane (dY double buffer + X ring)
+    __shared__ __attribute__((aligned(16))) bf16_t planes[3 * PL];   // 38.4 KB; the epilogue fold reuses the first 16 KB
+    float* smem = reinterpret_cast<float*>(planes);
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int co0 = tm * 32, cn0 = tn * 32;
+    const int chunks = p.ktiles, rows_per = p.kt_per_split;
+    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int tilesW = p.OW / 32;
+    const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
+    const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
+    const bool first = cn0 < p.C0;
+    const float* xsrc = first ? p.X0 : p.X1;
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+
+    // loads: 8 lanes x 16 bytes per pixel; all threads the dY row and X pixels 0..31, threads 0..15 X pixels 32, 33
+    const int px = tid >> 3, c4 = tid & 7;
+    const float* dy0 = p.DY + ((size_t)n * p.OH * p.OW + ow0 + px) * p.ldDY + co0 + c4 * 4;
+    const size_t dy_pitch = (size_t)p.OW * p.ldDY;
+    const int iw = ow0 - 1 + px, iw2 = iw + 32;
+    const float* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c4 * 4;
+    const size_t x_pitch = (size_t)p.IW * ldx;
+    const bool x_ok = iw >= 0, x2 = tid < 16, x2_ok = x2 && iw2 < p.IW;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rd = zero, rx = zero, rx2 = zero;
+    auto load_dy = [&](int r) { rd = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch); };
+    auto load_x = [&](int ih) {
+        rx = zero;
+        rx2 = zero;
+        if ((unsigned)ih < (unsigned)p.IH) {
+            if (x_ok) rx = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch);
+            if (x2_ok) rx2 = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx);
+        }
+    };
+    auto put = [&](int off, const float4 v) {       // off: element offset inside a plane
+        uint2 h, m, l;
+        split3x4(v, h, m, l);
+        *reinterpret_cast<uint2*>(planes + off) = h;
+        *reinterpret_cast<uint2*>(planes + PL + off) = m;
+        *reinterpret_cast<uint2*>(planes + 2 * PL + off) = l;
+    };
+    auto store_dy = [&](int buf) { put((buf * 32 + px) * 32 + c4 * 4, rd); };
+    auto store_x = [&](int ih) {
+        const int ring = 2 * 32 * 32 + ((ih + 4) & 3) * 34 * 32;
+        put(ring + px * 32 + c4 * 4, rx);
+        if (x2) put(ring + (32 + px) * 32 + c4 * 4, rx2);
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int q0 = 16 * (wk & 1);
+    const int flip = (blockIdx.x ^ (blockIdx.x >> 3) ^ blockIdx.y ^ (blockIdx.y >> 3)) & 1;
+    const int odd = (wk >> 1) ^ flip;
+    const int frow = q0 + 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    auto frag = [&](const bf16_t* base) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * 32));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    load_x(r0 - 1);
+    store_x(r0 - 1);
+    load_x(r0);
+    store_x(r0);
+    load_x(r0 + 1);
+    store_x(r0 + 1);
+    load_dy(r0);
+    store_dy(0);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            load_dy(r + 1);
+            load_x(r + 2);
+        }
+        const bf16_t* ab = planes + (buf * 32 + frow) * 32 + fcol;
+        const bf16x8 ah = frag(ab), am = frag(ab + PL), al = frag(ab + 2 * PL);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const bf16_t* row = planes + 2 * 32 * 32 + (((r - 1 + kh + 4) & 3) * 34 + frow) * 32 + fcol;   // input row r-1+kh
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = kh * 3 + kw;
+                if ((t & 1) != odd) continue;          // wave-uniform
+                const bf16x8 bh = frag(row + kw * 32), bm = frag(row + kw * 32 + PL), bl = frag(row + kw * 32 + 2 * PL);
+                f32x16 c = acc[t >> 1];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_dy(buf ^ 1);    // last read in step r-1 (all waves are past its barrier)
+            store_x(r + 2);       // ring slot of row r-2, idem
+        }
+        __syncthreads();
+    }
+
+    // fold the two k-groups of every tap through LDS and write the block's slab part[y][co][T][Ctot]
+    const size_t rowlen = (size_t)9 * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool mine = odd == (t & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = mine ? acc[t >> 1][r] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j;
+            const float v = (smem[e] + smem[1024 + e]) + (smem[2048 + e] + smem[3072 + e]);
+            const int r = e >> 6, ln = e & 63;
+            const int row = co0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + (ln & 31)] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // first stage of a two-level slab sum (many slabs, few elements): out2[g][i] = sum over the g-th group of slabs
 __global__ void wgrad_reduce_stage1_kernel(const float* __restrict__ part, int nslab, int per, size_t total,
                                            float* __restrict__ out2) {
@@ -912,8 +1050,9 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t s
 static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, const float* x1, int ldx1,
                       const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                       hipStream_t stream) {
-    xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3 covers forward / backward-data only: exact fp32 here
-    if (dcopy.math == XV2_MATH_F32X3) dcopy.math = XV2_MATH_F32;
+    xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3: the all-taps kernel has a split-bf16 variant; the other
+    const bool x3 = dcopy.math == XV2_MATH_F32X3;      // weight-gradient kernels run the exact fp32 MFMA
+    if (x3) dcopy.math = XV2_MATH_F32;
     const xv2_conv_desc* d = &dcopy;
     XV2_CHECK_ARG(d->KH * d->KW <= 52, "too many taps");
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
@@ -951,9 +1090,12 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
         static const int kid = prof_register("wgrad_alltaps_kernel");
         static const int kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
         static const int kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
-        prof_begin(hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+        static const int kidx3 = prof_register("wgrad_alltaps_kernel<f32x3>");
+        prof_begin(x3 ? kidx3 : hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
-        if (hs && use_tr_wgrad())
+        if (x3)
+            hipLaunchKernelGGL(wgrad_alltaps_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        else if (hs && use_tr_wgrad())
             hipLaunchKernelGGL(wgrad_alltaps_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs)
             hipLaunchKernelGGL((wgrad_alltaps_kernel<true, true>), dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);

@@ -120,6 +120,26 @@ __device__ __forceinline__ float4 bf16x4_to_f32(unsigned lo, unsigned hi) {
                        __uint_as_float(hi & 0xffff0000u));
 }
 
+// XV2_MATH_F32X3 operand split: x = h + m + l exactly, every term a bf16 (8 + 8 + 8 significant bits cover the 24 of an
+// fp32; round-to-nearest at each level keeps the residuals zero-mean).  Two elements per instruction: v_cvt_pk_bf16_f32,
+// two unpacks, one packed subtraction per level - 4.5 VALU per element.  Outputs are the packed bf16 planes.
+__device__ __forceinline__ void split3x2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    const f2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const f2 r1 = v - hf;                                   // exact
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2));
+    const f2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    const f2 r2 = r1 - mf;                                  // exact, <= 8 significant bits left
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2));
+}
+__device__ __forceinline__ void split3x4(const float4 v, uint2& h, uint2& m, uint2& l) {
+    split3x2(v.x, v.y, h.x, m.x, l.x);
+    split3x2(v.z, v.w, h.y, m.y, l.y);
+}
+
 #define XV2_CHECK_DTYPE(dt) XV2_CHECK_ARG((dt) == XV2_F32 || (dt) == XV2_BF16, "unknown activation dtype %d", (int)(dt))
 // run `call` with T bound to the storage type named by dtype
 #define XV2_DISPATCH_DTYPE(dt, ...)             \
