@@ -430,6 +430,181 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
     }
 }
 
+// XV2_MATH_F32X3 variant of wgrad_tr_kernel: fp32 dY / X tiles split into three bf16 planes on their way into LDS
+// (single-buffered, 60 KB for 128 x 128), six bf16 MFMAs per product.  Two raw register sets as in the implicit-GEMM
+// kernel: tile kt+1 is split on the VALU in the shadow of tile kt's MFMAs while tile kt+2 is in flight.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
+    constexpr int MR = BM / 64, NR = BN / 64;
+    constexpr int SA = BM + 32, SB = BN + 32;              // LDS row strides in bf16 elements
+    constexpr int PL = 32 * (SA + SB);                     // elements per plane
+    constexpr int ALPR = BM / 4, ARPP = 256 / ALPR, APASS = 32 / ARPP;   // 16-byte (4 float) lanes per row
+    constexpr int BLPR = BN / 4, BRPP = 256 / BLPR, BPASS = 32 / BRPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);          // [32 px][SA]   dY tile, plane 0 (planes PL apart)
+    bf16_t* Bs = As + 32 * SA;                             // [32 px][SB]   X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b = blockIdx.x;
+    const int tn = b % p.tiles_n;
+    b /= p.tiles_n;
+    const int tap = b % p.T;
+    const int co0 = (b / p.T) * BM, cn0 = tn * BN;
+    const bool first = cn0 < p.C0;
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+    const int dh = p.taps[tap].dh, dw = p.taps[tap].dw;
+    const int ohw = p.OH * p.OW;
+    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? p.X0 : p.X1), 0,
+                                                                   first ? p.bytesX0 : p.bytesX1, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.bytesDY, 0x00020000);
+    const int a_c4 = tid % ALPR, a_r = tid / ALPR, b_c4 = tid % BLPR, b_r = tid / BLPR;
+    int a_const[APASS], b_const[BPASS], b_k[BPASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) a_const[j] = (a_r + j * ARPP) * p.ldDY + co0 + a_c4 * 4;
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        b_k[j] = (b_r + j * BRPP) * p.stride + dw;
+        b_const[j] = b_k[j] * ldx + xch + b_c4 * 4;
+    }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    auto gload_into = [&](int kt, i32x4 (&ra)[APASS], i32x4 (&rb)[BPASS]) {   // a 32-pixel tile lies inside one output row
+        const int mb = kt * 32;
+        const int n = mb / ohw;
+        const int rem = mb - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow0 = rem - oh * p.OW;
+        const int ih = oh * p.stride + dh;
+        const bool rowok = (unsigned)ih < (unsigned)p.IH;
+        const int iw0 = ow0 * p.stride;
+        const int ubase = ((n * p.IH + ih) * p.IW + iw0) * ldx;
+        const int dbase = mb * p.ldDY;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsD, (dbase + a_const[j]) << 2, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const bool ok = rowok && (unsigned)(iw0 + b_k[j]) < (unsigned)p.IW;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((ubase + b_const[j]) << 2) : (int)0x80000000, 0, 0);
+        }
+    };
+    uint2 pk[APASS + BPASS][3];
+    auto split_regs = [&](const i32x4 (&xa)[APASS], const i32x4 (&xb)[BPASS]) {
+#pragma unroll
+        for (int j = 0; j < APASS + BPASS; ++j) {
+            const i32x4 v = j < APASS ? xa[j < APASS ? j : 0] : xb[j >= APASS ? j - APASS : 0];
+            split3x4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])),
+                     pk[j][0], pk[j][1], pk[j][2]);
+        }
+    };
+    auto store_planes = [&]() {
+#pragma unroll
+        for (int j = 0; j < APASS + BPASS; ++j) {
+            bf16_t* d = j < APASS ? As + (a_r + j * ARPP) * SA + a_c4 * 4 : Bs + (b_r + (j - APASS) * BRPP) * SB + b_c4 * 4;
+            *reinterpret_cast<uint2*>(d) = pk[j][0];
+            *reinterpret_cast<uint2*>(d + PL) = pk[j][1];
+            *reinterpret_cast<uint2*>(d + 2 * PL) = pk[j][2];
+        }
+    };
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int frow = 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    auto frag = [&](const bf16_t* base, int stride) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * stride));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto mfma_tile = [&]() {
+        const bf16_t* a = As + frow * SA + wm * (BM / 2) + fcol;
+        const bf16_t* bb = Bs + frow * SB + wn * (BN / 2) + fcol;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[MR], am[MR], al[MR], bh[NR], bm_[NR], bl[NR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                ah[i] = frag(a + (16 * ks) * SA + i * 32, SA);
+                am[i] = frag(a + PL + (16 * ks) * SA + i * 32, SA);
+                al[i] = frag(a + 2 * PL + (16 * ks) * SA + i * 32, SA);
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                bh[j] = frag(bb + (16 * ks) * SB + j * 32, SB);
+                bm_[j] = frag(bb + PL + (16 * ks) * SB + j * 32, SB);
+                bl[j] = frag(bb + 2 * PL + (16 * ks) * SB + j * 32, SB);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const bf16x8 x = t == 0 ? al[i] : t == 1 ? ah[i] : t == 2 ? am[i] : t == 3 ? am[i] : ah[i];
+                        const bf16x8 y = t == 0 ? bh[j] : t == 1 ? bl[j] : t == 2 ? bm_[j] : t == 3 ? bh[j] : t == 4 ? bm_[j] : bh[j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < APASS + BPASS; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
+        constexpr int NMFMA = 2 * 6 * MR * NR;
+#pragma unroll
+        for (int g = 0; g < NMFMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (APASS + BPASS) * 18 / NMFMA + 1, 0);
+        }
+    };
+    i32x4 ra0[APASS], rb0[BPASS], ra1[APASS], rb1[BPASS];
+    auto step = [&](int kt, i32x4 (&xa)[APASS], i32x4 (&xb)[BPASS]) {
+        split_regs(xa, xb);
+        mfma_tile();
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            store_planes();
+            if (kt + 3 < kt1) gload_into(kt + 3, xa, xb);
+        }
+        __syncthreads();
+    };
+    if (kt0 < kt1) {
+        gload_into(kt0, ra0, rb0);
+        split_regs(ra0, rb0);
+        store_planes();
+        if (kt0 + 1 < kt1) gload_into(kt0 + 1, ra1, rb1);
+        if (kt0 + 2 < kt1) gload_into(kt0 + 2, ra0, rb0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        step(kt, ra1, rb1);
+        if (kt + 1 < kt1) step(kt + 1, ra0, rb0);
+    }
+    // slab: part[split][co][T][Ctot]
+    const size_t rowlen = (size_t)p.T * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const size_t coloff = (size_t)tap * p.Ctot + cn0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                slab[(size_t)row * rowlen + coloff] = acc[i][j][r];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // All-taps variant for 3x3 / stride 1 / pad 1 layers with few channels (the 1024x1024 decoder level, 32 -> 32).
 // The per-tap kernel above re-reads the dY tile and a shifted X tile for every tap: 8 KB of L2->LDS traffic per
@@ -1112,6 +1287,21 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
             else rc = launch_wgrad<32, 64, 1, 2, 2, true, false, true>(p, pl, stream);
         } else if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
+    } else if (x3 && p.fast && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
+        static const int kid128 = prof_register("wgrad_tr_kernel<128,128,f32x3>");
+        static const int kid64 = prof_register("wgrad_tr_kernel<64,64,f32x3>");
+        prof_begin(pl.bm == 128 ? kid128 : kid64, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+                   4.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
+        if (pl.bm == 128) {
+            static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tr_x3_kernel<128, 128>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 320 * 2), 0);
+            (void)once;
+            hipLaunchKernelGGL((wgrad_tr_x3_kernel<128, 128>), dim3(pl.tiles, pl.splitk), dim3(256), 3 * 32 * 320 * 2, stream, p);
+        } else
+            hipLaunchKernelGGL((wgrad_tr_x3_kernel<64, 64>), dim3(pl.tiles, pl.splitk), dim3(256), 3 * 32 * 192 * 2, stream, p);
+        prof_end(stream);
+        XV2_CHECK_LAUNCH();
+        rc = XV2_OK;
     } else if (hs && p.fast && use_tr_wgrad() && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
         static const int kid128 = prof_register("wgrad_tr_kernel<128,128,bf16hbm>");
         static const int kid64 = prof_register("wgrad_tr_kernel<64,64,bf16hbm>");
