@@ -229,7 +229,9 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
         ops.MATH_MODE = old_mode
         ops.set_storage_dtype(None) if hasattr(ops, "set_storage_dtype") else None
     gf = F_ENC_GFLOP_PER_IMG.get(encoder, 0.0) * batch * (size / 1024.0) ** 2
-    peak = PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS
+    x3 = precision == 32 and ops.fp32_math() == ops.MATH_F32X3
+    peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else
+            PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
     mfma_ms = sum(r["ms"] for r in rows) / iters
     counted = sum(r["gflop"] for r in rows) / iters
     return {"encoder": encoder, "precision": precision, "batch": batch, "size": size,
@@ -237,6 +239,9 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
             "forward_ms": round(wall_ms, 3), "mfma_kernels_ms": round(mfma_ms, 3),
             "mfma_util_whole_forward": round(gf / wall_ms / peak, 4),
             "mfma_util_in_mfma_kernels": round(gf / mfma_ms / peak, 4) if mfma_ms else None,
+            "math": "f32x3 (3-way bf16 split, 6 bf16 MFMAs per product; peak = bf16 dense peak / 6)" if x3 else
+                    "fp32 MFMA" if precision == 32 else "bf16 MFMA, bf16 tensors",
+            "vs_fp32_mfma_peak_157.3": round(gf / wall_ms / PEAK_F32_MFMA_TFLOPS, 4) if precision == 32 else None,
             "eval_mode": {"forward_ms": round(wall_eval, 3),
                           "mfma_kernels_ms": round(sum(r["ms"] for r in rows_eval) / iters, 3),
                           "mfma_util_whole_forward": round(gf / wall_eval / peak, 4),
@@ -481,6 +486,11 @@ def main():
         peak = step_peak
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
+                "math": "f32x3: fp32 tensors and accumulation, each product = 6 bf16 MFMA products of exact 3-way bf16 "
+                        "operand splits; peak = bf16 dense MFMA peak / 6 (the instruction stream's own bound); "
+                        "achieved counts ALGORITHMIC fp32 flops (2*M*N*K)" if x3 else
+                        "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA",
+                "frac_of_fp32_mfma_peak_157.3": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if opt.precision == 32 else None,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                   "command on an earlier run (PMC collection is not possible inside this process)",
                 "kernel": top["kernel"],

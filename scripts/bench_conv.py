@@ -47,6 +47,8 @@ def prof_time(fn, iters=10):
 
 
 def main():
+    if os.environ.get("XV2_MATH") == "0":             # exact fp32 MFMA (the default is ops.fp32_math(): F32X3)
+        ops.MATH_MODE = ops.MATH_F32
     if os.environ.get("XV2_MATH") == "1":
         ops.MATH_MODE = ops.MATH_BF16
     if os.environ.get("XV2_MATH") == "3":

@@ -218,7 +218,10 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path,
     gr = res[0][3]
     cos = float((gr.double() * g.double()).sum() / (gr.double().norm() * g.double().norm()))
     # fp32 + training-mode BN conditioning (ResNeSt's split-attention BatchNorm sees 4 values per channel here)
-    assert cos > 0.9999 and rel(gr, g) <= (1e-2 if encoder == "resnet50" else 3e-2), (cos, rel(gr, g))
+    # (measured: resnet50 cos 1 - 2e-6; resnest50 1 - 2e-5 with the exact-fp32 MFMA, 1 - 1.8e-4 with the default split-bf16
+    #  products - the 2 x 2 and 1 x 4 runs tile and split their reductions differently, and this backward amplifies that)
+    assert cos > (0.9999 if encoder == "resnet50" else 0.9995) and \
+        rel(gr, g) <= (1e-2 if encoder == "resnet50" else 3e-2), (cos, rel(gr, g))
     # first AdamW step moves every weight by ~lr * sign(g): a near-zero gradient whose sign differs costs 2 * lr
     assert rel(res[0][6], opt.flat_p.cpu()) <= 2.5e-3
 

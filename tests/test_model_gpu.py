@@ -288,7 +288,7 @@ def test_precision16_bf16_storage_loss_and_label_agreement(name):
         lh = criterion.compute_loss(criterion.Loss(a), ph, y.to(DEV), a.deep_supervision)
         lh.backward()
     finally:
-        ops.MATH_MODE = ops.MATH_F32
+        ops.MATH_MODE = ops.fp32_math()
         ops.set_storage_dtype(None)
     po0 = po[0] if isinstance(po, list) else po
     ph0 = ph[0] if isinstance(ph, list) else ph
@@ -323,7 +323,7 @@ def test_precision16_training_tracks_fp32_training(name):
     x, y = model_input(a, batch=8).to(DEV), labels(a, batch=8).to(DEV)
     curves = {}
     for mode in ("fp32", "bf16"):
-        ops.MATH_MODE = ops.MATH_BF16 if mode == "bf16" else ops.MATH_F32
+        ops.MATH_MODE = ops.MATH_BF16 if mode == "bf16" else ops.fp32_math()
         ops.set_storage_dtype(torch.bfloat16 if mode == "bf16" else None)
         try:
             torch.manual_seed(0)
@@ -341,7 +341,7 @@ def test_precision16_training_tracks_fp32_training(name):
                 losses.append(float(loss))
             curves[mode] = losses
         finally:
-            ops.MATH_MODE = ops.MATH_F32
+            ops.MATH_MODE = ops.fp32_math()
             ops.set_storage_dtype(None)
     f, h = curves["fp32"], curves["bf16"]
     print("loss curves %s\n fp32 %s\n bf16 %s" % (name, ["%.4f" % v for v in f], ["%.4f" % v for v in h]))

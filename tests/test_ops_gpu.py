@@ -787,7 +787,7 @@ def test_f32x3_split_bf16_conv_keeps_the_fp32_tolerances(case):
             dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
             outs[mode] = (nchw(y), dx, wg.grad.detach().cpu())
         finally:
-            ops.MATH_MODE = ops.MATH_F32
+            ops.MATH_MODE = ops.fp32_math()
     y3, dx3, dw3 = outs[ops.MATH_F32X3]
     close(y3, yr, 2e-4, "f32x3 y")
     close(dx3, xr.grad, 5e-4, "f32x3 dx")

@@ -62,7 +62,7 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // X3 = true (XV2_MATH_F32X3): fp32 tensors, each operand element split into three bf16 terms on its way into LDS (three
 // bf16 planes per operand, single-buffered: 61 KB for the 128x128 tile), six bf16 MFMAs per fp32-grade product.
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
-__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+__global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;

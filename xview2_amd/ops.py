@@ -93,14 +93,18 @@ def _out_hw(IH, IW, g):
 
 
 MATH_F32, MATH_BF16, MATH_BF16_STORE, MATH_F32X3 = 0, 1, 2, 3
-MATH_MODE = MATH_F32     # process-wide default for fp32-stored tensors (set from --precision by the trainer / bench)
 
 
 def fp32_math():
-    """math mode of fp32-stored tensors: the exact-fp32 MFMA, or (opt-in, XV2_F32X3=1) the 3-way bf16 split with six
-    bf16 MFMAs per product (fp32-grade products, include/xv2.h XV2_MATH_F32X3)"""
-    return MATH_F32X3 if os.environ.get("XV2_F32X3", "0") == "1" else MATH_F32
+    """math mode of fp32-stored tensors (--precision 32).  Default XV2_MATH_F32X3: every operand element is split
+    exactly into three bf16 terms on its way into LDS and each product is issued as the six significant bf16 cross
+    products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms < 2^-23 of |a||b| per product, i.e. the
+    rounding class of an fp32 multiply) - 1.5-1.7x the exact-fp32 MFMA's throughput.  XV2_F32X3=0 selects the exact
+    fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain) everywhere."""
+    return MATH_F32 if os.environ.get("XV2_F32X3", "1") == "0" else MATH_F32X3
 
+
+MATH_MODE = fp32_math()  # process-wide mode for fp32-stored tensors (set from --precision by the trainer / bench)
 
 def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW, half=False):
     """half: the activations of this convolution are bf16 in HBM (XV2_MATH_BF16_STORE)"""
