@@ -23,6 +23,11 @@ def per_kernel(db, counter):
 
 def pretty(mangled):
     """mangled kernel symbol -> the name bench.py's in-library profiler registers (roofline.kernel)"""
+    if "wgrad_alltaps_x3_kernel" in mangled:
+        return "wgrad_alltaps_kernel<f32x3>"
+    m = re.match(r"_ZN3xv2\d+wgrad_tr_x3_kernelILi(\d+)ELi(\d+)E", mangled)
+    if m:
+        return "wgrad_tr_kernel<%s,%s,f32x3>" % (m.group(1), m.group(2))
     if "wgrad_alltaps_tr_kernel" in mangled:
         return "wgrad_alltaps_kernel<bf16hbm>"
     if "wgrad_alltaps_kernel" in mangled:
@@ -38,10 +43,11 @@ def pretty(mangled):
     if not m:
         return None
     args = re.findall(r"L([ib])(\d+)E", m.group(2))
-    vals = [int(v) for _, v in args] + [0, 0, 0]
+    vals = [int(v) for _, v in args] + [0, 0, 0, 0]
     if m.group(1) == "igemm":
-        smallc, bf16, hs = vals[4], vals[5], vals[6]
-        tag = ("rgb,bf16out" if hs else "rgb") if smallc else ("c32,bf16hbm" if hs else ("c32,bf16" if bf16 else "c32"))
+        smallc, bf16, hs, x3 = vals[4], vals[5], vals[6], vals[7]
+        tag = ("rgb,bf16out" if hs else "rgb") if smallc else (
+            "c32,bf16hbm" if hs else ("c32,f32x3" if x3 else ("c32,bf16" if bf16 else "c32")))
         return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], tag)
     smallc, bf16, hs = vals[5], vals[6], vals[7]
     tag = ("rgb" if smallc else ("c32,bf16" if bf16 else "c32")) + (",bf16hbm" if hs else "")
