@@ -523,8 +523,8 @@ def main():
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
-                                   "fp32 tensors, products as 3-way bf16 splits on the bf16 MFMA (XV2_F32X3=1; peak = bf16 "
-                                   "peak / 6 products)" if x3 else "fp32" if opt.precision == 32 else
+                                   "fp32 tensors, products as exact 3-way bf16 splits on the bf16 MFMA (6 MFMAs per product, "
+                                   "fp32 accumulate; XV2_F32X3=0 selects the exact-fp32 MFMA)" if x3 else "fp32" if opt.precision == 32 else
                                    "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
                    "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",

@@ -62,8 +62,10 @@ typedef struct xv2_conv_desc {
  * (x = hi + mid + lo, exact to 24 bits) while it is staged in LDS and the product is formed from the six significant
  * cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid with v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped
  * terms are below 2^-24 relative).  6 bf16 MFMAs of 16 k each replace 8 exact-fp32 MFMAs of 2 k each: 0.375x the
- * matrix-pipe time for fp32-level accuracy.  Implicit-GEMM forward / backward-data only; the weight-gradient and direct
- * 3x3 kernels and the RGB stem run their exact-fp32 forms under this mode. */
+ * matrix-pipe time for fp32-level accuracy.  Covers the implicit-GEMM kernel (forward, backward-data, transposed
+ * convolution) and the two main weight-gradient kernels (all-taps 3x3, transpose-read 1x1 / strided); the direct 3x3
+ * kernel, the RGB stem and odd-shaped weight-gradient layers run their exact-fp32 forms under this mode.  This is the
+ * mode the host layer uses for fp32 tensors by default (XV2_F32X3=0 in the environment selects XV2_MATH_F32). */
 #define XV2_MATH_F32X3 3
 
 /* element type of activation tensors for the non-convolution entry points (`dtype` arguments) */
