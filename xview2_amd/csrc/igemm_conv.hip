@@ -108,7 +108,11 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     const int kt_begin = blockIdx.z * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, ci.nkt);
 
-    const int c4 = tid % LPR, r0 = tid / LPR;
+    // row of the pass this thread loads / stores.  The bf16 LDS images have 80-byte rows and LDS stores are banked mod 32
+    // dwords per group of contiguous lanes (two rows per group): rows r and r+1 overlap on 4 banks, rows r and r+4 do not,
+    // so consecutive row slots of a wave are mapped to rows 0,4,8,12, 1,5,9,13, ... (a permutation inside 16 rows).
+    const int c4 = tid % LPR, q0 = tid / LPR;
+    const int r0 = (X3 || HIN) ? (((q0 & 3) << 2) | ((q0 >> 2) & 3) | (q0 & ~15)) : q0;
     const int ohw = ci.OHl * ci.OWl;
 
     int a_n[AROWS], a_h[AROWS], a_w[AROWS];
