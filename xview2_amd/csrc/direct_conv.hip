@@ -27,8 +27,12 @@ constexpr size_t D_SMEM = (size_t)(D_HALO * D_LD + 9 * 32 * D_LD) * 4 + 4 * 32 *
 constexpr int D_LDH = 40;
 constexpr int D_HLOADS_H = (D_HALO * 4 + 255) / 256;      // 16-byte loads (8 channels) per thread per halo (4)
 constexpr size_t D_SMEM_H = (size_t)(D_HALO + 9 * 32) * D_LDH * 2 + 4 * 32 * 2 * 4;
+// XV2_MATH_F32X3: three bf16 planes (hi / mid / lo terms of the exact split) of that bf16 image: 118 KB, one block per CU
+constexpr int D_PLH = D_HALO * D_LDH, D_PLW = 9 * 32 * D_LDH;      // plane sizes in elements
+constexpr size_t D_SMEM_X3 = (size_t)3 * (D_PLH + D_PLW) * 2 + 4 * 32 * 2 * 4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int hperm(int px) { return (px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3); }
 
 // BF16 = true (XV2_MATH_BF16, "--precision 16"): the same LDS-resident fp32 halo and weights, but a lane gathers 8
 // consecutive channels, rounds them to bf16 and issues v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 2 matrix
@@ -36,16 +40,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // HS = true (XV2_MATH_BF16_STORE): input, weights, output (and the inference residual) are bf16 in HBM; a halo element
 // (4 channels) is one 8-byte load widened to fp32 on its way into the same LDS image, the output row is rounded to bf16
 // and the BatchNorm statistics are taken on the rounded values.
-template <bool BF16, bool HS = false>
+// X3 = true (XV2_MATH_F32X3): fp32 tensors; halo and weights are split into three bf16 terms (split3x4) on their way
+// into LDS, every tap step is the six significant bf16 cross products: 108 MFMAs per wave and patch.
+template <bool BF16, bool HS = false, bool X3 = false>
 __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
+    static_assert(!X3 || (BF16 && !HS), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     constexpr int ESH = HS ? 1 : 2;
     typedef typename std::conditional<HS, bf16_t, float>::type OT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
     float* wts = smem + D_HALO * D_LD;          // [9][32][36]
-    float* red = HS ? smem + (D_HALO + 9 * 32) * D_LDH / 2 : wts + 9 * 32 * D_LD;           // [4][32][2]
-    __bf16* halo_h = reinterpret_cast<__bf16*>(smem);         // HS: [204][40] bf16
-    __bf16* wts_h = halo_h + D_HALO * D_LDH;                   // HS: [9][32][40] bf16
+    float* red = X3 ? smem + 3 * (D_PLH + D_PLW) / 2
+                    : HS ? smem + (D_HALO + 9 * 32) * D_LDH / 2 : wts + 9 * 32 * D_LD;   // [4][32][2]
+    __bf16* halo_h = reinterpret_cast<__bf16*>(smem);         // HS: [204][40] bf16;  X3: [3 planes][204][40]
+    __bf16* wts_h = halo_h + (X3 ? 3 : 1) * D_PLH;             // HS: [9][32][40] bf16; X3: [3 planes][9][32][40]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -63,7 +71,19 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     if (p0 >= p1) return;
 
     // weights, once: [tap][n][32 channels]
-    if constexpr (HS) {
+    if constexpr (X3) {
+        for (int e = tid; e < 9 * 32 * 8; e += 256) {
+            const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
+            const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
+            uint2 sh, sm, sl;
+            split3x4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), sh, sm, sl);
+            __bf16* d = wts_h + (t * 32 + nn) * D_LDH + c4 * 4;
+            *reinterpret_cast<uint2*>(d) = sh;
+            *reinterpret_cast<uint2*>(d + D_PLW) = sm;
+            *reinterpret_cast<uint2*>(d + 2 * D_PLW) = sl;
+        }
+    } else if constexpr (HS) {
         for (int e = tid; e < 9 * 32 * 4; e += 256) {
             const int c8 = e & 3, nn = (e >> 2) & 31, t = e >> 7;
             const int off = ((nn * p.T + p.taps[t].slot) * 32 + c8 * 8) << 1;
@@ -86,7 +106,9 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 #pragma unroll
     for (int j = 0; j < D_HLOADS; ++j) {
         const int e = tid + j * 256;
-        const int px = e / LPP, c4 = e % LPP;
+        const int c4 = e % LPP;
+        // X3: 8-byte LDS stores, two pixel rows per store lane group: rows 4 apart do not share banks (80-byte rows)
+        const int px = (X3 && e / LPP < 192) ? hperm(e / LPP) : e / LPP;
         hrow[j] = px / D_HW;
         hcol[j] = px - hrow[j] * D_HW;
         hrel[j] = e < D_HALO * LPP ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * (32 / LPP)) << ESH : 0;
@@ -110,7 +132,16 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         for (int j = 0; j < NHL; ++j) {
             const int e = tid + j * 256;
             if (e < D_HALO * LPP) {
-                if constexpr (HS)
+                if constexpr (X3) {
+                    const int px = (e >> 3) < 192 ? hperm(e >> 3) : (e >> 3);
+                    uint2 sh, sm, sl;
+                    split3x4(make_float4(__int_as_float(hr[j][0]), __int_as_float(hr[j][1]), __int_as_float(hr[j][2]),
+                                         __int_as_float(hr[j][3])), sh, sm, sl);
+                    __bf16* d = halo_h + px * D_LDH + (e & 7) * 4;
+                    *reinterpret_cast<uint2*>(d) = sh;
+                    *reinterpret_cast<uint2*>(d + D_PLH) = sm;
+                    *reinterpret_cast<uint2*>(d + 2 * D_PLH) = sl;
+                } else if constexpr (HS)
                     *reinterpret_cast<i32x4*>(halo_h + (e >> 2) * D_LDH + (e & 3) * 8) = hr[j];
                 else
                     *reinterpret_cast<i32x4*>(halo + (e >> 3) * D_LD + (e & 7) * 4) = hr[j];
@@ -137,6 +168,26 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dh = p.taps[t].dh, dw = p.taps[t].dw;
+            if constexpr (X3) {
+                const __bf16* a = halo_h + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LDH + 8 * h;
+                const __bf16* b = wts_h + (t * 32 + l31) * D_LDH + 8 * h;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + kk * 16);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(a + D_PLH + kk * 16);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 2 * D_PLH + kk * 16);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + kk * 16);
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8*>(b + D_PLW + kk * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + 2 * D_PLW + kk * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                continue;
+            }
             if constexpr (HS) {      // bf16 image in LDS: a 16-byte read IS the 8-channel MFMA operand
                 const __bf16* a = halo_h + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LDH + 8 * h;
                 const __bf16* b = wts_h + (t * 32 + l31) * D_LDH + 8 * h;
@@ -245,21 +296,29 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_H);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_X3);
         return e;
     }();
     XV2_CHECK_HIP(attr_rc);
     static const int kid = prof_register("direct3x3_n32_kernel");
     static const int kid16 = prof_register("direct3x3_n32_kernel<bf16>");
     static const int kid16s = prof_register("direct3x3_n32_kernel<bf16hbm>");
+    static const int kidx3 = prof_register("direct3x3_n32_kernel<f32x3>");
+    const bool x3 = p.math == XV2_MATH_F32X3;
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / (D_TH * D_TW);
     // persistent: 2 blocks per CU (fp32 LDS image, 71 KB), 4 per CU with the bf16 image (40 KB); each walks a run of patches
-    const int grid = std::min(npatches, p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
+    // (the three-plane image of F32X3, 118 KB: 1 per CU)
+    const int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
-    prof_begin(p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
-    if (p.math == XV2_MATH_BF16_STORE)
+    prof_begin(x3 ? kidx3 : p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
+    if (x3)
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(256), D_SMEM_X3, stream, p, npatches);
+    else if (p.math == XV2_MATH_BF16_STORE)
         hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, p, npatches);
     else if (p.math)
         hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);

@@ -803,7 +803,6 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         return XV2_OK;
     }
     if (direct3x3_eligible(p, smallc)) {
-        if (p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32;       // exact fp32 form of the direct kernel
         return direct3x3_launch(p, stream);
     }
     if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
