@@ -67,9 +67,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
     constexpr bool HIN = HS && !SMALLC;                 // bf16 operands in HBM
-    constexpr int LPR = HIN ? 4 : 8;                    // lanes per 32-channel row (16-byte loads)
-    constexpr int RPP = 256 / LPR;                      // rows per pass of the block
-    constexpr int EPL = 32 / LPR;                       // elements per lane per row
+    constexpr int LPR = (HIN || X3) ? 4 : 8;            // lanes per row of a load pass (16-byte loads); X3 loads 16-channel
+    constexpr int RPP = 256 / LPR;                      // half K-tiles: 4 lanes x 4 floats.  Rows per pass of the block
+    constexpr int EPL = X3 ? 4 : 32 / LPR;              // elements per lane per row
     constexpr int ESH = HIN ? 1 : 2;                    // log2(bytes per element)
     constexpr int AROWS = (BM + RPP - 1) / RPP, BROWS = (BN + RPP - 1) / RPP;
     static_assert(WGM * WGN == 4, "4 waves");
@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     // dwords per group of contiguous lanes (two rows per group): rows r and r+1 overlap on 4 banks, rows r and r+4 do not,
     // so consecutive row slots of a wave are mapped to rows 0,4,8,12, 1,5,9,13, ... (a permutation inside 16 rows).
     const int c4 = tid % LPR, q0 = tid / LPR;
-    const int r0 = (X3 || HIN) ? (((q0 & 3) << 2) | ((q0 >> 2) & 3) | (q0 & ~15)) : q0;
+    // (X3: 48-byte rows, four rows per store lane group: rows 0,2,4,6 / 1,3,5,7 partition the 32 banks)
+    const int r0 = X3 ? ((q0 & ~7) | ((q0 & 3) << 1) | ((q0 >> 2) & 1))
+                      : HIN ? (((q0 & 3) << 2) | ((q0 >> 2) & 3) | (q0 & ~15)) : q0;
     const int ohw = ci.OHl * ci.OWl;
 
     int a_n[AROWS], a_h[AROWS], a_w[AROWS];
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
 
     float4 ra[AROWS], rb[BROWS];
 
-    auto gload_into = [&](int kt, float4 (&ra)[AROWS], float4 (&rb)[BROWS]) {
+    auto gload_into = [&](int kt, float4 (&ra)[AROWS], float4 (&rb)[BROWS], int koff = 0) {
 #if XV2_ABL & 1
         return;
 #endif
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             const int dpix = t.dh * p.IW + t.dw;
             const bool first = cc < p.C0;
             const int ld = first ? p.ldA0 : p.ldA1;
-            const int ch = (first ? cc : cc - p.C0) + c4 * EPL;
+            const int ch = (first ? cc : cc - p.C0) + c4 * EPL + koff;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
                 const bool ok = (a_msk[j] >> tap) & 1u;
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                                       : __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0);
                 ra[j] = __builtin_bit_cast(float4, v);
             }
-            const int kb = t.slot * p.Ctot + cc;
+            const int kb = t.slot * p.Ctot + cc + koff;
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
                 const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << ESH, 0, 0);
@@ -283,17 +285,21 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if constexpr (X3) {
-        // planes: [hi | mid | lo] x ([A rows | B rows] x LDS_LD_H bf16); one buffer, two barriers per K-tile; the global
-        // loads of tile kt+1 are in flight while tile kt is multiplied
-        __bf16* pl0 = reinterpret_cast<__bf16*>(smem);
-        constexpr int PLANE = (BM + BN) * LDS_LD_H;
-        // software pipeline: the split of tile kt+1 (pure VALU on the registers the global loads filled) is issued in the
-        // shadow of tile kt's MFMAs (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles, a VALU op issues in 4), the
-        // LDS store of the packed terms and the next global loads sit between the two barriers
-        // Two raw register sets: while tile kt is multiplied out of LDS, tile kt+1 (loaded two iterations ago, long
-        // landed) is split on the VALU in the shadow of the MFMAs, and tile kt+2 is in flight into the other set.
+        // K advances in STAGES of 16 channels (half a K-tile).  LDS: two stage buffers, each three bf16 planes
+        // [hi | mid | lo] x ([A rows | B rows] x 24 bf16: 16 + 8 pad, 48-byte rows) - 73.7 KB for 128x128, the size of the
+        // fp32 double buffer.  Registers: two raw load sets and two fragment sets.  Iteration s multiplies stage s out of
+        // the fragment registers filled during iteration s-1, while (a) the fragments of stage s+1 are read from LDS,
+        // (b) the raw registers of stage s+2 are split on the VALU in the shadow of the MFMAs and stored into the LDS buffer
+        // stage s occupied, (c) stage s+3 is fetched from memory.  One barrier per stage, no LDS latency on the MFMA path.
+        constexpr int LDK = 24;
+        constexpr int PL = (BM + BN) * LDK, STG = 3 * PL;
+        static_assert((size_t)2 * STG * 2 <= (size_t)MAIN_FLOATS * 4, "stage buffers fit the fp32 operand buffers");
+        __bf16* sb = reinterpret_cast<__bf16*>(smem);
+        const int s_begin = 2 * kt_begin, s_end = 2 * kt_end;       // stage s = K-tile s / 2, channel half s & 1
         uint2 pk[AROWS + BROWS][3];
         float4 ra1[AROWS], rb1[BROWS];
+        bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
+        auto gstage = [&](int st, float4 (&xa)[AROWS], float4 (&xb)[BROWS]) { gload_into(st >> 1, xa, xb, (st & 1) * 16); };
         auto split_regs = [&](const float4 (&xa)[AROWS], const float4 (&xb)[BROWS]) {
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
@@ -301,81 +307,84 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                 split3x4(v, pk[j][0], pk[j][1], pk[j][2]);
             }
         };
-        auto store_planes = [&]() {
+        auto store_planes = [&](int buf) {
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
-                const int row = j < AROWS ? r0 + 32 * j : BM + r0 + 32 * (j - AROWS);
-                __bf16* d = pl0 + row * LDS_LD_H + c4 * 4;
-                *reinterpret_cast<uint2*>(d) = pk[j][0];
-                *reinterpret_cast<uint2*>(d + PLANE) = pk[j][1];
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = pk[j][2];
+                const int rr = r0 + RPP * (j < AROWS ? j : j - AROWS);
+                if (j < AROWS ? (BM % RPP == 0 || rr < BM) : (BN % RPP == 0 || rr < BN)) {
+                    __bf16* d = sb + buf * STG + ((j < AROWS ? 0 : BM) + rr) * LDK + c4 * 4;
+                    *reinterpret_cast<uint2*>(d) = pk[j][0];
+                    *reinterpret_cast<uint2*>(d + PL) = pk[j][1];
+                    *reinterpret_cast<uint2*>(d + 2 * PL) = pk[j][2];
+                }
             }
         };
-        auto mfma_tile = [&]() {
-            const __bf16* a = pl0 + (wm * WTM + l31) * LDS_LD_H + 8 * h;
-            const __bf16* b = pl0 + (BM + wn * WTN + l31) * LDS_LD_H + 8 * h;
+        auto read_frags = [&](int buf, bf16x8 (&fa)[MR][3], bf16x8 (&fb)[NR][3]) {
+            const __bf16* a = sb + buf * STG + (wm * WTM + l31) * LDK + 8 * h;
+            const __bf16* b = sb + buf * STG + (BM + wn * WTN + l31) * LDK + 8 * h;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 ah[MR], am[MR], al[MR], bh[NR], bm_[NR], bl[NR];
+            for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_LD_H + ks * 16);
-                    am[i] = *reinterpret_cast<const bf16x8*>(a + PLANE + i * 32 * LDS_LD_H + ks * 16);
-                    al[i] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE + i * 32 * LDS_LD_H + ks * 16);
-                }
+                for (int i = 0; i < MR; ++i) fa[i][q] = *reinterpret_cast<const bf16x8*>(a + q * PL + i * 32 * LDK);
 #pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_LD_H + ks * 16);
-                    bm_[j] = *reinterpret_cast<const bf16x8*>(b + PLANE + j * 32 * LDS_LD_H + ks * 16);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(b + 2 * PLANE + j * 32 * LDS_LD_H + ks * 16);
-                }
-                // smallest terms first; the accumulator tiles interleave, so dependent MFMAs are MR*NR issues apart
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < MR; ++i)
-#pragma unroll
-                        for (int j = 0; j < NR; ++j) {
-                            const bf16x8 x = t == 0 ? al[i] : t == 1 ? ah[i] : t == 2 ? am[i] : t == 3 ? am[i] : ah[i];
-                            const bf16x8 y = t == 0 ? bh[j] : t == 1 ? bl[j] : t == 2 ? bm_[j] : t == 3 ? bh[j] : t == 4 ? bm_[j] : bh[j];
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0);
-                        }
+                for (int j = 0; j < NR; ++j) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * PL + j * 32 * LDK);
             }
-            // pin the split results here: the instruction selector otherwise sinks the whole split below the barrier
-            // to its consumer (the LDS stores), out of reach of the scheduling groups that follow
+        };
+        auto mfma_stage = [&](const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3]) {
+            // smallest terms first (l*h, h*l, m*m, m*h, h*m, h*h); the accumulator tiles interleave, so dependent MFMAs
+            // are MR*NR issues apart
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+                        const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+                    }
+        };
+        // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; (xa, xb) hold the raw stage st+2; (ya, yb) are
+        // free and receive stage st+3
+        auto iter = [&](int st, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3], bf16x8 (&na)[MR][3],
+                        bf16x8 (&nb)[NR][3], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&ya)[AROWS],
+                        float4 (&yb)[BROWS]) {
+            if (st + 1 < s_end) read_frags((st + 1) & 1, na, nb);
+            if (st + 3 < s_end) gstage(st + 3, ya, yb);
+            split_regs(xa, xb);
+            mfma_stage(fa, fb);
+            // pin the split results here: the instruction selector otherwise sinks the whole split below its consumer
+            // (the LDS stores), out of reach of the scheduling groups that follow
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
-            // spread the split's VALU instructions between the MFMAs: ~4 VALU per 32-cycle MFMA slot
-            constexpr int NMFMA = 2 * 6 * MR * NR;
+            // per MFMA slot (32 cycles): one fragment read of the next stage while there are any, ~4 split VALU
+            constexpr int NMFMA = 6 * MR * NR, NRD = 3 * (MR + NR);
 #pragma unroll
             for (int g = 0; g < NMFMA; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 18 / NMFMA + 1, 0);
+                if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (AROWS + BROWS) * 20 / NMFMA + 1, 0);
             }
+            if (st + 2 < s_end) store_planes(st & 1);      // the buffer of stage st: every wave read it before the last barrier
+            __syncthreads();
         };
-        // one pipeline step: multiply tile kt (in LDS) while splitting tile kt+1 (in `xa/xb`), then store tile kt+1 and
-        // refill the same registers with tile kt+3
-        auto step = [&](int kt, float4 (&xa)[AROWS], float4 (&xb)[BROWS]) {
-            split_regs(xa, xb);
-            mfma_tile();
-            __syncthreads();                     // every wave is done reading tile kt
-            if (kt + 1 < kt_end) {
-                store_planes();
-                if (kt + 3 < kt_end) gload_into(kt + 3, xa, xb);
-            }
-            __syncthreads();                     // tile kt+1 is in LDS
-        };
-        gload_into(kt_begin, ra, rb);
+        gstage(s_begin, ra, rb);
+        gstage(s_begin + 1, ra1, rb1);
         split_regs(ra, rb);
-        store_planes();
-        if (kt_begin + 1 < kt_end) gload_into(kt_begin + 1, ra1, rb1);
-        if (kt_begin + 2 < kt_end) gload_into(kt_begin + 2, ra, rb);
+        store_planes(0);
+        if (s_begin + 2 < s_end) gstage(s_begin + 2, ra, rb);
+        split_regs(ra1, rb1);
+        store_planes(1);
         __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; kt += 2) {
-            step(kt, ra1, rb1);
-            if (kt + 1 < kt_end) step(kt + 1, ra, rb);
+        read_frags(0, fa0, fb0);
+        // the first fragments land before the loop is entered: otherwise the loop header, reached from here and from the
+        // back edge, waits for lgkmcnt(0) in EVERY iteration - on the next stage's reads it has just issued
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even
+            iter(st, fa0, fb0, fa1, fb1, ra, rb, ra1, rb1);
+            iter(st + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra, rb);
         }
     } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
@@ -690,7 +699,6 @@ constexpr size_t igemm_smem_bytes() {
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
-    static_assert(!X3 || (size_t)3 * (BM + BN) * LDS_LD_H_ * 2 <= (size_t)2 * (BM + BN) * LDS_LD * 4, "X3 planes fit the fp32 buffers");
     auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
