@@ -488,7 +488,9 @@ def main():
                 "frac": round(ach / peak, 4), "traffic": traffic,
                 "math": "f32x3: fp32 tensors and accumulation, each product = 6 bf16 MFMA products of exact 3-way bf16 "
                         "operand splits; peak = bf16 dense MFMA peak / 6 (the instruction stream's own bound); "
-                        "achieved counts ALGORITHMIC fp32 flops (2*M*N*K)" if x3 else
+                        "achieved counts ALGORITHMIC fp32 flops (2*M*N*K); peak is quoted at the 2.4 GHz maximum clock - "
+                        "under this kernel the chip is power-limited to ~1.67 GHz effective (GRBM_GUI_ACTIVE, "
+                        "profiles/r02_pmc_clock_f32x3.txt), where the same bound is ~289 TFLOP/s" if x3 else
                         "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA",
                 "frac_of_fp32_mfma_peak_157.3": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if opt.precision == 32 else None,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
