@@ -1119,7 +1119,7 @@ static int alltaps_max_tiles() {
     return v;
 }
 
-static WgradPlan make_plan(const xv2_conv_desc* d) {
+static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
     WgradPlan pl;
     const int Ctot = d->C0 + d->C1;
     pl.smallc = (d->C0 == 4 && d->C1 == 0);
@@ -1134,8 +1134,9 @@ static WgradPlan make_plan(const xv2_conv_desc* d) {
         pl.wk = 1;
         pl.tiles = (d->Cout / 32) * (Ctot / 32);
         const int strips = d->N * (d->OW / 32);
-        // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80)
-        const int cap = d->math ? 1024 : 512;
+        // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80),
+        // 3 per CU for the split-bf16 one (134 VGPRs, 38 KB of LDS)
+        const int cap = x3 ? 768 : d->math ? 1024 : 512;
         // row chunks per strip: the smallest count whose grid fills whole rounds of resident blocks (>= 90 %)
         const int maxchunks = std::max(1, d->OH / 8);
         int chunks = 1;
@@ -1231,7 +1232,7 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     const xv2_conv_desc* d = &dcopy;
     XV2_CHECK_ARG(d->KH * d->KW <= 52, "too many taps");
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
-    const WgradPlan pl = make_plan(d);
+    const WgradPlan pl = make_plan(d, x3);
     const bool hs = d->math == XV2_MATH_BF16_STORE;
     XV2_CHECK_ARG(pl.smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "backward_weight: C0=%d C1=%d must be multiples of 32", d->C0, d->C1);
@@ -1362,7 +1363,7 @@ extern "C" size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d_in
     xv2_conv_desc dcopy = *d_in;
     if (dcopy.math == XV2_MATH_F32X3) dcopy.math = XV2_MATH_F32;
     const xv2_conv_desc* d = &dcopy;
-    const WgradPlan pl = make_plan(d);
+    const WgradPlan pl = make_plan(d, d_in->math == XV2_MATH_F32X3);
     return (size_t)(pl.nslab + pl.groups) * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
 }
 
