@@ -766,9 +766,10 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& b
         best = c64;
         bm = 64;
     }
+    static const int ks_max = [] { const char* e = getenv("XV2_KSPLIT_MAX"); return e ? atoi(e) : 8; }();   // A/B runs
     if (bn == 128 && nkt >= 16) {
         const int64_t blocks128 = cdiv(M, 128) * ntn;
-        for (int ks = 2; ks <= 8 && nkt / ks >= 8; ++ks) {
+        for (int ks = 2; ks <= ks_max && nkt / ks >= 8; ++ks) {
             const double per = (double)cdiv(nkt, ks);
             // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab
             const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + 6.0);
