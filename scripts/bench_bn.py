@@ -44,7 +44,7 @@ def main():
     dev = "cuda:0"
     half = "--bf16" in sys.argv
     dt, code, esz = (torch.bfloat16, 1, 2) if half else (torch.float32, 0, 4)
-    tot = [0.0, 0.0, 0.0]
+    tot = [0.0, 0.0, 0.0, 0.0]
     print("%-20s %8s | %8s %8s %8s  GB/s   us: fwd reduce apply" % ("layer", "MB", "fwd", "reduce", "apply"))
     for name, npix, C, cnt, res in SHAPES:
         y = torch.randn(npix, C, device=dev).to(dt)
@@ -64,11 +64,18 @@ def main():
                                  ops.ACT_RELU, npix, C, sums2, dg, db, ws, code))
         ta = timeit(lambda: call("xv2_bn_act_backward_apply", dz, C, zz, C, y, C, mean, invstd, gamma, scale, shift,
                                  sums2, float(npix), ops.ACT_RELU, 1, dy, C, dres, C, npix, C, code))
+        def pair():
+            call("xv2_bn_act_backward_reduce", dz, C, zz, C, y, C, mean, invstd, scale, shift,
+                 ops.ACT_RELU, npix, C, sums2, dg, db, ws, code)
+            call("xv2_bn_act_backward_apply", dz, C, zz, C, y, C, mean, invstd, gamma, scale, shift,
+                 sums2, float(npix), ops.ACT_RELU, 1, dy, C, dres, C, npix, C, code)
+        tp = timeit(pair)
+        tot[3] += tp * cnt
         nf, nr, na = (3 if res else 2), (3 if res else 2), (5 if res else 3)
-        print("%-20s %8.1f | %8.0f %8.0f %8.0f         %7.1f %7.1f %7.1f   x%d" %
-              (name, mb, nf * mb / tf, nr * mb / tr, na * mb / ta, tf * 1e3, tr * 1e3, ta * 1e3, cnt))
+        print("%-20s %8.1f | %8.0f %8.0f %8.0f         %7.1f %7.1f %7.1f   x%d   reduce+apply in sequence %7.1f us" %
+              (name, mb, nf * mb / tf, nr * mb / tr, na * mb / ta, tf * 1e3, tr * 1e3, ta * 1e3, cnt, tp * 1e3))
         tot[0] += tf * cnt; tot[1] += tr * cnt; tot[2] += ta * cnt
-    print("per step: fwd %.3f ms  reduce %.3f ms  apply %.3f ms" % tuple(tot))
+    print("per step: fwd %.3f ms  reduce %.3f ms  apply %.3f ms  (reduce + apply in sequence %.3f ms)" % tuple(tot))
 
 
 if __name__ == "__main__":

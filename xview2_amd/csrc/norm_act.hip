@@ -441,12 +441,15 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
                                                           const float* __restrict__ shift,
                                                           const T* __restrict__ res, int ldr, int act,
                                                           T* __restrict__ z, int ldz, int64_t npix, int C,
-                                                          uint8_t* __restrict__ zmask) {
+                                                          uint8_t* __restrict__ zmask, int rev) {
     if constexpr (VEC) {
         constexpr int NV = Vec16<T>::NV, W = 4 * NV;     // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
         const int CW = C / W;
         const int64_t total = npix * CW;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // rev: last element first - the convolution that wrote y finished with its last rows, and the convolution that
+        // reads z starts with the first ones: both ends of this pass then meet data the memory-side cache still holds
+        for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = rev ? total - 1 - j : j;
             const int64_t row = i / CW;
             const int c = (int)(i - row * CW) * W;
             float4 v[NV], r[NV], o[NV];
@@ -560,7 +563,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
                                                                const double* __restrict__ sums2, double count, int act,
                                                                int train, T* __restrict__ dy, int lddy,
                                                                T* __restrict__ dres, int lddres, int64_t npix, int cgw,
-                                                               int rows_per_block, int zbits, int c4tot) {
+                                                               int rows_per_block, int zbits, int c4tot, int rev) {
     constexpr int NV = Vec16<T>::NV, W = 4 * NV;      // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
     const int CW = cgw / W, rpp = 256 / CW;
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
@@ -577,7 +580,9 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
         sc[k] = z ? 0.f : scale[c + k];
         sf[k] = z ? 0.f : shift[c + k];
     }
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    // row blocks run LAST-to-first: the column-sum pass that precedes this one walked dz / y first-to-last, so the tail
+    // of both tensors is what the memory-side cache (256 MB) still holds
+    const int64_t r0 = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
     const int64_t r1 = min(r0 + (int64_t)rows_per_block, npix);
     const bool need_y = train || !z;
     auto row = [&](int64_t r, const float4 (&dv)[NV], const float4 (&zv)[NV], const float4 (&yv)[NV], unsigned m) {
@@ -622,6 +627,12 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
         fetch(r, d0, z0, y0, m0);
         row(r, d0, z0, y0, m0);
     }
+}
+
+// XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply walk their tensors last-to-first
+static int bn_reverse(int bit) {
+    static const int v = [] { const char* e = getenv("XV2_BN_REVERSE"); return e ? atoi(e) : 3; }();
+    return (v >> bit) & 1;
 }
 
 static inline int ew_grid(int64_t total) {
@@ -740,10 +751,10 @@ static int bn_act_forward_impl(const T* y, int ldy, const float* scale, const fl
     const int grid = ew_grid(npix * (vec ? C / W : C));
     if (vec)
         hipLaunchKernelGGL((bn_act_fwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C, zmask);
+                           shift, residual, ldr, act, z, ldz, npix, C, zmask, bn_reverse(1));
     else
         hipLaunchKernelGGL((bn_act_fwd_kernel<false, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr);
+                           shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr, 0);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -824,7 +835,7 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
-                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4);
+                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4, bn_reverse(0));
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
