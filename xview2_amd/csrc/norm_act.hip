@@ -133,14 +133,24 @@ struct ColOp {
     }
 };
 
+// XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply, bit 2 = the backward column sums walk
+// their tensors last-to-first
+static int bn_reverse(int bit) {
+    static const int v = [] { const char* e = getenv("XV2_BN_REVERSE"); return e ? atoi(e) : 3; }();
+    return (v >> bit) & 1;
+}
+
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op, int64_t npix, int C, int rpb, int cgw,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, int rev) {
     __shared__ float sh[256 * 8 * Vec16<T>::NV];
     const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    // rev: the row chunks are dispatched last-to-first (same chunk -> rows -> partial-row mapping, same sums): the
+    // kernel that produced the tensors finished with their last rows
+    const int chunk = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rpb;
     const int64_t r1 = min(r0 + (int64_t)rpb, npix);
-    double* out = part + (size_t)blockIdx.x * C * 2;
+    double* out = part + (size_t)chunk * C * 2;
     if (cgw) {
         constexpr int NV = Vec16<T>::NV, W = 4 * NV;
         const int CW = cgw / W;
@@ -629,12 +639,6 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
     }
 }
 
-// XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply walk their tensors last-to-first
-static int bn_reverse(int bit) {
-    static const int v = [] { const char* e = getenv("XV2_BN_REVERSE"); return e ? atoi(e) : 3; }();
-    return (v >> bit) & 1;
-}
-
 static inline int ew_grid(int64_t total) {
     int64_t b = cdiv(total, 256);
     if (b > bn_blocks(256 * 16)) b = bn_blocks(256 * 16);
@@ -688,7 +692,7 @@ static int column_sums(const ColOp<MODE, T>& op, int64_t npix, int C, double* su
     double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
     hipLaunchKernelGGL((column_partials_kernel<MODE, T>), dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix,
-                       C, g.rpb, g.cgw, dpart);
+                       C, g.rpb, g.cgw, dpart, MODE == 1 ? bn_reverse(2) : 0);
     XV2_CHECK_LAUNCH();
     return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
