@@ -734,7 +734,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
 }
 
 // tile shape and split-K factor; `nkt` = K tiles of the (single-class) problem, 0 disables split-K
-static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& bn, int& ksplit) {
+static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& bm, int& bn, int& ksplit) {
     bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
     ksplit = 1;
     if (smallc || bn == 32) {
@@ -761,7 +761,10 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& b
     const double k = (double)std::max(nkt, 1);
     double best = rounds(cdiv(M, 128) * ntn, cap128) * 128.0 * k;
     bm = 128;
-    const double c64 = rounds(cdiv(M, 64) * ntn, cap64) * 64.0 * k / 0.92;
+    // per-FLOP efficiency of the 64-row tiles relative to 128 x 128: 0.92 with the fp32 MFMA; 0.65 in the split-bf16 form
+    // (6-12 MFMAs per stage and barrier; measured 143 vs 190 TFLOP/s on the 116-GFLOP decoder layers)
+    const double eff64 = math == XV2_MATH_F32X3 ? 0.65 : 0.92;
+    const double c64 = rounds(cdiv(M, 64) * ntn, cap64) * 64.0 * k / eff64;
     if (c64 < best * 0.97) {
         best = c64;
         bm = 64;
@@ -771,8 +774,9 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& b
         const int64_t blocks128 = cdiv(M, 128) * ntn;
         for (int ks = 2; ks <= ks_max && nkt / ks >= 8; ++ks) {
             const double per = (double)cdiv(nkt, ks);
-            // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab
-            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + 6.0);
+            // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab (3 measured against the
+            // split-bf16 form's 64-row alternative on the short-K 1x1 layers)
+            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + (math == XV2_MATH_F32X3 ? 3.0 : 6.0));
             if (c < best * 0.95) {
                 best = c;
                 bm = 128;
@@ -782,15 +786,15 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int& bm, int& b
     }
 }
 
-int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt) {
+int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
-    pick_tile(M, Nout, smallc, nkt, bm, bn, ks);
+    pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
     return ks > 1 ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
 }
 
-size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt) {
+size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
-    pick_tile(M, Nout, smallc, nkt, bm, bn, ks);
+    pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
     return ks > 1 ? (size_t)ks * M * Nout * sizeof(float) : 0;
 }
 
@@ -807,7 +811,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             *p.plan_tiles = p.cls[0].M / 128;
             return XV2_OK;
         }
-        pick_tile(maxM, p.Nout, smallc, splitk_ws ? p.cls[0].nkt : 0, bm, bn, ks);
+        pick_tile(maxM, p.Nout, smallc, splitk_ws ? p.cls[0].nkt : 0, p.math, bm, bn, ks);
         if (ks == 1 && bn >= 64) *p.plan_tiles = cdiv(maxM, bm);
         return XV2_OK;
     }
@@ -815,7 +819,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         return direct3x3_launch(p, stream);
     }
     if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
-    pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, bm, bn, ks);
+    pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, p.math, bm, bn, ks);
     if (getenv("XV2_DEBUG_TILE"))
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
                 splitk_ws != nullptr, bm, bn, ks);
@@ -943,14 +947,14 @@ static inline int fwd_nkt(const xv2_conv_desc* d) {
 using namespace xv2;
 
 extern "C" int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d) {
-    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d));
+    return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d) {
-    return igemm_splitk_bytes((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d));
+    return igemm_splitk_bytes((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {
     if (d->stride != 1) return 0;
-    return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK));
+    return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK), d->math);
 }
 
 struct BnbArgs {          // producer-layer BatchNorm backward statistics (IgemmParams::bnb_*)
