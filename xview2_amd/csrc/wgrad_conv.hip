@@ -1294,9 +1294,9 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
         prof_begin(pl.bm == 128 ? kid128 : kid64, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    4.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
         if (pl.bm == 128) {
-            static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tr_x3_kernel<128, 128>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 320 * 2), 0);
-            (void)once;
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tr_x3_kernel<128, 128>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 320 * 2);
+            XV2_CHECK_HIP(attr_rc);
             hipLaunchKernelGGL((wgrad_tr_x3_kernel<128, 128>), dim3(pl.tiles, pl.splitk), dim3(256), 3 * 32 * 320 * 2, stream, p);
         } else
             hipLaunchKernelGGL((wgrad_tr_x3_kernel<64, 64>), dim3(pl.tiles, pl.splitk), dim3(256), 3 * 32 * 192 * 2, stream, p);
