@@ -1,5 +1,6 @@
 """Tile / split-K sweep of the implicit-GEMM kernel per layer shape (forward and backward-data), against the cost
-model's own choice.  usage: python scripts/sweep_tiles.py [filter]"""
+model's own choice.  usage: [XV2_MATH=0|2] python scripts/sweep_tiles.py [filter]
+(default: the split-bf16 form of fp32 tensors; XV2_MATH=0: exact-fp32 MFMA; XV2_MATH=2: bf16 storage)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xview2_amd import ops
@@ -12,15 +13,18 @@ def main():
     filt = sys.argv[1:]
     dev = "cuda:0"
     ops.PACK_CACHE = False
+    if os.environ.get("XV2_MATH") == "0":
+        ops.MATH_MODE = ops.MATH_F32
+    adt = torch.bfloat16 if os.environ.get("XV2_MATH") == "2" else torch.float32
     for (name, N, H, W, C0, C1, Co, k, s, p) in SHAPES:
         if filt and not any(f in name for f in filt):
             continue
         g = ops.conv_cfg(k, k, s, p)
-        x0 = torch.randn(N, H, W, C0, device=dev)
-        x1 = torch.randn(N, H, W, C1, device=dev) if C1 else None
+        x0 = torch.randn(N, H, W, C0, device=dev).to(adt)
+        x1 = torch.randn(N, H, W, C1, device=dev).to(adt) if C1 else None
         w = torch.randn(Co, C0 + C1, k, k, device=dev) * 0.05
         OH, OW = ops._out_hw(H, W, g)
-        dy = torch.randn(N, OH, OW, Co, device=dev)
+        dy = torch.randn(N, OH, OW, Co, device=dev).to(adt)
         for what, fn in (("fwd", lambda: ops._conv_forward(x0, x1, w, g, None, True)),
                          ("dgrad", lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))):
             os.environ.pop("XV2_FORCE_TILE", None)

@@ -756,6 +756,37 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     // Candidates: 128-row tile, 64-row tile (measured ~8 % less efficient per FLOP), and for bn == 128 the 128-row
     // tile with K split 2..8 ways (partials reduced by splitk_reduce_kernel, charged as extra traffic).
     const int ntn = Nout / bn;
+    if (math == XV2_MATH_BF16_STORE) {
+        // bf16 storage: the kernels are throughput-bound (LDS / MFMA issue) once a CU holds 3 blocks, so a launch takes
+        // (blocks on the fullest CU) x (tile rows x K share), stretched for a last group of fewer than 3 blocks (latency
+        // not hidden: 0.55 alone, 0.9 in pairs) and for the 64-row tiles (0.8 per FLOP).  scripts/sweep_tiles.py.
+        auto cost = [&](int64_t blocks, double rows, double kshare, double eff) {
+            const int64_t n = cdiv(blocks, 256);                 // blocks on the fullest CU, run three at a time
+            const int r = (int)(n % 3);
+            const double units = (double)(n - r) + (r == 1 ? 1.0 / 0.55 : r == 2 ? 2.0 / 0.9 : 0.0);
+            return units * rows * kshare / eff;
+        };
+        const double kk = (double)std::max(nkt, 1);
+        double best = cost(cdiv(M, 128) * ntn, 128.0, kk, 1.0);
+        bm = 128;
+        const double c64 = cost(cdiv(M, 64) * ntn, 64.0, kk, 0.8);
+        if (c64 < best * 0.97) {
+            best = c64;
+            bm = 64;
+        }
+        if (bn == 128 && nkt >= 16) {
+            static const int ks_max_h = [] { const char* e = getenv("XV2_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
+            for (int ks = 2; ks <= ks_max_h && nkt / ks >= 8; ++ks) {
+                const double c = cost(cdiv(M, 128) * ntn * ks, 128.0, (double)cdiv(nkt, ks) + 4.0, 1.0);
+                if (c < best * 0.95) {
+                    best = c;
+                    bm = 128;
+                    ksplit = ks;
+                }
+            }
+        }
+        return;
+    }
     auto rounds = [&](int64_t blocks, int cap) { return (double)cdiv(blocks, cap); };
     const int cap128 = 512, cap64 = (bn == 64) ? 1024 : 512;
     const double k = (double)std::max(nkt, 1);
