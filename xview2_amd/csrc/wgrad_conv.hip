@@ -1110,6 +1110,11 @@ static bool use_tr_wgrad() {      // XV2_WGRAD_TR=0: fall back to the fp32-LDS g
     return v != 0;
 }
 
+static int wgrad_cap_override() {      // XV2_WGRAD_CAP: resident-block count the split planner fills (A/B runs)
+    static const int v = [] { const char* e = getenv("XV2_WGRAD_CAP"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 static int alltaps_max_tiles() {
     static int v = -1;
     if (v < 0) {
@@ -1136,7 +1141,7 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
         const int strips = d->N * (d->OW / 32);
         // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80),
         // 3 per CU for the split-bf16 one (134 VGPRs, 38 KB of LDS)
-        const int cap = x3 ? 768 : d->math ? 1024 : 512;
+        const int cap = wgrad_cap_override() ? wgrad_cap_override() : x3 ? 768 : d->math ? 1024 : 512;
         // row chunks per strip: the smallest count whose grid fills whole rounds of resident blocks (>= 90 %)
         const int maxchunks = std::max(1, d->OH / 8);
         int chunks = 1;
@@ -1180,7 +1185,8 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
     // split the pixel reduction so that the grid fills the chip in whole "rounds": capacity = resident blocks
     // (LDS-limited: 2 per CU for the 128x128 tile, 4 otherwise); among the split factors that keep >= 8 K-tiles
     // per block take the smallest one whose last round is >= 90 % full (fewer slabs = less reduce traffic).
-    const int cap = 256 * ((bm == 128) ? 2 : 4);
+    // (the split-bf16 64 x 64 kernel measured best when planned for 2 per CU as well: 1x1 @256^2 layers 0.063 -> 0.054 ms)
+    const int cap = wgrad_cap_override() ? wgrad_cap_override() : 256 * ((bm == 128 || x3) ? 2 : 4);
     const int maxsplit = std::max(1, pl.ktiles / 8);
     int best = 1;
     double best_eff = 0.0;
