@@ -1185,8 +1185,10 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
     // split the pixel reduction so that the grid fills the chip in whole "rounds": capacity = resident blocks
     // (LDS-limited: 2 per CU for the 128x128 tile, 4 otherwise); among the split factors that keep >= 8 K-tiles
     // per block take the smallest one whose last round is >= 90 % full (fewer slabs = less reduce traffic).
-    // (the split-bf16 64 x 64 kernel measured best when planned for 2 per CU as well: 1x1 @256^2 layers 0.063 -> 0.054 ms)
-    const int cap = wgrad_cap_override() ? wgrad_cap_override() : 256 * ((bm == 128 || x3) ? 2 : 4);
+    // (the split-bf16 and bf16-storage 64 x 64 kernels measured best when planned for 2 per CU as well: 1x1 @256^2
+    // layers 0.063 -> 0.054 ms and 0.039 -> 0.031 ms)
+    const int cap = wgrad_cap_override() ? wgrad_cap_override()
+                                         : 256 * ((bm == 128 || x3 || d->math == XV2_MATH_BF16_STORE) ? 2 : 4);
     const int maxsplit = std::max(1, pl.ktiles / 8);
     int best = 1;
     double best_eff = 0.0;
