@@ -3,7 +3,7 @@ model's own choice.  usage: [XV2_MATH=0|2] python scripts/sweep_tiles.py [filter
 (default: the split-bf16 form of fp32 tensors; XV2_MATH=0: exact-fp32 MFMA; XV2_MATH=2: bf16 storage)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from xview2_amd import ops
+from xview2_amd import _capi, ops
 from scripts.bench_conv import SHAPES, prof_time
 
 CANDS = [(128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 2), (128, 128, 3), (128, 128, 4), (128, 128, 6)]
@@ -28,15 +28,18 @@ def main():
         for what, fn in (("fwd", lambda: ops._conv_forward(x0, x1, w, g, None, True)),
                          ("dgrad", lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))):
             os.environ.pop("XV2_FORCE_TILE", None)
+            _capi.query_cache_clear()
             base = prof_time(fn, 10)
             res = []
             for c in CANDS:
                 os.environ["XV2_FORCE_TILE"] = "%d,%d,%d" % c
+                _capi.query_cache_clear()
                 try:
                     res.append((prof_time(fn, 10), c))
                 except RuntimeError:
                     pass
             os.environ.pop("XV2_FORCE_TILE", None)
+            _capi.query_cache_clear()
             base = min(base, prof_time(fn, 10))       # again at the end: clocks have settled by now
             res.sort()
             print("%-28s %-5s model %.3f ms | best %.3f %s  (%+.1f%%) | %s" % (

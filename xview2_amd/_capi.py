@@ -131,12 +131,17 @@ def call(name, *args):
 _query_cache = {}
 
 
+def query_cache_clear():
+    """Tuning tools that change a planner knob the library re-reads at every call (XV2_FORCE_TILE) must drop the memoised
+    workspace sizes / tile counts: a stale workspace size under a different plan is a memory fault."""
+    _query_cache.clear()
+
+
 def query(name, *args):
     """Value-returning helper (workspace sizes, tile counts): no stream argument.  Pure functions of a convolution
     descriptor are memoised (the same ~100 geometries recur every step)."""
     if len(args) >= 1 and isinstance(args[0], ConvDesc) and all(isinstance(a, int) for a in args[1:]):
-        # XV2_FORCE_TILE (tuning sweeps) is re-read by the library at every plan: it is part of the key
-        key = (name, args[0].key(), os.environ.get("XV2_FORCE_TILE")) + tuple(args[1:])
+        key = (name, args[0].key()) + tuple(args[1:])
         v = _query_cache.get(key)
         if v is None:
             v = _func(name)(*[_conv(a) for a in args])
