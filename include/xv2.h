@@ -226,6 +226,28 @@ int xv2_bn_act_backward_apply_mask(const void* dz, int lddz, const uint8_t* zmas
                                    const double* sums2, double count, int act, int train, void* dy,
                                    int lddy, void* dres, int lddres, int64_t npix, int C, int dtype, void* stream);
 
+/* ---- layer-level entry points ---------------------------------------------------------------
+ * One call = the launch sequence of one reference layer (model/layers.py:89-100 ConvLayer: conv -> norm -> activation;
+ * the bottleneck convolutions of the encoders), issued in the same order on the same stream as the op-level calls
+ * they replace - results are bit-identical.  They exist because a --precision 16 step is bound by the host's call
+ * rate: every ABI call costs the binding ~9 us of marshalling on top of its launches.
+ * xv2_conv_bn_act_forward = xv2_conv2d_forward (with statistics partials; `tiles` = xv2_conv2d_forward_stats_tiles)
+ *   + xv2_bn_reduce_finalize + xv2_bn_act_forward[_mask] (zmask != NULL selects the mask form).  Single-process
+ *   training-mode BatchNorm only (SyncBatchNorm keeps the op-level calls around its all-reduce).
+ * xv2_bn_act_backward = xv2_bn_act_backward_reduce[_mask] + xv2_bn_act_backward_apply[_mask] (training mode). */
+int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                            const void* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
+                            float* workspace, double* sums, double* scratch, double count,
+                            const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, float* mean, float* invstd,
+                            float* scale, float* shift, const void* residual, int ldr, int act, void* z,
+                            int ldz, uint8_t* zmask, int dtype, void* stream);
+int xv2_bn_act_backward(const void* dz, int lddz, const void* z, int ldz, const uint8_t* zmask, const void* y,
+                        int ldy, const float* mean, const float* invstd, const float* gamma,
+                        const float* scale, const float* shift, int act, double count, void* dy, int lddy,
+                        void* dres, int lddres, int64_t npix, int C, double* sums2, float* dgamma,
+                        float* dbeta, float* workspace, int dtype, void* stream);
+
 /* ---- pooling / resampling ----------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order) */
 int xv2_maxpool3x3s2_forward(const void* x, int N, int H, int W, int C, void* y, uint8_t* idx,

@@ -320,6 +320,48 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     return y, sums
 
 
+LAYER_CALLS = os.environ.get("XV2_LAYER_CALLS", "1") != "0"      # layer-level ABI calls (include/xv2.h); 0: op by op
+
+
+def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask):
+    """Training-mode conv + BatchNorm + (residual) + activation of one ungrouped layer as ONE ABI call
+    (xv2_conv_bn_act_forward = the three launches of _conv_forward + _bn_forward, same order, same stream).
+    Returns y, z, zmask, (mean, invstd, count, scale, shift), or None when the shape has to go op by op."""
+    N, IH, IW, C0t = x0.shape
+    C1t = x1.shape[3] if x1 is not None else 0
+    Cout = weight.shape[0]
+    OH, OW = _out_hw(IH, IW, g)
+    rgb = C0t == 4 and x1 is None
+    half = (STORAGE == torch.bfloat16) if rgb else x0.dtype == torch.bfloat16
+    if x1 is not None and x1.dtype != x0.dtype:
+        raise RuntimeError("convolution sources of different element types (%s, %s)" % (x0.dtype, x1.dtype))
+    ohwi, ihwo = _pack(weight.contiguous(), C0t + C1t, True, ihwo_out is not None, half)
+    d = _desc(N, IH, IW, C0t, C1t, Cout, g, OH, OW, half)
+    tiles = query("xv2_conv2d_forward_stats_tiles", d)
+    if tiles <= 0:
+        return None
+    if ihwo_out is not None:
+        ihwo_out.append(ihwo)
+    dev = x0.device
+    y = _act((N, OH, OW, Cout), x0, torch.bfloat16 if half else torch.float32)
+    z = torch.empty_like(y)
+    sums = torch.empty((Cout, 2), dtype=torch.float64, device=dev)
+    blob = _f32((4, Cout), x0)                                   # mean, invstd, scale, shift
+    part = _f32((tiles, Cout, 2), x0)
+    wsb = query("xv2_conv2d_forward_workspace", d)
+    npix = N * OH * OW
+    zmask = None
+    if want_mask and _mask_ok(Cout, act, half):
+        zmask = torch.empty((npix * (Cout // 4),), dtype=torch.uint8, device=dev)
+    residual = _same(residual, y)
+    bn_stats_changed()
+    call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles, _ws(wsb, x0) if wsb else None,
+         sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
+         bn.running_mean, bn.running_var, blob[0], blob[1], blob[2], blob[3], residual, Cout, act, z, Cout, zmask,
+         _dt(y))
+    return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
+
+
 def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
     the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
@@ -619,6 +661,13 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
         if z is None and S == 1 and rec.token == (dz.data_ptr(), dz._version):
             pre = (rec.part, rec.tiles)
         rec.part, rec.token = None, None
+    if LAYER_CALLS and training and S == 1 and pre is None and not _sync_group(bn):
+        # column sums + apply as one ABI call (xv2_bn_act_backward: the same two launches)
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if want_res else None
+        call("xv2_bn_act_backward", dz, C, None if (z is None or masked) else z, C, z if masked else None, y, C, mean,
+             invstd, gamma, scale, shift, act, float(count), dy, C, dres, C, rows, C, sums2, dgamma, dbeta, ws, dt)
+        return dy, dres, dgamma, dbeta
     tmp = (_f32((C,), y), _f32((C,), y)) if S > 1 else None
     for h in range(S):
         o, oc = h * rows * C, h * C
@@ -703,9 +752,17 @@ class ConvBnActFn(torch.autograd.Function):
         need_dx = x0.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.ihwo = [] if need_dx else None
         ctx.split = BN_SPLIT if (training and x0.shape[0] % BN_SPLIT == 0) else 1
-        y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
         ctx.has_res = residual is not None
-        if ctx.has_res:
+        fast = None
+        if LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
+            fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res)
+        if fast is not None:
+            y, z, zmask, stats = fast
+        else:
+            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
+        if fast is not None:
+            pass
+        elif ctx.has_res:
             z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split)
         else:
             z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split)
