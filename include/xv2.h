@@ -138,6 +138,13 @@ size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
                                const void* x1, int ldx1, const void* dy, int lddy,
                                float* dw_oihw, int cin_real, float* workspace, void* stream);
+/* xv2_conv2d_backward_weight launched on `side_stream`, ordered behind the work enqueued so far on `stream` (event
+ * record / wait inside the call).  The weight gradient is consumed only by the optimizer / gradient all-reduce, so it
+ * can overlap the rest of the backward pass; the caller joins `side_stream` before reading dw_oihw and keeps the
+ * operands and the workspace alive until then. */
+int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                                     const void* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
+                                     void* side_stream, void* stream);
 
 /* nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83).  `d` describes the
  * EQUIVALENT convolution (input = the large 2H x 2W tensor with C0 = conv-transpose output

@@ -461,13 +461,41 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
         except RuntimeError:      # not inside a backward pass (direct call): stay synchronous
             return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
     side = _side_stream()
-    side.wait_stream(torch.cuda.current_stream())          # dy (and x) are ready on the compute stream
-    with torch.cuda.stream(side):
-        dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
+    if LAYER_CALLS and g.groups == 1:
+        # one ABI call: event record on the compute stream, wait + launch on the side stream (the Python event /
+        # stream-switch sequence below costs ~20 us of host time per layer).  The side stream runs its launches in
+        # order, so they share one grow-only workspace that lives on that stream.
+        N, IH, IW, C0t = x0.shape
+        C1t = x1.shape[3] if x1 is not None else 0
+        _, OH, OW, Cout_t = dy.shape
+        d = _desc(N, IH, IW, C0t, C1t, Cout_t, g, OH, OW, dy.dtype == torch.bfloat16)
+        ws = _side_workspace(query("xv2_conv2d_backward_weight_workspace", d), side, dy.device)
+        call("xv2_conv2d_backward_weight_async", d, x0, C0t, x1, C1t, dy, Cout_t, out, weight.shape[1], ws,
+             side.cuda_stream)
+        dw = out
+    else:
+        side.wait_stream(torch.cuda.current_stream())          # dy (and x) are ready on the compute stream
+        with torch.cuda.stream(side):
+            dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
     for t in (x0, x1, dy):                                 # keep the caching allocator from recycling them early
         if t is not None:
             t.record_stream(side)
     return dw
+
+
+_side_ws = {}
+
+
+def _side_workspace(nbytes, side, device):
+    """grow-only weight-gradient workspace owned by the side stream (allocated under it, so the caching allocator only
+    ever recycles it behind that stream's work)"""
+    n = (int(nbytes) + 3) // 4 + 4
+    t = _side_ws.get(device.index)
+    if t is None or t.numel() < n:
+        with torch.cuda.stream(side):
+            t = torch.empty((max(n, 2 * (t.numel() if t is not None else 0)),), dtype=torch.float32, device=device)
+        _side_ws[device.index] = t
+    return t
 
 
 def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
