@@ -184,6 +184,47 @@ def test_train_step_parity(name, batch):
             assert int(sh[k]) == int(so[k]), k
 
 
+@pytest.mark.parametrize("name,precision", [("pre_resnet50", 32), ("pre_resnest50", 16), ("post_siamese_coral", 32)])
+def test_layer_level_abi_calls_are_bit_identical_to_the_op_level_sequences(name, precision):
+    """include/xv2.h layer-level entry points (xv2_conv_bn_act_forward, xv2_bn_act_backward,
+    xv2_conv2d_backward_weight_async) issue the launches of the op-level calls they replace, in the same order: one
+    training step with them (default) and without (XV2_LAYER_CALLS=0) must agree bit for bit - logits, loss, every
+    gradient, the BatchNorm running statistics."""
+    from xview2_amd import criterion, ops
+    a = ARGS(**MODEL_CASES[name])
+    _, hip = build_pair(a)
+    x, y = model_input(a, batch=2).to(DEV), labels(a, batch=2).to(DEV)
+    sd = copy.deepcopy(hip.state_dict())
+    lh_fn = criterion.Loss(a)
+    res = {}
+    old_mode, old_layer = ops.MATH_MODE, ops.LAYER_CALLS
+    try:
+        if precision == 16:
+            ops.MATH_MODE = ops.MATH_BF16
+            ops.set_storage_dtype(torch.bfloat16)
+        for layer_calls in (True, False):
+            ops.LAYER_CALLS = layer_calls
+            hip.load_state_dict(sd)
+            hip.train()
+            hip.zero_grad()
+            ph = hip(x)
+            loss = criterion.compute_loss(lh_fn, ph, y, a.deep_supervision)
+            loss.backward()
+            torch.cuda.synchronize()
+            ph0 = ph[0] if isinstance(ph, list) else ph
+            res[layer_calls] = (ph0.detach().float().clone(), loss.detach().clone(),
+                                [p.grad.detach().clone() for p in hip.parameters() if p.grad is not None],
+                                [b.detach().clone() for b in hip.buffers()])
+    finally:
+        ops.LAYER_CALLS = old_layer
+        ops.MATH_MODE = old_mode
+        ops.set_storage_dtype(None)
+    on, off = res[True], res[False]
+    assert torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
+    assert len(on[2]) == len(off[2]) and all(torch.equal(u, v) for u, v in zip(on[2], off[2]))
+    assert all(torch.equal(u, v) for u, v in zip(on[3], off[3]))
+
+
 @pytest.mark.parametrize("name,batch", [("pre_resnet50", 2), ("pre_resnest50", 8), ("post_fusedEnc_resnet50", 2)])
 def test_exact_fp32_mfma_mode_and_split_bf16_mode_agree(name, batch):
     """--precision 32 has two arithmetic modes (include/xv2.h): XV2_MATH_F32X3 (default: exact 3-way bf16 operand
