@@ -321,6 +321,19 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
 
 
 LAYER_CALLS = os.environ.get("XV2_LAYER_CALLS", "1") != "0"      # layer-level ABI calls (include/xv2.h); 0: op by op
+_persist_bufs = {}
+
+
+def _persist(tag, nfloats, device):
+    """grow-only fp32 scratch on the COMPUTE stream for data that is produced and consumed inside one layer-level call
+    (statistics partials, split-K slabs, BatchNorm-backward partials): the stream runs those calls in order, so one
+    buffer per purpose replaces an allocation per layer"""
+    key = (tag, device.index)
+    t = _persist_bufs.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty((max(int(nfloats), 2 * (t.numel() if t is not None else 0)),), dtype=torch.float32, device=device)
+        _persist_bufs[key] = t
+    return t
 
 
 def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask):
@@ -347,7 +360,7 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     z = torch.empty_like(y)
     sums = torch.empty((Cout, 2), dtype=torch.float64, device=dev)
     blob = _f32((4, Cout), x0)                                   # mean, invstd, scale, shift
-    part = _f32((tiles, Cout, 2), x0)
+    part = _persist("stats", tiles * Cout * 2, dev)
     wsb = query("xv2_conv2d_forward_workspace", d)
     npix = N * OH * OW
     zmask = None
@@ -355,7 +368,8 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         zmask = torch.empty((npix * (Cout // 4),), dtype=torch.uint8, device=dev)
     residual = _same(residual, y)
     bn_stats_changed()
-    call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles, _ws(wsb, x0) if wsb else None,
+    call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles,
+         _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
          sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
          bn.running_mean, bn.running_var, blob[0], blob[1], blob[2], blob[3], residual, Cout, act, z, Cout, zmask,
          _dt(y))
@@ -681,7 +695,8 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
     dt = _dt(y)
     sums2 = torch.empty((S, C, 2) if S > 1 else (C, 2), dtype=torch.float64, device=y.device)
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
-    ws = _ws(query("xv2_bn_backward_workspace", rows, C), y)
+    wsn = query("xv2_bn_backward_workspace", rows, C)
+    ws = _persist("bnbwd", (wsn + 3) // 4 + 4, y.device) if (LAYER_CALLS and S == 1) else _ws(wsn, y)
     masked = z is not None and z.dtype == torch.uint8
     pre = None
     if rec is not None and rec.part is not None:
