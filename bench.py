@@ -37,17 +37,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 (--precision 16 runs only)
 F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
 F_ENC_GFLOP_PER_IMG = {"resnet50": 170.8, "resnest50": 224.3}   # encoder forward only
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
+HBM_ACHIEVABLE_GBS = 6290.0            # ... 6.29 TB/s measured (float4 copy)
+GRAD_REL_CPU32_VS_F64 = 1.852e-2       # profiles/r02_full_size_grad_parity.json: CPU fp32 oracle vs its fp64 run, cfg2 full size
 
 
-def synthetic_batch(args_ns, batch, size, seed, device):
-    """uint8 RGB uniform[0,255] -> A.Normalize() (data_loading/pytorch_loader.py:63), masks with
-    guaranteed building pixels (seeded rectangles covering ~5-10 %)."""
+def synthetic_tiles(args_ns, batch, size, seed):
+    """uint8 tiles uniform[0,255] in the loader's HWC layout (3 channels, or the 6-channel pre|post
+    pair; data_loading/pytorch_loader.py:38,113) and masks with guaranteed building pixels (seeded rectangles)."""
     g = torch.Generator().manual_seed(seed)
     c = 3 if args_ns.type == "pre" else 6
-    img = torch.randint(0, 256, (batch, c, size, size), generator=g, dtype=torch.uint8).float() / 255.0
-    mean = torch.tensor([0.485, 0.456, 0.406] * (c // 3)).view(1, c, 1, 1)
-    std = torch.tensor([0.229, 0.224, 0.225] * (c // 3)).view(1, c, 1, 1)
-    img = (img - mean) / std
+    img = torch.randint(0, 256, (batch, size, size, c), generator=g, dtype=torch.uint8)
     mask = torch.zeros(batch, size, size, dtype=torch.uint8)
     hi = 2 if args_ns.type == "pre" else 5
     for b in range(batch):
@@ -56,7 +56,20 @@ def synthetic_batch(args_ns, batch, size, seed, device):
             y0 = int(torch.randint(0, size - h, (1,), generator=g))
             x0 = int(torch.randint(0, size - w, (1,), generator=g))
             mask[b, y0:y0 + h, x0:x0 + w] = int(torch.randint(1, hi, (1,), generator=g))
-    return img.to(device), mask.to(device)
+    return img, mask
+
+
+def synthetic_batch(args_ns, batch, size, seed, device):
+    """-> (image, mask) on `device`.  On the GPU the image stays the uint8 HWC tile batch (ops.DeviceImage: resident in
+    HBM before the timed region; the network's first launch applies A.Normalize() and lays it out as NHWC -
+    xv2_normalize_u8_to_nhwc); the CPU oracle gets the reference loader's product, the host-normalised
+    fp32 NCHW tensor (pytorch_loader.py:63,90-91) - the same values bit for bit."""
+    from xview2_amd.data import normalize_host
+    img, mask = synthetic_tiles(args_ns, batch, size, seed)
+    if str(device).startswith("cuda") and os.environ.get("XV2_HOST_NORMALIZE", "0") != "1":
+        from xview2_amd.ops import DeviceImage
+        return DeviceImage(img.to(device)), mask.to(device)
+    return normalize_host(img).to(device), mask.to(device)
 
 
 def make_args(encoder="resnet50", ttype="pre", loss_str="dice", dmg_model="siamese", **kw):
@@ -111,7 +124,7 @@ def cpu_baseline(a, size, batch, seed, timed_steps=3):
             "seconds": dt, "seconds_all": [round(t, 3) for t in times], "loss": ref["loss"]}, ref
 
 
-def parity_block(ref, hip, precision):
+def parity_block(ref, hip, precision, size=1024):
     """full-size first-step comparison of the HIP path with the CPU oracle (same batch, same key-seeded weights)"""
     lo, lh = ref["loss"], hip["loss"]
     zo, zh = ref["logits"].double(), hip["logits"].double().cpu()
@@ -135,6 +148,7 @@ def parity_block(ref, hip, precision):
             rels.append((d / n, k))
     rels.sort()
     gate = 1e-3 if precision == 32 else None
+    agree = float((ao == ah).float().mean())
     out = {"hip_first_loss": lh, "oracle_loss": lo, "rel": abs(lh - lo) / max(abs(lo), 1e-12),
            "logits_rel": logits_rel, "argmax_mismatch_px": int(diff.sum()),
            "argmax_mismatch_px_outside_ties": int((diff & (gap > 1e-3)).sum()), "pixels": int(diff.numel()),
@@ -145,8 +159,21 @@ def parity_block(ref, hip, precision):
            "what": "first training step at the bench shape, HIP path vs CPU oracle: loss rel, logits max-abs error / "
                    "max-abs reference, argmax label maps (ties = top-2 gap <= 1e-3 of the logit range), per-tensor "
                    "||g_hip - g_cpu|| / ||g_cpu|| of every parameter gradient"}
+    out["argmax_agreement"] = agree
     if gate is not None:
-        out["pass"] = bool(out["rel"] <= gate and logits_rel <= gate and out["argmax_mismatch_px_outside_ties"] == 0)
+        # gradients: both fp32 paths sit ~1.9e-2 from the fp64 gradient at this size and 1.5e-2 from each other
+        # (profiles/r02_full_size_grad_parity.json: cpu32-vs-f64 global 1.852e-2); more than twice that is a regression
+        # (the figure was measured at 1024 x 1024; smaller tiles are worse conditioned - 5e-2 at 64 x 64 - and not gated)
+        out["grad_gate"] = 2.0 * GRAD_REL_CPU32_VS_F64 if size >= 1024 else None
+        out["pass"] = bool(out["rel"] <= gate and logits_rel <= gate and out["argmax_mismatch_px_outside_ties"] == 0 and
+                           (not rels or out["grad_gate"] is None or out["grad_rel_global"] <= out["grad_gate"]))
+    else:
+        # --precision 16 (bf16 storage): reported separately from the fp32 gate - loss within 1e-2 of the
+        # fp32 oracle, label-map agreement stated and floored, finite gradients
+        out["gate"] = {"loss_rel": 1e-2, "argmax_agreement_min": 0.90}
+        finite = all(bool(torch.isfinite(g).all()) for g in hip["grads"].values())
+        out["grads_finite"] = finite
+        out["pass"] = bool(out["rel"] <= 1e-2 and agree >= 0.90 and finite)
     return out
 
 
@@ -253,6 +280,103 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
                            for r in rows]}
 
 
+def config_leg(name, a, precision, size, batch, dev, steps=10, warmup=3, parity=True):
+    """A short driver-visible leg for another BASELINE configuration on the same GPU (default line: cfg3 = --encoder
+    resnest50 --precision 16, 2 x 1024 x 1024): `warmup` untimed steps, `steps` timed steps between synchronisations
+    (no event brackets: --no-prof style), then two bracketed steps that only COUNT the convolutions' algorithmic FLOPs
+    and bytes (each conv reads its input once, writes its output once, weights once; fwd + backward-data +
+    weight gradient), and - parity - the first step against ONE step of the CPU oracle on the same tiles and weights."""
+    from xview2_amd import _capi, criterion, networks, ops
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    old_mode = ops.MATH_MODE
+    set_precision(precision)
+    try:
+        torch.manual_seed(0)
+        model = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
+        deterministic_init_(model, 1)
+        model.to(dev).train()
+        loss_fn = criterion.Loss(a)
+        optim = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.0)
+        x, y = synthetic_batch(a, batch, size, 1, dev)
+        last = {}
+
+        def step():
+            optim.zero_grad()
+            pred = model(x)
+            loss = criterion.compute_loss(loss_fn, pred, y, a.deep_supervision)
+            loss.backward()
+            optim.step()
+            last["pred"] = pred
+            return loss
+        first = None
+        for i in range(max(1, warmup)):
+            l0 = step()
+            if i == 0 and parity:
+                pred = last["pred"]
+                p0 = (pred[0] if isinstance(pred, list) else pred).detach().float()
+                names = {id(p): k for k, p in model.named_parameters()}
+                first = {"loss": float(l0.detach()), "logits": p0.clone(), "labels": ops.argmax_labels(p0),
+                         "grads": {names[id(p)]: optim.flat_g[o:o + p.numel()].view(p.shape).clone()
+                                   for p, o in zip(optim.params, optim.offsets) if id(p) in names}}
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        _capi.query("xv2_prof_enable", 1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        rows = collect_prof(_capi)
+        _capi.query("xv2_prof_enable", 0)
+        final_loss = float(loss.detach())
+        del model, optim
+        torch.cuda.empty_cache()
+    finally:
+        ops.MATH_MODE = old_mode
+        ops.set_storage_dtype(None)
+    ms = dt / steps * 1e3
+    gflop = sum(r["gflop"] for r in rows) / 2
+    gbytes = sum(r["mbytes"] for r in rows) / 2e3
+    x3 = precision == 32 and ops.fp32_math() == ops.MATH_F32X3
+    peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
+    out = {"config": name, "value": round(batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(ms, 3),
+           "steps": steps, "warmup": max(1, warmup), "dtype": "f32" if precision == 32 else "bf16", "loss": final_loss,
+           "launch": "eager, no per-launch event brackets in the timed steps",
+           "roofline": {
+               "mfma": {"achieved": round(gflop / ms, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gflop / ms / peak, 4),
+                        "gflop_per_step": round(gflop, 1)},
+               "hbm": {"achieved": round(gbytes / ms * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(gbytes / ms * 1e3 / HBM_PEAK_GBS, 4),
+                       "frac_of_achievable_6290": round(gbytes / ms * 1e3 / HBM_ACHIEVABLE_GBS, 4),
+                       "algorithmic_gbytes_per_step": round(gbytes, 3)},
+               "note": "whole-step figures: the convolutions' algorithmic FLOPs (2*M*N*K of forward, backward-data, weight "
+                       "gradient) and algorithmic bytes (each conv pass reads its operands once and writes its result "
+                       "once, in the storage type) summed over the step's MFMA launches, divided by the WHOLE step time "
+                       "(BatchNorm, split attention, loss and AdamW kernels included in the time, not in the numerators)"}}
+    if parity and first is not None:
+        from oracle import torch_ref
+        torch.manual_seed(0)
+        m = torch_ref.build_model(a)
+        deterministic_init_(m, 1)
+        m.train()
+        xc, yc = synthetic_batch(a, batch, size, 1, "cpu")
+        t0 = time.time()
+        pred = m(xc)
+        lo = torch_ref.compute_loss(torch_ref.Loss(a), pred, yc, a.deep_supervision)
+        lo.backward()
+        p0 = pred[0] if isinstance(pred, list) else pred
+        ref = {"loss": float(lo), "logits": p0.detach(),
+               "grads": {k: p.grad.detach() for k, p in m.named_parameters() if p.grad is not None}}
+        out["parity"] = parity_block(ref, first, precision, size)
+        out["parity"]["oracle_step_seconds"] = round(time.time() - t0, 1)
+        if out["parity"].get("pass") is False:
+            sys.stderr.write("PARITY GATE FAILED (%s): %s\n" % (name, json.dumps(out["parity"])))
+    return out
+
+
 def set_precision(precision):
     from xview2_amd import ops
     ops.MATH_MODE = ops.MATH_BF16 if precision == 16 else ops.fp32_math()
@@ -282,6 +406,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoder-probe", action="store_true",
                     help="skip the resnest50 encoder-forward utilisation block of the default line")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short cfg3 leg (resnest50, precision 16) of the default line")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
     ap.add_argument("--graph", action="store_true",
@@ -538,13 +664,22 @@ def main():
     if rank == 0 and world == 1 and not opt.no_encoder_probe:
         # north_star target figure (configs[2] model): MFMA utilisation of the resnest50 encoder forward, both math modes
         del model, optim, reducer
+        model = optim = reducer = None
         torch.cuda.empty_cache()
         out["encoder_forward"] = [encoder_forward_probe("resnest50", pr, opt.size, opt.batch, dev) for pr in (32, 16)]
+    if rank == 0 and world == 1 and not opt.no_other_configs:
+        # BASELINE configs[2] (cfg3: --type pre --encoder resnest50, 1024 x 1024 bs 2, precision 16 = bf16 storage) on this
+        # same GPU: a driver-timed number with its own MFMA and HBM rooflines (SURVEY 8d calls this configuration HBM-bound)
+        model = optim = reducer = None
+        torch.cuda.empty_cache()
+        out["other_configs"] = [config_leg("cfg3: --type pre --encoder resnest50 --loss_str dice --precision 16, %dx%d, batch %d"
+                                           % (opt.size, opt.size, opt.batch), make_args("resnest50", "pre", "dice"), 16,
+                                           opt.size, opt.batch, dev, parity=not opt.no_cpu_baseline)]
     if rank == 0 and not opt.no_cpu_baseline and world == 1:
         cb, ref = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
         out["cpu_baseline"] = cb
         if hip_first is not None and (opt.cpu_size or opt.size) == opt.size:
-            out["parity"] = parity_block(ref, hip_first, opt.precision)
+            out["parity"] = parity_block(ref, hip_first, opt.precision, opt.size)
             if out["parity"].get("pass") is False:
                 sys.stderr.write("PARITY GATE FAILED: %s\n" % json.dumps(out["parity"]))
     if rank == 0:

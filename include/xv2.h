@@ -87,6 +87,10 @@ int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, voi
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]
  * (tile count = xv2_conv2d_forward_stats_tiles(d)), consumed by xv2_bn_reduce_stats. */
 int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
+/* rows (output pixels) per statistics tile of that plan: 64 or 128.  A caller that reduces tile RANGES separately
+ * (several BatchNorm batches back to back in one launch: the Siamese pre/post passes) needs every range to end on a
+ * tile boundary */
+int64_t xv2_conv2d_forward_stats_tile_rows(const xv2_conv_desc* d);
 /* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
  * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
 size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
@@ -338,6 +342,15 @@ int xv2_axpby(float alpha, const float* a, float beta, const float* b, float* ou
 int xv2_nchw_to_nhwc(const float* x, int64_t x_batch_stride, int N, int C, int H, int W,
                      float* y, int Cp, void* stream);
 int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, int W, float* y, void* stream);
+/* Input hand-over on the device: uint8 HWC tiles [N][H][W][csrc] exactly as cv2.imread /
+ * np.concatenate produce them (data_loading/pytorch_loader.py:38,113; csrc = 3, or 6 for the pre|post pair) ->
+ * A.Normalize() (pytorch_loader.py:63,90,145: (v - mean*255) * (1 / (std*255)), fp32, statistics applied in STORED
+ * channel order) -> fp32 NHWC [N][H][W][4] (channel 3 = 0) of channels c0 .. c0+2, with an optional horizontal /
+ * vertical flip (pytorch_loader.py:59-60; model/plt.py:42-48 TTA).  Replaces the host-side normalise + the
+ * HWC->CHW transpose (pytorch_loader.py:91,147,170) + xv2_nchw_to_nhwc: the kernels are NHWC. */
+int xv2_normalize_u8_to_nhwc(const uint8_t* img_hwc, int csrc, int c0, int N, int H, int W, int hflip,
+                             int vflip, const float* mean3, const float* std3, float* out_nhwc4,
+                             void* stream);
 /* strided channel copy: dst[p][doff + c] = src[p][soff + c] (materialised concat) */
 int xv2_copy_channels(const void* src, int lds, void* dst, int ldd, int64_t npix, int C,
                       int dtype, void* stream);

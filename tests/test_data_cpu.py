@@ -50,8 +50,33 @@ def test_load_pair_is_bgr_like_cv2_and_eval_sample_is_normalised_exactly(tree):
     want = np.concatenate([(x[:, :, ::-1] / 255.0 - mean) / std for x in (rgb_pre, rgb_post)], 2).transpose(2, 0, 1)
     assert s["image"].dtype == np.float32 and s["image"].shape == (6, S, S)
     np.testing.assert_allclose(s["image"], want, rtol=0, atol=1e-6)
+    # raw hand-over form of the same sample (device-side normalisation): the uint8 HWC tile in B,G,R order
+    raw = pl.TestDataset(os.path.join(root, "holdout"), "post", raw_u8=True)[2]
+    assert raw["image"].dtype == np.uint8 and raw["image"].shape == (S, S, 6)
+    assert np.array_equal(raw["image"][:, :, :3], rgb_pre[:, :, ::-1].astype(np.uint8))
+    assert np.array_equal(pl._finish(raw["image"], raw["mask"], False)["image"], s["image"])
     assert s["mask"].dtype == np.uint8 and set(np.unique(s["mask"]).tolist()) == {0, 3}   # the POST label (loader :166)
     assert pl.TestDataset(os.path.join(root, "holdout"), "pre")[2]["image"].shape == (3, S, S)
+
+
+def test_normalize_is_albumentations_arithmetic_known_answers():
+    """A.Normalize() (pytorch_loader.py:63) = albumentations functional.normalize: fp32 mean*255, fp32 reciprocal of
+    std*255, one subtraction, one multiplication.  Hand-computed answers in exactly that arithmetic; the device kernel
+    (xv2_normalize_u8_to_nhwc) is held to the same bits in tests/test_ops_gpu.py."""
+    f = np.float32
+    img = np.array([[[0, 128, 255]]], np.uint8)
+    out = pl.normalize(img)
+    assert out.dtype == np.float32
+    for c, v in enumerate((0, 128, 255)):
+        m255 = f(pl.MEAN[c]) * f(255.0)
+        den = f(1.0) / (f(pl.STD[c]) * f(255.0))
+        assert out[0, 0, c] == (f(v) - m255) * den
+    # and it is the textbook (v/255 - mean)/std to fp32 rounding
+    np.testing.assert_allclose(out[0, 0], (np.array([0, 128, 255], f) / 255.0 - pl.MEAN) / pl.STD, rtol=0, atol=5e-7)
+    from xview2_amd import data as syn
+    t = syn.normalize_host(torch.from_numpy(np.arange(6 * 4, dtype=np.uint8).reshape(2, 2, 6)))
+    want = np.concatenate([pl.normalize(np.arange(24, dtype=np.uint8).reshape(2, 2, 6)[:, :, i:i + 3]) for i in (0, 3)], 2)
+    assert t.shape == (6, 2, 2) and np.array_equal(t.numpy(), want.transpose(2, 0, 1))
 
 
 def test_training_samples_follow_the_index_and_always_contain_buildings(tree):

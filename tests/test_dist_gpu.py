@@ -277,3 +277,8 @@ def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size():
     enc = {e["precision"]: e for e in line["encoder_forward"]}
     assert enc[32]["encoder"] == "resnest50" and 0 < enc[32]["mfma_util_whole_forward"] < 1
     assert abs(enc[32]["gflop_counted_by_launches"] / enc[32]["gflop_per_pass"] - 1) < 0.02
+    # cfg3 leg (resnest50, precision 16): its own throughput, MFMA + HBM rooflines and the bf16 parity gate
+    cfg3 = line["other_configs"][0]
+    assert cfg3["dtype"] == "bf16" and cfg3["value"] > 0 and "resnest50" in cfg3["config"]
+    assert 0 < cfg3["roofline"]["mfma"]["frac"] < 1 and 0 < cfg3["roofline"]["hbm"]["frac"] < 1
+    assert cfg3["parity"]["pass"] is True and cfg3["parity"]["rel"] <= 1e-2 and cfg3["parity"]["argmax_agreement"] >= 0.9

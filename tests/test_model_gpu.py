@@ -549,16 +549,19 @@ def test_fused_inference_path_is_bit_identical_to_the_unfused_eval_forward(name)
         xnn.FUSED_INFERENCE = True
 
 
-@pytest.mark.parametrize("name", ["post_siamese_resnest50_ds", "post_siamese_coral", "post_siameseEnc_resnet50"])
-def test_batched_siamese_passes_equal_two_sequential_passes(name):
+@pytest.mark.parametrize("name,B,size", [("post_siamese_resnest50_ds", 4, 64), ("post_siamese_coral", 4, 64),
+                                         ("post_siameseEnc_resnet50", 4, 64),
+                                         # 160 x 160, B = 2: the /32 level has M = 4 * 25 = 100 rows, 50 per pass - no
+                                         # statistics tile (64 / 128 rows) ends on the pass boundary
+                                         ("post_siameseEnc_resnet50", 2, 160), ("post_siamese_coral", 1, 160)])
+def test_batched_siamese_passes_equal_two_sequential_passes(name, B, size):
     """SiameseUNet runs its shared-weight U-Net on the pre and the post image (model/unet.py:232-233).  The default
     here sends both through as ONE batch of 2B with per-part BatchNorm statistics (ops.BN_SPLIT); it must reproduce
     the two sequential passes: logits, loss, every gradient, running statistics (updated pre then post) and
     num_batches_tracked (+2)."""
     from xview2_amd import criterion, networks
     a = ARGS(**MODEL_CASES[name])
-    B = 4
-    x, y = model_input(a, batch=B).to(DEV), labels(a, batch=B).to(DEV)
+    x, y = model_input(a, batch=B, size=size).to(DEV), labels(a, batch=B, size=size).to(DEV)
     res = {}
     for batched in (False, True):
         networks.BATCH_SIAMESE = batched
@@ -578,9 +581,119 @@ def test_batched_siamese_passes_equal_two_sequential_passes(name):
     assert set(ga) == set(gb)
     num = sum(float((gb[k].double() - ga[k].double()).pow(2).sum()) for k in ga)
     den = sum(float(ga[k].double().pow(2).sum()) for k in ga)
-    assert (num / den) ** 0.5 <= 5e-3, (num / den) ** 0.5
+    # power-of-two tiles: both runs take the statistics from the conv epilogue's tiles, most of the arithmetic is bit
+    # identical and the whole gradient agrees to 5e-3; at the odd sizes the batched run folds some layers' statistics
+    # from column sums instead (different rounding), and the ill-conditioned backward of these tiny problems turns 1e-7
+    # differences into 1e-2 (test_train_step_parity: ANY two fp32 paths differ by 2e-2 .. 5e-2 there).  What the
+    # tile-straddling bug would have corrupted - logits, loss, running statistics - is gated tightly above and below.
+    assert (num / den) ** 0.5 <= (5e-3 if size == 64 else 4e-2), (num / den) ** 0.5
     for k in sa:
         if k.endswith("num_batches_tracked"):
             assert int(sa[k]) == int(sb[k]) and int(sb[k]) in (1, 2), k       # shared modules ran twice
         elif k.endswith("running_mean") or k.endswith("running_var"):
             assert rel(sb[k], sa[k]) <= 1e-4, k
+
+
+# ---- block-by-block parity from the HIP path's own activations ------------------------------------------------------
+# Training-mode BatchNorm over the per-GPU batch of 2 makes whole-network comparisons vacuous for the ResNeSt models
+# (split attention's bn1 normalises TWO values per channel: gamma * sign(v0 - v1) + beta, slope 1/sqrt(eps) = 316 near
+# v0 = v1; test_train_step_parity measures the CPU fp32 oracle itself 2e-2 .. 1.0 away from its fp64 run there).  The
+# arithmetic can still be pinned exactly: the oracle is run with every residual block / fusion block / decoder block
+# TEACHER-FORCED - a forward hook compares the oracle block's output with the HIP block's output and then REPLACES it
+# by the HIP output, so each oracle block computes from the very input its HIP twin saw.  Every block must then agree to
+# 1e-3 (max-abs error / max-abs reference) and the chain ends in the north_star gate proper: logits within 1e-3, label
+# maps identical outside ties, loss within 1e-3 - at batch 2, for cfg3 / cfg4 / cfg5's own models.
+FORCED_CLASSES = ("StBottleneck", "Bottleneck", "TVBottleneck", "FusionBlock", "UpsampleBlock")
+BLOCK_CASES = [("pre_resnest50", 2, 32), ("pre_resnest50_dil2", 2, 32), ("pre_resnest101_attn", 2, 32),
+               ("post_siamese_resnest50_ds", 2, 32), ("post_siamese_resnest101", 2, 32),
+               ("post_fused_resnest50_attn_ds", 2, 32), ("post_fused_resnest200_attn_ds", 2, 32),
+               ("post_fused_resnest200_attn_ds", 4, 32), ("pre_resnet50", 2, 32),
+               ("pre_resnest50", 2, 16), ("post_fused_resnest200_attn_ds", 2, 16), ("post_fused_resnest200_attn_ds", 4, 16)]
+
+
+def _nchw_cpu(t):
+    return (t.detach().float().permute(0, 3, 1, 2) if t.dim() == 4 else t.detach().float()).contiguous().cpu()
+
+
+def _rms_rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("name,batch,precision", BLOCK_CASES, ids=["%s-b%d-p%d" % c for c in BLOCK_CASES])
+def test_blockwise_teacher_forced_parity(name, batch, precision):
+    from oracle import torch_ref
+    from xview2_amd import criterion, ops
+    a = ARGS(**MODEL_CASES[name])
+    ora, hip = build_pair(a)
+    ora.train()
+    hip.train()
+    x, y = model_input(a, batch=batch), labels(a, batch=batch)
+    names = [n for n, m in hip.named_modules() if type(m).__name__ in FORCED_CLASSES]
+    omods = dict(ora.named_modules())
+    assert len(names) >= 10 and all(n in omods and type(omods[n]).__name__ in FORCED_CLASSES for n in names)
+    seen = {n: [] for n in names}
+    handles = [m.register_forward_hook(lambda mod, inp, out, n=n: seen[n].append(_nchw_cpu(out)))
+               for n, m in hip.named_modules() if n in seen]
+    try:
+        if precision == 16:
+            ops.MATH_MODE = ops.MATH_BF16
+            ops.set_storage_dtype(torch.bfloat16)
+        ph = hip(x.to(DEV))
+        loss_h = criterion.compute_loss(criterion.Loss(a), ph, y.to(DEV), a.deep_supervision)
+        loss_h.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.MATH_MODE = ops.fp32_math()
+        ops.set_storage_dtype(None)
+        for h in handles:
+            h.remove()
+    assert all(torch.isfinite(p.grad).all() for p in hip.parameters() if p.grad is not None)
+    errs, calls = [], {n: 0 for n in names}
+
+    def force(n):
+        def hook(mod, inp, out):
+            i = calls[n]
+            calls[n] += 1
+            got = seen[n]
+            if len(got) == 1 and got[0].shape[0] == 2 * out.shape[0]:      # shared-weight passes batched as one (BN_SPLIT)
+                ref = got[0][i * out.shape[0]:(i + 1) * out.shape[0]]
+            else:
+                ref = got[i]
+            assert ref.shape == out.shape, (n, ref.shape, out.shape)
+            errs.append((rel(ref, out), _rms_rel(ref, out.detach()), n))
+            return ref.to(out.dtype)
+        return hook
+    handles = [omods[n].register_forward_hook(force(n)) for n in names]
+    try:
+        with torch.no_grad():
+            po = ora(x)
+            loss_o = torch_ref.compute_loss(torch_ref.Loss(a), po, y, a.deep_supervision)
+    finally:
+        for h in handles:
+            h.remove()
+    assert all(calls[n] >= 1 for n in names)
+    po = po if isinstance(po, list) else [po]
+    ph = ph if isinstance(ph, list) else [ph]
+    worst = max(errs)
+    worst_rms = max(e[1] for e in errs)
+    lrel = max(rel(h, o) for h, o in zip(ph, po))
+    loss_rel = abs(float(loss_h) - float(loss_o)) / max(abs(float(loss_o)), 1e-12)
+    row = {"case": name, "batch": batch, "mode": "train, block-by-block from HIP inputs, precision %d" % precision,
+           "branch": "every block 1e-3 + logits 1e-3 + exact argmax" if precision == 32 else "bf16: per-block rms, loss 1e-2",
+           "blocks": len(errs), "block_max_rel": worst[0], "block_max_rel_at": worst[2], "block_max_rms_rel": worst_rms,
+           "hip_vs_cpu32": lrel, "loss_hip": float(loss_h), "loss_cpu32": float(loss_o), "loss_rel": loss_rel}
+    if precision == 32:
+        row["argmax_mismatch_outside_ties"] = argmax_mismatch(ph[0], po[0])
+        log_parity(row)
+        assert worst[0] <= 1e-3, "block %s: %.3e" % (worst[2], worst[0])
+        assert lrel <= 1e-3 and loss_rel <= 1e-3, (lrel, loss_rel)
+        assert row["argmax_mismatch_outside_ties"] == 0
+    else:
+        agree = float((torch.argmax(ph[0].float().cpu(), 1) == torch.argmax(po[0], 1)).float().mean())
+        row["argmax_agreement"] = agree
+        log_parity(row)
+        # bf16 storage rounds every stored element to 2^-9 relative: per block the rms error stays at the few-1e-3 level;
+        # single elements (max-abs) can be larger where split attention's bn1 is steep, hence the rms form of the gate
+        assert worst_rms <= 3e-2, (worst_rms, [e for e in errs if e[1] > 3e-2][:3])
+        assert loss_rel <= 1e-2 and agree >= 0.97, (loss_rel, agree)

@@ -795,3 +795,58 @@ def test_f32x3_split_bf16_conv_keeps_the_fp32_tolerances(case):
     close(y3, outs[ops.MATH_F32][0], 2e-6, "f32x3 vs exact fp32 MFMA, y")
     close(dx3, outs[ops.MATH_F32][1], 2e-6, "f32x3 vs exact fp32 MFMA, dx")
     close(dw3, outs[ops.MATH_F32][2], 2e-6, "f32x3 vs exact fp32 MFMA, dw")
+
+
+# ---- input hand-over on the device -----------------------------------------------------------------
+@pytest.mark.parametrize("C,c0,hflip,vflip", [(3, 0, False, False), (3, 0, True, False), (6, 3, False, True),
+                                               (6, 0, True, True)])
+def test_normalize_u8_to_nhwc_is_bit_exact_with_the_loader_arithmetic(C, c0, hflip, vflip):
+    """xv2_normalize_u8_to_nhwc vs the numpy port of A.Normalize() (data_loading/pytorch_loader.py:63,90-91) on a uint8
+    HWC tile covering every byte value: identical bits, channel 3 zero, flips = np.flip of the tile"""
+    import numpy as np
+    from xview2_amd import ops
+    from xview2_amd.data_loading import pytorch_loader as pl
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, (2, 37, 53, C), dtype=np.uint8)
+    u8[0, 0, :, 0] = np.arange(53) * 4 % 256
+    u8[1, :, 0, -1] = np.arange(37) * 7 % 256
+    u8[0, 1, :3, :] = (0, 255, 128)[:1] * C
+    got = ops.normalize_u8_to_nhwc(torch.from_numpy(u8).cuda(), c0, hflip, vflip).cpu().numpy()
+    src = u8[..., c0:c0 + 3]
+    if hflip:
+        src = np.flip(src, 2)
+    if vflip:
+        src = np.flip(src, 1)
+    want = np.stack([pl.normalize(t) for t in src])
+    assert got.shape == (2, 37, 53, 4) and got.dtype == np.float32
+    assert np.array_equal(got[..., :3], want)
+    assert not got[..., 3].any()
+
+
+@pytest.mark.parametrize("kind", ["pre", "post_siamese", "post_fused", "post_diff"])
+def test_device_image_equals_the_host_normalised_nchw_batch(kind):
+    """ops.DeviceImage (uint8 HWC tiles on the device, normalised by the network's first launch) must drive every
+    model family to the bits the reference-style input (host A.Normalize + CHW transpose -> fp32 NCHW) produces:
+    logits of a training-mode forward, with and without the TTA flips of model/plt.py:42-48"""
+    from tests.golden.cases import ARGS
+    from xview2_amd import data as syn, networks, ops
+    from xview2_amd.lightning import Model
+    from xview2_amd.weights import deterministic_init_
+    a = {"pre": ARGS(), "post_siamese": ARGS(type="post", dmg_model="siamese", loss_str="focal+dice"),
+         "post_fused": ARGS(type="post", dmg_model="fused", loss_str="focal+dice"),
+         "post_diff": ARGS(type="post", dmg_model="diff", loss_str="focal+dice")}[kind]
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.stack([syn.synthetic_tile(a.type, 64, g)[0] for _ in range(2)])
+    host = syn.normalize_host(u8).cuda()                       # fp32 [2, 3|6, 64, 64]
+    dimg = ops.DeviceImage(u8.cuda())
+    assert tuple(dimg.shape) == tuple(host.shape) and dimg.is_cuda
+    assert torch.equal(dimg.float_nchw(), host)
+    torch.manual_seed(0)
+    m = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
+    deterministic_init_(m, 1)
+    m.cuda().train()
+    with torch.no_grad():
+        assert torch.equal(m(dimg), m(host))
+        for dims in Model.tta_flips:
+            assert torch.equal(m(Model.flip(dimg, list(dims))), m(Model.flip(host, list(dims))))
+        assert torch.equal(m(dimg[:1]), m(host[:1]))

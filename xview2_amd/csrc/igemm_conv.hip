@@ -823,6 +823,12 @@ int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt, int math) {
     return ks > 1 ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
 }
 
+int igemm_stats_tile_rows(int64_t M, int Nout, bool smallc, int nkt, int math) {
+    int bm, bn, ks;
+    pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
+    return ks > 1 ? SPLITK_ROWS : bm;
+}
+
 size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
@@ -979,6 +985,9 @@ using namespace xv2;
 
 extern "C" int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d) {
     return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
+}
+extern "C" int64_t xv2_conv2d_forward_stats_tile_rows(const xv2_conv_desc* d) {
+    return igemm_stats_tile_rows((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d) {
     return igemm_splitk_bytes((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);

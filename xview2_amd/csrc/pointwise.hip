@@ -233,6 +233,31 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int ldx, int N,
         y[i] = x[(n * hw + q) * ldx + c];
     }
 }
+// uint8 HWC tile (what cv2.imread / np.concatenate hand to A.Normalize, data_loading/pytorch_loader.py:38,63,113) ->
+// normalised fp32 NHWC padded to 4 channels, optional horizontal / vertical flip on the way (A.HorizontalFlip /
+// A.VerticalFlip, pytorch_loader.py:59-60,86-87; the TTA flips of model/plt.py:42-48).  One thread per OUTPUT pixel:
+// 3 byte loads, one 16-byte store.  Arithmetic of albumentations' normalize(): (float(v) - mean*255) * (1 / (std*255)),
+// two fp32 roundings, the per-channel constants prepared on the host in fp32.
+struct NormConsts {
+    float mean255[3];
+    float rdenom[3];
+};
+__global__ void normalize_u8_kernel(const uint8_t* __restrict__ src, int csrc, int c0, int N, int H, int W, int hflip,
+                                    int vflip, NormConsts k, float* __restrict__ dst) {
+    const int64_t hw = (int64_t)H * W, total = (int64_t)N * hw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / hw, q = i - n * hw;
+        const int oh = (int)(q / W), ow = (int)(q - (int64_t)oh * W);
+        const int ih = vflip ? H - 1 - oh : oh, iw = hflip ? W - 1 - ow : ow;
+        const uint8_t* s = src + ((n * H + ih) * (int64_t)W + iw) * csrc + c0;
+        float4 o;
+        o.x = __fmul_rn(__fsub_rn((float)s[0], k.mean255[0]), k.rdenom[0]);
+        o.y = __fmul_rn(__fsub_rn((float)s[1], k.mean255[1]), k.rdenom[1]);
+        o.z = __fmul_rn(__fsub_rn((float)s[2], k.mean255[2]), k.rdenom[2]);
+        o.w = 0.f;
+        *reinterpret_cast<float4*>(dst + i * 4) = o;
+    }
+}
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
                                      int64_t npix, int C) {
@@ -805,6 +830,25 @@ extern "C" int xv2_nchw_to_nhwc(const float* x, int64_t x_batch_stride, int N, i
     XV2_CHECK_ARG(Cp >= C, "nchw_to_nhwc: Cp < C");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
                        x_batch_stride, N, C, (int64_t)H * W, y, Cp);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_normalize_u8_to_nhwc(const uint8_t* img_hwc, int csrc, int c0, int N, int H, int W, int hflip,
+                                        int vflip, const float* mean3, const float* std3, float* out_nhwc4,
+                                        void* stream) {
+    XV2_CHECK_ARG(img_hwc && out_nhwc4 && mean3 && std3, "normalize_u8_to_nhwc: null operand");
+    XV2_CHECK_ARG(N > 0 && H > 0 && W > 0 && c0 >= 0 && c0 + 3 <= csrc, "normalize_u8_to_nhwc: channels [%d, %d) of %d", c0,
+                  c0 + 3, csrc);
+    XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(out_nhwc4) & 15) == 0, "normalize_u8_to_nhwc: output must be 16-byte aligned");
+    NormConsts k;
+    for (int c = 0; c < 3; ++c) {      // albumentations.augmentations.functional.normalize, max_pixel_value = 255
+        const float m = mean3[c] * 255.0f, sd = std3[c] * 255.0f;
+        XV2_CHECK_ARG(sd > 0.f, "normalize_u8_to_nhwc: std[%d] must be positive", c);
+        k.mean255[c] = m;
+        k.rdenom[c] = 1.0f / sd;       // host division: correctly rounded, as np.reciprocal(dtype=float32)
+    }
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, img_hwc,
+                       csrc, c0, N, H, W, hflip ? 1 : 0, vflip ? 1 : 0, k, out_nhwc4);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

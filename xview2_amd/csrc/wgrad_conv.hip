@@ -1395,7 +1395,13 @@ extern "C" int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const vo
                                                 const void* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                                                 void* side_stream, void* stream) {
     XV2_CHECK_ARG(side_stream && side_stream != stream, "backward_weight_async: a distinct side stream is required");
-    static thread_local hipEvent_t ev = nullptr;      // re-recorded per call: a wait captures the record that precedes it
+    // one event per (host thread, device): an event belongs to the device that was current when it was created, and a host
+    // thread may drive streams of several devices.  Re-recorded per call: a wait captures the record that precedes it.
+    static thread_local hipEvent_t evs[64] = {};
+    int dev = 0;
+    XV2_CHECK_HIP(hipGetDevice(&dev));
+    XV2_CHECK_ARG(dev >= 0 && dev < 64, "backward_weight_async: device index %d out of range", dev);
+    hipEvent_t& ev = evs[dev];
     if (!ev) XV2_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     XV2_CHECK_HIP(hipEventRecord(ev, (hipStream_t)stream));
     XV2_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev, 0));

@@ -22,7 +22,13 @@ class _OnDevice:
 
     def __iter__(self):
         for batch in self.loader:
-            yield {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            out = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            img = out.get("image")
+            if torch.is_tensor(img) and img.dtype == torch.uint8 and img.is_cuda:
+                # raw uint8 HWC tiles: normalised on the device straight into the stem's NHWC input
+                from ..ops import DeviceImage
+                out["image"] = DeviceImage(img)
+            yield out
 
 
 class DataModule:
@@ -32,6 +38,9 @@ class DataModule:
         self.val_path = os.path.join(args.data, "test")
         self.test_path = os.path.join(args.data, "holdout")
         pin = str(device).startswith("cuda")
+        # device-side input hand-over: workers deliver uint8 HWC tiles, the GPU normalises them into
+        # NHWC (xv2_normalize_u8_to_nhwc).  XV2_HOST_NORMALIZE=1 restores the reference's host normalise + CHW transpose.
+        self.raw_u8 = pin and os.environ.get("XV2_HOST_NORMALIZE", "0") != "1"
         self.train_loader_kwargs = {"batch_size": args.batch_size, "pin_memory": pin, "num_workers": args.num_workers,
                                     "drop_last": True, "shuffle": True}
         self.test_loader_kwargs = {"batch_size": args.val_batch_size, "pin_memory": pin,
@@ -43,12 +52,12 @@ class DataModule:
             from torch.utils.data.distributed import DistributedSampler
             # the dataset is built once and re-wrapped with the sampler (no second glob / index parse)
             probe = fetch_pytorch_loader(path, self.args.type, training, {"batch_size": 1},
-                                         getattr(self.args, "autoaugment", False)).dataset
+                                         getattr(self.args, "autoaugment", False), self.raw_u8).dataset
             kwargs["sampler"] = DistributedSampler(probe, self.world_size, self.rank, shuffle=kwargs.pop("shuffle"))
             loader = torch.utils.data.DataLoader(probe, worker_init_fn=seed_worker, **kwargs)
         else:
             loader = fetch_pytorch_loader(path, self.args.type, training, kwargs,
-                                          getattr(self.args, "autoaugment", False))
+                                          getattr(self.args, "autoaugment", False), self.raw_u8)
         return _OnDevice(loader, self.device)
 
     def train_dataloader(self):

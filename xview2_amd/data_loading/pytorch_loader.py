@@ -153,13 +153,32 @@ def random_brightness_contrast(img, p=0.2, limit=0.2):
 
 
 def normalize(img):
-    """A.Normalize(): (img / 255 - mean) / std, statistics applied in STORED channel order (B,G,R here)"""
-    return (img.astype(np.float32) / 255.0 - MEAN) / STD
+    """A.Normalize() with its defaults, in albumentations' own arithmetic (functional.normalize: fp32 mean * 255,
+    fp32 reciprocal of std * 255, subtract, multiply), statistics applied in STORED channel order (B,G,R here).  The
+    device hand-over (include/xv2.h xv2_normalize_u8_to_nhwc) computes the same two roundings bit for bit."""
+    mean = MEAN * np.float32(255.0)
+    denominator = np.reciprocal(STD * np.float32(255.0), dtype=np.float32)
+    out = img.astype(np.float32)
+    out -= mean
+    out *= denominator
+    return out
+
+
+# RAW_U8 datasets skip normalise + HWC->CHW (pytorch_loader.py:90-91,145-147,166-170) and hand the uint8 HWC tile to the
+# loader; the device normalises it into the stem's NHWC input (ops.DeviceImage).  Augmentations are unchanged: they all
+# run on uint8 tiles BEFORE the normalisation in the reference too.
+def _finish(img_u8, mask, raw_u8):
+    if raw_u8:
+        return {"image": np.ascontiguousarray(img_u8), "mask": np.ascontiguousarray(mask)}
+    parts = [normalize(img_u8[:, :, i:i + 3]) for i in range(0, img_u8.shape[2], 3)]
+    img = np.concatenate(parts, 2)
+    return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": np.ascontiguousarray(mask)}
 
 
 class _TrainBase(Dataset):
-    def __init__(self, autoaugment):
+    def __init__(self, autoaugment, raw_u8=False):
         self.use_autoaugment = bool(autoaugment)
+        self.raw_u8 = bool(raw_u8)
         if self.use_autoaugment:
             from .autoaugment import ImageNetPolicy
             self.autoaugment = ImageNetPolicy()
@@ -170,9 +189,8 @@ class _TrainBase(Dataset):
             parts = [Image.fromarray(np.ascontiguousarray(img[:, :, i:i + 3])) for i in range(0, img.shape[2], 3)]
             out = self.autoaugment(parts[0], Image.fromarray(np.ascontiguousarray(mask)), *parts[1:])
             mask = np.asarray(out[1])
-            parts = [normalize(np.asarray(p)) for p in (out[0],) + tuple(out[2:])]
-            img = np.concatenate(parts, 2)
-            return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": np.ascontiguousarray(mask)}
+            img = np.concatenate([np.asarray(p) for p in (out[0],) + tuple(out[2:])], 2)
+            return _finish(img, mask, self.raw_u8)
         img, mask = random_scale(img, mask)
         img, mask = crop_non_empty_mask_if_exists(img, mask)
         img, mask = flip(img, mask, 1)      # HorizontalFlip
@@ -180,14 +198,12 @@ class _TrainBase(Dataset):
         parts = [img[:, :, i:i + 3] for i in range(0, img.shape[2], 3)]
         parts = [gauss_noise(p) for p in parts]                 # drawn per image, like two A.GaussNoise calls
         parts = [random_brightness_contrast(p) for p in parts]
-        parts = [normalize(p) for p in parts]
-        img = np.concatenate(parts, 2)
-        return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": np.ascontiguousarray(mask)}
+        return _finish(np.concatenate(parts, 2), mask, self.raw_u8)
 
 
 class TrainPreDataset(_TrainBase):  # pytorch_loader.py:53-94
-    def __init__(self, path, _, autoaugment=False, index_csv=None):
-        super().__init__(autoaugment)
+    def __init__(self, path, _, autoaugment=False, index_csv=None, raw_u8=False):
+        super().__init__(autoaugment, raw_u8)
         self.imgs_pre, self.lbls_pre = load_data(path, "pre")
         self.idx = _index(path, index_csv)["idx"]
 
@@ -200,8 +216,8 @@ class TrainPreDataset(_TrainBase):  # pytorch_loader.py:53-94
 
 
 class TrainPostDataset(_TrainBase):  # pytorch_loader.py:97-148
-    def __init__(self, path, _, autoaugment=False, index_csv=None):
-        super().__init__(autoaugment)
+    def __init__(self, path, _, autoaugment=False, index_csv=None, raw_u8=False):
+        super().__init__(autoaugment, raw_u8)
         self.imgs_pre, self.lbls_pre = load_data(path, "pre")
         self.imgs_post, self.lbls_post = load_data(path, "post")
         assert len(self.imgs_pre) == len(self.imgs_post)
@@ -223,8 +239,9 @@ class TrainPostDataset(_TrainBase):  # pytorch_loader.py:97-148
 
 
 class TestDataset(Dataset):  # pytorch_loader.py:151-171
-    def __init__(self, path, mode, _=False):
+    def __init__(self, path, mode, _=False, raw_u8=False):
         self.mode = mode
+        self.raw_u8 = bool(raw_u8)
         self.imgs_pre, self.lbls_pre = load_data(path, "pre")
         self.imgs_post, self.lbls_post = load_data(path, "post")
         assert len(self.imgs_pre) == len(self.imgs_post)
@@ -235,11 +252,10 @@ class TestDataset(Dataset):  # pytorch_loader.py:151-171
 
     def __getitem__(self, i):
         img, lbl = load_pair(self.imgs_pre[i], self.lbls_pre[i])
-        img = normalize(img)
         if self.mode == "post":
             img_post, lbl = load_pair(self.imgs_post[i], self.lbls_post[i])
-            img = np.concatenate((img, normalize(img_post)), 2)
-        return {"image": np.ascontiguousarray(np.transpose(img, (2, 0, 1))), "mask": lbl}
+            img = np.concatenate((img, img_post), 2)
+        return _finish(img, lbl, self.raw_u8)
 
 
 def _index(path, index_csv):
@@ -252,11 +268,11 @@ def _index(path, index_csv):
     return build_index(path, local if os.access(path, os.W_OK) else None)
 
 
-def fetch_pytorch_loader(path, mode, training, loader_kwargs, autoaugment=False):  # pytorch_loader.py:22-28
+def fetch_pytorch_loader(path, mode, training, loader_kwargs, autoaugment=False, raw_u8=False):  # pytorch_loader.py:22-28
     if not training:
         dataset = TestDataset
     elif mode == "pre":
         dataset = TrainPreDataset
     else:
         dataset = TrainPostDataset
-    return DataLoader(dataset(path, mode, autoaugment), worker_init_fn=seed_worker, **loader_kwargs)
+    return DataLoader(dataset(path, mode, autoaugment, raw_u8=raw_u8), worker_init_fn=seed_worker, **loader_kwargs)

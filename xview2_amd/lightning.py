@@ -16,7 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import criterion, networks
+from . import criterion, networks, ops
 from .optim import FlatAdamW
 from .utils.f1 import F1
 from .utils.scheduler import NoamLR
@@ -123,6 +123,8 @@ class Model(_Base):
     # ---- forward / steps ----------------------------------------------------------------------------------------
     @staticmethod
     def flip(data, axis):
+        if isinstance(data, ops.DeviceImage):       # uint8 tiles on the device: the flip rides in the normalise launch
+            return data.flip(axis)
         return torch.flip(data, dims=axis)
 
     def forward(self, img):

@@ -297,7 +297,11 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
              None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part,
              _ws(wsb, x0) if wsb else None)
-        if want_stats and S > 1 and ((N * OH * OW) % tiles != 0 or tiles % S != 0):
+        if want_stats and S > 1 and (((N * OH * OW) // S) % query("xv2_conv2d_forward_stats_tile_rows", d) != 0
+                                     or tiles % S != 0):
+            # a part's rows must END on a statistics-tile boundary of the plan (64- or 128-row M tiles, 64-row split-K
+            # reduce tiles): otherwise the middle tile straddles two BatchNorm batches (e.g. 2 x 10 x 10 rows at /32 of
+            # a 320 x 320 tile: M = 200, four 64-row tiles, 100 rows per part)
             stats_ok = False
         elif want_stats:
             scratch = _stats_scratch(Coutg, x0.device)
@@ -1261,9 +1265,122 @@ class LossFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# Input hand-over on the device.  The reference's datasets normalise uint8 HWC tiles on the host and
+# transpose them to CHW (data_loading/pytorch_loader.py:63,90-91,145-147); the kernels here are NHWC, so a tile can go
+# to the device as the uint8 HWC array cv2.imread produced (a quarter of the bytes over PCIe) and be normalised straight
+# into the stem convolution's input layout: no host normalise, no CHW transpose, no xv2_nchw_to_nhwc.
+NORM_MEAN, NORM_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # A.Normalize() defaults
+_norm_consts = {}
+
+
+def normalize_u8_to_nhwc(u8, c0=0, hflip=False, vflip=False, out=None):
+    """u8: uint8 [N, H, W, 3|6] on the device -> fp32 NHWC [N, H, W, 4] of channels c0..c0+2, A.Normalize()d, channel
+    3 zero; hflip / vflip mirror W / H on the way.  `out`: a [N, H, W, 4] fp32 view to fill (pair batches)."""
+    _need_cuda(u8)
+    if u8.dtype != torch.uint8 or u8.dim() != 4:
+        raise RuntimeError("normalize_u8_to_nhwc: uint8 [N, H, W, C] expected, got %s %s" % (u8.dtype, tuple(u8.shape)))
+    u8 = u8.contiguous()
+    N, H, W, C = u8.shape
+    k = _norm_consts.get(u8.device)
+    if k is None:
+        k = _norm_consts[u8.device] = (torch.tensor(NORM_MEAN, dtype=torch.float32), torch.tensor(NORM_STD, dtype=torch.float32))
+    y = out if out is not None else torch.empty((N, H, W, 4), dtype=torch.float32, device=u8.device)
+    call("xv2_normalize_u8_to_nhwc", u8, C, int(c0), N, H, W, 1 if hflip else 0, 1 if vflip else 0,
+         k[0].data_ptr(), k[1].data_ptr(), y)
+    return y
+
+
+class DeviceImage:
+    """A batch of uint8 HWC tiles on the device standing in for the reference's normalised fp32 NCHW `batch["image"]`
+    (model/plt.py:51).  It answers what the network code asks of that tensor - `.shape` in NCHW terms, `.is_cuda`, the
+    pre / post channel slices `data[:, :3]` / `data[:, 3:]` (model/unet.py:232-233), `torch.flip` over H / W (TTA,
+    model/plt.py:42-48), batch slices - lazily: flips and slices only set flags, and the stem's NHWC fp32 input is
+    produced by ONE xv2_normalize_u8_to_nhwc launch (`nhwc()`).  Anything else goes through `float_nchw()`."""
+    __slots__ = ("u8", "c0", "nch", "hflip", "vflip")
+
+    def __init__(self, u8, c0=0, nch=None, hflip=False, vflip=False):
+        if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[3] not in (3, 6):
+            raise RuntimeError("DeviceImage: uint8 [N, H, W, 3|6] expected, got %s %s" % (u8.dtype, tuple(u8.shape)))
+        self.u8, self.c0, self.hflip, self.vflip = u8, c0, hflip, vflip
+        self.nch = u8.shape[3] - c0 if nch is None else nch
+
+    # ---- what the model code reads ----
+    @property
+    def shape(self):
+        N, H, W, _ = self.u8.shape
+        return torch.Size((N, self.nch, H, W))
+
+    @property
+    def is_cuda(self):
+        return self.u8.is_cuda
+
+    @property
+    def device(self):
+        return self.u8.device
+
+    def to(self, *a, **k):
+        return DeviceImage(self.u8.to(*a, **k), self.c0, self.nch, self.hflip, self.vflip)
+
+    def flip(self, dims):
+        h, v = self.hflip, self.vflip
+        for d in dims:
+            d = d % 4
+            if d == 3:
+                h = not h
+            elif d == 2:
+                v = not v
+            else:
+                raise RuntimeError("DeviceImage.flip: only the H / W axes (2, 3) can be flipped lazily")
+        return DeviceImage(self.u8, self.c0, self.nch, h, v)
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        u8 = self.u8[idx[0]] if not isinstance(idx[0], int) else self.u8[idx[0]:idx[0] + 1]
+        c0, nch = self.c0, self.nch
+        if len(idx) > 1:
+            sl = idx[1]
+            if not isinstance(sl, slice) or sl.step not in (None, 1) or len(idx) > 2:
+                return self.float_nchw()[idx]
+            lo, hi, _ = sl.indices(nch)
+            c0, nch = c0 + lo, hi - lo
+        return DeviceImage(u8, c0, nch, self.hflip, self.vflip)
+
+    def __sub__(self, other):            # DiffUNet: data[:, :3] - data[:, 3:] (model/unet.py:547)
+        return self.float_nchw() - (other.float_nchw() if isinstance(other, DeviceImage) else other)
+
+    # ---- materialisation ----
+    def nhwc(self, out=None):
+        """normalised fp32 NHWC [N, H, W, 4] of this view's three channels"""
+        if self.nch != 3:
+            raise RuntimeError("DeviceImage.nhwc: a 3-channel view expected (got %d channels)" % self.nch)
+        return normalize_u8_to_nhwc(self.u8, self.c0, self.hflip, self.vflip, out)
+
+    def pair_nhwc(self):
+        """[2N, H, W, 4]: the pre images then the post images (nchw_pair_to_nhwc for a uint8 pair)"""
+        if self.nch != 6:
+            raise RuntimeError("DeviceImage.pair_nhwc: a 6-channel pre|post pair expected")
+        N, H, W, _ = self.u8.shape
+        y = torch.empty((2 * N, H, W, 4), dtype=torch.float32, device=self.u8.device)
+        normalize_u8_to_nhwc(self.u8, self.c0, self.hflip, self.vflip, y[:N])
+        normalize_u8_to_nhwc(self.u8, self.c0 + 3, self.hflip, self.vflip, y[N:])
+        return y
+
+    def float_nchw(self):
+        """the tensor the reference's loader would have produced: fp32 [N, nch, H, W]"""
+        parts = [nhwc_to_nchw(normalize_u8_to_nhwc(self.u8, self.c0 + o, self.hflip, self.vflip)[..., :3].contiguous())
+                 for o in range(0, self.nch, 3)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+
+
+# ------------------------------------------------------------------------------------------------
 # layout helpers (no gradient: images do not require grad; outputs of nhwc_to_nchw are for tests / eval)
 def nchw_to_nhwc(x, c_pad=None):
     """x: NCHW (possibly a channel slice of a wider NCHW tensor) -> NHWC with channels padded to c_pad."""
+    if isinstance(x, DeviceImage):
+        if c_pad not in (None, 4):
+            raise RuntimeError("DeviceImage converts to 4-channel NHWC only")
+        return x.nhwc()
     _need_cuda(x)
     N, C, H, W = x.shape
     if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
@@ -1277,6 +1394,8 @@ def nchw_to_nhwc(x, c_pad=None):
 def nchw_pair_to_nhwc(x, c_pad=4):
     """[B, 6, H, W] pre/post pair (model/unet.py:232-233 slices it) -> ONE NHWC batch [2B, H, W, c_pad]:
     rows 0..B-1 the pre images (channels 0..2), rows B..2B-1 the post images (channels 3..5)"""
+    if isinstance(x, DeviceImage):
+        return x.pair_nhwc()
     _need_cuda(x)
     B, C6, H, W = x.shape
     if C6 != 6:
