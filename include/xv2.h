@@ -91,6 +91,22 @@ int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
  * (several BatchNorm batches back to back in one launch: the Siamese pre/post passes) needs every range to end on a
  * tile boundary */
 int64_t xv2_conv2d_forward_stats_tile_rows(const xv2_conv_desc* d);
+/* Convolution + training-mode BatchNorm statistics in ONE launch (model/layers.py:92-93 conv -> norm; the encoder
+ * blocks): the convolution epilogue writes the per-tile partials and the LAST blocks to arrive (two levels of
+ * device-scope tickets, fixed summation order: bit-reproducible) reduce them to sums[parts][part_stride][2] (fp64 sum
+ * and sum of squares per channel) and - when `mean` != NULL - derive mean / invstd / scale / shift [parts][part_stride]
+ * and update the running statistics, part after part.  Replaces xv2_conv2d_forward + xv2_bn_reduce_stats /
+ * xv2_bn_reduce_finalize (two launches).  parts > 1: the batch holds that many independent BatchNorm batches back to back
+ * (the Siamese pre / post passes); every part must end on a statistics-tile boundary
+ * ((N*OH*OW / parts) % xv2_conv2d_forward_stats_tile_rows(d) == 0).  SyncBatchNorm: pass mean = NULL, all-reduce `sums`,
+ * then xv2_bn_finalize.  stats_partials: xv2_conv2d_forward_stats_tiles(d) * Cout * 2 floats; scratch:
+ * XV2_BN_SCRATCH_ROWS * Cout * 2 doubles; workspace as for xv2_conv2d_forward. */
+int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                          const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
+                          int parts, int part_stride, double* sums, double* scratch, double count,
+                          const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                          float* shift, void* stream);
 /* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
  * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
 size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);

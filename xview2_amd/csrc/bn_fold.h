@@ -1,0 +1,197 @@
+// In-launch fold of per-tile BatchNorm statistics partials: the kernel that PRODUCES the partials (convolution epilogue,
+// split-K slab sum, column sums of the BatchNorm backward) also reduces them and, for a single-process training-mode
+// nn.BatchNorm2d (model/layers.py:93, the encoder blocks), derives the coefficients and running statistics - no
+// separate reduction launch.  Two levels of device-scope tickets:
+//   * every block publishes its row of partials with write-through (sc1) stores and draws a ticket of its GROUP of G
+//     consecutive tiles; the group's last arriver adds the G rows in tile order into scratch[group] (fp64);
+//   * it then draws the TOP ticket of its column tile; the last group's block adds the group rows in group order, writes
+//     the sums and finalises.
+// Which block does the adding is timing dependent, WHAT it adds and in which order is not: results are bit-reproducible.
+// Hand-off form (MI355X guide, Guideline 16): payload = 8-byte agent-scope relaxed atomic stores (write-through), every
+// storing wave drains with an asm s_waitcnt before the block barrier, one lane draws the ticket, the consumer reads with
+// agent-scope relaxed atomic loads; tickets return to zero inside the launch (the pool is shared by later launches).
+// S > 1: the tiles hold S independent BatchNorm batches back to back (ops.BN_SPLIT: the Siamese pre / post passes);
+// groups never straddle a part, sums / coefficients are per part and the running statistics see the parts in order.
+#pragma once
+#include "xv2_common.h"
+
+namespace xv2 {
+
+struct BnFinalize {
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    float* mean;      // nullptr: sums only
+    float* invstd;
+    float* scale;
+    float* shift;
+};
+
+// contraction off: every kernel that inlines this must agree bit for bit (hipcc contracts a*b+c by default)
+__device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1, double s2, int out_off = 0) {
+#pragma clang fp contract(off)
+    const double m = s1 / f.count;
+    const double mm = m * m;
+    double var = s2 / f.count - mm;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)f.eps);
+    f.mean[out_off + c] = (float)m;
+    f.invstd[out_off + c] = (float)is;
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    const float sc = g * (float)is;
+    const float msc = (float)m * sc;
+    f.scale[out_off + c] = sc;
+    f.shift[out_off + c] = b - msc;
+    if (f.running_mean) {
+        const double vc = var * f.count;
+        const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;
+        const float keep = 1.f - f.momentum;
+        const float km = keep * f.running_mean[c], kv = keep * f.running_var[c];
+        const float am = f.momentum * (float)m, av = f.momentum * (float)unb;
+        f.running_mean[c] = km + am;
+        f.running_var[c] = kv + av;
+    }
+}
+
+struct StatsFold {
+    double* scratch;      // [S * ngroups][C][2]
+    unsigned* tickets;    // [S * ngroups * ntn] group tickets, then [ntn] top tickets; zero between launches
+    double* sums;         // [S][C][2] out (may be nullptr)
+    float* f0;            // optional fp32 copies of the two sums (BatchNorm backward: dbeta, dgamma); S == 1 only
+    float* f1;
+    int S, tiles_per_part, G, ngroups, ntn, C;
+    int part_stride;      // channels between the outputs (sums, coefficients) of consecutive parts (>= C: channel groups)
+    int on;               // 0: no in-launch fold (partials only)
+    BnFinalize fin;       // outputs of part s at offset s * part_stride
+};
+
+// host: group size so that level 1 and level 2 are balanced and S * ngroups rows fit the scratch (XV2_BN_SCRATCH_ROWS)
+static inline bool stats_fold_plan(StatsFold& f, int64_t tiles, int S, int ntn, int C) {
+    f.on = 0;
+    if (S < 1 || tiles <= 0 || tiles % S != 0 || S > XV2_BN_SCRATCH_ROWS) return false;
+    const int64_t tpp = tiles / S;
+    int64_t G = 1;
+    while (G * G < tpp) ++G;                                         // ceil(sqrt(tpp))
+    const int64_t maxg = XV2_BN_SCRATCH_ROWS / S;
+    if (cdiv(tpp, G) > maxg) G = cdiv(tpp, maxg);
+    f.S = S;
+    f.tiles_per_part = (int)tpp;
+    f.G = (int)G;
+    f.ngroups = (int)cdiv(tpp, G);
+    f.ntn = ntn;
+    f.C = C;
+    f.on = 1;
+    return true;
+}
+static inline int stats_fold_tickets(const StatsFold& f) { return f.S * f.ngroups * f.ntn + f.ntn; }
+
+unsigned* take_tickets(int n);      // norm_act.hip: zero-initialised device pool, handed out round-robin
+bool bn_fold_enabled();             // norm_act.hip: XV2_BN_FOLD=0 restores the separate reduction launches (A/B runs)
+
+// write-through store of one (s1, s2) partial
+__device__ __forceinline__ void fold_store(float* p, float s1, float s2) {
+    const unsigned long long v = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fold_store(double* p, double s1, double s2) {
+    __hip_atomic_store(p, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fold_load(const float* p) {
+    return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fold_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sum of `n` rows of one column, `stride` elements apart: SIXTEEN device-scope loads in flight (each is a memory round
+// trip - the producers stored write-through), fixed association: ((q0+q1)+(q2+q3)) + ... independent of who adds
+template <typename PT>
+__device__ __forceinline__ double fold_rows(const PT* p, size_t stride, int n) {
+    double q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j] = 0.0;
+    int r = 0;
+    for (; r + 16 <= n; r += 16) {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = fold_load(p + (size_t)(r + j) * stride);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] += t[j];
+    }
+    {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = r + j < n ? fold_load(p + (size_t)(r + j) * stride) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] += t[j];
+    }
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; ++j) q[j] += q[j + w];
+    return q[0];
+}
+
+// Called by ALL threads of a block (blockDim.x == 256) after the block's threads stored its row of partials
+// part[tile][C][2] for columns [col0, col0 + ncols) with fold_store().  `flag`: one int of LDS.
+// DRAIN = false: the storing waves already drained their partial stores (asm s_waitcnt vmcnt(0)) before this call.
+template <typename PT, bool DRAIN = true>
+__device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* part, int tile, int tn, int col0, int ncols,
+                                                volatile int* flag) {
+    const int tid = threadIdx.x;
+    const int s = tile / f.tiles_per_part, tl = tile - s * f.tiles_per_part;
+    const int g = tl / f.G;
+    const int gfirst = g * f.G, gcount = min(f.G, f.tiles_per_part - gfirst);
+    // ---- level 1: the group's last arriver folds the group's rows
+    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its rows are at the coherence point
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* t = f.tickets + ((size_t)(s * f.ngroups + g) * f.ntn + tn);
+        const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)(gcount - 1);
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int grow = s * f.ngroups + g;
+    for (int v = tid; v < ncols * 2; v += 256) {
+        const size_t i = (size_t)(col0 + (v >> 1)) * 2 + (v & 1), stride = (size_t)f.C * 2;
+        const PT* p = part + (size_t)(s * f.tiles_per_part + gfirst) * stride + i;
+        __hip_atomic_store(f.scratch + (size_t)grow * stride + i, fold_rows(p, stride, gcount), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- level 2: the column tile's last group folds the group rows of every part, in order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* t = f.tickets + (size_t)f.S * f.ngroups * f.ntn + tn;
+        const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)(f.S * f.ngroups - 1);
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    for (int v0 = 0; v0 < ncols * 2; v0 += 256) {       // uniform trip count: the shuffle below needs whole lane pairs
+        const int v = v0 + tid;
+        const bool ok = v < ncols * 2;
+        const int c = col0 + (v >> 1), which = v & 1;
+        const size_t i = (size_t)c * 2 + which, stride = (size_t)f.C * 2;
+        for (int sp = 0; sp < f.S; ++sp) {
+            const double a = ok ? fold_rows(f.scratch + (size_t)sp * f.ngroups * stride + i, stride, f.ngroups) : 0.0;
+            const double other = __shfl_xor(a, 1, 64);
+            if (!ok) continue;
+            if (f.sums) f.sums[(size_t)sp * f.part_stride * 2 + i] = a;
+            if (f.f0 && !which) f.f0[c] = (float)a;
+            if (f.f1 && which) f.f1[c] = (float)a;
+            if (f.fin.mean && !which) bn_finalize_channel(f.fin, c, a, other, sp * f.part_stride);
+        }
+    }
+}
+
+}  // namespace xv2

@@ -65,10 +65,23 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
 
-    // contiguous range of patches per block (neighbouring patches share halo columns in L2)
-    const int per = (npatches + gridDim.x - 1) / gridDim.x;
-    const int p0 = blockIdx.x * per, p1 = min(p0 + per, npatches);
-    if (p0 >= p1) return;
+    // contiguous range of patches per block (neighbouring patches share halo columns in L2).  With the in-launch
+    // statistics fold (bn_fold.h) the grid is a multiple of the S BatchNorm parts and a block's run stays inside one part:
+    // the block is the fold's "tile" (it sums its own patches in patch order), fold.tiles_per_part = blocks per part.
+    int p0, p1;
+    if (p.fold.on) {
+        const int bpp = p.fold.tiles_per_part, ppp = npatches / p.fold.S;
+        const int sp = blockIdx.x / bpp, bl = blockIdx.x - sp * bpp;
+        const int per = (ppp + bpp - 1) / bpp;
+        p0 = sp * ppp + min(bl * per, ppp);
+        p1 = sp * ppp + min(bl * per + per, ppp);
+    } else {
+        const int per = (npatches + gridDim.x - 1) / gridDim.x;
+        p0 = blockIdx.x * per;
+        p1 = min(p0 + per, npatches);
+        if (p0 >= p1) return;
+    }
+    double fsum1 = 0.0, fsum2 = 0.0;            // fold: this block's statistics (threads 0..31 = channel)
 
     // weights, once: [tap][n][32 channels]
     if constexpr (X3) {
@@ -156,8 +169,10 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     const float bmu = bnb ? p.bnb_mean[l31] : 0.f, bis = bnb ? p.bnb_invstd[l31] : 0.f;
     const float bsc = bnb ? p.bnb_scale[l31] : 0.f, bsf = bnb ? p.bnb_shift[l31] : 0.f;
 
-    hload(p0);
-    hstore();
+    if (p0 < p1) {
+        hload(p0);
+        hstore();
+    }
     __syncthreads();
     for (int patch = p0; patch < p1; ++patch) {
         if (patch + 1 < p1) hload(patch + 1);
@@ -267,12 +282,22 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
                 a1 += red[(w * 32 + tid) * 2 + 0];
                 a2 += red[(w * 32 + tid) * 2 + 1];
             }
-            float* st = p.stats + ((size_t)patch * 32 + tid) * 2;
-            st[0] = a1;
-            st[1] = a2;
+            if (p.fold.on) {
+                fsum1 += (double)a1;
+                fsum2 += (double)a2;
+            } else {
+                float* st = p.stats + ((size_t)patch * 32 + tid) * 2;
+                st[0] = a1;
+                st[1] = a2;
+            }
         }
         if (patch + 1 < p1) hstore();
         __syncthreads();
+    }
+    if (p.fold.on) {
+        // (an empty run - more blocks than patches of a part - still takes part with a zero row: the ticket counts blocks)
+        if (tid < 32) fold_store(p.stats + ((size_t)blockIdx.x * 32 + tid) * 2, (float)fsum1, (float)fsum2);
+        stats_fold_tile<float>(p.fold, p.stats, blockIdx.x, 0, 0, 32, reinterpret_cast<int*>(red));
     }
 }
 
@@ -311,19 +336,31 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     const int npatches = c.M / (D_TH * D_TW);
     // persistent: 2 blocks per CU (fp32 LDS image, 71 KB), 4 per CU with the bf16 image (40 KB); each walks a run of patches
     // (the three-plane image of F32X3, 118 KB: 1 per CU)
-    const int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
+    int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
+    IgemmParams q = p;
+    if (p.fold.on) {
+        const int S = p.fold.S;
+        XV2_CHECK_ARG(p.stats && S >= 1 && npatches % S == 0, "direct3x3: %d patches do not split into %d BatchNorm parts",
+                      npatches, S);
+        grid = std::max(S, grid / S * S);
+        StatsFold f = p.fold;
+        XV2_CHECK_ARG(stats_fold_plan(f, grid, S, 1, 32), "direct3x3: statistics fold plan failed");
+        f.tickets = take_tickets(stats_fold_tickets(f));
+        XV2_CHECK_ARG(f.tickets, "direct3x3: ticket pool allocation failed");
+        q.fold = f;
+    }
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
     prof_begin(x3 ? kidx3 : p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
     if (x3)
-        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(256), D_SMEM_X3, stream, p, npatches);
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(256), D_SMEM_X3, stream, q, npatches);
     else if (p.math == XV2_MATH_BF16_STORE)
-        hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, p, npatches);
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, q, npatches);
     else if (p.math)
-        hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+        hipLaunchKernelGGL(direct3x3_n32_kernel<true>, dim3(grid), dim3(256), D_SMEM, stream, q, npatches);
     else
-        hipLaunchKernelGGL(direct3x3_n32_kernel<false>, dim3(grid), dim3(256), D_SMEM, stream, p, npatches);
+        hipLaunchKernelGGL(direct3x3_n32_kernel<false>, dim3(grid), dim3(256), D_SMEM, stream, q, npatches);
     prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;

@@ -21,6 +21,7 @@
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
 #include "igemm_params.h"
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <type_traits>
 
@@ -522,6 +523,25 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         }
     }
     __syncthreads();
+    if (hh == 0 && do_stats && tid < BN) {
+        // this tile's row of statistics partials (red[] is complete behind the barrier above).  With the in-launch fold the
+        // row is published write-through and drained HERE, ahead of the output stores: a drain at the end of the kernel
+        // would wait for the whole tile's stores
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) {
+            s1 += red[(w * BN + tid) * 2 + 0];
+            s2 += red[(w * BN + tid) * 2 + 1];
+        }
+        float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
+        if (p.fold.on) {
+            fold_store(st, s1, s2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            st[0] = s1;
+            st[1] = s2;
+        }
+    }
     {
         constexpr int F4R = BN / 4;
         float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
@@ -604,17 +624,8 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     }
     if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
   }
-    if (do_stats && tid < BN) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WGM; ++w) {
-            s1 += red[(w * BN + tid) * 2 + 0];
-            s2 += red[(w * BN + tid) * 2 + 1];
-        }
-        float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-        st[0] = s1;
-        st[1] = s2;
-    }
+    // the tile rows are reduced (and the BatchNorm coefficients derived) by the last blocks to arrive: bn_fold.h
+    if (do_stats && p.fold.on) stats_fold_tile<float, false>(p.fold, p.stats, tm, tn, n0, BN, rowoff);
 }
 
 // Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
@@ -628,8 +639,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              float* __restrict__ stats, int accum,
                                                              const float* __restrict__ ep_scale,
                                                              const float* __restrict__ ep_shift,
-                                                             const OT* __restrict__ ep_res, int ep_ldres, int ep_act) {
+                                                             const OT* __restrict__ ep_res, int ep_ldres, int ep_act,
+                                                             const StatsFold fold) {
     __shared__ float sh[256 * 8];
+    __shared__ int fold_flag;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
     const size_t slab = (size_t)M * Nout;
@@ -682,11 +695,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                         a1 += sh[(w * 64 + tx) * 8 + k];
                         a2 += sh[(w * 64 + tx) * 8 + 4 + k];
                     }
-                    stats[((size_t)blockIdx.x * Nout + c + k) * 2] = a1;
-                    stats[((size_t)blockIdx.x * Nout + c + k) * 2 + 1] = a2;
+                    float* st = stats + ((size_t)blockIdx.x * Nout + c + k) * 2;
+                    if (fold.on) {
+                        fold_store(st, a1, a2);
+                    } else {
+                        st[0] = a1;
+                        st[1] = a2;
+                    }
                 }
             }
             __syncthreads();
+            // (the grid covers the columns exactly once: gridDim.y = ceil(Nout / 256), one pass of this loop per block)
+            if (fold.on) stats_fold_tile<float>(fold, stats, blockIdx.x, blockIdx.y, cb, min(256, Nout - cb), &fold_flag);
         }
     }
 }
@@ -835,6 +855,18 @@ size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
     return ks > 1 ? (size_t)ks * M * Nout * sizeof(float) : 0;
 }
 
+// complete the in-launch statistics fold for the tiling that was picked (bn_fold.h)
+static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
+    if (!p.fold.on) return XV2_OK;
+    StatsFold f = p.fold;
+    XV2_CHECK_ARG(p.stats && p.ncls == 1 && stats_fold_plan(f, tiles, p.fold.S, ntn, p.Nout),
+                  "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, p.fold.S);
+    f.tickets = take_tickets(stats_fold_tickets(f));
+    XV2_CHECK_ARG(f.tickets, "conv2d_forward_bn: ticket pool allocation failed");
+    p.fold = f;
+    return XV2_OK;
+}
+
 int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stream) {
     XV2_CHECK_ARG(p.Nout % 32 == 0, "igemm: Nout=%d must be a multiple of 32", p.Nout);
     XV2_CHECK_ARG(p.ncls >= 1 && p.cls[0].M > 0, "igemm: empty problem");
@@ -867,8 +899,13 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         int mk = 0;
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
+        if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
+        // split-K: the slab-sum kernel takes the statistics (64-row tiles, 256-column tiles) and folds them
+        if (int rc = complete_fold(p, cdiv(maxM, SPLITK_ROWS), (int)cdiv(p.Nout, 256))) return rc;
+        const StatsFold fold = p.fold;
+        p.fold.on = 0;
         int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                  : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
@@ -879,11 +916,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (p.math == XV2_MATH_BF16_STORE)
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum,
-                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act);
+                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum, p.ep_scale, p.ep_shift,
-                               p.ep_res, p.ep_ldres, p.ep_act);
+                               p.ep_res, p.ep_ldres, p.ep_act, fold);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -961,6 +998,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
     p.bnb_ldy = p.bnb_act = 0;
     p.plan_tiles = nullptr;
+    memset(&p.fold, 0, sizeof(p.fold));
     XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_F32X3, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
@@ -1024,11 +1062,12 @@ struct FwdEpilogue {
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
-                             long long* plan = nullptr) {
+                             long long* plan = nullptr, const StatsFold* fold = nullptr) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
     p.plan_tiles = plan;
+    if (fold) p.fold = *fold;
     if (ep) {
         XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
         XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(ep->scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(ep->shift) & 15) == 0 &&
@@ -1082,6 +1121,45 @@ extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const void* x0, int ld
                                   float* stats, float* workspace, void* stream) {
     return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, bias, (float*)y, ldy,
                              stats, workspace, stream, nullptr);
+}
+
+extern "C" int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                                     const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
+                                     int parts, int part_stride, double* sums, double* scratch, double count,
+                                     const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                     float* shift, void* stream) {
+    XV2_CHECK_ARG(stats_partials && scratch && sums, "conv2d_forward_bn: partials, scratch and sums are required");
+    XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn: parts=%d part_stride=%d", parts, part_stride);
+    XV2_CHECK_ARG(!mean || (invstd && scale && shift), "conv2d_forward_bn: mean, invstd, scale and shift go together");
+    if (!bn_fold_enabled()) {       // A/B runs (XV2_BN_FOLD=0): the launches this entry point replaces
+        int rc = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
+        if (rc) return rc;
+        const int64_t tiles = xv2_conv2d_forward_stats_tiles(d);
+        XV2_CHECK_ARG(tiles % parts == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, parts);
+        const int64_t tpp = tiles / parts;
+        for (int s = 0; s < parts && !rc; ++s) {
+            const float* ps = stats_partials + (size_t)s * tpp * d->Cout * 2;
+            double* ss = sums + (size_t)s * part_stride * 2;
+            const size_t o = (size_t)s * part_stride;
+            rc = mean ? xv2_bn_reduce_finalize(ps, tpp, d->Cout, ss, scratch, count, gamma, beta, eps, momentum, running_mean,
+                                               running_var, mean + o, invstd + o, scale + o, shift + o, stream)
+                      : xv2_bn_reduce_stats(ps, tpp, d->Cout, ss, scratch, stream);
+        }
+        return rc;
+    }
+    StatsFold f;
+    memset(&f, 0, sizeof(f));
+    f.on = 1;
+    f.S = parts;
+    f.part_stride = part_stride;
+    f.scratch = scratch;
+    f.sums = sums;
+    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
+    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
+    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
+    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
+                             stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f);
 }
 
 extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,

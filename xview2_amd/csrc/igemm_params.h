@@ -1,6 +1,6 @@
 // Shared launch parameters of the gather-GEMM convolution kernels (igemm_conv.hip, direct_conv.hip).
 #pragma once
-#include "xv2_common.h"
+#include "bn_fold.h"
 
 namespace xv2 {
 
@@ -57,6 +57,9 @@ struct IgemmParams {
     const float* bnb_shift;
     int bnb_ldy, bnb_act;
     long long* plan_tiles;   // dry run: report the M-tile count of the plan (0 = no fused BN-backward form) and launch nothing
+    // in-launch fold of the BatchNorm statistics partials (bn_fold.h); the caller fills scratch / sums / S / part_stride /
+    // fin and sets fold.on = 1, the launcher completes the plan (group size, tickets) for the tiling it picks
+    StatsFold fold;
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

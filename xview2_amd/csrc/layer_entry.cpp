@@ -15,10 +15,11 @@ extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, i
                                        float* running_mean, float* running_var, float* mean, float* invstd,
                                        float* scale, float* shift, const void* residual, int ldr, int act, void* z,
                                        int ldz, uint8_t* zmask, int dtype, void* stream) {
-    int rc = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
-    if (rc) return rc;
-    rc = xv2_bn_reduce_finalize(stats_partials, tiles, d->Cout, sums, scratch, count, gamma, beta, eps, momentum,
-                                running_mean, running_var, mean, invstd, scale, shift, stream);
+    // convolution + statistics + coefficients: ONE launch (the last blocks to arrive fold the tile partials, bn_fold.h)
+    (void)tiles;
+    int rc = xv2_conv2d_forward_bn(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
+                                   scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                                   scale, shift, stream);
     if (rc) return rc;
     const int64_t npix = (int64_t)d->N * d->OH * d->OW;
     if (zmask)

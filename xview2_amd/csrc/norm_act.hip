@@ -4,7 +4,7 @@
 // Reference sites: nn.BatchNorm2d + activation at model/layers.py:16-17,36-37,72,93-94 and in the
 // un-vendored ResNet/ResNeSt blocks; torch semantics (biased batch variance for normalisation,
 // unbiased for running_var, momentum 0.1, eps 1e-5).
-#include "xv2_common.h"
+#include "bn_fold.h"
 #include <mutex>
 #include <cstring>
 #include <algorithm>
@@ -135,6 +135,18 @@ struct ColOp {
 
 // XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply, bit 2 = the backward column sums walk
 // their tensors last-to-first
+// XV2_BN_FOLD (A/B runs): bit 0 = the convolution kernels fold their statistics tiles in-launch (default ON: measured
+// -0.2 ms per cfg2 fp32 step, -1.7 ms per resnest50 bf16 step against the separate reduction launch); bit 1 = the column
+// sums of the BatchNorm backward do the same (default OFF: under that HBM-streaming kernel every device-scope load of
+// the fold is a ~2.5 us round trip and the two-level tail costs +16.7 us per launch where the separate, idle-chip
+// reduction kernel takes 12.5 us - profiles/r03_fold_ab.md)
+static int bn_fold_bits() {
+    static const int v = [] { const char* e = getenv("XV2_BN_FOLD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+bool bn_fold_enabled() { return (bn_fold_bits() & 1) != 0; }
+static bool bn_fold_backward() { return (bn_fold_bits() & 2) != 0; }
+
 static int bn_reverse(int bit) {
     static const int v = [] { const char* e = getenv("XV2_BN_REVERSE"); return e ? atoi(e) : 3; }();
     return (v >> bit) & 1;
@@ -142,8 +154,9 @@ static int bn_reverse(int bit) {
 
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op, int64_t npix, int C, int rpb, int cgw,
-                                                              double* __restrict__ part, int rev) {
+                                                              double* __restrict__ part, int rev, const StatsFold fold) {
     __shared__ float sh[256 * 8 * Vec16<T>::NV];
+    __shared__ int fold_flag;
     const int tid = threadIdx.x;
     // rev: the row chunks are dispatched last-to-first (same chunk -> rows -> partial-row mapping, same sums): the
     // kernel that produced the tensors finished with their last rows
@@ -202,10 +215,17 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op,
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                out[(blockIdx.y * cgw + tid * 4 + k) * 2 + 0] = a0[k];
-                out[(blockIdx.y * cgw + tid * 4 + k) * 2 + 1] = a1[k];
+                double* o = out + (blockIdx.y * cgw + tid * 4 + k) * 2;
+                if (fold.on) {
+                    fold_store(o, a0[k], a1[k]);
+                } else {
+                    o[0] = a0[k];
+                    o[1] = a1[k];
+                }
             }
         }
+        // in-launch fold of the chunk rows (bn_fold.h): the chunk is the "tile", the channel group the column tile
+        if (fold.on) stats_fold_tile<double>(fold, part, chunk, blockIdx.y, blockIdx.y * cgw, cgw, &fold_flag);
     } else {
         // generic fallback: 64 channel lanes x 4 row lanes
         const int tx = tid & 63, ty = tid >> 6;
@@ -237,11 +257,16 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op,
                     a0 += shd[(q * 64 + tx) * 2];
                     a1 += shd[(q * 64 + tx) * 2 + 1];
                 }
-                out[c * 2] = a0;
-                out[c * 2 + 1] = a1;
+                if (fold.on) {
+                    fold_store(out + c * 2, a0, a1);
+                } else {
+                    out[c * 2] = a0;
+                    out[c * 2 + 1] = a1;
+                }
             }
             __syncthreads();
         }
+        if (fold.on) stats_fold_tile<double>(fold, part, chunk, 0, 0, C, &fold_flag);
     }
 }
 
@@ -249,46 +274,6 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op,
 // tiles for 32 channels into scratch[s][C][2]; the LAST block of a channel group to arrive (device-scope ticket)
 // then adds the S scratch rows in index order - so the result does not depend on which block that is - and, when
 // `fin.mean` is set, derives the BatchNorm coefficients and running statistics for its channels on the spot.
-struct BnFinalize {
-    double count;
-    const float* gamma;
-    const float* beta;
-    float eps, momentum;
-    float* running_mean;
-    float* running_var;
-    float* mean;      // nullptr: sums only
-    float* invstd;
-    float* scale;
-    float* shift;
-};
-
-// contraction off: the one-launch and the two-launch path inline this into different kernels and must agree bit
-// for bit (hipcc contracts a*b+c by default, and HIP's __dmul_rn & co. are plain operators)
-__device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1, double s2) {
-#pragma clang fp contract(off)
-    const double m = s1 / f.count;
-    const double mm = m * m;
-    double var = s2 / f.count - mm;
-    if (var < 0.0) var = 0.0;
-    const double is = 1.0 / sqrt(var + (double)f.eps);
-    f.mean[c] = (float)m;
-    f.invstd[c] = (float)is;
-    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-    const float sc = g * (float)is;
-    const float msc = (float)m * sc;
-    f.scale[c] = sc;
-    f.shift[c] = b - msc;
-    if (f.running_mean) {
-        const double vc = var * f.count;
-        const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;
-        const float keep = 1.f - f.momentum;
-        const float km = keep * f.running_mean[c], kv = keep * f.running_var[c];
-        const float am = f.momentum * (float)m, av = f.momentum * (float)unb;
-        f.running_mean[c] = km + am;
-        f.running_var[c] = kv + av;
-    }
-}
-
 template <typename T>
 __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__ part, int64_t tiles, int C, int S,
                                                            double* __restrict__ scratch, unsigned* __restrict__ tickets,
@@ -386,7 +371,7 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
 
 // ticket counters for reduce_stats_kernel: a zero-initialised device pool handed out round-robin; every user
 // returns its counters to zero, so concurrent launches on different streams never share a live ticket.
-static unsigned* take_tickets(int n) {
+unsigned* take_tickets(int n) {
     static unsigned* pool = nullptr;
     static size_t cursor = 0;
     static std::mutex mu;
@@ -691,9 +676,22 @@ static int column_sums(const ColOp<MODE, T>& op, int64_t npix, int C, double* su
     part = (part + 15) & ~(size_t)15;
     double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
+    // XV2_BN_FOLD bit 1: the chunk rows are folded inside the launch (bn_fold.h); default: the separate reduction launch
+    StatsFold fold;
+    memset(&fold, 0, sizeof(fold));
+    if (bn_fold_backward() && stats_fold_plan(fold, g.chunks, 1, g.cgw ? g.groups : 1, C)) {
+        fold.scratch = scratch;
+        fold.sums = sums;
+        fold.f0 = f0;
+        fold.f1 = f1;
+        fold.part_stride = C;
+        fold.tickets = take_tickets(stats_fold_tickets(fold));
+        XV2_CHECK_ARG(fold.tickets, "column_sums: ticket pool allocation failed");
+    }
     hipLaunchKernelGGL((column_partials_kernel<MODE, T>), dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix,
-                       C, g.rpb, g.cgw, dpart, MODE == 1 ? bn_reverse(2) : 0);
+                       C, g.rpb, g.cgw, dpart, MODE == 1 ? bn_reverse(2) : 0, fold);
     XV2_CHECK_LAUNCH();
+    if (fold.on) return XV2_OK;
     return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
 

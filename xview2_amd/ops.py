@@ -148,6 +148,13 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
         return ohwi, ihwo
     key = (w_oihw.data_ptr(), Cout, Cin, KH, KW, cin_pad, code)
     e = _packs.get(key)
+    base = w_oihw._base if w_oihw._base is not None else w_oihw
+    if e is not None and e.owner() is not base:
+        # the address alone is not an identity: the allocator hands a freed model's parameter storage to the next model,
+        # whose fresh tensors carry the same version counter - the entry must belong to this very parameter
+        e = None
+        del _packs[key]
+        _pack_table = None
     fresh = e is not None and e.version == w_oihw._version and e.epoch == WEIGHT_EPOCH
     _pack_tick += 1
     if fresh and (e.ohwi is not None or not want_ohwi) and (e.ihwo is not None or not want_ihwo):
@@ -173,7 +180,6 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
         e.ihwo = _act((cin_pad, KH * KW, Cout), w_oihw, pdt)
         _pack_table = None
     e.w = w_oihw.detach()
-    base = w_oihw._base if w_oihw._base is not None else w_oihw
     e.owner = weakref.ref(base)        # the parameter; once it is gone the entry only wastes memory
     e.tick = _pack_tick
     call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo, code)
@@ -283,10 +289,6 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         if ihwo_out is not None:
             ihwo_out.append(ihwo)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
-        part = None
-        if want_stats:
-            tiles = query("xv2_conv2d_forward_stats_tiles", d)
-            part = _f32((tiles, Coutg, 2), x0)
         wsb = query("xv2_conv2d_forward_workspace", d)
         if fused is not None:
             fsc, fsh, fres, fact = fused
@@ -294,28 +296,31 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
                  Ptr(fsh, gi * Coutg), None if fres is None else Ptr(fres, gi * Coutg), Cout_t, fact,
                  Ptr(y, gi * Coutg), Cout_t, _ws(wsb, x0) if wsb else None)
             continue
-        call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
-             None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, part,
-             _ws(wsb, x0) if wsb else None)
-        if want_stats and S > 1 and (((N * OH * OW) // S) % query("xv2_conv2d_forward_stats_tile_rows", d) != 0
-                                     or tiles % S != 0):
+        fold_ok = False
+        if want_stats:
+            tiles = query("xv2_conv2d_forward_stats_tiles", d)
             # a part's rows must END on a statistics-tile boundary of the plan (64- or 128-row M tiles, 64-row split-K
             # reduce tiles): otherwise the middle tile straddles two BatchNorm batches (e.g. 2 x 10 x 10 rows at /32 of
             # a 320 x 320 tile: M = 200, four 64-row tiles, 100 rows per part)
-            stats_ok = False
-        elif want_stats:
-            scratch = _stats_scratch(Coutg, x0.device)
-            tp = tiles // S
-            for h in range(S):                   # part h = rows [h*M/S, (h+1)*M/S) = tiles [h*tp, (h+1)*tp)
-                ph = Ptr(part, h * tp * Coutg * 2)
-                o = h * Cout_t + gi * Coutg
-                if coeffs is None:
-                    call("xv2_bn_reduce_stats", ph, tp, Coutg, Ptr(sums, o * 2), scratch)
-                else:
-                    og = gi * Coutg
-                    call("xv2_bn_reduce_finalize", ph, tp, Coutg, Ptr(sums, o * 2), scratch, float(N * OH * OW // S),
-                         _off(bn.weight, og), _off(bn.bias, og), float(bn.eps), float(bn.momentum),
-                         _off(bn.running_mean, og), _off(bn.running_var, og), *(Ptr(t, o) for t in coeffs))
+            fold_ok = tiles > 0 and (S == 1 or (tiles % S == 0 and
+                                                ((N * OH * OW) // S) % query("xv2_conv2d_forward_stats_tile_rows", d) == 0))
+        if fold_ok:
+            # convolution + statistics (+ coefficients) in one launch: the last blocks to arrive fold the tile partials
+            og = gi * Coutg
+            fin = [None] * 4 if coeffs is None else [Ptr(t, og) for t in coeffs]
+            call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
+                 _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
+                 S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
+                 _off(bn.weight, og) if bn is not None else None, _off(bn.bias, og) if bn is not None else None,
+                 float(bn.eps) if bn is not None else 0.0, float(bn.momentum) if bn is not None else 0.0,
+                 _off(bn.running_mean, og) if coeffs is not None else None,
+                 _off(bn.running_var, og) if coeffs is not None else None, *fin)
+        else:
+            call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
+                 None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, None,
+                 _ws(wsb, x0) if wsb else None)
+            if want_stats:
+                stats_ok = False
     assert cin_w <= C0g + C1t
     if want_stats and not stats_ok:
         sums, coeffs = None, None           # _bn_forward takes the statistics of each part from y
