@@ -153,7 +153,12 @@ __device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* pa
         unsigned* t = f.tickets + ((size_t)(s * f.ngroups + g) * f.ntn + tn);
         const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)(gcount - 1);
-        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) {
+            __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // partial and scratch rows live in buffers that are re-used launch after launch: one agent-scope acquire
+            // drops whatever this CU / XCD still caches of them before the rows are read
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         *flag = last;
     }
     __syncthreads();
@@ -172,7 +177,10 @@ __device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* pa
         unsigned* t = f.tickets + (size_t)f.S * f.ngroups * f.ntn + tn;
         const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (unsigned)(f.S * f.ngroups - 1);
-        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) {
+            __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         *flag = last;
     }
     __syncthreads();

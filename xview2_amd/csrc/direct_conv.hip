@@ -176,9 +176,12 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     __syncthreads();
     for (int patch = p0; patch < p1; ++patch) {
         if (patch + 1 < p1) hload(patch + 1);
-        f32x16 acc;
+        // TWO accumulators, alternating: a wave owns ONE 32 x 32 output tile, so with a single accumulator every MFMA
+        // waits for the previous one (v_mfma_f32_32x32x16_bf16: 64 cycles result latency against 32 cycles of issue) and
+        // with one wave per SIMD nothing else fills the pipe - the 108-MFMA chain of the F32X3 form ran at half rate
+        f32x16 acc, acc2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.f;
         // 9 taps x 32 channels out of LDS; wave = output row, lane&31 = output column
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -195,21 +198,21 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
                     const bf16x8 bm = *reinterpret_cast<const bf16x8*>(b + D_PLW + kk * 16);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + 2 * D_PLW + kk * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2, 0, 0, 0);
                 }
                 continue;
             }
             if constexpr (HS) {      // bf16 image in LDS: a 16-byte read IS the 8-channel MFMA operand
                 const __bf16* a = halo_h + ((wave + 1 + dh) * D_HW + (l31 + 1 + dw)) * D_LDH + 8 * h;
                 const __bf16* b = wts_h + (t * 32 + l31) * D_LDH + 8 * h;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a + kk * 16),
-                                                                  *reinterpret_cast<const bf16x8*>(b + kk * 16), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a),
+                                                              *reinterpret_cast<const bf16x8*>(b), acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a + 16),
+                                                               *reinterpret_cast<const bf16x8*>(b + 16), acc2, 0, 0, 0);
                 continue;
             }
             if constexpr (BF16) {
@@ -223,7 +226,8 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
                                        (__bf16)a1.x, (__bf16)a1.y, (__bf16)a1.z, (__bf16)a1.w};
                     const bf16x8 bf = {(__bf16)b0.x, (__bf16)b0.y, (__bf16)b0.z, (__bf16)b0.w,
                                        (__bf16)b1.x, (__bf16)b1.y, (__bf16)b1.z, (__bf16)b1.w};
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                    if (kk == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+                    else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2, 0, 0, 0);
                 }
                 continue;
             }
@@ -238,6 +242,10 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
             }
+        }
+        if constexpr (BF16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         }
         // epilogue straight from registers: a pixel's 32 channels are one 128-byte line (lanes 0..31)
         const int tw = patch % tiles_w;

@@ -49,6 +49,22 @@ constexpr int igemm_main_floats() {
     return loop > epi ? loop : epi;
 }
 
+// 16-byte device-scope (write-through / L1-bypassing) accesses of the in-launch split-K sum
+__device__ __forceinline__ void sk_store(float* p, const float4& v) {
+    typedef unsigned long long u64;
+    const u64 lo = ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const u64 hi = ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store(reinterpret_cast<u64*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 sk_load(const float* p) {
+    typedef unsigned long long u64;
+    const u64 lo = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 hi = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                       __uint_as_float((unsigned)(hi >> 32)));
+}
+
 // bf16-compute variant ("--precision 16"): operands stay fp32 in HBM, are rounded to bf16 (RNE) while being staged
 // into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything outside the MFMA is unchanged.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -165,8 +181,8 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         const int m = m0 + tid;
         int off = -1;
         if (m < ci.M) {
-            if (p.ksplit > 1) {
-                off = m;   // slab rows are plain GEMM rows
+            if (p.ksplit > 1 && !p.sk_tickets) {
+                off = m;   // slab rows are plain GEMM rows (summed by splitk_reduce_kernel)
             } else {
                 const int n = m / ohw;
                 const int rem = m - n * ohw;
@@ -483,6 +499,27 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     constexpr int CLD = BN + 4;
     constexpr int HROWS = BM / NH;          // rows staged per pass
     float* Cs = smem;
+    // Split-K summed IN the launch (p.sk_tickets): the K-split blocks of an output tile draw an arrival ticket; the LAST
+    // to arrive is the tile's reducer - it keeps its partial tile in LDS, waits until the others (all of them already in
+    // their epilogues) have published their slabs write-through, adds the slabs in slab order (its own share taken from
+    // LDS: the same bits it would have written) and runs the ordinary epilogue.  One slab write and one slab read per
+    // tile saved against the separate slab-sum kernel, and that launch with them; bit-reproducible (fixed slab order).
+    // (not for bf16 storage: the reducer needs its slab loads in flight - 28 registers - and that kernel lives on three
+    // blocks per CU at 152 of 168 registers; its slabs keep going to splitk_reduce_kernel)
+    const bool skf = !HS && p.ksplit > 1 && p.sk_tickets != nullptr;
+    bool sk_reducer = false;
+    unsigned* skt = nullptr;
+    if (skf) {
+        skt = p.sk_tickets + 2 * ((size_t)tm * ntn + tn);
+        int* flag = reinterpret_cast<int*>(red);
+        if (tid == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(skt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = prev == (unsigned)(gridDim.z - 1);
+        }
+        __syncthreads();
+        sk_reducer = *flag != 0;
+    }
+    float4 ss1 = make_float4(0, 0, 0, 0), ss2 = ss1;      // reducer: statistics of the summed tile (this thread's 4 channels)
     const bool do_stats = p.stats && p.ksplit == 1 && !p.bnb_y;
     if (do_stats) {
 #pragma unroll
@@ -542,9 +579,24 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             st[1] = s2;
         }
     }
+    if (skf && sk_reducer && hh == 0) {
+        // every other K-split block of this tile has arrived, i.e. is past its main loop: wait for their slabs
+        if (tid == 0) {
+            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+                if (__hip_atomic_load(skt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __hip_atomic_store(skt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(skt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the slab workspace is re-used launch after launch: drop whatever this CU / XCD still caches of it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
     {
         constexpr int F4R = BN / 4;
-        float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
+        float* slab = (p.ksplit > 1 && !(skf && sk_reducer)) ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
+        const size_t slab_elems = (size_t)ci.M * p.Nout;
         // BN-backward statistics of the producer layer (see IgemmParams::bnb_*): a thread keeps ONE group of 4
         // channels through the loop (256 % F4R == 0), so its coefficients are loaded once
         const bool bnb = p.bnb_y && !slab;
@@ -564,8 +616,36 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             float4 v = *reinterpret_cast<const float4*>(Cs + (row - hh * HROWS) * CLD + c);
             const int col = n0 + c;
             if (slab) {
-                *reinterpret_cast<float4*>(slab + (size_t)off * p.Nout + col) = v;
+                float* dst = slab + (size_t)(skf ? m0 + row : off) * p.Nout + col;
+                if (skf) {        // write-through (sc1): the reducer on another XCD reads it in this launch
+                    sk_store(dst, v);
+                } else {
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
                 continue;
+            }
+            if (skf) {            // reducer: slabs in slab order, own share from LDS
+                const float* src = p.part + (size_t)(m0 + row) * p.Nout + col;
+                float4 t[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    t[z] = make_float4(0, 0, 0, 0);
+                    if (z < (int)gridDim.z && z != (int)blockIdx.z) t[z] = sk_load(src + (size_t)z * slab_elems);
+                }
+                float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int z = 0; z < 8; ++z) {
+                    if (z < (int)gridDim.z) {
+                        const float4 u = z == (int)blockIdx.z ? v : t[z];
+                        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                    }
+                }
+                v = a;
+                if (p.stats) {    // statistics on the values as they will be stored
+                    const float4 q = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));
+                    ss1.x += q.x; ss1.y += q.y; ss1.z += q.z; ss1.w += q.w;
+                    ss2.x += q.x * q.x; ss2.y += q.y * q.y; ss2.z += q.z * q.z; ss2.w += q.w * q.w;
+                }
             }
             if (p.bias) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
@@ -624,6 +704,39 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     }
     if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
   }
+    if (skf && !sk_reducer) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its slab stores are at the coherence point
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(skt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (skf && p.stats) {
+        constexpr int F4R = BN / 4;
+        __syncthreads();                           // every thread is done reading Cs: reuse it for the fold
+        float* sb = smem + tid * 8;
+        sb[0] = ss1.x; sb[1] = ss1.y; sb[2] = ss1.z; sb[3] = ss1.w;
+        sb[4] = ss2.x; sb[5] = ss2.y; sb[6] = ss2.z; sb[7] = ss2.w;
+        __syncthreads();
+        if (tid < BN) {
+            constexpr int RL = 256 / F4R;          // row lanes holding the same channel group
+            const int grp = tid >> 2, comp = tid & 3;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                s1 += smem[(grp + F4R * q) * 8 + comp];
+                s2 += smem[(grp + F4R * q) * 8 + 4 + comp];
+            }
+            float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
+            if (p.fold.on) {
+                fold_store(st, s1, s2);
+            } else {
+                st[0] = s1;
+                st[1] = s2;
+            }
+        }
+        if (p.fold.on) stats_fold_tile<float, true>(p.fold, p.stats, tm, tn, n0, BN, rowoff);
+        return;
+    }
     // the tile rows are reduced (and the BatchNorm coefficients derived) by the last blocks to arrive: bn_fold.h
     if (do_stats && p.fold.on) stats_fold_tile<float, false>(p.fold, p.stats, tm, tn, n0, BN, rowoff);
 }
@@ -837,16 +950,22 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     }
 }
 
+// XV2_SPLITK_FOLD=0 (A/B runs): split-K slabs summed by the separate splitk_reduce_kernel launch (rounds 1-2)
+static bool splitk_fold_enabled() {
+    static const int v = [] { const char* e = getenv("XV2_SPLITK_FOLD"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
 int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
-    return ks > 1 ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
+    return (ks > 1 && !(splitk_fold_enabled() && math != XV2_MATH_BF16_STORE)) ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
 }
 
 int igemm_stats_tile_rows(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
-    return ks > 1 ? SPLITK_ROWS : bm;
+    return (ks > 1 && !(splitk_fold_enabled() && math != XV2_MATH_BF16_STORE)) ? SPLITK_ROWS : bm;
 }
 
 size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
@@ -902,6 +1021,18 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
+        if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8) {
+            // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
+            // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
+            const int64_t ntiles = cdiv(maxM, 128) * (p.Nout / 128);
+            p.sk_tickets = take_tickets((int)(2 * ntiles));
+            XV2_CHECK_ARG(p.sk_tickets, "igemm: ticket pool allocation failed");
+            if (int rc = complete_fold(p, cdiv(maxM, 128), p.Nout / 128)) return rc;
+            return p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                   : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
+                   : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
+                                                 : launch_one<128, 128, 2, 2, false>(p, stream);
+        }
         // split-K: the slab-sum kernel takes the statistics (64-row tiles, 256-column tiles) and folds them
         if (int rc = complete_fold(p, cdiv(maxM, SPLITK_ROWS), (int)cdiv(p.Nout, 256))) return rc;
         const StatsFold fold = p.fold;
@@ -989,6 +1120,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bias = nullptr;
     p.stats = nullptr;
     p.part = nullptr;
+    p.sk_tickets = nullptr;
     p.ksplit = 1;
     p.cin_real = 3;
     p.math = d->math;

@@ -28,6 +28,8 @@ struct IgemmParams {
     float* Out1;
     float* stats;
     float* part;       // split-K slabs [ksplit][M][Nout] (ksplit > 1 only)
+    unsigned* sk_tickets;   // != NULL: the slabs are summed in-launch by the last K-split block of each output tile
+                            // (two zero-initialised counters per tile: arrivals, published slabs)
     unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
     int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
     int ldA0, ldA1;

@@ -322,7 +322,11 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
         if (threadIdx.x == 0) {          // ... before the ticket is drawn
             const unsigned prev = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             is_last = (prev == (unsigned)(S - 1));
-            if (is_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (is_last) {
+                __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the scratch rows are re-used launch after launch: drop what this CU / XCD still caches of them
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
         }
         __syncthreads();
         if (!is_last) return;

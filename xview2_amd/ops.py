@@ -425,6 +425,9 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
 # on a side stream concurrently with the backward-data / BatchNorm chain: the tails of the many ~100 us encoder
 # launches overlap instead of serialising.  join_wgrad_stream() is called before anything consumes the gradients.
 ASYNC_WGRAD = os.environ.get("XV2_ASYNC_WGRAD", "1") != "0"
+# which weight gradients go to the side stream: "all" (default) | "3x3" (only multi-tap layers; the 1x1 layers run on the
+# compute stream right after their backward-data - VERDICT r02 item 6 A/B) | "1x1"
+WGRAD_SIDE = os.environ.get("XV2_WGRAD_SIDE", "all")
 _wgrad_stream = None
 
 
@@ -468,7 +471,8 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
     # Asynchronous only for the first gradient a parameter receives in a step AND when it goes straight into the
     # flat buffer: autograd then merely adopts the tensor.  Any other case (plain autograd accumulation, shared
     # weights' second contribution) involves an accumulation kernel on the compute stream and stays in order.
-    out = grad_slot(weight if wparam is None else wparam) if ASYNC_WGRAD else None
+    side_ok = ASYNC_WGRAD and (WGRAD_SIDE == "all" or (WGRAD_SIDE == "3x3") == (g.kh * g.kw > 1))
+    out = grad_slot(weight if wparam is None else wparam) if side_ok else None
     if out is None:
         # Second (third ...) gradient of a SHARED weight in this step (SiameseUNet, ParallelUNet): the first one may
         # still be in flight on the side stream, and autograd's accumulation / the reducer's copy of the slot run on
