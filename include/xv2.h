@@ -429,6 +429,23 @@ int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* tot
 int xv2_prof_num_records(void);
 int xv2_prof_record(int i, int* kid, double* ms, double* flops, double* algorithmic_bytes);
 
+/* ---- SyncBatchNorm statistics exchange without a collective library call ------------------------------------------
+ * (reference: Trainer(sync_batchnorm=gpus > 1), main.py:106 - torch.nn.SyncBatchNorm exchanges <= 32 KB per BatchNorm
+ * layer and direction, 126 ... 606 times per step).  Every rank allocates one exchange buffer (xv2_xchg_alloc returns
+ * its 64-byte hipIpc handle), the ranks of the node swap handles through their process group and map each other's
+ * buffers (xv2_xchg_open).  xv2_xchg_allreduce then sums `n` doubles over the ranks IN PLACE with one single-block launch:
+ * each rank stores its vector straight into every peer's buffer over xGMI (write-through 8-byte stores + a sequence-number
+ * flag), waits for the `world` flags of its own buffer and adds the rows in RANK order (identical bits on every rank).
+ * `seq` counts the exchanges of the job (same value on every rank); `peers_dev` = device array of the `world` mapped base
+ * pointers (own buffer at index `rank`); `timeout_flag` (device int) becomes non-zero if a peer never arrived. */
+size_t xv2_xchg_bytes(int world, size_t row_doubles);
+int xv2_xchg_alloc(int world, size_t row_doubles, void** base_out, unsigned char* handle64);
+int xv2_xchg_open(const unsigned char* handle64, void** peer_base);
+int xv2_xchg_close(void* peer_base);
+int xv2_xchg_free(void* base);
+int xv2_xchg_allreduce(double* vals, int n, const void* peers_dev, int world, int rank, size_t row_doubles,
+                       uint64_t seq, int* timeout_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,115 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path,
     assert rel(res[0][6], opt.flat_p.cpu()) <= 2.5e-3
 
 
+def _peer_exchange_worker(rank, world, port, outdir):
+    """one of `world` processes sharing cuda:0: the one-shot peer exchange against the rank-ordered sum computed on the
+    host, many rounds, ragged sizes, uneven arrival (one rank sleeps / runs a kernel burst before some exchanges)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import time
+    import torch.distributed as dist
+    from xview2_amd import dist as xdist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        px = xdist.PeerExchange()
+        bad = 0
+        g = torch.Generator().manual_seed(7)                  # same stream of sizes / values on every rank
+        burn = torch.randn(2048, 2048, device="cuda")
+        for it in range(300):
+            n = int(torch.randint(1, 4097, (1,), generator=g))
+            rows = torch.randn(world, n, generator=g, dtype=torch.float64) * (10.0 ** float(torch.randint(-3, 4, (1,), generator=g)))
+            want = rows[0].clone()
+            for r in range(1, world):
+                want += rows[r]                               # rank order, like the kernel
+            t = rows[rank].cuda()
+            if it % 7 == rank:                                # uneven load: this rank arrives late
+                time.sleep(0.002)
+                for _ in range(3):
+                    burn = burn @ burn * 1e-3
+            px.all_reduce_(t)
+            if not torch.equal(t.cpu(), want):
+                bad += 1
+        px.check()
+        # latency probe: back-to-back exchanges of a 2 x 256-channel statistics vector (what a mid-size BatchNorm sends)
+        t = torch.ones(512, dtype=torch.float64, device="cuda")
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(200):
+            px.all_reduce_(t)
+            t.fill_(1.0)
+        torch.cuda.synchronize()
+        us = (time.time() - t0) / 200 * 1e6
+        px.seq -= 200
+        try:
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                   "r03_xchg_latency.txt"), "a") as fh:
+                fh.write("world %d rank %d: %.1f us per one-shot exchange of 512 doubles (launch + peer stores + flags + sum, "
+                         "ranks sharing one GPU)\n" % (world, rank, us))
+        except OSError:
+            pass
+        torch.save((rank, bad, px.seq), os.path.join(outdir, "px%d.pt" % rank))
+        dist.barrier()
+        px.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_shot_peer_exchange_sums_in_rank_order_under_uneven_load(tmp_path, world):
+    """include/xv2.h xv2_xchg_allreduce (the SyncBatchNorm statistics exchange without a collective call): `world`
+    processes on cuda:0 map each other's exchange buffers over hipIpc; 300 exchanges of 1 .. 4096 doubles must equal the
+    rank-ordered host sum BIT FOR BIT on every rank, with one rank arriving late every few rounds"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_peer_exchange_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for r in range(world):
+        rank, bad, seq = torch.load(os.path.join(str(tmp_path), "px%d.pt" % r), weights_only=False)
+        assert rank == r and bad == 0 and seq == 300
+
+
+def _two_rank_worker_oneshot(rank, world, port, outdir, encoder):
+    os.environ["XV2_SYNCBN"] = "oneshot"
+    _two_rank_worker(rank, world, port, outdir, encoder)
+
+
+def test_one_shot_syncbn_equals_the_collective_path_bit_for_bit(tmp_path):
+    """the two-rank SyncBatchNorm training step with XV2_SYNCBN=oneshot (statistics exchanged by xv2_xchg_allreduce) must
+    reproduce the run whose statistics travel through torch.distributed.all_reduce: loss, logits, gradients, running
+    statistics, updated parameters - every bit (both sum two fp64 rows in rank order)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for mode, target in (("rccl", _two_rank_worker), ("oneshot", _two_rank_worker_oneshot)):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        out = tmp_path / mode
+        out.mkdir()
+        procs = [ctx.Process(target=target, args=(r, 2, port, str(out), "resnest50")) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+        res[mode] = [torch.load(os.path.join(str(out), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    for r in range(2):
+        a, b = res["rccl"][r], res["oneshot"][r]
+        assert a[1] == b[1]
+        for u, v in zip(a[2:], b[2:]):
+            assert torch.equal(u, v)
+
+
 def _run_bench(*argv, timeout=900):
     import json
     import subprocess

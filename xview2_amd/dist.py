@@ -139,3 +139,90 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.side)
         self.handles = []
         return 1.0 / self.world
+
+
+class PeerExchange:
+    """One-shot peer-to-peer all-reduce of small fp64 vectors (include/xv2.h xv2_xchg_*): the SyncBatchNorm statistics
+    exchange as ONE single-block launch on the compute stream - every rank stores its vector straight into its peers'
+    exchange buffers (hipIpc-mapped, xGMI stores) and adds the rows in rank order - instead of one RCCL collective
+    (~20-30 us of launch + ring latency) per BatchNorm layer and direction.  All ranks must live on one node.
+    Opt-in: XV2_SYNCBN=oneshot (the default keeps torch.distributed.all_reduce = RCCL: the peer path could only be
+    developed with ranks sharing ONE GPU here - tests/test_dist_gpu.py - never on a multi-GPU box)."""
+    ROW = 2 * 2 * 4096          # doubles per row: S <= 2 parts x [C <= 4096][2]
+
+    def __init__(self, group=None):
+        import ctypes
+        from ._lib import lib
+        self.lib = lib()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        base = ctypes.c_void_p()
+        handle = (ctypes.c_ubyte * 64)()
+        self._check(self.lib.xv2_xchg_alloc(self.world, ctypes.c_size_t(self.ROW), ctypes.byref(base), handle))
+        self.base = base.value
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        self.peers = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                self.peers.append(self.base)
+                continue
+            pb = ctypes.c_void_p()
+            buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+            self._check(self.lib.xv2_xchg_open(buf, ctypes.byref(pb)))
+            self.peers.append(pb.value)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.peers_dev = torch.tensor(self.peers, dtype=torch.int64).to(dev)
+        self.timeout = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seq = 0
+        dist.barrier(group=group)            # every rank has mapped every buffer before the first store
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("peer exchange: %s" % self.lib.xv2_last_error().decode())
+
+    def all_reduce_(self, t):
+        """in-place SUM over the ranks of a contiguous fp64 device tensor (<= ROW elements), rank-ordered (bit-identical
+        on every rank), enqueued on the current stream"""
+        from ._capi import call
+        if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() > self.ROW:
+            raise RuntimeError("PeerExchange.all_reduce_: contiguous fp64 tensor of <= %d elements expected" % self.ROW)
+        call("xv2_xchg_allreduce", t, t.numel(), self.peers_dev, self.world, self.rank, self.ROW, self.seq, self.timeout)
+        self.seq += 1
+        return t
+
+    def check(self):
+        """host-side: did any exchange give up waiting for a peer? (synchronises)"""
+        v = int(self.timeout.item())
+        if v:
+            raise RuntimeError("peer exchange timed out waiting for rank %d" % (v - 1))
+
+    def close(self):
+        for r, pb in enumerate(self.peers):
+            if r != self.rank and pb:
+                self.lib.xv2_xchg_close(ctypes_voidp(pb))
+        self.peers = []
+
+
+def ctypes_voidp(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+_peer_exchange = None
+
+
+def stats_all_reduce_(t):
+    """SUM all-reduce of a BatchNorm statistics vector (fp64, in place): RCCL by default, the one-shot peer exchange with
+    XV2_SYNCBN=oneshot"""
+    global _peer_exchange
+    if os.environ.get("XV2_SYNCBN", "rccl") == "oneshot" and t.is_cuda and t.numel() <= PeerExchange.ROW:
+        if _peer_exchange is None:
+            _peer_exchange = PeerExchange()
+        return _peer_exchange.all_reduce_(t)
+    dist.all_reduce(t)
+    return t
+
+
+def reset_peer_exchange():
+    global _peer_exchange
+    _peer_exchange = None

@@ -568,7 +568,8 @@ def _bn_train_coeffs(sums, count, bn, like, S=1):
         # every rank holds the same per-GPU batch (weak scaling), so the global count is local*world and the
         # exchange is ONE in-place all-reduce of the fp64 (sum, sum-of-squares) vector - no host round trip; the S
         # parts of a split batch travel in the same collective
-        dist.all_reduce(sums)
+        from .dist import stats_all_reduce_
+        stats_all_reduce_(sums)
         count = float(count) * dist.get_world_size()
     shape = (S, C) if S > 1 else (C,)
     mean, invstd, scale, shift = (_f32(shape, like) for _ in range(4))
@@ -745,7 +746,8 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
             dgamma.add_(tmp[0])
             dbeta.add_(tmp[1])
     if training and _sync_group(bn):
-        dist.all_reduce(sums2)
+        from .dist import stats_all_reduce_
+        stats_all_reduce_(sums2)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
     for h in range(S):
