@@ -253,6 +253,18 @@ int xv2_bn_act_backward_apply_mask(const void* dz, int lddz, const uint8_t* zmas
                                    const double* sums2, double count, int act, int train, void* dy,
                                    int lddy, void* dres, int lddres, int64_t npix, int C, int dtype, void* stream);
 
+/* BatchNorm over a handful of rows: y [parts * rows][C] fp32, rows <= 64 (ResNeSt split attention's bn1 on the pooled
+ * [N, inter] vector, model/unet.py:52 -> resnest SplAtConv2d).  ONE launch each way: batch statistics (two-pass fp64 per
+ * channel), running-statistics update (part after part), coefficients [parts][C] and z = act(bn(y)) forward;
+ * dy, dgamma, dbeta (summed over the parts) backward, the activation derivative taken from z.  Same arithmetic as the
+ * general path (xv2_bn_tensor_stats + xv2_bn_finalize + xv2_bn_act_forward / xv2_bn_act_backward_*) to fp32 rounding. */
+int xv2_bn_rows_forward(const float* y, int rows, int C, int parts, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, int train, int act,
+                        float* mean, float* invstd, float* scale, float* shift, float* z, void* stream);
+int xv2_bn_rows_backward(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                         const float* gamma, int rows, int C, int parts, int act, int train, float* dy,
+                         float* dgamma, float* dbeta, void* stream);
+
 /* ---- layer-level entry points ---------------------------------------------------------------
  * One call = the launch sequence of one reference layer (model/layers.py:89-100 ConvLayer: conv -> norm -> activation;
  * the bottleneck convolutions of the encoders), issued in the same order on the same stream as the op-level calls

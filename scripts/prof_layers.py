@@ -6,6 +6,9 @@ from xview2_amd import _capi, criterion, networks
 from xview2_amd.optim import FlatAdamW
 from xview2_amd.weights import deterministic_init_
 a = bench.make_args(sys.argv[1] if len(sys.argv) > 1 else "resnet50")
+if len(sys.argv) > 2 and sys.argv[2] == "16":
+    bench.set_precision(16)
+TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 45
 m = networks.UNetLoc(a); deterministic_init_(m, 1); m.cuda().train()
 opt = FlatAdamW(m.parameters()); lf = criterion.Loss(a)
 x, y = bench.synthetic_batch(a, 2, 1024, 1, "cuda")
@@ -26,7 +29,7 @@ tot = sum(r[0] for r in rows)
 print("launches %d total %.2f ms" % (n, tot))
 rows.sort(reverse=True)
 acc = 0
-for ms, gf, mb, name, i in rows[:45]:
+for ms, gf, mb, name, i in rows[:TOP]:
     acc += ms
     print("#%3d %-34s %7.3f ms %8.2f GF %7.1f TF  %7.1f MB(alg) cum %.1f%%" % (i, name, ms, gf, gf / ms, mb, 100 * acc / tot))
 # efficiency buckets

@@ -742,8 +742,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
 }
 
 // Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
-// for 64-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.
-constexpr int SPLITK_ROWS = 64;
+// for 32-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.  (32 rows, all slabs
+// of a row in flight: 64-row tiles left a 128-block grid latency-bound - cfg3 bf16 20.5 -> 19.2 ms; 16 rows: slower)
+constexpr int SPLITK_ROWS = 32;
 template <typename OT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M,
                                                              int Nout, const float* __restrict__ bias,
@@ -765,9 +766,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         if (c < Nout) {
             float4 bv = make_float4(0, 0, 0, 0);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll 2
             for (int r = r0 + ty; r < min(r0 + SPLITK_ROWS, M); r += 4) {
+                // all slabs of the row in flight at once (ksplit <= 8), then the fixed-order sum
+                float4 t[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z)
+                    t[z] = z < ksplit ? *reinterpret_cast<const float4*>(part + z * slab + (size_t)r * Nout + c)
+                                      : make_float4(0, 0, 0, 0);
                 float4 a = make_float4(0, 0, 0, 0);
-                for (int z = 0; z < ksplit; ++z) {
+#pragma unroll
+                for (int z = 0; z < 8; ++z)
+                    if (z < ksplit) {
+                        a.x += t[z].x; a.y += t[z].y; a.z += t[z].z; a.w += t[z].w;
+                    }
+                for (int z = 8; z < ksplit; ++z) {
                     const float4 v = *reinterpret_cast<const float4*>(part + z * slab + (size_t)r * Nout + c);
                     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                 }

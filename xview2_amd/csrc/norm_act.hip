@@ -628,6 +628,86 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
     }
 }
 
+// BatchNorm over a HANDFUL of rows (split attention's bn1 on the [N, inter] vector of pooled features, N = the batch:
+// ResNeSt SplAtConv2d, model/unet.py:52): statistics, running-statistics update, coefficients, normalise + activation in
+// ONE launch, one thread per channel (two-pass fp64 statistics over its <= 64 rows).  Replaces the five launches of the
+// general path (column partials, fold, un-shift, finalise, apply) - ~4 us each on a [2, 256] tensor, 16 .. 66 times per
+// forward.  S parts = S independent BatchNorm batches back to back (ops.BN_SPLIT), running statistics in part order.
+__global__ void __launch_bounds__(256) bn_rows_fwd_kernel(const float* __restrict__ y, int rows, int C, int S, int act,
+                                                           int train, BnFinalize fin, float* __restrict__ z) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* ys = y + (size_t)s * rows * C + c;
+        double m, var;
+        if (train) {
+            double a = 0.0;
+            for (int r = 0; r < rows; ++r) a += (double)ys[(size_t)r * C];
+            m = a / rows;
+            double v = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                const double d = (double)ys[(size_t)r * C] - m;
+                v += d * d;
+            }
+            var = v / rows;
+        } else {
+            m = (double)fin.running_mean[c];
+            var = (double)fin.running_var[c];
+        }
+        const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+        const float sc = g * is;
+        const float sh = b - (float)m * sc;
+        fin.mean[s * C + c] = (float)m;
+        fin.invstd[s * C + c] = is;
+        fin.scale[s * C + c] = sc;
+        fin.shift[s * C + c] = sh;
+        if (train && fin.running_mean) {
+            const double unb = rows > 1 ? var * rows / (rows - 1.0) : var;
+            fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+            fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unb;
+        }
+        for (int r = 0; r < rows; ++r)
+            z[((size_t)s * rows + r) * C + c] = apply_act(__fmaf_rn(ys[(size_t)r * C], sc, sh), act);
+    }
+}
+
+// backward of the same: dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)), g = dz * act'(z); dgamma / dbeta are the
+// sums over all parts
+__global__ void __launch_bounds__(256) bn_rows_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           int rows, int C, int S, int act, int train,
+                                                           float* __restrict__ dy, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float gm = gamma ? gamma[c] : 1.f;
+    float tg = 0.f, tb = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const size_t o = (size_t)s * rows * C + c;
+        const float mu = mean[s * C + c], is = invstd[s * C + c];
+        float sg = 0.f, sgx = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const size_t i = o + (size_t)r * C;
+            const float g = dz[i] * act_grad_from_output(z[i], act);
+            sg += g;
+            sgx += g * ((y[i] - mu) * is);
+        }
+        const float invn = 1.f / (float)rows;
+        for (int r = 0; r < rows; ++r) {
+            const size_t i = o + (size_t)r * C;
+            const float g = dz[i] * act_grad_from_output(z[i], act);
+            const float xh = (y[i] - mu) * is;
+            dy[i] = train ? gm * is * (g - sg * invn - xh * sgx * invn) : gm * is * g;
+        }
+        tg += sgx;
+        tb += sg;
+    }
+    dgamma[c] = tg;
+    dbeta[c] = tb;
+}
+
 static inline int ew_grid(int64_t total) {
     int64_t b = cdiv(total, 256);
     if (b > bn_blocks(256 * 16)) b = bn_blocks(256 * 16);
@@ -880,4 +960,31 @@ extern "C" int xv2_bn_act_backward_apply_mask(const void* dz, int lddz, const ui
                                                          (const T*)y, ldy, mean, invstd, gamma, nullptr, nullptr, sums2,
                                                          count, act, train, (T*)dy, lddy, (T*)dres, lddres, npix, C,
                                                          stream));
+}
+
+extern "C" int xv2_bn_rows_forward(const float* y, int rows, int C, int parts, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int train, int act,
+                                   float* mean, float* invstd, float* scale, float* shift, float* z, void* stream) {
+    XV2_CHECK_ARG(y && z && mean && invstd && scale && shift && rows >= 1 && rows <= 64 && C >= 1 && parts >= 1,
+                  "bn_rows_forward: rows=%d (1..64) C=%d parts=%d", rows, C, parts);
+    XV2_CHECK_ARG(train || (running_mean && running_var), "bn_rows_forward: eval mode needs the running statistics");
+    BnFinalize f;
+    f.count = rows; f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
+    f.running_mean = running_mean; f.running_var = running_var;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    hipLaunchKernelGGL(bn_rows_fwd_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, y, rows, C, parts,
+                       act, train, f, z);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_bn_rows_backward(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                                    const float* gamma, int rows, int C, int parts, int act, int train, float* dy,
+                                    float* dgamma, float* dbeta, void* stream) {
+    XV2_CHECK_ARG(dz && z && y && mean && invstd && dy && dgamma && dbeta && rows >= 1 && rows <= 64 && C >= 1 && parts >= 1,
+                  "bn_rows_backward: rows=%d (1..64) C=%d parts=%d", rows, C, parts);
+    hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dz, z, y, mean,
+                       invstd, gamma, rows, C, parts, act, train, dy, dgamma, dbeta);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
 }

@@ -100,7 +100,12 @@ def fp32_math():
     exactly into three bf16 terms on its way into LDS and each product is issued as the six significant bf16 cross
     products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms < 2^-23 of |a||b| per product, i.e. the
     rounding class of an fp32 multiply) - 1.5-1.7x the exact-fp32 MFMA's throughput.  XV2_F32X3=0 selects the exact
-    fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain) everywhere."""
+    fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain) everywhere.
+    Two differences to keep in mind: (1) non-finite operands - the split forms inf - bf16(inf) = NaN in its residual terms,
+    so an operand that is +-Inf yields NaN where the fp32 MFMA would propagate Inf (both are already-diverged training
+    states; finite inputs are unaffected); (2) the producer-layer BatchNorm-backward statistics in the backward-data
+    epilogue (XV2_FUSE_BN_BWD, off by default) exist in the exact-fp32 kernels only: the *_bn_tiles queries return 0 in
+    this mode and the caller takes the separate column-sum pass."""
     return MATH_F32 if os.environ.get("XV2_F32X3", "1") == "0" else MATH_F32X3
 
 
@@ -655,6 +660,16 @@ def _mask_ok(C, act, half=False):
             (C % 256 == 0 or (C // W <= 256 and 256 % (C // W) == 0)))
 
 
+def _bn_rows_ok(y, rows, bn, training):
+    """the one-launch form for BatchNorm over a handful of rows (xv2_bn_rows_*): fp32 [rows, C] without a SyncBatchNorm
+    exchange (XV2_BN_ROWS=0: the general path, A/B runs)"""
+    return (BN_ROWS and y.dim() == 2 and y.dtype == torch.float32 and rows <= 64 and y.is_contiguous() and
+            not (training and _sync_group(bn)))
+
+
+BN_ROWS = os.environ.get("XV2_BN_ROWS", "1") != "0"
+
+
 def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False, split=1):
     """y raw [.., C]; returns z and the context needed by _bn_backward.  `coeffs`: (mean, invstd, scale, shift)
     when the statistics reduction already derived them (xv2_bn_reduce_finalize).  want_mask: also return the
@@ -664,6 +679,15 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
     npix = y.numel() // C
     S = split if training else 1
     rows = npix // S
+    if _bn_rows_ok(y, rows, bn, training) and residual is None and sums is None and coeffs is None and not want_mask:
+        # a handful of rows (split attention's bn1 on the pooled [N, inter] vector): one launch
+        blob = _f32((4, S, C) if S > 1 else (4, C), y)
+        z = torch.empty_like(y)
+        if training:
+            bn_stats_changed()
+        call("xv2_bn_rows_forward", y, rows, C, S, bn.weight, bn.bias, float(bn.eps), float(bn.momentum), bn.running_mean,
+             bn.running_var, 1 if training else 0, act, blob[0], blob[1], blob[2], blob[3], z)
+        return z, (blob[0], blob[1], float(rows), blob[2], blob[3])
     if training and coeffs is not None:
         mean, invstd, scale, shift = coeffs
         count = float(rows)
@@ -707,6 +731,12 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
     rows = npix // S
     dz = _same(dz, y).contiguous()
     dt = _dt(y)
+    if (_bn_rows_ok(y, rows, bn, training) and z is not None and z.dtype == torch.float32 and not want_res and rec is None
+            and mean.numel() == S * C):
+        dy = torch.empty_like(y)
+        dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
+        call("xv2_bn_rows_backward", dz, z, y, mean, invstd, gamma, rows, C, S, act, 1 if training else 0, dy, dgamma, dbeta)
+        return dy, None, dgamma, dbeta
     sums2 = torch.empty((S, C, 2) if S > 1 else (C, 2), dtype=torch.float64, device=y.device)
     dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
     wsn = query("xv2_bn_backward_workspace", rows, C)
