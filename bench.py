@@ -620,13 +620,17 @@ def main():
                         "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA",
                 "frac_of_fp32_mfma_peak_157.3": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if opt.precision == 32 else None,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command on an earlier run (PMC collection is not possible inside this process)",
+                                  "command on an earlier run of THIS round's kernels (scripts/profile_bench.sh; PMC "
+                                  "collection is not possible inside this process)",
                 "kernel": top["kernel"],
                 "algorithmic_bytes_per_launch": round(top["mbytes"] / top["launches"] * 1e6),
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                 "launches_timed": top["launches"],
-                "note": "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
+                "note": "since round 3 the launches of this kernel CONTAIN the split-K slab sums (57 per step, formerly "
+                        "splitk_reduce_kernel: 1.2 ms per step) and the BatchNorm statistics fold - same FLOPs over a longer "
+                        "launch, the step itself is faster (DESIGN.md section 4); "
+                        "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
                         "(weight-gradient kernels co-scheduled on a side stream); 'isolated' = same kernel with every "
                         "launch alone on the chip; per_kernel/all_mfma_kernels: an extra untimed pass with every "
                         "MFMA launch bracketed",

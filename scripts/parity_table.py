@@ -29,7 +29,11 @@ def main(src, dst):
             ("argmax_mismatch_cpu32_vs_f64", "argmax cpu32 vs f64"), ("loss_hip", "loss hip"),
             ("loss_cpu32", "loss cpu32"), ("grad_median_ratio_hip_over_cpu32", "grad err ratio hip/cpu32 (median)"),
             ("grad_median_err_hip", "grad err hip vs f64 (median)"),
-            ("grad_median_err_cpu32", "grad err cpu32 vs f64 (median)")]
+            ("grad_median_err_cpu32", "grad err cpu32 vs f64 (median)"),
+            # block-by-block rows (test_blockwise_teacher_forced_parity): oracle blocks fed with the HIP path's own inputs
+            ("blocks", "blocks compared"), ("block_max_rel", "worst block (max-abs rel)"),
+            ("block_max_rms_rel", "worst block (rms rel)"), ("block_max_rel_at", "at"),
+            ("argmax_agreement", "label agreement"), ("loss_rel", "loss rel")]
     out = ["# Model-level parity table (tests/test_model_gpu.py on MI355X)", "",
            "Logits errors are max-abs error / max-abs reference. `cond` is the CPU-fp32 oracle against an fp64 run of the",
            "same oracle (how well-conditioned the case is in fp32 at all); `strict` = plain 1e-3 gate against the CPU-fp32",
