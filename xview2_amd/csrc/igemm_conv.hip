@@ -879,6 +879,12 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     return XV2_OK;
 }
 
+// planner knob (tuning sweeps): K-tiles' worth of work charged per split-K block for writing / re-reading its slab
+static double slab_cost(double dflt) {
+    static const double v = [] { const char* e = getenv("XV2_SLAB_COST"); return e ? atof(e) : -1.0; }();
+    return v >= 0.0 ? v : dflt;
+}
+
 // tile shape and split-K factor; `nkt` = K tiles of the (single-class) problem, 0 disables split-K
 static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& bm, int& bn, int& ksplit) {
     bn = (Nout % 128 == 0) ? 128 : (Nout % 64 == 0 ? 64 : 32);
@@ -923,7 +929,7 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
         if (bn == 128 && nkt >= 16) {
             static const int ks_max_h = [] { const char* e = getenv("XV2_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
             for (int ks = 2; ks <= ks_max_h && nkt / ks >= 8; ++ks) {
-                const double c = cost(cdiv(M, 128) * ntn * ks, 128.0, (double)cdiv(nkt, ks) + 4.0, 1.0);
+                const double c = cost(cdiv(M, 128) * ntn * ks, 128.0, (double)cdiv(nkt, ks) + slab_cost(4.0), 1.0);
                 if (c < best * 0.95) {
                     best = c;
                     bm = 128;
@@ -940,7 +946,9 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     bm = 128;
     // per-FLOP efficiency of the 64-row tiles relative to 128 x 128: 0.92 with the fp32 MFMA; 0.65 in the split-bf16 form
     // (6-12 MFMAs per stage and barrier; measured 143 vs 190 TFLOP/s on the 116-GFLOP decoder layers)
-    const double eff64 = math == XV2_MATH_F32X3 ? 0.65 : 0.92;
+    // (64-channel outputs, round 3: 128 x 64 measured 5 % FASTER than 64 x 64 at equal rounds - dec4.c1 132 vs 126, l1.conv2 104
+    //  vs 98 TFLOP/s - so there the 64-row tile only wins when it needs fewer rounds)
+    const double eff64 = math == XV2_MATH_F32X3 ? (bn == 64 ? 0.48 : 0.65) : 0.92;
     const double c64 = rounds(cdiv(M, 64) * ntn, cap64) * 64.0 * k / eff64;
     if (c64 < best * 0.97) {
         best = c64;
@@ -953,7 +961,7 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
             const double per = (double)cdiv(nkt, ks);
             // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab (3 measured against the
             // split-bf16 form's 64-row alternative on the short-K 1x1 layers)
-            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + (math == XV2_MATH_F32X3 ? 3.0 : 6.0));
+            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + slab_cost(math == XV2_MATH_F32X3 ? 3.0 : 6.0));
             if (c < best * 0.95) {
                 best = c;
                 bm = 128;
@@ -963,9 +971,15 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     }
 }
 
-// XV2_SPLITK_FOLD=0 (A/B runs): split-K slabs summed by the separate splitk_reduce_kernel launch (rounds 1-2)
+// XV2_SPLITK_FOLD=1 (A/B runs): the split-K slabs of the fp32 kernels are summed INSIDE the launch by the last K-split
+// block of every output tile (epilogue of igemm_kernel) instead of by splitk_reduce_kernel.  Built, bit-reproducible and
+// measured (profiles/r03_fold_ab.md): against the 64-row slab-sum kernel of round 2 it won 0.4 ms per cfg2 step, against
+// this round's 32-row / all-slabs-in-flight slab-sum kernel it LOSES (isolated l3.conv1 0.035 -> 0.061 ms, l4.conv2 0.063 ->
+// 0.090 ms; cfg2 step 28.57 -> 28.74 ms): the sums run at the tail of each tile's last block, when only 1/ksplit of the
+// blocks is still resident, with a device-scope round trip per dependent step - the separate kernel uses the whole chip.
+// Default off.
 static bool splitk_fold_enabled() {
-    static const int v = [] { const char* e = getenv("XV2_SPLITK_FOLD"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("XV2_SPLITK_FOLD"); return e ? atoi(e) : 0; }();
     return v != 0;
 }
 
