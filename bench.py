@@ -280,7 +280,7 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
                            for r in rows]}
 
 
-def config_leg(name, a, precision, size, batch, dev, steps=10, warmup=3, parity=True):
+def config_leg(name, a, precision, size, batch, dev, steps=10, warmup=3, parity=True, unit="images/sec"):
     """A short driver-visible leg for another BASELINE configuration on the same GPU (default line: cfg3 = --encoder
     resnest50 --precision 16, 2 x 1024 x 1024): `warmup` untimed steps, `steps` timed steps between synchronisations
     (no event brackets: --no-prof style), then two bracketed steps that only COUNT the convolutions' algorithmic FLOPs
@@ -342,7 +342,7 @@ def config_leg(name, a, precision, size, batch, dev, steps=10, warmup=3, parity=
     gbytes = sum(r["mbytes"] for r in rows) / 2e3
     x3 = precision == 32 and ops.fp32_math() == ops.MATH_F32X3
     peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
-    out = {"config": name, "value": round(batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(ms, 3),
+    out = {"config": name, "value": round(batch * steps / dt, 3), "unit": unit, "ms_per_step": round(ms, 3),
            "steps": steps, "warmup": max(1, warmup), "dtype": "f32" if precision == 32 else "bf16", "loss": final_loss,
            "launch": "eager, no per-launch event brackets in the timed steps",
            "roofline": {
@@ -408,6 +408,8 @@ def main():
                     help="skip the resnest50 encoder-forward utilisation block of the default line")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short cfg3 leg (resnest50, precision 16) of the default line")
+    ap.add_argument("--no-big-configs", action="store_true",
+                    help="skip the per-GPU-step legs of cfg4 (siamese resnest101) and cfg5 (fused resnest200) of the default line")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
     ap.add_argument("--graph", action="store_true",
@@ -679,6 +681,21 @@ def main():
         out["other_configs"] = [config_leg("cfg3: --type pre --encoder resnest50 --loss_str dice --precision 16, %dx%d, batch %d"
                                            % (opt.size, opt.size, opt.batch), make_args("resnest50", "pre", "dice"), 16,
                                            opt.size, opt.batch, dev, parity=not opt.no_cpu_baseline)]
+        if not opt.no_big_configs:
+            # BASELINE configs[3] / configs[4] are 8-GPU configurations; their per-GPU step (batch 2 per GPU, what every
+            # rank runs between the collectives) is timed here on this one GPU so that the numbers are driver-visible.
+            # No oracle leg: a resnest101 / resnest200 CPU step takes minutes (parity: tests/test_model_gpu.py).
+            out["other_configs"].append(config_leg(
+                "cfg4 per-GPU step: --type post --dmg_model siamese --encoder resnest101 --loss_str focal+dice, fp32 tensors, "
+                "%dx%d pre+post pairs, batch %d (one rank of the 8-GPU configuration, no collectives)" % (opt.size, opt.size, opt.batch),
+                make_args("resnest101", "post", "focal+dice", "siamese"), 32, opt.size, opt.batch, dev, steps=5, warmup=2,
+                parity=False, unit="pairs/sec"))
+            out["other_configs"].append(config_leg(
+                "cfg5 per-GPU step: --type post --dmg_model fused --encoder resnest200 --attention --ppm --deep_supervision "
+                "--precision 16, %dx%d pre+post pairs, batch %d (one rank of the 8-GPU configuration, no collectives)"
+                % (opt.size, opt.size, opt.batch),
+                make_args("resnest200", "post", "focal+dice", "fused", attention=True, ppm=True, deep_supervision=True), 16,
+                opt.size, opt.batch, dev, steps=5, warmup=2, parity=False, unit="pairs/sec"))
     if rank == 0 and not opt.no_cpu_baseline and world == 1:
         cb, ref = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
         out["cpu_baseline"] = cb

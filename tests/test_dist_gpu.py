@@ -402,7 +402,7 @@ def test_bench_self_launches_two_ranks_over_rccl():
 def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size():
     """the default bench line at a reduced tile (256 x 256 so that the CPU oracle leg takes seconds): contract keys,
     the first-step parity block against the oracle and the resnest50 encoder-forward utilisation block"""
-    r, line = _run_bench("--steps", "3", "--warmup", "2", "--size", "256")
+    r, line = _run_bench("--steps", "3", "--warmup", "2", "--size", "256", "--no-big-configs")
     assert r.returncode == 0, r.stderr[-2000:]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "encoder_forward"):
