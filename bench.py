@@ -629,9 +629,8 @@ def main():
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                 "launches_timed": top["launches"],
-                "note": "since round 3 the launches of this kernel CONTAIN the split-K slab sums (57 per step, formerly "
-                        "splitk_reduce_kernel: 1.2 ms per step) and the BatchNorm statistics fold - same FLOPs over a longer "
-                        "launch, the step itself is faster (DESIGN.md section 4); "
+                "note": "since round 3 the unsplit launches of this kernel also fold their BatchNorm statistics (bn_fold.h; "
+                        "split-K slabs are summed by splitk_reduce_kernel, DESIGN.md section 4); "
                         "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
                         "(weight-gradient kernels co-scheduled on a side stream); 'isolated' = same kernel with every "
                         "launch alone on the chip; per_kernel/all_mfma_kernels: an extra untimed pass with every "
@@ -688,14 +687,14 @@ def main():
             out["other_configs"].append(config_leg(
                 "cfg4 per-GPU step: --type post --dmg_model siamese --encoder resnest101 --loss_str focal+dice, fp32 tensors, "
                 "%dx%d pre+post pairs, batch %d (one rank of the 8-GPU configuration, no collectives)" % (opt.size, opt.size, opt.batch),
-                make_args("resnest101", "post", "focal+dice", "siamese"), 32, opt.size, opt.batch, dev, steps=5, warmup=2,
+                make_args("resnest101", "post", "focal+dice", "siamese"), 32, opt.size, opt.batch, dev, steps=8, warmup=4,
                 parity=False, unit="pairs/sec"))
             out["other_configs"].append(config_leg(
                 "cfg5 per-GPU step: --type post --dmg_model fused --encoder resnest200 --attention --ppm --deep_supervision "
                 "--precision 16, %dx%d pre+post pairs, batch %d (one rank of the 8-GPU configuration, no collectives)"
                 % (opt.size, opt.size, opt.batch),
                 make_args("resnest200", "post", "focal+dice", "fused", attention=True, ppm=True, deep_supervision=True), 16,
-                opt.size, opt.batch, dev, steps=5, warmup=2, parity=False, unit="pairs/sec"))
+                opt.size, opt.batch, dev, steps=8, warmup=4, parity=False, unit="pairs/sec"))
     if rank == 0 and not opt.no_cpu_baseline and world == 1:
         cb, ref = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
         out["cpu_baseline"] = cb

@@ -1,30 +1,32 @@
-"""Which parameters still receive their gradient through torch (a copy into the flat buffer at step time) instead of
-a HIP kernel writing into the flat gradient slot?  usage: python scripts/foreign_grads.py <golden case name>"""
-import sys, os, torch, collections
+"""which parameters' gradients did NOT land in their slice of the flat gradient buffer (each costs a copy launch per step)?
+usage: python scripts/foreign_grads.py [precision]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.golden.cases import ARGS, MODEL_CASES, labels, model_input
-from xview2_amd import criterion, networks
+import torch
+import bench
+from xview2_amd import networks, criterion, ops
 from xview2_amd.optim import FlatAdamW
+from xview2_amd.weights import deterministic_init_
 
-name = sys.argv[1] if len(sys.argv) > 1 else "pre_resnest50"
-a = ARGS(**MODEL_CASES[name])
-m = (networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)).cuda().train()
-opt = FlatAdamW(m.parameters(), lr=1e-3)
-x, y = model_input(a, batch=2).cuda(), labels(a, batch=2).cuda()
-opt.zero_grad()
-criterion.compute_loss(criterion.Loss(a), m(x), y, a.deep_supervision).backward()
-base = opt.flat_g.data_ptr()
-ids = {id(p): n for n, p in m.named_parameters()}
-kinds = collections.Counter()
-ex = {}
-for p, o in zip(opt.params, opt.offsets):
-    n = ids.get(id(p), "?")
-    if p.grad is None:
-        kinds["no grad"] += 1
-    elif p.grad.data_ptr() != base + 4 * o:
-        k = n.split(".")[-2] + "." + n.split(".")[-1]
-        kinds[k] += 1
-        ex.setdefault(k, n)
-print(name, "params", len(opt.params))
-for k, v in kinds.most_common(30):
-    print("%5d  %-28s e.g. %s" % (v, k, ex.get(k, "")))
+prec = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda:0")
+a = bench.make_args("resnet50", "pre", "dice")
+bench.set_precision(prec)
+model = networks.UNetLoc(a)
+deterministic_init_(model, 1)
+model.to(dev).train()
+loss_fn = criterion.Loss(a)
+opt = FlatAdamW(model.parameters(), lr=3e-4)
+x, y = bench.synthetic_batch(a, 2, 256, 1, dev)
+for _ in range(2):
+    opt.zero_grad()
+    loss = criterion.compute_loss(loss_fn, model(x), y, a.deep_supervision)
+    loss.backward()
+    names = {id(p): k for k, p in model.named_parameters()}
+    base = opt.flat_g.data_ptr()
+    foreign = [(names[id(p)], tuple(p.shape)) for p, o in zip(opt.params, opt.offsets)
+               if p.grad is not None and p.grad.data_ptr() != base + 4 * o]
+    opt.step()
+print(len(foreign), "foreign gradients of", len(opt.params))
+for n, s in foreign:
+    print(" ", n, s)

@@ -28,8 +28,12 @@ constexpr int D_LDH = 40;
 constexpr int D_HLOADS_H = (D_HALO * 4 + 255) / 256;      // 16-byte loads (8 channels) per thread per halo (4)
 constexpr size_t D_SMEM_H = (size_t)(D_HALO + 9 * 32) * D_LDH * 2 + 4 * 32 * 2 * 4;
 // XV2_MATH_F32X3: three bf16 planes (hi / mid / lo terms of the exact split) of that bf16 image: 118 KB, one block per CU
-constexpr int D_PLH = D_HALO * D_LDH, D_PLW = 9 * 32 * D_LDH;      // plane sizes in elements
-constexpr size_t D_SMEM_X3 = (size_t)3 * (D_PLH + D_PLW) * 2 + 4 * 32 * 2 * 4;
+// The F32X3 form works on 8 x 32 pixel patches with EIGHT waves (two per SIMD: while one wave is in its epilogue or waits
+// for fragments the other one feeds the matrix pipe; with 4-row patches the 118 KB image left one wave per SIMD alone and
+// the 108-MFMA chain per patch ran at 0.27 of the pipe): 10 x 34 halo, 153 KB.
+constexpr int D_TH_X3 = 8, D_HALO_X3 = (D_TH_X3 + 2) * D_HW;      // 340 pixels
+constexpr int D_PLH = D_HALO_X3 * D_LDH, D_PLW = 9 * 32 * D_LDH;      // plane sizes in elements
+constexpr size_t D_SMEM_X3 = (size_t)3 * (D_PLH + D_PLW) * 2 + D_TH_X3 * 32 * 2 * 4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int hperm(int px) { return (px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3); }
@@ -43,23 +47,25 @@ __device__ __forceinline__ int hperm(int px) { return (px & ~15) | ((px & 3) << 
 // X3 = true (XV2_MATH_F32X3): fp32 tensors; halo and weights are split into three bf16 terms (split3x4) on their way
 // into LDS, every tap step is the six significant bf16 cross products: 108 MFMAs per wave and patch.
 template <bool BF16, bool HS = false, bool X3 = false>
-__global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
+__global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
     static_assert(!X3 || (BF16 && !HS), "split-bf16 mode: fp32 tensors, bf16 MFMA");
+    constexpr int TH = X3 ? D_TH_X3 : D_TH, NT = TH * 64, NW = TH;      // patch rows = waves
+    constexpr int HALO = (TH + 2) * D_HW, HPERM = HALO / 16 * 16, PLH = HALO * D_LDH;
     constexpr int ESH = HS ? 1 : 2;
     typedef typename std::conditional<HS, bf16_t, float>::type OT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
     float* wts = smem + D_HALO * D_LD;          // [9][32][36]
-    float* red = X3 ? smem + 3 * (D_PLH + D_PLW) / 2
+    float* red = X3 ? smem + 3 * (PLH + D_PLW) / 2
                     : HS ? smem + (D_HALO + 9 * 32) * D_LDH / 2 : wts + 9 * 32 * D_LD;   // [4][32][2]
     __bf16* halo_h = reinterpret_cast<__bf16*>(smem);         // HS: [204][40] bf16;  X3: [3 planes][204][40]
-    __bf16* wts_h = halo_h + (X3 ? 3 : 1) * D_PLH;             // HS: [9][32][40] bf16; X3: [3 planes][9][32][40]
+    __bf16* wts_h = halo_h + (X3 ? 3 : 1) * PLH;             // HS: [9][32][40] bf16; X3: [3 planes][9][32][40]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const ClassInfo ci = p.cls[0];
     const int OH = ci.OHl, OW = ci.OWl;
-    const int tiles_w = OW / D_TW, tiles_h = OH / D_TH;
+    const int tiles_w = OW / D_TW, tiles_h = OH / TH;
 
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
@@ -85,7 +91,7 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 
     // weights, once: [tap][n][32 channels]
     if constexpr (X3) {
-        for (int e = tid; e < 9 * 32 * 8; e += 256) {
+        for (int e = tid; e < 9 * 32 * 8; e += NT) {
             const int c4 = e & 7, nn = (e >> 3) & 31, t = e >> 8;
             const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
             const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
@@ -110,28 +116,29 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         }
     }
 
-    i32x4 hr[D_HLOADS];
+    constexpr int HLOADS = X3 ? (HALO * 8 + NT - 1) / NT : D_HLOADS;      // 6 (X3) / 7
+    i32x4 hr[HLOADS];
     // this thread's D_HLOADS halo elements: (row, column) inside the 6 x 34 halo and the byte offset relative to the
     // patch origin - fixed for the whole kernel
-    int hrow[D_HLOADS], hcol[D_HLOADS], hrel[D_HLOADS];
+    int hrow[HLOADS], hcol[HLOADS], hrel[HLOADS];
     constexpr int LPP = HS ? 4 : 8;              // 16-byte lanes per halo pixel
-    constexpr int NHL = HS ? D_HLOADS_H : D_HLOADS;
+    constexpr int NHL = HS ? D_HLOADS_H : HLOADS;
 #pragma unroll
-    for (int j = 0; j < D_HLOADS; ++j) {
-        const int e = tid + j * 256;
+    for (int j = 0; j < HLOADS; ++j) {
+        const int e = tid + j * NT;
         const int c4 = e % LPP;
         // X3: 8-byte LDS stores, two pixel rows per store lane group: rows 4 apart do not share banks (80-byte rows)
-        const int px = (X3 && e / LPP < 192) ? hperm(e / LPP) : e / LPP;
+        const int px = (X3 && e / LPP < HPERM) ? hperm(e / LPP) : e / LPP;
         hrow[j] = px / D_HW;
         hcol[j] = px - hrow[j] * D_HW;
-        hrel[j] = e < D_HALO * LPP ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * (32 / LPP)) << ESH : 0;
-        if (e >= D_HALO * LPP) hrow[j] = -(1 << 20);      // never valid
+        hrel[j] = e < HALO * LPP ? (((hrow[j] - 1) * p.IW + (hcol[j] - 1)) * p.ldA0 + c4 * (32 / LPP)) << ESH : 0;
+        if (e >= HALO * LPP) hrow[j] = -(1 << 20);      // never valid
     }
     auto hload = [&](int patch) {
         const int tw = patch % tiles_w;
         const int th = (patch / tiles_w) % tiles_h;
         const int n = patch / (tiles_w * tiles_h);
-        const int oh0 = th * D_TH, ow0 = tw * D_TW;
+        const int oh0 = th * TH, ow0 = tw * D_TW;
         const int base = (((n * p.IH + oh0) * p.IW + ow0) * p.ldA0) << ESH;
 #pragma unroll
         for (int j = 0; j < NHL; ++j) {
@@ -143,17 +150,17 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
     auto hstore = [&]() {
 #pragma unroll
         for (int j = 0; j < NHL; ++j) {
-            const int e = tid + j * 256;
-            if (e < D_HALO * LPP) {
+            const int e = tid + j * NT;
+            if (e < HALO * LPP) {
                 if constexpr (X3) {
-                    const int px = (e >> 3) < 192 ? hperm(e >> 3) : (e >> 3);
+                    const int px = (e >> 3) < HPERM ? hperm(e >> 3) : (e >> 3);
                     uint2 sh, sm, sl;
                     split3x4(make_float4(__int_as_float(hr[j][0]), __int_as_float(hr[j][1]), __int_as_float(hr[j][2]),
                                          __int_as_float(hr[j][3])), sh, sm, sl);
                     __bf16* d = halo_h + px * D_LDH + (e & 7) * 4;
                     *reinterpret_cast<uint2*>(d) = sh;
-                    *reinterpret_cast<uint2*>(d + D_PLH) = sm;
-                    *reinterpret_cast<uint2*>(d + 2 * D_PLH) = sl;
+                    *reinterpret_cast<uint2*>(d + PLH) = sm;
+                    *reinterpret_cast<uint2*>(d + 2 * PLH) = sl;
                 } else if constexpr (HS)
                     *reinterpret_cast<i32x4*>(halo_h + (e >> 2) * D_LDH + (e & 3) * 8) = hr[j];
                 else
@@ -192,8 +199,8 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + kk * 16);
-                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(a + D_PLH + kk * 16);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 2 * D_PLH + kk * 16);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8*>(a + PLH + kk * 16);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 2 * PLH + kk * 16);
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + kk * 16);
                     const bf16x8 bm = *reinterpret_cast<const bf16x8*>(b + D_PLW + kk * 16);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + 2 * D_PLW + kk * 16);
@@ -251,7 +258,7 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
         const int tw = patch % tiles_w;
         const int th = (patch / tiles_w) % tiles_h;
         const int n = patch / (tiles_w * tiles_h);
-        const size_t rowpix = ((size_t)n * OH + th * D_TH + wave) * OW + tw * D_TW;
+        const size_t rowpix = ((size_t)n * OH + th * TH + wave) * OW + tw * D_TW;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -283,18 +290,27 @@ __global__ void __launch_bounds__(256) direct3x3_n32_kernel(const IgemmParams p,
             }
         }
         __syncthreads();                       // halo fully consumed, red complete
-        if (p.stats && tid < 32) {
+        // one statistics row per 128 pixels (four patch rows), as the implicit-GEMM tiles: an 8-row patch writes two
+        if (p.stats && tid < 32 * (NW / 4)) {
+            const int half = tid >> 5, ch = tid & 31;
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                a1 += red[(w * 32 + tid) * 2 + 0];
-                a2 += red[(w * 32 + tid) * 2 + 1];
+                a1 += red[((half * 4 + w) * 32 + ch) * 2 + 0];
+                a2 += red[((half * 4 + w) * 32 + ch) * 2 + 1];
             }
             if (p.fold.on) {
-                fsum1 += (double)a1;
-                fsum2 += (double)a2;
+                if (NW > 4) {      // both halves onto the channel's thread (fixed order: rows 0-3, then 4-7)
+                    const float b1 = __shfl_down(a1, 32, 64), b2 = __shfl_down(a2, 32, 64);
+                    a1 += b1;
+                    a2 += b2;
+                }
+                if (tid < 32) {
+                    fsum1 += (double)a1;
+                    fsum2 += (double)a2;
+                }
             } else {
-                float* st = p.stats + ((size_t)patch * 32 + tid) * 2;
+                float* st = p.stats + (((size_t)patch * (NW / 4) + half) * 32 + ch) * 2;
                 st[0] = a1;
                 st[1] = a2;
             }
@@ -313,7 +329,8 @@ bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
     if (smallc || p.accum != 0 || p.ncls != 1 || p.Nout != 32 || p.N0 != 32 || p.s_in != 1) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 9 || c.tap0 != 0 || c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl) return false;
-    if (c.OWl % D_TW != 0 || c.OHl % D_TH != 0 || c.OHl != p.IH || c.OWl != p.IW) return false;
+    const int th = p.math == XV2_MATH_F32X3 ? D_TH_X3 : D_TH;
+    if (c.OWl % D_TW != 0 || c.OHl % th != 0 || c.OHl != p.IH || c.OWl != p.IW) return false;
     for (int t = 0; t < 9; ++t)
         if (p.taps[t].dh < -1 || p.taps[t].dh > 1 || p.taps[t].dw < -1 || p.taps[t].dw > 1) return false;
     return p.Ctot == 32 && p.C1 == 0;
@@ -341,7 +358,7 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     static const int kidx3 = prof_register("direct3x3_n32_kernel<f32x3>");
     const bool x3 = p.math == XV2_MATH_F32X3;
     const ClassInfo& c = p.cls[0];
-    const int npatches = c.M / (D_TH * D_TW);
+    const int npatches = c.M / ((x3 ? D_TH_X3 : D_TH) * D_TW);
     // persistent: 2 blocks per CU (fp32 LDS image, 71 KB), 4 per CU with the bf16 image (40 KB); each walks a run of patches
     // (the three-plane image of F32X3, 118 KB: 1 per CU)
     int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
@@ -362,7 +379,7 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
     prof_begin(x3 ? kidx3 : p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
     if (x3)
-        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(256), D_SMEM_X3, stream, q, npatches);
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(512), D_SMEM_X3, stream, q, npatches);
     else if (p.math == XV2_MATH_BF16_STORE)
         hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, q, npatches);
     else if (p.math)

@@ -1084,6 +1084,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     }
     if (smallc) {
         if (p.math == XV2_MATH_BF16_STORE) {
+            // (bf16 MFMA on the rounded image was measured SLOWER here, 0.36 vs 0.22 ms: the gather loader sets the pace
+            // and the 16 exact-fp32 instructions per K-tile hide it; the weight-gradient twin does use bf16 MFMA)
             if (bn == 128) return launch_one<128, 128, 2, 2, true, false, true>(p, stream);
             if (bn == 64) return launch_one<128, 64, 2, 2, true, false, true>(p, stream);
             return launch_one<128, 32, 4, 1, true, false, true>(p, stream);

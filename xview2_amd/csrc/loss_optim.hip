@@ -306,6 +306,47 @@ constexpr int PK_TC = 9;
 __host__ __device__ inline int64_t pack_tiles(int Cout, int CinP, int T) {
     return (int64_t)((Cout + 31) / 32) * ((CinP + 31) / 32) * ((T + PK_TC - 1) / PK_TC);
 }
+// TCC: taps per tile as a compile-time constant (1, 4, 9: every index division below becomes a multiply-shift; the
+// runtime-divisor form spent more time in integer division than in memory: 226 us for the 25.5 M parameters of cfg2), 0 = generic
+template <int TCC>
+__device__ __forceinline__ void pack_tile(float* sh, const float* __restrict__ w, float* __restrict__ ohwi,
+                                          float* __restrict__ ihwo, int Cout, int Cin, int T, int CinP, bool half, int t0,
+                                          int tcr, int co0, int ci0) {
+    const int tc = TCC ? TCC : tcr;
+    const int ldco = 32 * tc + 1;
+    const int cnt = 32 * 32 * tc;
+    // OIHW -> LDS[co][ci][t]  (a co row of the tile is 32*tc consecutive floats when tc == T)
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int col = i / (32 * tc), r = i - col * (32 * tc);
+        const int cil = r / tc, tl = r - cil * tc;
+        const int co = co0 + col, ci = ci0 + cil;
+        sh[col * ldco + r] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t0 + tl] : 0.f;
+    }
+    __syncthreads();
+    if (ohwi)
+        for (int i = threadIdx.x; i < cnt; i += 256) {       // (co, t, ci): ci fastest
+            const int cil = i & 31, q = i >> 5;
+            const int col = q / tc, tl = q - col * tc;
+            const int co = co0 + col, ci = ci0 + cil;
+            if (co < Cout && ci < CinP) {
+                const size_t o = ((size_t)co * T + t0 + tl) * CinP + ci;
+                if (half) reinterpret_cast<bf16_t*>(ohwi)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
+                else ohwi[o] = sh[col * ldco + cil * tc + tl];
+            }
+        }
+    if (ihwo)
+        for (int i = threadIdx.x; i < cnt; i += 256) {       // (ci, t, co): co fastest
+            const int col = i & 31, q = i >> 5;
+            const int cil = q / tc, tl = q - cil * tc;
+            const int co = co0 + col, ci = ci0 + cil;
+            if (co < Cout && ci < CinP) {
+                const size_t o = ((size_t)ci * T + t0 + tl) * Cout + co;
+                if (half) reinterpret_cast<bf16_t*>(ihwo)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
+                else ihwo[o] = sh[col * ldco + cil * tc + tl];
+            }
+        }
+}
+
 __global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* __restrict__ table, int n) {
     __shared__ float sh[32 * (32 * PK_TC + 1)];
     int lo = 0, hi = n - 1;
@@ -328,38 +369,12 @@ __global__ void __launch_bounds__(256) pack_weights_table_kernel(const int64_t* 
     const int cib = j % cis, cob = j / cis;
     const int t0 = tcb * PK_TC, tc = min(PK_TC, T - t0);
     const int co0 = cob * 32, ci0 = cib * 32;
-    const int ldco = 32 * tc + 1;
-    const int cnt = 32 * 32 * tc;
-    // OIHW -> LDS[co][ci][t]  (a co row of the tile is 32*tc consecutive floats when tc == T)
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const int col = i / (32 * tc), r = i - col * (32 * tc);
-        const int cil = r / tc, tl = r - cil * tc;
-        const int co = co0 + col, ci = ci0 + cil;
-        sh[col * ldco + r] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * T + t0 + tl] : 0.f;
+    switch (tc) {       // block-uniform
+        case 1: pack_tile<1>(sh, w, ohwi, ihwo, Cout, Cin, T, CinP, half, t0, tc, co0, ci0); break;
+        case 4: pack_tile<4>(sh, w, ohwi, ihwo, Cout, Cin, T, CinP, half, t0, tc, co0, ci0); break;
+        case 9: pack_tile<9>(sh, w, ohwi, ihwo, Cout, Cin, T, CinP, half, t0, tc, co0, ci0); break;
+        default: pack_tile<0>(sh, w, ohwi, ihwo, Cout, Cin, T, CinP, half, t0, tc, co0, ci0);
     }
-    __syncthreads();
-    if (ohwi)
-        for (int i = threadIdx.x; i < cnt; i += 256) {       // (co, t, ci): ci fastest
-            const int cil = i & 31, q = i >> 5;
-            const int tl = q % tc, col = q / tc;
-            const int co = co0 + col, ci = ci0 + cil;
-            if (co < Cout && ci < CinP) {
-                const size_t o = ((size_t)co * T + t0 + tl) * CinP + ci;
-                if (half) reinterpret_cast<bf16_t*>(ohwi)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
-                else ohwi[o] = sh[col * ldco + cil * tc + tl];
-            }
-        }
-    if (ihwo)
-        for (int i = threadIdx.x; i < cnt; i += 256) {       // (ci, t, co): co fastest
-            const int col = i & 31, q = i >> 5;
-            const int tl = q % tc, cil = q / tc;
-            const int co = co0 + col, ci = ci0 + cil;
-            if (co < Cout && ci < CinP) {
-                const size_t o = ((size_t)ci * T + t0 + tl) * Cout + co;
-                if (half) reinterpret_cast<bf16_t*>(ihwo)[o] = f32_to_bf16(sh[col * ldco + cil * tc + tl]);
-                else ihwo[o] = sh[col * ldco + cil * tc + tl];
-            }
-        }
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

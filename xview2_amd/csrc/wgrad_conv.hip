@@ -1297,8 +1297,8 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
         rc = XV2_OK;
     } else if (pl.smallc) {
         if (hs) {
-            if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true, false, true>(p, pl, stream);
-            else rc = launch_wgrad<32, 64, 1, 2, 2, true, false, true>(p, pl, stream);
+            if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true, true, true>(p, pl, stream);
+            else rc = launch_wgrad<32, 64, 1, 2, 2, true, true, true>(p, pl, stream);
         } else if (pl.bm == 64) rc = launch_wgrad<64, 64, 2, 2, 1, true>(p, pl, stream);
         else rc = launch_wgrad<32, 64, 1, 2, 2, true>(p, pl, stream);
     } else if (x3 && p.fast && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
