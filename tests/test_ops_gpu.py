@@ -1,6 +1,7 @@
 """Op-level numerics of the HIP kernels (through the C ABI) against plain PyTorch fp32 on CPU.
 Tolerances: fp32 MFMA is an exact-fp32 fmaf chain, so only summation order differs: 2e-4 relative to the
 tensor's max magnitude for convolutions with K up to ~14k, 1e-5-class for streaming kernels."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -795,6 +796,47 @@ def test_f32x3_split_bf16_conv_keeps_the_fp32_tolerances(case):
     close(y3, outs[ops.MATH_F32][0], 2e-6, "f32x3 vs exact fp32 MFMA, y")
     close(dx3, outs[ops.MATH_F32][1], 2e-6, "f32x3 vs exact fp32 MFMA, dx")
     close(dw3, outs[ops.MATH_F32][2], 2e-6, "f32x3 vs exact fp32 MFMA, dw")
+
+
+HALO_SNIPPET = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from xview2_amd import ops
+dev = "cuda:0"
+ops.MATH_MODE = ops.MATH_F32X3
+worst = 0.0
+# (N, H, W, C0, C1, Cout): an unsplit 128x128 tile plan, a 64-column plan, a virtual concat, a split-K plan (small M, deep K)
+for (N, H, W, C0, C1, Co) in [(2, 32, 64, 64, 0, 128), (1, 64, 64, 32, 0, 64), (2, 16, 32, 64, 96, 128), (2, 16, 16, 512, 0, 256)]:
+    torch.manual_seed(N + H + C0 + Co)
+    x = torch.randn(N, C0 + C1, H, W)
+    w = torch.randn(Co, C0 + C1, 3, 3) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, 1, 1)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    a = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    a0 = a[..., :C0].contiguous().requires_grad_(True)
+    a1 = a[..., C0:].contiguous().requires_grad_(True) if C1 else None
+    y = ops.ConvFn.apply(a0, a1, w.to(dev), None, ops.conv_cfg(3, 3, 1, 1))
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(dev))
+    dx = a0.grad if not C1 else torch.cat([a0.grad, a1.grad], 3)
+    e1 = float((y.permute(0, 3, 1, 2).cpu() - yr).abs().max() / yr.abs().max())
+    e2 = float((dx.permute(0, 3, 1, 2).cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    worst = max(worst, e1, e2)
+    assert e1 <= 2e-4 and e2 <= 5e-4, (N, H, W, C0, C1, Co, e1, e2)
+print("halo ok %%.2e" %% worst)
+"""
+
+
+def test_halo_form_of_the_f32x3_kernel_in_a_subprocess():
+    """igemm_kernel<..., HALO> (XV2_HALO=1, read once per process): 3x3 forward and backward-data with the 10 x 18 halo of
+    every 16-channel slice resident in LDS for all nine taps.  Opt-in after measurement; this keeps it exact."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XV2_HALO="1")
+    r = subprocess.run([sys.executable, "-c", HALO_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "halo ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ---- input hand-over on the device (SURVEY 8f row 4) -----------------------------------------------------------------

@@ -35,6 +35,12 @@
 #define XV2_ABL 0   // debug ablations (scripts/ablate.sh): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 #endif
 
+#ifndef XV2_PF
+#define XV2_PF 3      // F32X3 main loop: stages between a global load and its split (3: two raw register sets, 4: three -
+                      // measured identical on every cfg2 layer and on the step, 256 instead of 240 VGPRs: the loads are not
+                      // latency-exposed; under this kernel the chip is power-limited)
+#endif
+
 namespace xv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -78,9 +84,15 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // source (SMALLC) stays an fp32 image with fp32 weights and exact-fp32 MFMA; only its output is bf16.
 // X3 = true (XV2_MATH_F32X3): fp32 tensors, each operand element split into three bf16 terms on its way into LDS (three
 // bf16 planes per operand, single-buffered: 61 KB for the 128x128 tile), six bf16 MFMAs per fp32-grade product.
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
+// HALO = true (F32X3, 3x3 / stride 1 / pad 1 forward and backward-data): the M tile is an 8 x 16 pixel PATCH of one
+// image and the K loop runs chunk-major over 16-channel slices: the 10 x 18 halo of a slice is fetched, split and stored
+// into LDS ONCE and serves all nine taps (shifted fragment addresses) - global loads, operand splits and LDS stores of
+// the activation operand drop 6.4x; the weight operand streams per tap as before.  Opt-in: see halo_enabled().
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
+          bool HALO = false>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
+    static_assert(!HALO || (X3 && BM == 128), "halo form: F32X3, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
     constexpr bool HIN = HS && !SMALLC;                 // bf16 operands in HBM
@@ -177,6 +189,20 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1 ? p.A1 : p.A0), 0, p.A1 ? p.bytesA1 : p.bytesA0, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
     }
+    constexpr int PW = 16, PH = BM / PW;        // HALO: patch width / height
+    int h_n = 0, h_oh0 = 0, h_ow0 = 0;         // HALO: image and patch origin of this tile
+    if constexpr (HALO) {
+        const int tiles_w = ci.OWl / PW, tiles_h = ci.OHl / PH;
+        const int tw = tm % tiles_w, q = tm / tiles_w;
+        h_n = q / tiles_h;
+        h_oh0 = (q - h_n * tiles_h) * PH;
+        h_ow0 = tw * PW;
+        if (tid < BM) {
+            const int oh = h_oh0 + tid / PW, ow = h_ow0 + tid % PW;
+            rowoff[tid] = (p.ksplit > 1 && !p.sk_tickets) ? (h_n * ci.OHl + oh) * ci.OWl + ow      // slab row = GEMM row
+                                                          : h_n * p.osN + oh * p.osH + ow * p.osW + ci.os0;
+        }
+    } else
     if (tid < BM) {
         const int m = m0 + tid;
         int off = -1;
@@ -301,7 +327,179 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (X3) {
+    if constexpr (X3 && HALO) {
+        constexpr int LDK = 24, HWD = PW + 2, NHP = (PH + 2) * HWD;      // 10 x 18 = 180 halo pixels
+        constexpr int NHPP = (NHP + 7) / 8 * 8, PLA = NHPP * LDK;        // halo plane [184][24] bf16
+        constexpr int PLB = BN * LDK, STB = 3 * PLB;                     // weight stage: three planes [BN][24]
+        constexpr int HL = (NHP * 4 + 255) / 256;                        // 16-byte halo loads per thread (3)
+        static_assert((size_t)(3 * PLA + 2 * STB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + weight stages fit the operand buffers");
+        __bf16* sa = reinterpret_cast<__bf16*>(smem);                    // [3][NHPP][LDK]
+        __bf16* sbw = sa + 3 * PLA;                                      // [2][3][BN][LDK]
+        const int ntp = ci.ntaps;                                        // 9
+        // split-K ranges are whole 32-channel chunks (kt_per_split % ntaps == 0, igemm_launch)
+        const int cs_begin = 2 * (kt_begin / ntp), cs_end = 2 * (kt_end / ntp);      // 16-channel slices
+        const int s_begin = cs_begin * ntp, s_end = cs_end * ntp;        // stage = (slice, tap)
+        // this thread's halo elements: pixel (permuted inside groups of 8 rows: conflict-free 8-byte LDS stores) x 4 channels
+        int hpix[HL], hrow[HL];
+#pragma unroll
+        for (int j = 0; j < HL; ++j) {
+            const int e = tid + j * 256, hq = e >> 2;
+            const int hp = hq < NHP / 8 * 8 ? ((hq & ~7) | ((hq & 3) << 1) | ((hq >> 2) & 1)) : hq;
+            const int hr = hp / HWD, hc = hp - hr * HWD;
+            const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
+            const bool ok = hq < NHP && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            hpix[j] = ok ? (h_n * p.IH + ih) * p.IW + iw : -1;
+            hrow[j] = hq < NHP ? hp : -1;
+        }
+        // fragment rows: A tile i of this wave = two patch rows of 16 pixels; halo row of (pixel, tap (0,0))
+        int abase[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + (l31 >> 4) + 1) * HWD + (l31 & 15) + 1;
+        float4 hraw[HL], rbb[BROWS], rbb1[BROWS];
+        uint2 pkb[BROWS][3], pkh[HL][3];
+        bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
+        auto hload = [&](int cs) {
+            const int cc = (cs >> 1) * BK + (cs & 1) * 16;
+            const bool first = cc < p.C0;
+            const int ld = first ? p.ldA0 : p.ldA1;
+            const int ch = (first ? cc : cc - p.C0) + (tid & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < HL; ++j) {
+                const int off = hpix[j] >= 0 ? ((hpix[j] * ld + ch) << 2) : (int)0x80000000;
+                const i32x4 v = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, off, 0, 0)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rsA1, off, 0, 0);
+                hraw[j] = __builtin_bit_cast(float4, v);
+            }
+        };
+        auto hsplit = [&]() {
+#pragma unroll
+            for (int j = 0; j < HL; ++j) split3x4(hraw[j], pkh[j][0], pkh[j][1], pkh[j][2]);
+        };
+        auto hstore = [&]() {
+#pragma unroll
+            for (int j = 0; j < HL; ++j)
+                if (hrow[j] >= 0) {
+                    __bf16* d = sa + hrow[j] * LDK + (tid & 3) * 4;
+                    *reinterpret_cast<uint2*>(d) = pkh[j][0];
+                    *reinterpret_cast<uint2*>(d + PLA) = pkh[j][1];
+                    *reinterpret_cast<uint2*>(d + 2 * PLA) = pkh[j][2];
+                }
+        };
+        auto bload = [&](int st, float4 (&xb)[BROWS]) {      // weights of stage st = (slice st / ntp, tap st % ntp)
+            const int cs = st / ntp, tp = st - cs * ntp;
+            const int kb = taps[tp].slot * p.Ctot + (cs >> 1) * BK + (cs & 1) * 16;
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j)
+                xb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << 2, 0, 0));
+        };
+        auto bsplit = [&](const float4 (&xb)[BROWS]) {
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) split3x4(xb[j], pkb[j][0], pkb[j][1], pkb[j][2]);
+        };
+        auto bstore = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) {
+                const int rr = r0 + RPP * j;
+                if (BN % RPP == 0 || rr < BN) {
+                    __bf16* d = sbw + buf * STB + rr * LDK + c4 * 4;
+                    *reinterpret_cast<uint2*>(d) = pkb[j][0];
+                    *reinterpret_cast<uint2*>(d + PLB) = pkb[j][1];
+                    *reinterpret_cast<uint2*>(d + 2 * PLB) = pkb[j][2];
+                }
+            }
+        };
+        auto read_a = [&](int tp, bf16x8 (&fa)[MR][3]) {
+            const int toff = taps[tp].dh * HWD + taps[tp].dw;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+                    fa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * PLA + (abase[i] + toff) * LDK + 8 * h);
+        };
+        auto read_b = [&](int buf, bf16x8 (&fb)[NR][3]) {
+            const __bf16* b = sbw + buf * STB + (wn * WTN + l31) * LDK + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * PLB + j * 32 * LDK);
+        };
+        auto mfma_stage = [&](const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3]) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) {
+                        const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+                        const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
+                    }
+        };
+        int tp = 0, cs = cs_begin;       // tap and slice of the stage being multiplied
+        // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; xb holds the raw weights of st+2 (split here);
+        // yb is free and receives st+3.  At the last tap of a slice the next slice's halo (in flight since the slice began)
+        // is split and replaces the halo in LDS - nobody reads it any more: the A fragments of the last tap were fetched one
+        // iteration earlier - and the first tap's A fragments are read behind the barrier.
+        auto iter = [&](int st, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3], bf16x8 (&na)[MR][3],
+                        bf16x8 (&nb)[NR][3], float4 (&xb)[BROWS], float4 (&yb)[BROWS]) {
+            const bool last = tp == ntp - 1;
+            const bool more = st + 1 < s_end;
+            if (more) {
+                read_b((st + 1) & 1, nb);
+                if (!last) read_a(tp + 1, na);
+            }
+            if (st + 3 < s_end) bload(st + 3, yb);
+            bsplit(xb);
+            mfma_stage(fa, fb);
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pkb[j][q].x), "+v"(pkb[j][q].y));
+            constexpr int NMFMA = 6 * MR * NR, NRD = 3 * (MR + NR);
+#pragma unroll
+            for (int g = 0; g < NMFMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, BROWS * 20 / NMFMA + 1, 0);
+            }
+            if (st + 2 < s_end) bstore(st & 1);
+            const bool swap = last && more;
+            if (swap) {
+                hsplit();
+                hstore();
+            }
+            __syncthreads();
+            if (swap) {
+                read_a(0, na);
+                if (cs + 2 < cs_end) hload(cs + 2);
+            }
+            if (last) {
+                tp = 0;
+                ++cs;
+            } else {
+                ++tp;
+            }
+        };
+        hload(cs_begin);
+        bload(s_begin, rbb);
+        bload(s_begin + 1, rbb1);
+        hsplit();
+        hstore();
+        bsplit(rbb);
+        bstore(0);
+        if (s_begin + 2 < s_end) bload(s_begin + 2, rbb);
+        bsplit(rbb1);
+        bstore(1);
+        if (cs_begin + 1 < cs_end) hload(cs_begin + 1);
+        __syncthreads();
+        read_a(0, fa0);
+        read_b(0, fb0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even (two slices per 32-channel chunk)
+            iter(st, fa0, fb0, fa1, fb1, rbb, rbb1);
+            iter(st + 1, fa1, fb1, fa0, fb0, rbb1, rbb);
+        }
+    } else if constexpr (X3) {
         // K advances in STAGES of 16 channels (half a K-tile).  LDS: two stage buffers, each three bf16 planes
         // [hi | mid | lo] x ([A rows | B rows] x 24 bf16: 16 + 8 pad, 48-byte rows) - 73.7 KB for 128x128, the size of the
         // fp32 double buffer.  Registers: two raw load sets and two fragment sets.  Iteration s multiplies stage s out of
@@ -321,10 +519,19 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
                 const float4 v = j < AROWS ? xa[j < AROWS ? j : 0] : xb[j >= AROWS ? j - AROWS : 0];
+#if XV2_ABL & 16
+                pk[j][0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+                pk[j][1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+                pk[j][2] = pk[j][0];
+#else
                 split3x4(v, pk[j][0], pk[j][1], pk[j][2]);
+#endif
             }
         };
         auto store_planes = [&](int buf) {
+#if XV2_ABL & 2
+            return;
+#endif
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j) {
                 const int rr = r0 + RPP * (j < AROWS ? j : j - AROWS);
@@ -361,13 +568,13 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
                     }
         };
-        // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; (xa, xb) hold the raw stage st+2; (ya, yb) are
-        // free and receive stage st+3
+        // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; (xa, xb) hold the raw stage st+2 (split here);
+        // (za, zb) are free and receive stage st+XV2_PF (XV2_PF == 4: stage st+3 is in flight in a third register set)
         auto iter = [&](int st, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3], bf16x8 (&na)[MR][3],
-                        bf16x8 (&nb)[NR][3], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&ya)[AROWS],
-                        float4 (&yb)[BROWS]) {
+                        bf16x8 (&nb)[NR][3], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&za)[AROWS],
+                        float4 (&zb)[BROWS]) {
             if (st + 1 < s_end) read_frags((st + 1) & 1, na, nb);
-            if (st + 3 < s_end) gstage(st + 3, ya, yb);
+            if (st + XV2_PF < s_end) gstage(st + XV2_PF, za, zb);
             split_regs(xa, xb);
             mfma_stage(fa, fb);
             // pin the split results here: the instruction selector otherwise sinks the whole split below its consumer
@@ -394,15 +601,34 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         if (s_begin + 2 < s_end) gstage(s_begin + 2, ra, rb);
         split_regs(ra1, rb1);
         store_planes(1);
+#if XV2_PF == 4
+        float4 ra2[AROWS], rb2[BROWS];
+        if (s_begin + 3 < s_end) gstage(s_begin + 3, ra1, rb1);
+#endif
         __syncthreads();
         read_frags(0, fa0, fb0);
         // the first fragments land before the loop is entered: otherwise the loop header, reached from here and from the
         // back edge, waits for lgkmcnt(0) in EVERY iteration - on the next stage's reads it has just issued
         __builtin_amdgcn_s_waitcnt(0xc07f);
+#if XV2_PF == 4
+        // raw sets rotate with period 3, fragment sets with period 2: six iterations per trip (the stage count is even;
+        // iterations past s_end are skipped as a whole)
+        for (int st = s_begin; st < s_end; st += 6) {
+            iter(st, fa0, fb0, fa1, fb1, ra, rb, ra2, rb2);
+            iter(st + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra, rb);
+            if (st + 2 >= s_end) break;
+            iter(st + 2, fa0, fb0, fa1, fb1, ra2, rb2, ra1, rb1);
+            iter(st + 3, fa1, fb1, fa0, fb0, ra, rb, ra2, rb2);
+            if (st + 4 >= s_end) break;
+            iter(st + 4, fa0, fb0, fa1, fb1, ra1, rb1, ra, rb);
+            iter(st + 5, fa1, fb1, fa0, fb0, ra2, rb2, ra1, rb1);
+        }
+#else
         for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even
             iter(st, fa0, fb0, fa1, fb1, ra, rb, ra1, rb1);
             iter(st + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra, rb);
         }
+#endif
     } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
     // (tile kt).  The LDS store of the next tile sits at the START of an iteration, so nothing but the MFMA
@@ -842,10 +1068,11 @@ constexpr size_t igemm_smem_bytes() {
     return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1>() * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false>
+template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
+          bool HALO = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3>;
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -854,7 +1081,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? "c32,f32x3" : (BF16 ? "c32,bf16" : "c32"))));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? (HALO ? "c32,f32x3,halo" : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -1013,6 +1240,25 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
     return XV2_OK;
 }
 
+// the halo form of the F32X3 kernel (igemm_kernel<..., HALO>): 3x3 taps around the output pixel on a same-size input.
+// Exact (the op and true-size layer tests pass with it on) and MEASURED NO FASTER: cfg2 3x3 layers 0.93 - 1.03x of the
+// per-tap form (dec1 116 GFLOP forward 0.673 -> 0.720 ms, dec5-level 0.259 -> 0.251 ms) although the activation operand's
+// loads, splits and LDS stores drop 6.4x - what bounds the kernel is the matrix pipe + fragment reads + the weight
+// stream under the power limit, not the activation producer.  Off by default (XV2_HALO=1 for A/B runs).
+static bool halo_enabled() {
+    static const int v = [] { const char* e = getenv("XV2_HALO"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
+static bool halo_eligible(const IgemmParams& p, bool smallc) {
+    if (!halo_enabled() || smallc || p.math != XV2_MATH_F32X3 || p.ncls != 1 || p.s_in != 1 || p.Nout % 64 != 0) return false;
+    const ClassInfo& c = p.cls[0];
+    if (c.ntaps != 9 || c.tap0 != 0 || c.OHl != p.IH || c.OWl != p.IW || c.OHl % 8 != 0 || c.OWl % 16 != 0) return false;
+    if (p.C0 % 32 != 0 || p.Ctot % 32 != 0 || c.nkt != 9 * (p.Ctot / BK)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.taps[t].dh < -1 || p.taps[t].dh > 1 || p.taps[t].dw < -1 || p.taps[t].dw > 1) return false;
+    return true;
+}
+
 int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stream) {
     XV2_CHECK_ARG(p.Nout % 32 == 0, "igemm: Nout=%d must be a multiple of 32", p.Nout);
     XV2_CHECK_ARG(p.ncls >= 1 && p.cls[0].M > 0, "igemm: empty problem");
@@ -1046,8 +1292,21 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
         if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
+        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc))
+            return bn == 128 ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
+                             : launch_one<128, 64, 2, 2, false, true, false, true, true>(p, stream);
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
+        bool halo = !splitk_fold_enabled() && halo_eligible(p, smallc);
+        if (halo) {      // K ranges of whole 32-channel chunks (all nine taps of a halo slice stay in one block)
+            const int nch = p.cls[0].nkt / 9, cps = (int)cdiv(nch, p.ksplit), nks = (int)cdiv(nch, cps);
+            if (nks > 1) {
+                p.kt_per_split = 9 * cps;
+                p.ksplit = nks;
+            } else {
+                halo = false;
+            }
+        }
         if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8) {
             // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
             // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
@@ -1065,6 +1324,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         const StatsFold fold = p.fold;
         p.fold.on = 0;
         int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                 : halo                        ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                  : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
                                                : launch_one<128, 128, 2, 2, false>(p, stream);
