@@ -35,6 +35,9 @@
 #define XV2_ABL 0   // debug ablations (scripts/ablate.sh): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no epilogue
 #endif
 
+#ifndef XV2_HABL
+#define XV2_HABL 0      // halo-form ablations (debug): 1 no halo stores, 2 unshifted fragment rows
+#endif
 #ifndef XV2_PF
 #define XV2_PF 3      // F32X3 main loop: stages between a global load and its split (3: two raw register sets, 4: three -
                       // measured identical on every cfg2 layer and on the step, 256 instead of 240 VGPRs: the loads are not
@@ -87,7 +90,7 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // HALO = true (F32X3, 3x3 / stride 1 / pad 1 forward and backward-data): the M tile is an 8 x 16 pixel PATCH of one
 // image and the K loop runs chunk-major over 16-channel slices: the 10 x 18 halo of a slice is fetched, split and stored
 // into LDS ONCE and serves all nine taps (shifted fragment addresses) - global loads, operand splits and LDS stores of
-// the activation operand drop 6.4x; the weight operand streams per tap as before.  Opt-in: see halo_enabled().
+// the activation operand drop 6.4x; the weight operand streams per tap as before.  Default for eligible layers: halo_enabled().
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
           bool HALO = false>
 __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
@@ -328,10 +331,13 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if constexpr (X3 && HALO) {
-        constexpr int LDK = 24, HWD = PW + 2, NHP = (PH + 2) * HWD;      // 10 x 18 = 180 halo pixels
-        constexpr int NHPP = (NHP + 7) / 8 * 8, PLA = NHPP * LDK;        // halo plane [184][24] bf16
+        // 10 x 18 halo pixels, kept in LDS with a row pitch of HWD = 24 pixels: a 32-pixel MFMA tile is two patch rows of 16,
+        // and with a pitch that is a multiple of 8 rows (8 x 48 B = 3 bank periods) its second half lands on the banks 16
+        // consecutive rows further would - a pitch of 18 gave 2.1e7 bank-conflict cycles per launch (SQ_LDS_BANK_CONFLICT)
+        constexpr int LDK = 24, HWD = 24, HUSE = PW + 2, NHP = (PH + 2) * HWD;      // 240 LDS rows
+        constexpr int PLA = NHP * LDK;                                   // halo plane [240][24] bf16
         constexpr int PLB = BN * LDK, STB = 3 * PLB;                     // weight stage: three planes [BN][24]
-        constexpr int HL = (NHP * 4 + 255) / 256;                        // 16-byte halo loads per thread (3)
+        constexpr int HL = (NHP * 4 + 255) / 256;                        // 16-byte halo loads per thread (4, a quarter idle)
         static_assert((size_t)(3 * PLA + 2 * STB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + weight stages fit the operand buffers");
         __bf16* sa = reinterpret_cast<__bf16*>(smem);                    // [3][NHPP][LDK]
         __bf16* sbw = sa + 3 * PLA;                                      // [2][3][BN][LDK]
@@ -344,12 +350,13 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
 #pragma unroll
         for (int j = 0; j < HL; ++j) {
             const int e = tid + j * 256, hq = e >> 2;
-            const int hp = hq < NHP / 8 * 8 ? ((hq & ~7) | ((hq & 3) << 1) | ((hq >> 2) & 1)) : hq;
+            const int hp = (hq & ~7) | ((hq & 3) << 1) | ((hq >> 2) & 1);      // LDS row (NHP is a multiple of 8)
             const int hr = hp / HWD, hc = hp - hr * HWD;
             const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
-            const bool ok = hq < NHP && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            const bool used = hq < NHP && hc < HUSE;
+            const bool ok = used && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
             hpix[j] = ok ? (h_n * p.IH + ih) * p.IW + iw : -1;
-            hrow[j] = hq < NHP ? hp : -1;
+            hrow[j] = used ? hp : -1;
         }
         // fragment rows: A tile i of this wave = two patch rows of 16 pixels; halo row of (pixel, tap (0,0))
         int abase[MR];
@@ -376,6 +383,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             for (int j = 0; j < HL; ++j) split3x4(hraw[j], pkh[j][0], pkh[j][1], pkh[j][2]);
         };
         auto hstore = [&]() {
+#if XV2_HABL & 1
+            return;
+#endif
 #pragma unroll
             for (int j = 0; j < HL; ++j)
                 if (hrow[j] >= 0) {
@@ -385,9 +395,12 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                     *reinterpret_cast<uint2*>(d + 2 * PLA) = pkh[j][2];
                 }
         };
+        // taps are the 3 x 3 neighbourhood in slot order, (dh, dw) = sgn * (t / 3 - 1, t % 3 - 1) with sgn = +1 (forward) or
+        // -1 (backward-data) - checked by halo_eligible(): scalar arithmetic instead of a dynamically indexed table load
+        const int sgn = __builtin_amdgcn_readfirstlane(taps[0].dh < 0 ? 1 : -1);
         auto bload = [&](int st, float4 (&xb)[BROWS]) {      // weights of stage st = (slice st / ntp, tap st % ntp)
             const int cs = st / ntp, tp = st - cs * ntp;
-            const int kb = taps[tp].slot * p.Ctot + (cs >> 1) * BK + (cs & 1) * 16;
+            const int kb = tp * p.Ctot + (cs >> 1) * BK + (cs & 1) * 16;
 #pragma unroll
             for (int j = 0; j < BROWS; ++j)
                 xb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[j] + kb) << 2, 0, 0));
@@ -397,6 +410,9 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             for (int j = 0; j < BROWS; ++j) split3x4(xb[j], pkb[j][0], pkb[j][1], pkb[j][2]);
         };
         auto bstore = [&](int buf) {
+#if XV2_HABL & 4
+            return;
+#endif
 #pragma unroll
             for (int j = 0; j < BROWS; ++j) {
                 const int rr = r0 + RPP * j;
@@ -409,7 +425,12 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             }
         };
         auto read_a = [&](int tp, bf16x8 (&fa)[MR][3]) {
-            const int toff = taps[tp].dh * HWD + taps[tp].dw;
+            const int th = tp / 3;
+#if XV2_HABL & 2
+            const int toff = 0;
+#else
+            const int toff = sgn * ((th - 1) * HWD + (tp - th * 3 - 1));
+#endif
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -417,7 +438,11 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                     fa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * PLA + (abase[i] + toff) * LDK + 8 * h);
         };
         auto read_b = [&](int buf, bf16x8 (&fb)[NR][3]) {
+#if XV2_HABL & 8
+            const __bf16* b = sbw + buf * STB + l31 * 8 + 256 * h;      // conflict-free by construction (wrong data)
+#else
             const __bf16* b = sbw + buf * STB + (wn * WTN + l31) * LDK + 8 * h;
+#endif
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -435,13 +460,13 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
                     }
         };
-        int tp = 0, cs = cs_begin;       // tap and slice of the stage being multiplied
         // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; xb holds the raw weights of st+2 (split here);
         // yb is free and receives st+3.  At the last tap of a slice the next slice's halo (in flight since the slice began)
         // is split and replaces the halo in LDS - nobody reads it any more: the A fragments of the last tap were fetched one
         // iteration earlier - and the first tap's A fragments are read behind the barrier.
-        auto iter = [&](int st, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3], bf16x8 (&na)[MR][3],
-                        bf16x8 (&nb)[NR][3], float4 (&xb)[BROWS], float4 (&yb)[BROWS]) {
+        // (tp, cs = tap and slice of stage st, by value: as captured loop state they ended up in scratch memory)
+        auto iter = [&](int st, const int tp, const int cs, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3],
+                        bf16x8 (&na)[MR][3], bf16x8 (&nb)[NR][3], float4 (&xb)[BROWS], float4 (&yb)[BROWS]) {
             const bool last = tp == ntp - 1;
             const bool more = st + 1 < s_end;
             if (more) {
@@ -473,12 +498,6 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
                 read_a(0, na);
                 if (cs + 2 < cs_end) hload(cs + 2);
             }
-            if (last) {
-                tp = 0;
-                ++cs;
-            } else {
-                ++tp;
-            }
         };
         hload(cs_begin);
         bload(s_begin, rbb);
@@ -495,9 +514,18 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         read_a(0, fa0);
         read_b(0, fb0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        int tp = 0, cs = cs_begin;
         for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even (two slices per 32-channel chunk)
-            iter(st, fa0, fb0, fa1, fb1, rbb, rbb1);
-            iter(st + 1, fa1, fb1, fa0, fb0, rbb1, rbb);
+            iter(st, tp, cs, fa0, fb0, fa1, fb1, rbb, rbb1);
+            if (++tp == ntp) {
+                tp = 0;
+                ++cs;
+            }
+            iter(st + 1, tp, cs, fa1, fb1, fa0, fb0, rbb1, rbb);
+            if (++tp == ntp) {
+                tp = 0;
+                ++cs;
+            }
         }
     } else if constexpr (X3) {
         // K advances in STAGES of 16 channels (half a K-tile).  LDS: two stage buffers, each three bf16 planes
@@ -1241,12 +1269,14 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
 }
 
 // the halo form of the F32X3 kernel (igemm_kernel<..., HALO>): 3x3 taps around the output pixel on a same-size input.
-// Exact (the op and true-size layer tests pass with it on) and MEASURED NO FASTER: cfg2 3x3 layers 0.93 - 1.03x of the
-// per-tap form (dec1 116 GFLOP forward 0.673 -> 0.720 ms, dec5-level 0.259 -> 0.251 ms) although the activation operand's
-// loads, splits and LDS stores drop 6.4x - what bounds the kernel is the matrix pipe + fragment reads + the weight
-// stream under the power limit, not the activation producer.  Off by default (XV2_HALO=1 for A/B runs).
+// First version measured 0.93 - 1.03x of the per-tap form; rocprofv3 PMC on it showed why (profiles/r03_pmc_halo.md): the
+// effective clock DID rise (1.59 -> 1.87 GHz: the activation operand's loads, splits and plane stores drop 6.4x) but the
+// matrix pipe's duty fell from 0.66 to 0.50 - the tap / slice counters, captured by reference in the iteration lambda,
+// lived in scratch memory (3 extra VMEM round trips per stage) and the tap table was read with vector loads.  With both
+// gone: dec2 / dec3 116-GFLOP layers 0.592 -> 0.547 / 0.605 -> 0.553 ms, dec4 0.565 -> 0.483, l1.conv2 0.093 -> 0.077.
+// XV2_HALO=0 restores the per-tap form (A/B runs).
 static bool halo_enabled() {
-    static const int v = [] { const char* e = getenv("XV2_HALO"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("XV2_HALO"); return e ? atoi(e) : 1; }();
     return v != 0;
 }
 static bool halo_eligible(const IgemmParams& p, bool smallc) {
@@ -1254,8 +1284,9 @@ static bool halo_eligible(const IgemmParams& p, bool smallc) {
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 9 || c.tap0 != 0 || c.OHl != p.IH || c.OWl != p.IW || c.OHl % 8 != 0 || c.OWl % 16 != 0) return false;
     if (p.C0 % 32 != 0 || p.Ctot % 32 != 0 || c.nkt != 9 * (p.Ctot / BK)) return false;
-    for (int t = 0; t < 9; ++t)
-        if (p.taps[t].dh < -1 || p.taps[t].dh > 1 || p.taps[t].dw < -1 || p.taps[t].dw > 1) return false;
+    const int sgn = p.taps[0].dh < 0 ? 1 : -1;
+    for (int t = 0; t < 9; ++t)       // slot order, (dh, dw) = sgn * (t / 3 - 1, t % 3 - 1): the kernel derives them
+        if (p.taps[t].slot != t || p.taps[t].dh != sgn * (t / 3 - 1) || p.taps[t].dw != sgn * (t % 3 - 1)) return false;
     return true;
 }
 
