@@ -38,6 +38,9 @@
 #ifndef XV2_HABL
 #define XV2_HABL 0      // halo-form ablations (debug): 1 no halo stores, 2 unshifted fragment rows
 #endif
+#ifndef XV2_HB3
+#define XV2_HB3 0      // halo form, 64-column tiles: force 3 blocks per CU (168 VGPRs)
+#endif
 #ifndef XV2_PF
 #define XV2_PF 3      // F32X3 main loop: stages between a global load and its split (3: two raw register sets, 4: three -
                       // measured identical on every cfg2 layer and on the step, 256 instead of 240 VGPRs: the loads are not
@@ -51,8 +54,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LDS_LD = BK + 4;
 constexpr int LDS_LD_H_ = BK + 8;
 // floats of LDS shared by the main-loop operand buffers and the epilogue staging tile
-template <int BM, int BN, bool HIN, int NH>
+template <int BM, int BN, bool HIN, int NH, bool HALO = false>
 constexpr int igemm_main_floats() {
+    if (HALO) {      // three halo planes [208][24] bf16 + two weight stages of three planes [BN][24] bf16, or the epilogue tile
+        const int loop = (3 * 208 * 24 + 2 * 3 * BN * 24) / 2, epi = BM * (BN + 4);
+        return loop > epi ? loop : epi;
+    }
     if (!HIN) return 2 * (BM + BN) * LDS_LD;
     const int loop = 2 * (BM + BN) * LDS_LD_H_ / 2, epi = (BM / NH) * (BN + 4);
     return loop > epi ? loop : epi;
@@ -87,13 +94,13 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // source (SMALLC) stays an fp32 image with fp32 weights and exact-fp32 MFMA; only its output is bf16.
 // X3 = true (XV2_MATH_F32X3): fp32 tensors, each operand element split into three bf16 terms on its way into LDS (three
 // bf16 planes per operand, single-buffered: 61 KB for the 128x128 tile), six bf16 MFMAs per fp32-grade product.
-// HALO = true (F32X3, 3x3 / stride 1 / pad 1 forward and backward-data): the M tile is an 8 x 16 pixel PATCH of one
-// image and the K loop runs chunk-major over 16-channel slices: the 10 x 18 halo of a slice is fetched, split and stored
+// HALO = true (F32X3, 3x3 / stride 1 / pad 1 forward and backward-data): the M tile is a 4 x 32 pixel PATCH of one
+// image and the K loop runs chunk-major over 16-channel slices: the 6 x 34 halo of a slice is fetched, split and stored
 // into LDS ONCE and serves all nine taps (shifted fragment addresses) - global loads, operand splits and LDS stores of
 // the activation operand drop 6.4x; the weight operand streams per tap as before.  Default for eligible layers: halo_enabled().
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
           bool HALO = false>
-__global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
+__global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     static_assert(!HALO || (X3 && BM == 128), "halo form: F32X3, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -112,7 +119,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
     // bf16 operands: the LDS image is half as large, and with the epilogue staged in two row halves a block needs
     // ~45 KB instead of 74 KB - three blocks per CU instead of two hide more of the global-load latency
     constexpr int NH = (HIN && WGM >= 2) ? 2 : 1;       // epilogue staging passes
-    constexpr int MAIN_FLOATS = igemm_main_floats<BM, BN, HIN, NH>();
+    constexpr int MAIN_FLOATS = igemm_main_floats<BM, BN, HIN, NH, HALO>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
         rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A1 ? p.A1 : p.A0), 0, p.A1 ? p.bytesA1 : p.bytesA0, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
     }
-    constexpr int PW = 16, PH = BM / PW;        // HALO: patch width / height
+    constexpr int PW = 32, PH = BM / PW;        // HALO: patch width / height (one MFMA row tile = 32 pixels of ONE patch row)
     int h_n = 0, h_oh0 = 0, h_ow0 = 0;         // HALO: image and patch origin of this tile
     if constexpr (HALO) {
         const int tiles_w = ci.OWl / PW, tiles_h = ci.OHl / PH;
@@ -331,10 +338,10 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if constexpr (X3 && HALO) {
-        // 10 x 18 halo pixels, kept in LDS with a row pitch of HWD = 24 pixels: a 32-pixel MFMA tile is two patch rows of 16,
-        // and with a pitch that is a multiple of 8 rows (8 x 48 B = 3 bank periods) its second half lands on the banks 16
-        // consecutive rows further would - a pitch of 18 gave 2.1e7 bank-conflict cycles per launch (SQ_LDS_BANK_CONFLICT)
-        constexpr int LDK = 24, HWD = 24, HUSE = PW + 2, NHP = (PH + 2) * HWD;      // 240 LDS rows
+        // 6 x 34 halo pixels.  The patch is 4 x 32 so that the 32 lanes of an MFMA row tile read 32 CONSECUTIVE LDS rows
+        // whatever the tap: with 8 x 16 patches (two patch rows per tile, a jump of 18 or 24 LDS rows between lanes 15 and
+        // 16) SQ_LDS_BANK_CONFLICT counted 2.1e7 cycles per launch, 8 % of the kernel; consecutive rows: 0.
+        constexpr int LDK = 24, HWD = PW + 2, HUSE = PW + 2, NHP = ((PH + 2) * HWD + 7) / 8 * 8;      // 204 -> 208 LDS rows
         constexpr int PLA = NHP * LDK;                                   // halo plane [240][24] bf16
         constexpr int PLB = BN * LDK, STB = 3 * PLB;                     // weight stage: three planes [BN][24]
         constexpr int HL = (NHP * 4 + 255) / 256;                        // 16-byte halo loads per thread (4, a quarter idle)
@@ -353,15 +360,15 @@ __global__ void __launch_bounds__(256, X3 ? 2 : 1) igemm_kernel(const IgemmParam
             const int hp = (hq & ~7) | ((hq & 3) << 1) | ((hq >> 2) & 1);      // LDS row (NHP is a multiple of 8)
             const int hr = hp / HWD, hc = hp - hr * HWD;
             const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
-            const bool used = hq < NHP && hc < HUSE;
+            const bool used = hq < NHP && hr < PH + 2 && hc < HUSE;
             const bool ok = used && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
             hpix[j] = ok ? (h_n * p.IH + ih) * p.IW + iw : -1;
             hrow[j] = used ? hp : -1;
         }
-        // fragment rows: A tile i of this wave = two patch rows of 16 pixels; halo row of (pixel, tap (0,0))
+        // fragment rows: A tile i of this wave = one patch row of 32 pixels; halo row of (pixel, tap (0,0))
         int abase[MR];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + (l31 >> 4) + 1) * HWD + (l31 & 15) + 1;
+        for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + 1) * HWD + l31 + 1;
         float4 hraw[HL], rbb[BROWS], rbb1[BROWS];
         uint2 pkb[BROWS][3], pkh[HL][3];
         bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
@@ -1091,15 +1098,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool HIN, int WGM>
+template <int BM, int BN, bool HIN, int WGM, bool HALO = false>
 constexpr size_t igemm_smem_bytes() {
-    return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1>() * 4 + BM * 4 + 4 * BN * 2 * 4;
+    return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1, HALO>() * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
           bool HALO = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
-    constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM>();
+    constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM, HALO>();
     auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
@@ -1274,7 +1281,8 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
 // matrix pipe's duty fell from 0.66 to 0.50 - the tap / slice counters, captured by reference in the iteration lambda,
 // lived in scratch memory (3 extra VMEM round trips per stage) and the tap table was read with vector loads.  With both
 // gone: dec2 / dec3 116-GFLOP layers 0.592 -> 0.547 / 0.605 -> 0.553 ms, dec4 0.565 -> 0.483, l1.conv2 0.093 -> 0.077.
-// XV2_HALO=0 restores the per-tap form (A/B runs).
+// (Eight channels per thread with 16-byte plane stores - half the store instructions for the same bytes - measured 2-3 %
+// slower than the 4-channel / 8-byte form.)  XV2_HALO=0 restores the per-tap form (A/B runs).
 static bool halo_enabled() {
     static const int v = [] { const char* e = getenv("XV2_HALO"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -1282,7 +1290,7 @@ static bool halo_enabled() {
 static bool halo_eligible(const IgemmParams& p, bool smallc) {
     if (!halo_enabled() || smallc || p.math != XV2_MATH_F32X3 || p.ncls != 1 || p.s_in != 1 || p.Nout % 64 != 0) return false;
     const ClassInfo& c = p.cls[0];
-    if (c.ntaps != 9 || c.tap0 != 0 || c.OHl != p.IH || c.OWl != p.IW || c.OHl % 8 != 0 || c.OWl % 16 != 0) return false;
+    if (c.ntaps != 9 || c.tap0 != 0 || c.OHl != p.IH || c.OWl != p.IW || c.OHl % 4 != 0 || c.OWl % 32 != 0) return false;
     if (p.C0 % 32 != 0 || p.Ctot % 32 != 0 || c.nkt != 9 * (p.Ctot / BK)) return false;
     const int sgn = p.taps[0].dh < 0 ? 1 : -1;
     for (int t = 0; t < 9; ++t)       // slot order, (dh, dw) = sgn * (t / 3 - 1, t % 3 - 1): the kernel derives them
