@@ -83,6 +83,24 @@ int xv2_pack_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int 
 int64_t xv2_pack_weights_tiles(int Cout, int KH, int KW, int cin_pad);
 int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, void* stream);
 
+/* Packed fp32 weight operands PRE-SPLIT into three bf16 planes (XV2_MATH_F32X3: every fp32 value = hi + mid + lo exactly,
+ * xv2_common.h split3x4) for the halo form of the implicit-GEMM kernel: the 3x3 / stride-1 forward and backward-data
+ * launches of nn.Conv2d (model/layers.py:92, ConvLayer) then stream their weight operand global -> LDS with direct-to-LDS
+ * loads - no registers, no split, no LDS store instructions for it.
+ * `b_fp32` = a packed layout [nrows][T][ctot] as xv2_pack_weight writes it (w_ohwi: nrows = Cout, ctot = cin_pad; w_ihwo:
+ * nrows = cin_pad, ctot = Cout); `x3` = xv2_presplit_bytes() bytes, 16-byte aligned, laid out
+ * [nrows/64][T][ctot/16][3 planes][64 rows][16] bf16 (the LDS image of a weight stage).  xv2_presplit_weights() fills x3
+ * AND remembers the pair: convolutions handed `b_fp32` afterwards read the planes, so the caller must refresh them on the
+ * same stream whenever the packed weights change (xv2_presplit_table: all pairs of a device table [n][6] int64 =
+ * {b_fp32, x3 (pointers), nrows, T, ctot, first block} in one launch, an entry owns xv2_presplit_blocks() blocks) and call
+ * xv2_presplit_forget(b_fp32) before releasing either buffer (NULL: forget every pair).  XV2_PRESPLIT=0 ignores the pairs. */
+int xv2_presplit_supported(int nrows, int T, int ctot);
+size_t xv2_presplit_bytes(int nrows, int T, int ctot);
+int64_t xv2_presplit_blocks(int nrows, int T, int ctot);
+int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int ctot, void* x3, void* stream);
+int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream);
+int xv2_presplit_forget(const void* b_fp32);
+
 /* y = conv2d(cat(x0,x1), w) [+ bias]; replaces F.conv2d.  If `stats` != NULL the kernel also
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]
  * (tile count = xv2_conv2d_forward_stats_tiles(d)), consumed by xv2_bn_reduce_stats. */

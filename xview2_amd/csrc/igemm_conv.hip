@@ -24,6 +24,8 @@
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
+#include <mutex>
+#include <unordered_map>
 
 #ifndef XV2_SCHED
 #define XV2_SCHED 0
@@ -98,9 +100,13 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // image and the K loop runs chunk-major over 16-channel slices: the 6 x 34 halo of a slice is fetched, split and stored
 // into LDS ONCE and serves all nine taps (shifted fragment addresses) - global loads, operand splits and LDS stores of
 // the activation operand drop 6.4x; the weight operand streams per tap as before.  Default for eligible layers: halo_enabled().
+// BX3 = true (halo form only): the weight operand arrives PRE-SPLIT (three bf16 planes, xv2_presplit_weights: once per
+// optimizer step) and goes global -> LDS with direct-to-LDS buffer loads: no registers, no split, no ds_write for it.
+// PMC had shown the plane stores as the most expensive producer step in clock; emulated first (garbage data): -12 %.
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
-          bool HALO = false>
+          bool HALO = false, bool BX3 = false>
 __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
+    static_assert(!BX3 || HALO, "pre-split weights: halo form only");
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     static_assert(!HALO || (X3 && BM == 128), "halo form: F32X3, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -348,6 +354,10 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         static_assert((size_t)(3 * PLA + 2 * STB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + weight stages fit the operand buffers");
         __bf16* sa = reinterpret_cast<__bf16*>(smem);                    // [3][NHPP][LDK]
         __bf16* sbw = sa + 3 * PLA;                                      // [2][3][BN][LDK]
+        // BX3: ring of three weight stages, each [BN / 64 units][3 planes][64 rows][16] bf16 with the two 16-byte halves of a
+        // row swapped on rows 4..7 mod 8 (conflict-free 16-byte fragment reads without padding), 1 KB per DMA instruction
+        constexpr int STBX = 3 * BN * 16;                                // elements per pre-split weight stage
+        static_assert(!BX3 || (size_t)(3 * PLA + 3 * STBX) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + three weight stages fit");
         const int ntp = ci.ntaps;                                        // 9
         // split-K ranges are whole 32-channel chunks (kt_per_split % ntaps == 0, igemm_launch)
         const int cs_begin = 2 * (kt_begin / ntp), cs_end = 2 * (kt_end / ntp);      // 16-channel slices
@@ -506,6 +516,89 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 if (cs + 2 < cs_end) hload(cs + 2);
             }
         };
+        if constexpr (BX3) {
+            constexpr int NCH = STBX * 2 / 1024;                 // 1 KB DMA chunks per stage: 12 (BN = 128) / 6 (BN = 64)
+            constexpr int CPW = (NCH + 3) / 4;                   // per wave: 3 / 2 (BN = 64: two chunks are fetched twice)
+            const int nsl = p.Ctot / 16;
+            __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bx3), 0, p.bytesBx3, 0x00020000);
+            auto dma = [&](int st, int buf) {                    // weights of stage st -> ring slot buf
+                const int cs = st / ntp, tp = st - cs * ntp;
+#pragma unroll
+                for (int u = 0; u < CPW; ++u) {
+                    const int chunk = (wave * CPW + u) % NCH;
+                    const int unit = chunk / 6, cq = chunk - unit * 6;
+                    const int goff = (((tn * (BN / 64) + unit) * p.T + tp) * nsl + cs) * 6144 + cq * 1024 + lane * 16;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsX, (__attribute__((address_space(3))) void*)(sbw + buf * STBX + unit * 3072 + cq * 512), 16, goff, 0, 0, 0);
+                }
+            };
+            auto read_bx = [&](int buf, bf16x8 (&fb)[NR][3]) {
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int row = wn * WTN + j * 32 + l31, unit = row >> 6, r = row & 63;
+                    const __bf16* b = sbw + buf * STBX + unit * 3072 + r * 16 + ((h ^ ((r >> 2) & 1)) * 8);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * 1024);
+                }
+            };
+            // iteration st (ring slot bc = st % 3): fragments of st in (fa, fb); (na, nb) receive st+1; the DMA of st+2 (issued
+            // one iteration ago) must have landed by the barrier, the DMA of st+3 is issued here into the slot of st
+            auto iterx = [&](int st, const int tp, const int cs, const int bc, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3],
+                             bf16x8 (&na)[MR][3], bf16x8 (&nb)[NR][3]) {
+                const bool last = tp == ntp - 1;
+                const bool more = st + 1 < s_end;
+                if (more) {
+                    read_bx(bc == 2 ? 0 : bc + 1, nb);
+                    if (!last) read_a(tp + 1, na);
+                }
+                const bool pf = st + 3 < s_end;
+                if (pf) dma(st + 3, bc);
+                mfma_stage(fa, fb);
+                const bool swap = last && more;
+                if (swap) {
+                    hsplit();
+                    hstore();
+                }
+                if (pf) {
+                    if constexpr (CPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (swap) {
+                    read_a(0, na);
+                    if (cs + 2 < cs_end) hload(cs + 2);
+                }
+            };
+            hload(cs_begin);
+            dma(s_begin, 0);
+            dma(s_begin + 1, 1);
+            hsplit();
+            hstore();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (s_begin + 2 < s_end) dma(s_begin + 2, 2);
+            if (cs_begin + 1 < cs_end) hload(cs_begin + 1);
+            __syncthreads();
+            read_a(0, fa0);
+            read_bx(0, fb0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            int tp = 0, cs = cs_begin, bc = 0;
+            for (int st = s_begin; st < s_end; st += 2) {
+                iterx(st, tp, cs, bc, fa0, fb0, fa1, fb1);
+                if (++tp == ntp) {
+                    tp = 0;
+                    ++cs;
+                }
+                bc = bc == 2 ? 0 : bc + 1;
+                iterx(st + 1, tp, cs, bc, fa1, fb1, fa0, fb0);
+                if (++tp == ntp) {
+                    tp = 0;
+                    ++cs;
+                }
+                bc = bc == 2 ? 0 : bc + 1;
+            }
+        } else {
         hload(cs_begin);
         bload(s_begin, rbb);
         bload(s_begin + 1, rbb1);
@@ -534,6 +627,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 ++cs;
             }
         }
+        }      // !BX3
     } else if constexpr (X3) {
         // K advances in STAGES of 16 channels (half a K-tile).  LDS: two stage buffers, each three bf16 planes
         // [hi | mid | lo] x ([A rows | B rows] x 24 bf16: 16 + 8 pad, 48-byte rows) - 73.7 KB for 128x128, the size of the
@@ -1104,10 +1198,10 @@ constexpr size_t igemm_smem_bytes() {
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
-          bool HALO = false>
+          bool HALO = false, bool BX3 = false>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM, HALO>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO>;
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO, BX3>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1116,7 +1210,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? (HALO ? "c32,f32x3,halo" : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? (HALO ? (BX3 ? "c32,f32x3,halo,wx3" : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -1275,6 +1369,59 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
     return XV2_OK;
 }
 
+// ---- weights pre-split into bf16 planes (igemm_kernel<..., BX3>) ------------------------------------------------------
+// x3 layout of a packed fp32 operand B [nrows][T][ctot]:  [nrows / 64][T][ctot / 16][3 planes][64 rows][16] bf16, the two
+// 8-element halves of a row swapped on rows with bit 2 set (the LDS image of a weight stage, copied 1:1 by the DMA loads).
+struct PresplitEntry {
+    const void* x3;
+    int nrows, T, ctot;
+};
+static std::mutex g_presplit_mu;
+static std::unordered_map<const void*, PresplitEntry> g_presplit;
+
+__device__ __forceinline__ void presplit_store(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int ctot,
+                                               int64_t e4) {
+    const int c4n = ctot / 4;
+    const int c = (int)(e4 % c4n) * 4;
+    const int64_t rt = e4 / c4n;
+    const int t = (int)(rt % T), row = (int)(rt / T);
+    const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)row * T + t) * ctot + c);
+    uint2 pk[3];
+    split3x4(v, pk[0], pk[1], pk[2]);
+    const int unit = row >> 6, r = row & 63, cs = c >> 4, k0 = c & 15;
+    const int half = (k0 >> 3) ^ ((r >> 2) & 1);
+    __bf16* d = dst + (((size_t)unit * T + t) * (ctot / 16) + cs) * 3072 + r * 16 + half * 8 + (k0 & 7);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = pk[q];
+}
+__global__ void __launch_bounds__(256) presplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
+                                                       int T, int ctot) {
+    const int64_t n4 = (int64_t)nrows * T * (ctot / 4);
+    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) presplit_store(src, dst, T, ctot, e);
+}
+// table[n][6]: {src, dst, nrows, T, ctot, first block}; a block = 256 groups of 4 elements
+__global__ void __launch_bounds__(256) presplit_table_kernel(const int64_t* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6 + 5] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t* e = table + lo * 6;
+    const int nrows = (int)e[2], T = (int)e[3], ctot = (int)e[4];
+    const int64_t e4 = (blk - e[5]) * 256 + threadIdx.x;
+    if (e4 < (int64_t)nrows * T * (ctot / 4))
+        presplit_store(reinterpret_cast<const float*>(e[0]), reinterpret_cast<__bf16*>(e[1]), T, ctot, e4);
+}
+static bool presplit_lookup(const void* b, int nrows, int T, int ctot, const void** x3) {
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    auto it = g_presplit.find(b);
+    if (it == g_presplit.end() || it->second.nrows != nrows || it->second.T != T || it->second.ctot != ctot) return false;
+    *x3 = it->second.x3;
+    return true;
+}
+
 // the halo form of the F32X3 kernel (igemm_kernel<..., HALO>): 3x3 taps around the output pixel on a same-size input.
 // First version measured 0.93 - 1.03x of the per-tap form; rocprofv3 PMC on it showed why (profiles/r03_pmc_halo.md): the
 // effective clock DID rise (1.59 -> 1.87 GHz: the activation operand's loads, splits and plane stores drop 6.4x) but the
@@ -1285,6 +1432,10 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
 // slower than the 4-channel / 8-byte form.)  XV2_HALO=0 restores the per-tap form (A/B runs).
 static bool halo_enabled() {
     static const int v = [] { const char* e = getenv("XV2_HALO"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+static bool presplit_enabled() {      // XV2_PRESPLIT=0: weights split in the kernel (A/B runs)
+    static const int v = [] { const char* e = getenv("XV2_PRESPLIT"); return e ? atoi(e) : 1; }();
     return v != 0;
 }
 static bool halo_eligible(const IgemmParams& p, bool smallc) {
@@ -1331,9 +1482,17 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
         if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
-        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc))
+        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc)) {
+            const void* x3 = nullptr;
+            if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
+                p.Bx3 = reinterpret_cast<const float*>(x3);
+                p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 6);
+                return bn == 128 ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
+                                 : launch_one<128, 64, 2, 2, false, true, false, true, true, true>(p, stream);
+            }
             return bn == 128 ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
                              : launch_one<128, 64, 2, 2, false, true, false, true, true>(p, stream);
+        }
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
         bool halo = !splitk_fold_enabled() && halo_eligible(p, smallc);
@@ -1342,6 +1501,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             if (nks > 1) {
                 p.kt_per_split = 9 * cps;
                 p.ksplit = nks;
+                const void* x3 = nullptr;
+                if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
+                    p.Bx3 = reinterpret_cast<const float*>(x3);
+                    p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 6);
+                }
             } else {
                 halo = false;
             }
@@ -1363,6 +1527,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         const StatsFold fold = p.fold;
         p.fold.on = 0;
         int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                 : (halo && p.Bx3)             ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
                  : halo                        ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                  : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
@@ -1449,6 +1614,8 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.stats = nullptr;
     p.part = nullptr;
     p.sk_tickets = nullptr;
+    p.Bx3 = nullptr;
+    p.bytesBx3 = 0;
     p.ksplit = 1;
     p.cin_real = 3;
     p.math = d->math;
@@ -1779,4 +1946,43 @@ extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
                                                   const void* w_ohwi, void* dx, int lddx, void* stream) {
     return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
+}
+
+// ---- pre-split weights (see PresplitEntry) ---------------------------------------------------------------------------
+extern "C" size_t xv2_presplit_bytes(int nrows, int T, int ctot) { return (size_t)nrows * T * ctot * 6; }
+
+extern "C" int xv2_presplit_supported(int nrows, int T, int ctot) { return (T == 9 && nrows % 64 == 0 && ctot % 32 == 0) ? 1 : 0; }
+
+static int presplit_register(const float* b_fp32, int nrows, int T, int ctot, void* x3) {
+    XV2_CHECK_ARG(b_fp32 && x3 && xv2_presplit_supported(nrows, T, ctot), "presplit: unsupported operand %d x %d x %d", nrows, T, ctot);
+    XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(x3) & 15) == 0 && (reinterpret_cast<uintptr_t>(b_fp32) & 15) == 0 &&
+                      xv2_presplit_bytes(nrows, T, ctot) < (1ull << 31), "presplit: alignment / size");
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    g_presplit[b_fp32] = PresplitEntry{x3, nrows, T, ctot};
+    return XV2_OK;
+}
+
+// split the packed fp32 operand `b_fp32` [nrows][T][ctot] into `x3` and remember the pair: convolutions that are handed
+// `b_fp32` afterwards read the planes (the caller refreshes them whenever the weights change, on the same stream)
+extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int ctot, void* x3, void* stream) {
+    if (int rc = presplit_register(b_fp32, nrows, T, ctot, x3)) return rc;
+    const int64_t n4 = (int64_t)nrows * T * (ctot / 4);
+    hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       b_fp32, reinterpret_cast<__bf16*>(x3), nrows, T, ctot);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { return cdiv((int64_t)nrows * T * (ctot / 4), 256); }
+// every registered pair of a device table in one launch (after the optimizer step); rows as in presplit_table_kernel
+extern "C" int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "presplit_table: bad table");
+    hipLaunchKernelGGL(presplit_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_presplit_forget(const void* b_fp32) {
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    if (b_fp32) g_presplit.erase(b_fp32);
+    else g_presplit.clear();
+    return XV2_OK;
 }

@@ -31,6 +31,8 @@ struct IgemmParams {
     unsigned* sk_tickets;   // != NULL: the slabs are summed in-launch by the last K-split block of each output tile
                             // (two zero-initialised counters per tile: arrivals, published slabs)
     unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
+    const float* Bx3;                   // halo form: B pre-split into three bf16 planes (xv2_presplit_weights), or nullptr
+    unsigned bytesBx3;
     int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
     int ldA0, ldA1;
     int IH, IW;        // spatial size of A

@@ -137,7 +137,48 @@ PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is
 
 
 class _PackEntry:
-    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype")
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype", "x3")
+
+
+PRESPLIT = os.environ.get("XV2_PRESPLIT", "1") != "0"
+
+
+def _presplit_geoms(e):
+    """(packed fp32 layout, rows, taps, channels) of the entry's layouts that the halo form of the split-bf16 kernel can
+    read pre-split (xv2_presplit_weights: 3x3 taps, 64-row units, 32-channel chunks; fp32 tensors only)"""
+    Cout, Cin, T, cin_pad = e.geom
+    out = []
+    if not PRESPLIT or e.dtype != XV2_F32 or cin_pad == 4:
+        return out
+    if e.ohwi is not None and query("xv2_presplit_supported", Cout, T, cin_pad) == 1:
+        out.append((e.ohwi, Cout, T, cin_pad))
+    if e.ihwo is not None and query("xv2_presplit_supported", cin_pad, T, Cout) == 1:
+        out.append((e.ihwo, cin_pad, T, Cout))
+    return out
+
+
+def _presplit_entry(e):
+    """bf16-plane copies of the entry's packed layouts (the weight operand of the halo kernels goes global -> LDS by DMA)"""
+    for src, rows, T, ch in _presplit_geoms(e):
+        key = src.data_ptr()
+        if e.x3 is None:
+            e.x3 = {}
+        if key not in e.x3:
+            e.x3[key] = torch.empty((query("xv2_presplit_bytes", rows, T, ch) // 2,), dtype=torch.bfloat16, device=src.device)
+        call("xv2_presplit_weights", src, rows, T, ch, e.x3[key])
+
+
+def _forget_entry(e):
+    if e.x3:
+        for key in e.x3:
+            query("xv2_presplit_forget", key)
+        e.x3 = None
+
+
+def _del_pack(k):
+    e = _packs.pop(k, None)
+    if e is not None:
+        _forget_entry(e)
 
 
 def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
@@ -158,7 +199,7 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
         # the address alone is not an identity: the allocator hands a freed model's parameter storage to the next model,
         # whose fresh tensors carry the same version counter - the entry must belong to this very parameter
         e = None
-        del _packs[key]
+        _del_pack(key)
         _pack_table = None
     fresh = e is not None and e.version == w_oihw._version and e.epoch == WEIGHT_EPOCH
     _pack_tick += 1
@@ -171,9 +212,9 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
         if len(_packs) >= PACK_CACHE_MAX:
             cut = sorted(v.tick for v in _packs.values())[len(_packs) // 2]
             for k in [k for k, v in _packs.items() if v.tick < cut]:
-                del _packs[k]
+                _del_pack(k)
         e = _PackEntry()
-        e.ohwi = e.ihwo = None
+        e.ohwi = e.ihwo = e.x3 = None
         e.geom = (Cout, Cin, KH * KW, cin_pad)
         _packs[key] = e
         _pack_table = None
@@ -188,6 +229,7 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
     e.owner = weakref.ref(base)        # the parameter; once it is gone the entry only wastes memory
     e.tick = _pack_tick
     call("xv2_pack_weight", w_oihw, Cout, Cin, KH, KW, cin_pad, e.ohwi, e.ihwo, code)
+    _presplit_entry(e)
     e.version, e.epoch = w_oihw._version, WEIGHT_EPOCH
     return e.ohwi, e.ihwo
 
@@ -196,7 +238,7 @@ def _drop_dead_packs():
     global _pack_table
     dead = [k for k, e in _packs.items() if e.owner() is None]
     for k in dead:
-        del _packs[k]
+        _del_pack(k)
     if dead:
         _pack_table = None
 
@@ -217,7 +259,7 @@ def repack_all():
     stale = [k for k, e in _packs.items() if e.tick <= _repack_tick]     # not touched since the last refresh
     if stale:
         for k in stale:
-            del _packs[k]
+            _del_pack(k)
         _pack_table = None
     _repack_tick = _pack_tick
     if not _packs:
@@ -230,16 +272,26 @@ def repack_all():
                          e.ihwo.data_ptr() if e.ihwo is not None else 0, Cout, Cin, T | (e.dtype << 16), cin_pad, start])
             start += query("xv2_pack_weights_tiles", Cout, T, 1, cin_pad)
         dev = next(iter(_packs.values())).w.device
-        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start)
-    table, n, total = _pack_table
+        xrows, xstart = [], 0
+        for e in _packs.values():      # the bf16-plane copies, refreshed by a second table-driven launch
+            for src, nr, T, ch in _presplit_geoms(e):
+                if e.x3 and src.data_ptr() in e.x3:
+                    xrows.append([src.data_ptr(), e.x3[src.data_ptr()].data_ptr(), nr, T, ch, xstart])
+                    xstart += query("xv2_presplit_blocks", nr, T, ch)
+        xt = (torch.tensor(xrows, dtype=torch.int64).to(dev), len(xrows), xstart) if xrows else None
+        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start, xt)
+    table, n, total, xt = _pack_table
     call("xv2_pack_weights_table", table, n, total)
+    if xt is not None:
+        call("xv2_presplit_table", xt[0], xt[1], xt[2])
     for e in _packs.values():
         e.version, e.epoch = e.w._version, WEIGHT_EPOCH
 
 
 def clear_pack_cache():
     global _pack_table
-    _packs.clear()
+    for k in list(_packs):
+        _del_pack(k)
     _pack_table = None
 
 
