@@ -43,11 +43,12 @@ def pretty(mangled):
     if not m:
         return None
     args = re.findall(r"L([ib])(\d+)E", m.group(2))
-    vals = [int(v) for _, v in args] + [0, 0, 0, 0]
+    vals = [int(v) for _, v in args] + [0, 0, 0, 0, 0, 0]
     if m.group(1) == "igemm":
-        smallc, bf16, hs, x3 = vals[4], vals[5], vals[6], vals[7]
+        smallc, bf16, hs, x3, halo, bx3 = vals[4], vals[5], vals[6], vals[7], vals[8], vals[9]
+        x3tag = "c32,f32x3" + (",halo" if halo else "") + (",wx3" if bx3 else "")
         tag = ("rgb,bf16out" if hs else "rgb") if smallc else (
-            "c32,bf16hbm" if hs else ("c32,f32x3" if x3 else ("c32,bf16" if bf16 else "c32")))
+            "c32,bf16hbm" if hs else (x3tag if x3 else ("c32,bf16" if bf16 else "c32")))
         return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], tag)
     smallc, bf16, hs = vals[5], vals[6], vals[7]
     tag = ("rgb" if smallc else ("c32,bf16" if bf16 else "c32")) + (",bf16hbm" if hs else "")

@@ -1379,27 +1379,29 @@ struct PresplitEntry {
 static std::mutex g_presplit_mu;
 static std::unordered_map<const void*, PresplitEntry> g_presplit;
 
-__device__ __forceinline__ void presplit_store(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int ctot,
-                                               int64_t e4) {
-    const int c4n = ctot / 4;
-    const int c = (int)(e4 % c4n) * 4;
-    const int64_t rt = e4 / c4n;
-    const int t = (int)(rt % T), row = (int)(rt / T);
-    const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)row * T + t) * ctot + c);
+// one block = one (64-row unit, tap, 16-channel slice): 256 threads = 64 rows x 4 channel quads, so that every plane of the
+// slice is written as ONE contiguous 2 KB run (the first version wrote 32-byte pieces 6 KB apart: 210 us per cfg2 step)
+__device__ __forceinline__ void presplit_block(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int ctot,
+                                               int64_t blk) {
+    const int nsl = ctot / 16;
+    const int cs = (int)(blk % nsl);
+    const int64_t ut = blk / nsl;
+    const int t = (int)(ut % T), unit = (int)(ut / T);
+    const int r = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)(unit * 64 + r) * T + t) * ctot + cs * 16 + k0);
     uint2 pk[3];
     split3x4(v, pk[0], pk[1], pk[2]);
-    const int unit = row >> 6, r = row & 63, cs = c >> 4, k0 = c & 15;
     const int half = (k0 >> 3) ^ ((r >> 2) & 1);
-    __bf16* d = dst + (((size_t)unit * T + t) * (ctot / 16) + cs) * 3072 + r * 16 + half * 8 + (k0 & 7);
+    __bf16* d = dst + (size_t)blk * 3072 + r * 16 + half * 8 + (k0 & 7);
 #pragma unroll
     for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = pk[q];
 }
 __global__ void __launch_bounds__(256) presplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
                                                        int T, int ctot) {
-    const int64_t n4 = (int64_t)nrows * T * (ctot / 4);
-    for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) presplit_store(src, dst, T, ctot, e);
+    const int64_t nb = (int64_t)(nrows / 64) * T * (ctot / 16);
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) presplit_block(src, dst, T, ctot, b);
 }
-// table[n][6]: {src, dst, nrows, T, ctot, first block}; a block = 256 groups of 4 elements
+// table[n][6]: {src, dst, nrows, T, ctot, first block}; a block = one (unit, tap, slice)
 __global__ void __launch_bounds__(256) presplit_table_kernel(const int64_t* __restrict__ table, int n) {
     int lo = 0, hi = n - 1;
     const int64_t blk = blockIdx.x;
@@ -1409,10 +1411,7 @@ __global__ void __launch_bounds__(256) presplit_table_kernel(const int64_t* __re
         else hi = mid - 1;
     }
     const int64_t* e = table + lo * 6;
-    const int nrows = (int)e[2], T = (int)e[3], ctot = (int)e[4];
-    const int64_t e4 = (blk - e[5]) * 256 + threadIdx.x;
-    if (e4 < (int64_t)nrows * T * (ctot / 4))
-        presplit_store(reinterpret_cast<const float*>(e[0]), reinterpret_cast<__bf16*>(e[1]), T, ctot, e4);
+    presplit_block(reinterpret_cast<const float*>(e[0]), reinterpret_cast<__bf16*>(e[1]), (int)e[3], (int)e[4], blk - e[5]);
 }
 static bool presplit_lookup(const void* b, int nrows, int T, int ctot, const void** x3) {
     std::lock_guard<std::mutex> lk(g_presplit_mu);
@@ -1966,13 +1965,13 @@ static int presplit_register(const float* b_fp32, int nrows, int T, int ctot, vo
 // `b_fp32` afterwards read the planes (the caller refreshes them whenever the weights change, on the same stream)
 extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int ctot, void* x3, void* stream) {
     if (int rc = presplit_register(b_fp32, nrows, T, ctot, x3)) return rc;
-    const int64_t n4 = (int64_t)nrows * T * (ctot / 4);
-    hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, (hipStream_t)stream,
+    const int64_t nb = (int64_t)(nrows / 64) * T * (ctot / 16);
+    hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)std::min<int64_t>(nb, 16384)), dim3(256), 0, (hipStream_t)stream,
                        b_fp32, reinterpret_cast<__bf16*>(x3), nrows, T, ctot);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { return cdiv((int64_t)nrows * T * (ctot / 4), 256); }
+extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { return (int64_t)(nrows / 64) * T * (ctot / 16); }
 // every registered pair of a device table in one launch (after the optimizer step); rows as in presplit_table_kernel
 extern "C" int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream) {
     XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "presplit_table: bad table");
