@@ -1379,29 +1379,39 @@ struct PresplitEntry {
 static std::mutex g_presplit_mu;
 static std::unordered_map<const void*, PresplitEntry> g_presplit;
 
-// one block = one (64-row unit, tap, 16-channel slice): 256 threads = 64 rows x 4 channel quads, so that every plane of the
-// slice is written as ONE contiguous 2 KB run (the first version wrote 32-byte pieces 6 KB apart: 210 us per cfg2 step)
+// one block = one (64-row unit, 16-channel slice), all taps: 256 threads = 64 rows x 4 channel quads, so that every plane of
+// a (tap, slice) is written as ONE contiguous 2 KB run (the first version wrote 32-byte pieces 6 KB apart: 210 us per cfg2
+// step; one block per tap spent its time in the table search: 35 K blocks x 7 dependent loads, 110 us)
 __device__ __forceinline__ void presplit_block(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int ctot,
                                                int64_t blk) {
     const int nsl = ctot / 16;
-    const int cs = (int)(blk % nsl);
-    const int64_t ut = blk / nsl;
-    const int t = (int)(ut % T), unit = (int)(ut / T);
+    const int cs = (int)(blk % nsl), unit = (int)(blk / nsl);
     const int r = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)(unit * 64 + r) * T + t) * ctot + cs * 16 + k0);
-    uint2 pk[3];
-    split3x4(v, pk[0], pk[1], pk[2]);
     const int half = (k0 >> 3) ^ ((r >> 2) & 1);
-    __bf16* d = dst + (size_t)blk * 3072 + r * 16 + half * 8 + (k0 & 7);
+    const float* sp = src + (size_t)(unit * 64 + r) * T * ctot + cs * 16 + k0;
+    __bf16* dp = dst + ((size_t)unit * T * nsl + cs) * 3072 + r * 16 + half * 8 + (k0 & 7);
+    for (int t0 = 0; t0 < T; t0 += 3) {        // three taps in flight
+        float4 v[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = pk[q];
+        for (int u = 0; u < 3; ++u)
+            if (t0 + u < T) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)(t0 + u) * ctot);
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (t0 + u < T) {
+                uint2 pk[3];
+                split3x4(v[u], pk[0], pk[1], pk[2]);
+                __bf16* d = dp + (size_t)(t0 + u) * nsl * 3072;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = pk[q];
+            }
+    }
 }
 __global__ void __launch_bounds__(256) presplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
                                                        int T, int ctot) {
-    const int64_t nb = (int64_t)(nrows / 64) * T * (ctot / 16);
+    const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) presplit_block(src, dst, T, ctot, b);
 }
-// table[n][6]: {src, dst, nrows, T, ctot, first block}; a block = one (unit, tap, slice)
+// table[n][6]: {src, dst, nrows, T, ctot, first block}; a block = one (unit, slice)
 __global__ void __launch_bounds__(256) presplit_table_kernel(const int64_t* __restrict__ table, int n) {
     int lo = 0, hi = n - 1;
     const int64_t blk = blockIdx.x;
@@ -1965,13 +1975,13 @@ static int presplit_register(const float* b_fp32, int nrows, int T, int ctot, vo
 // `b_fp32` afterwards read the planes (the caller refreshes them whenever the weights change, on the same stream)
 extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int ctot, void* x3, void* stream) {
     if (int rc = presplit_register(b_fp32, nrows, T, ctot, x3)) return rc;
-    const int64_t nb = (int64_t)(nrows / 64) * T * (ctot / 16);
+    const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
     hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)std::min<int64_t>(nb, 16384)), dim3(256), 0, (hipStream_t)stream,
                        b_fp32, reinterpret_cast<__bf16*>(x3), nrows, T, ctot);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { return (int64_t)(nrows / 64) * T * (ctot / 16); }
+extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { (void)T; return (int64_t)(nrows / 64) * (ctot / 16); }
 // every registered pair of a device table in one launch (after the optimizer step); rows as in presplit_table_kernel
 extern "C" int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream) {
     XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "presplit_table: bad table");
