@@ -148,8 +148,8 @@ def _presplit_geoms(e):
     read pre-split (xv2_presplit_weights: 3x3 taps, 64-row units, 32-channel chunks; fp32 tensors only)"""
     Cout, Cin, T, cin_pad = e.geom
     out = []
-    if not PRESPLIT or e.dtype != XV2_F32 or cin_pad == 4:
-        return out
+    if not PRESPLIT or e.dtype != XV2_F32 or cin_pad == 4 or MATH_MODE != MATH_F32X3:
+        return out      # (planes made under F32X3 stay registered if the mode is switched later: harmless, just unused)
     if e.ohwi is not None and query("xv2_presplit_supported", Cout, T, cin_pad) == 1:
         out.append((e.ohwi, Cout, T, cin_pad))
     if e.ihwo is not None and query("xv2_presplit_supported", cin_pad, T, Cout) == 1:
@@ -159,7 +159,11 @@ def _presplit_geoms(e):
 
 def _presplit_entry(e):
     """bf16-plane copies of the entry's packed layouts (the weight operand of the halo kernels goes global -> LDS by DMA)"""
-    for src, rows, T, ch in _presplit_geoms(e):
+    geoms = _presplit_geoms(e)
+    if not geoms:
+        _forget_entry(e)       # (a mode switch: planes that are no longer refreshed must not stay registered)
+        return
+    for src, rows, T, ch in geoms:
         key = src.data_ptr()
         if e.x3 is None:
             e.x3 = {}
@@ -274,7 +278,10 @@ def repack_all():
         dev = next(iter(_packs.values())).w.device
         xrows, xstart = [], 0
         for e in _packs.values():      # the bf16-plane copies, refreshed by a second table-driven launch
-            for src, nr, T, ch in _presplit_geoms(e):
+            geoms = _presplit_geoms(e)
+            if not geoms:
+                _forget_entry(e)
+            for src, nr, T, ch in geoms:
                 if e.x3 and src.data_ptr() in e.x3:
                     xrows.append([src.data_ptr(), e.x3[src.data_ptr()].data_ptr(), nr, T, ch, xstart])
                     xstart += query("xv2_presplit_blocks", nr, T, ch)
