@@ -828,6 +828,45 @@ print("halo ok %%.2e" %% worst)
 """
 
 
+def test_halo_form_of_the_bf16_storage_kernel_in_a_subprocess():
+    """igemm_kernel<..., bf16hbm, HALO> (XV2_HALO_BF16=1, opt-in after measurement): halo and weight tiles global -> LDS by
+    direct-to-LDS loads, swizzled 64-byte rows.  3x3 forward and backward-data against fp32 PyTorch on the bf16-rounded
+    operands (gate 3e-2 of the tensor maximum, the bf16 rounding of the stored result)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+from xview2_amd import ops
+dev = "cuda:0"
+worst = 0.0
+for (N, H, W, C0, C1, Co) in [(2, 32, 64, 64, 0, 128), (1, 64, 64, 32, 0, 64), (2, 16, 32, 64, 96, 128), (2, 16, 16, 512, 0, 256)]:
+    torch.manual_seed(N + H + C0 + Co)
+    x = torch.randn(N, C0 + C1, H, W).bfloat16().float()
+    w = (torch.randn(Co, C0 + C1, 3, 3) * (2.0 / (9 * (C0 + C1))) ** 0.5)
+    wr = w.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    dy = torch.randn_like(yr).bfloat16().float()
+    yr.backward(dy)
+    a = x.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    a0 = a[..., :C0].contiguous().requires_grad_(True)
+    a1 = a[..., C0:].contiguous().requires_grad_(True) if C1 else None
+    y = ops.ConvFn.apply(a0, a1, w.to(dev), None, ops.conv_cfg(3, 3, 1, 1))
+    y.backward(dy.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16())
+    dx = a0.grad if not C1 else torch.cat([a0.grad, a1.grad], 3)
+    e1 = float((y.float().permute(0, 3, 1, 2).cpu() - yr).abs().max() / yr.abs().max())
+    e2 = float((dx.float().permute(0, 3, 1, 2).cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    worst = max(worst, e1, e2)
+    assert e1 <= 3e-2 and e2 <= 3e-2, (N, H, W, C0, C1, Co, e1, e2)
+print("halo ok %%.2e" %% worst)
+""" % root
+    env = dict(os.environ, XV2_HALO_BF16="1")
+    r = subprocess.run([sys.executable, "-c", snippet], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "halo ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_halo_form_of_the_f32x3_kernel_in_a_subprocess():
     """igemm_kernel<..., HALO> (XV2_HALO=1, read once per process): 3x3 forward and backward-data with the 10 x 18 halo of
     every 16-channel slice resident in LDS for all nine taps.  Opt-in after measurement; this keeps it exact."""

@@ -58,6 +58,10 @@ constexpr int LDS_LD_H_ = BK + 8;
 // floats of LDS shared by the main-loop operand buffers and the epilogue staging tile
 template <int BM, int BN, bool HIN, int NH, bool HALO = false>
 constexpr int igemm_main_floats() {
+    if (HALO && HIN) {      // bf16 storage: two halo buffers [208][32] bf16 + three weight stages [BN][32] bf16, or half the tile
+        const int loop = (2 * 208 * 32 + 3 * BN * 32) / 2, epi = (BM / NH) * (BN + 4);
+        return loop > epi ? loop : epi;
+    }
     if (HALO) {      // three halo planes [208][24] bf16 + two weight stages of three planes [BN][24] bf16, or the epilogue tile
         const int loop = (3 * 208 * 24 + 2 * 3 * BN * 24) / 2, epi = BM * (BN + 4);
         return loop > epi ? loop : epi;
@@ -108,7 +112,7 @@ template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool
 __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!BX3 || HALO, "pre-split weights: halo form only");
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
-    static_assert(!HALO || (X3 && BM == 128), "halo form: F32X3, 128-pixel patches");
+    static_assert(!HALO || ((X3 || (HS && !SMALLC)) && BM == 128), "halo form: F32X3 or bf16 storage, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MR = WTM / 32, NR = WTN / 32;
     constexpr bool HIN = HS && !SMALLC;                 // bf16 operands in HBM
@@ -343,7 +347,130 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (X3 && HALO) {
+    if constexpr (HS && HALO) {
+        // bf16 storage, halo form: NO register path for the operands at all.  Per 32-channel slice the 6 x 34 halo of the 4 x 32
+        // patch (204 pixels x 64 B) and, per tap, the [BN][32] weight tile go global -> LDS with direct-to-LDS loads (16 B per
+        // lane, each lane its own global address: the gather and the LDS swizzle are one address computation); the nine taps
+        // read shifted rows of the same halo.  LDS rows are 64 B, the four 16-byte chunks of row r stored at position
+        // chunk ^ ((r >> 1) & 3): 8 consecutive rows x one chunk = 8 different 16-byte bank groups.
+        constexpr int HWD = PW + 2, NHR = ((PH + 2) * HWD + 7) / 8 * 8;          // 204 -> 208 halo rows
+        constexpr int HB = NHR * 32, WB = BN * 32;                               // elements per halo buffer / weight stage
+        static_assert((size_t)(2 * HB + 3 * WB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo buffers + weight ring fit");
+        __bf16* sh = reinterpret_cast<__bf16*>(smem);                            // [2][NHR][32]
+        __bf16* sw = sh + 2 * HB;                                                // [3][BN][32]
+        const int ntp = ci.ntaps;
+        const int sl_begin = kt_begin / ntp, sl_end = kt_end / ntp;              // 32-channel slices
+        const int s_begin = sl_begin * ntp, s_end = sl_end * ntp;                // stage = (slice, tap)
+        const int sgn = __builtin_amdgcn_readfirstlane(taps[0].dh < 0 ? 1 : -1);
+        // halo DMA: granule g = 16 B of LDS = (row g / 4, position g % 4) <- chunk position ^ ((row >> 1) & 3) of that pixel;
+        // instruction j of this wave covers granules (4 * j + wave) * 64 + lane  (13 instructions per buffer: wave 0 issues 4)
+        constexpr int HNI = NHR * 4 / 64;                                        // 13
+        int hoff[4];                                                             // byte offset of the pixel chunk, channel 0; < 0: zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (4 * j + wave) * 64 + lane, row = g >> 2, pos = g & 3;
+            const int hr = row / HWD, hc = row - hr * HWD;
+            const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
+            const bool ok = row < (PH + 2) * HWD && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            hoff[j] = ok ? ((h_n * p.IH + ih) * p.IW + iw) : -1;                 // pixel index; scaled by ld per source below
+            if (!ok) hoff[j] = -1;
+            hoff[j] = ok ? hoff[j] * 4 + (pos ^ ((row >> 1) & 3)) : -1;          // pixel * 4 + chunk
+        }
+        auto hdma = [&](int sl, int buf) {
+            const int cc = sl * BK;
+            const bool first = cc < p.C0;
+            const int ld = first ? p.ldA0 : p.ldA1, ch = first ? cc : cc - p.C0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (4 * j + wave < HNI) {                                        // wave-uniform
+                    const int off = hoff[j] >= 0 ? (((hoff[j] >> 2) * ld + ch) << 1) + (hoff[j] & 3) * 16 : (int)0x80000000;
+                    if (first)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsA0, (__attribute__((address_space(3))) void*)(sh + buf * HB + (4 * j + wave) * 512), 16, off, 0, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsA1, (__attribute__((address_space(3))) void*)(sh + buf * HB + (4 * j + wave) * 512), 16, off, 0, 0, 0);
+                }
+            }
+        };
+        // weight DMA: BN rows x 4 chunks = BN / 16 instructions per stage, BN / 64 per wave
+        constexpr int WNI = BN / 64;
+        // (offsets recomputed per call: a captured int[WNI] array here made clang drop the HOST stub of this instantiation)
+        const int wrow0 = (WNI * wave * 64 + lane) >> 2, wpos = lane & 3;
+        auto wdma = [&](int st, int slot) {
+            const int sl = st / ntp, tp = st - sl * ntp;
+            const int kb = (tp * p.Ctot + sl * BK) << 1;
+#pragma unroll
+            for (int j = 0; j < WNI; ++j) {
+                const int row = wrow0 + j * 16;
+                const int off = (((n0 + row) * p.T * p.Ctot) << 1) + (wpos ^ ((row >> 1) & 3)) * 16 + kb;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsB, (__attribute__((address_space(3))) void*)(sw + slot * WB + (WNI * wave + j) * 512), 16, off, 0, 0, 0);
+            }
+        };
+        int abase[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + 1) * HWD + l31 + 1;
+        auto stage = [&](int tp, int hbuf, int slot) {
+            const int th = tp / 3;
+            const int toff = sgn * ((th - 1) * HWD + (tp - th * 3 - 1));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[MR], bf[NR];
+#pragma unroll
+                for (int i = 0; i < MR; ++i) {
+                    const int row = abase[i] + toff;
+                    af[i] = *reinterpret_cast<const bf16x8*>(sh + hbuf * HB + row * 32 + (((ks * 2 + h) ^ ((row >> 1) & 3)) * 8));
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int row = wn * WTN + j * 32 + l31;
+                    bf[j] = *reinterpret_cast<const bf16x8*>(sw + slot * WB + row * 32 + (((ks * 2 + h) ^ ((row >> 1) & 3)) * 8));
+                }
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        // stage st: its weights landed one barrier ago; issue the weights of st+2 (ring) and, at the first tap of a slice, the
+        // NEXT slice's halo into the other halo buffer; then wait for exactly what the next stage needs (in-order completion)
+        hdma(sl_begin, 0);
+        wdma(s_begin, 0);
+        wdma(s_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int tp = 0, sl = sl_begin, slot = 0, hbuf = 0;
+        for (int st = s_begin; st < s_end; ++st) {
+            const bool pf = st + 2 < s_end;
+            const bool nh = tp == 0 && sl + 1 < sl_end;
+            if (nh) hdma(sl + 1, hbuf ^ 1);
+            if (pf) wdma(st + 2, slot >= 1 ? slot - 1 : 2);                   // slot of stage st-1: free since the last barrier
+            stage(tp, hbuf, slot);
+            // outstanding allowed: what was issued in THIS iteration (the weights of st+1 and everything older must be in LDS)
+            auto wait_n = [&](int n) {      // literal immediates (an "n" operand broke the host-side stub of the kernel)
+                switch (n) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                }
+            };
+            const int nhalo = nh ? (wave == 0 ? 4 : 3) : 0;      // wave-uniform
+            wait_n((pf ? WNI : 0) + nhalo);
+            __syncthreads();
+            slot = slot == 2 ? 0 : slot + 1;
+            if (++tp == ntp) {
+                tp = 0;
+                ++sl;
+                hbuf ^= 1;
+            }
+        }
+    } else if constexpr (X3 && HALO) {
         // 6 x 34 halo pixels.  The patch is 4 x 32 so that the 32 lanes of an MFMA row tile read 32 CONSECUTIVE LDS rows
         // whatever the tap: with 8 x 16 patches (two patch rows per tile, a jump of 18 or 24 LDS rows between lanes 15 and
         // 16) SQ_LDS_BANK_CONFLICT counted 2.1e7 cycles per launch, 8 % of the kernel; consecutive rows: 0.
@@ -1210,7 +1337,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? "c32,bf16hbm" : (X3 ? (HALO ? (BX3 ? "c32,f32x3,halo,wx3" : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? (HALO ? "c32,bf16hbm,halo" : "c32,bf16hbm") : (X3 ? (HALO ? (BX3 ? "c32,f32x3,halo,wx3" : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -1447,8 +1574,17 @@ static bool presplit_enabled() {      // XV2_PRESPLIT=0: weights split in the ke
     static const int v = [] { const char* e = getenv("XV2_PRESPLIT"); return e ? atoi(e) : 1; }();
     return v != 0;
 }
-static bool halo_eligible(const IgemmParams& p, bool smallc) {
-    if (!halo_enabled() || smallc || p.math != XV2_MATH_F32X3 || p.ncls != 1 || p.s_in != 1 || p.Nout % 64 != 0) return false;
+// halo form of the bf16-storage kernel (both operands global -> LDS by DMA, no register path): exact, and measured NOT
+// faster than the per-tap form - cfg2 3x3 layers forward 550 -> 526, backward-data 598 -> 559 TFLOP/s (dec1 0.164 -> 0.203 ms,
+// dec2 / dec3 equal, l4.conv2 0.029 -> 0.026): that kernel has no split and no conversion to save, its producer is already
+// one 16-byte load + one 16-byte LDS store per 8 channels.  Opt-in (XV2_HALO_BF16=1).
+static bool halo_bf16_enabled() {
+    static const int v = [] { const char* e = getenv("XV2_HALO_BF16"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
+static bool halo_eligible(const IgemmParams& p, bool smallc, int math = XV2_MATH_F32X3) {
+    if (math == XV2_MATH_F32X3 ? !halo_enabled() : !halo_bf16_enabled()) return false;
+    if (smallc || p.math != math || p.ncls != 1 || p.s_in != 1 || p.Nout % 64 != 0) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 9 || c.tap0 != 0 || c.OHl != p.IH || c.OWl != p.IW || c.OHl % 4 != 0 || c.OWl % 32 != 0) return false;
     if (p.C0 % 32 != 0 || p.Ctot % 32 != 0 || c.nkt != 9 * (p.Ctot / BK)) return false;
@@ -1491,6 +1627,9 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
         if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
+        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc, XV2_MATH_BF16_STORE))
+            return bn == 128 ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
+                             : launch_one<128, 64, 2, 2, false, true, true, false, true>(p, stream);
         if (bm == 128 && bn >= 64 && halo_eligible(p, smallc)) {
             const void* x3 = nullptr;
             if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
@@ -1504,14 +1643,15 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         }
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
-        bool halo = !splitk_fold_enabled() && halo_eligible(p, smallc);
+        const bool halo16 = halo_eligible(p, smallc, XV2_MATH_BF16_STORE);
+        bool halo = (!splitk_fold_enabled() && halo_eligible(p, smallc)) || halo16;
         if (halo) {      // K ranges of whole 32-channel chunks (all nine taps of a halo slice stay in one block)
             const int nch = p.cls[0].nkt / 9, cps = (int)cdiv(nch, p.ksplit), nks = (int)cdiv(nch, cps);
             if (nks > 1) {
                 p.kt_per_split = 9 * cps;
                 p.ksplit = nks;
                 const void* x3 = nullptr;
-                if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
+                if (!halo16 && presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
                     p.Bx3 = reinterpret_cast<const float*>(x3);
                     p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 6);
                 }
@@ -1535,7 +1675,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (int rc = complete_fold(p, cdiv(maxM, SPLITK_ROWS), (int)cdiv(p.Nout, 256))) return rc;
         const StatsFold fold = p.fold;
         p.fold.on = 0;
-        int rc = p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+        int rc = (halo && halo16)              ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
+                 : p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
                  : (halo && p.Bx3)             ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
                  : halo                        ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
