@@ -828,6 +828,34 @@ print("halo ok %%.2e" %% worst)
 """
 
 
+def test_presplit_weight_planes_are_the_exact_three_way_split():
+    """xv2_presplit_weights: the three bf16 planes of a packed fp32 weight operand, laid out as the LDS image of a weight
+    stage ([rows/64][tap][channels/16][plane][64 rows][16], the two 8-element halves of a row swapped on rows with bit 2
+    set).  Undoing the layout and adding hi + mid + lo in fp32 must give the packed fp32 operand back BIT FOR BIT (the split
+    is exact: 8 + 8 + 8 significant bits), for the forward (OHWI) and the backward-data (IHWO) operand."""
+    from xview2_amd import ops
+    if ops.MATH_MODE != ops.MATH_F32X3 or not ops.PRESPLIT:
+        pytest.skip("pre-split planes are made under XV2_MATH_F32X3 only")
+    torch.manual_seed(5)
+    Cout, Cin = 128, 192         # both layouts need 64-row units and 32-channel chunks
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).to(dev())
+    w[0, 0, 0, 0] = 1e-30            # a denormal-range residual and a large value survive the split as well
+    w[1, 2, 1, 1] = 3.0e4
+    ohwi, ihwo = ops._pack(w, Cin, True, True, False)
+    key = (w.data_ptr(), Cout, Cin, 3, 3, Cin, ops.XV2_F32)
+    e = ops._packs[key]
+    assert e.x3 and len(e.x3) == 2
+    for packed, rows, ch in ((ohwi, Cout, Cin), (ihwo, Cin, Cout)):
+        planes = e.x3[packed.data_ptr()].view(rows // 64, 9, ch // 16, 3, 64, 2, 8).float()
+        r = torch.arange(64, device=planes.device)
+        swap = ((r >> 2) & 1).bool()
+        planes = torch.where(swap.view(1, 1, 1, 1, 64, 1, 1), planes.flip(5), planes)       # undo the half swap
+        total = planes[:, :, :, 0] + planes[:, :, :, 1] + planes[:, :, :, 2]                   # [unit][tap][slice][64][2][8]
+        back = total.reshape(rows // 64, 9, ch // 16, 64, 16).permute(0, 3, 1, 2, 4).reshape(rows, 9, ch)
+        assert torch.equal(back, packed.reshape(rows, 9, ch)), "hi + mid + lo != packed fp32 operand"
+    ops.clear_pack_cache()
+
+
 def test_halo_form_of_the_bf16_storage_kernel_in_a_subprocess():
     """igemm_kernel<..., bf16hbm, HALO> (XV2_HALO_BF16=1, opt-in after measurement): halo and weight tiles global -> LDS by
     direct-to-LDS loads, swizzled 64-byte rows.  3x3 forward and backward-data against fp32 PyTorch on the bf16-rounded
