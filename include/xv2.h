@@ -125,6 +125,20 @@ int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int ldx0, cons
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                           float* shift, void* stream);
+/* BatchNorm + activation of the PRODUCING layer applied in this convolution's operand load (model/layers.py:96-100: the
+ * BatchNorm + activation between the two convolutions of a bottleneck / decoder block): `y0` is the
+ * RAW output of the producing convolution, z0 = act(y0 * pre_scale[c] + pre_shift[c]) (training-mode coefficients, as
+ * xv2_bn_act_forward would write it) is formed while the input halo is staged into LDS - zero padding stays zero, z0 is
+ * never written to memory.  Results identical bit for bit to xv2_bn_act_forward + xv2_conv2d_forward_bn.  Only for the halo
+ * plan of XV2_MATH_F32X3 (3x3, stride 1, pad 1, one source, fp32 tensors): ask xv2_conv2d_forward_pre_supported(d) first;
+ * the statistics fold (XV2_BN_FOLD) must be on.  Other arguments as for xv2_conv2d_forward_bn. */
+int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d);
+int xv2_conv2d_forward_bn_pre(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
+                              const float* pre_shift, int pre_act, const void* w_ohwi, void* y, int ldy,
+                              float* stats_partials, float* workspace, int parts, int part_stride, double* sums,
+                              double* scratch, double count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                              float* scale, float* shift, void* stream);
 /* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
  * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
 size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
@@ -183,6 +197,13 @@ int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
 int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                                      const void* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                                      void* side_stream, void* stream);
+/* the weight gradient of a convolution that ran as xv2_conv2d_forward_bn_pre: its X operand is the producing layer's RAW
+ * output y0 and z0 = act(y0 * pre_scale + pre_shift) is formed on load (all-taps XV2_MATH_F32X3 plan, one source: ask
+ * xv2_conv2d_backward_weight_pre_supported(d)).  side_stream == NULL or == stream: launched on `stream`. */
+int xv2_conv2d_backward_weight_pre_supported(const xv2_conv_desc* d);
+int xv2_conv2d_backward_weight_pre_async(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
+                                         const float* pre_shift, int pre_act, const void* dy, int lddy,
+                                         float* dw_oihw, float* workspace, void* side_stream, void* stream);
 
 /* nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83).  `d` describes the
  * EQUIVALENT convolution (input = the large 2H x 2W tensor with C0 = conv-transpose output

@@ -507,6 +507,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
         for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + 1) * HWD + l31 + 1;
         float4 hraw[HL], rbb[BROWS], rbb1[BROWS];
+        float4 hsc = make_float4(1.f, 1.f, 1.f, 1.f), hsf = make_float4(0.f, 0.f, 0.f, 0.f);      // pre_scale / pre_shift of hraw's slice
         uint2 pkb[BROWS][3], pkh[HL][3];
         bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
         auto hload = [&](int cs) {
@@ -514,6 +515,10 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             const bool first = cc < p.C0;
             const int ld = first ? p.ldA0 : p.ldA1;
             const int ch = (first ? cc : cc - p.C0) + (tid & 3) * 4;
+            if (p.pre_scale) {      // single source (checked on the host): this thread's four channels of the slice
+                hsc = *reinterpret_cast<const float4*>(p.pre_scale + ch);
+                hsf = *reinterpret_cast<const float4*>(p.pre_shift + ch);
+            }
 #pragma unroll
             for (int j = 0; j < HL; ++j) {
                 const int off = hpix[j] >= 0 ? ((hpix[j] * ld + ch) << 2) : (int)0x80000000;
@@ -524,7 +529,16 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         };
         auto hsplit = [&]() {
 #pragma unroll
-            for (int j = 0; j < HL; ++j) split3x4(hraw[j], pkh[j][0], pkh[j][1], pkh[j][2]);
+            for (int j = 0; j < HL; ++j) {
+                float4 v = hraw[j];
+                if (p.pre_scale && hpix[j] >= 0) {      // same arithmetic as bn_act_fwd_kernel; the padding stays zero
+                    v.x = apply_act(__fmaf_rn(v.x, hsc.x, hsf.x), p.pre_act);
+                    v.y = apply_act(__fmaf_rn(v.y, hsc.y, hsf.y), p.pre_act);
+                    v.z = apply_act(__fmaf_rn(v.z, hsc.z, hsf.z), p.pre_act);
+                    v.w = apply_act(__fmaf_rn(v.w, hsc.w, hsf.w), p.pre_act);
+                }
+                split3x4(v, pkh[j][0], pkh[j][1], pkh[j][2]);
+            }
         };
         auto hstore = [&]() {
 #if XV2_HABL & 1
@@ -1612,6 +1626,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         return XV2_OK;
     }
     if (direct3x3_eligible(p, smallc)) {
+        if (p.plan_halo) {
+            *p.plan_halo = 0;
+            return XV2_OK;
+        }
+        XV2_CHECK_ARG(!p.pre_scale, "conv2d_forward_bn_pre: the direct 3x3 plan has no pre-activation form");
         return direct3x3_launch(p, stream);
     }
     if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
@@ -1627,10 +1646,16 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
         if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
-        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc, XV2_MATH_BF16_STORE))
+        if (!p.plan_halo && bm == 128 && bn >= 64 && halo_eligible(p, smallc, XV2_MATH_BF16_STORE))
             return bn == 128 ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
                              : launch_one<128, 64, 2, 2, false, true, true, false, true>(p, stream);
-        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc)) {
+        const bool halo1 = bm == 128 && bn >= 64 && halo_eligible(p, smallc);
+        if (p.plan_halo) {
+            *p.plan_halo = halo1 ? 1 : 0;
+            return XV2_OK;
+        }
+        XV2_CHECK_ARG(!p.pre_scale || halo1, "conv2d_forward_bn_pre: this shape is not planned as the halo form (query _pre_supported)");
+        if (halo1) {
             const void* x3 = nullptr;
             if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
                 p.Bx3 = reinterpret_cast<const float*>(x3);
@@ -1659,6 +1684,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
                 halo = false;
             }
         }
+        if (p.plan_halo) {
+            *p.plan_halo = (halo && !halo16) ? 1 : 0;
+            return XV2_OK;
+        }
+        XV2_CHECK_ARG(!p.pre_scale || (halo && !halo16), "conv2d_forward_bn_pre: this shape is not planned as the halo form");
         if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8) {
             // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
             // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
@@ -1775,6 +1805,9 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
     p.bnb_ldy = p.bnb_act = 0;
     p.plan_tiles = nullptr;
+    p.plan_halo = nullptr;
+    p.pre_scale = p.pre_shift = nullptr;
+    p.pre_act = 0;
     memset(&p.fold, 0, sizeof(p.fold));
     XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_F32X3, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
@@ -1835,15 +1868,29 @@ struct FwdEpilogue {
     const float* res;
     int ldres, act;
 };
+struct PreAct {           // IgemmParams::pre_*
+    const float* scale;
+    const float* shift;
+    int act;
+};
 
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
-                             long long* plan = nullptr, const StatsFold* fold = nullptr) {
+                             long long* plan = nullptr, const StatsFold* fold = nullptr, const PreAct* pre = nullptr,
+                             int* plan_halo = nullptr) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
     p.plan_tiles = plan;
+    p.plan_halo = plan_halo;
+    const bool dry = plan_halo != nullptr;
+    if (pre) {
+        XV2_CHECK_ARG(pre->scale && pre->shift && !x1 && d->C1 == 0 && (reinterpret_cast<uintptr_t>(pre->scale) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(pre->shift) & 15) == 0,
+                      "conv2d_forward_bn_pre: one source, 16-byte aligned scale / shift");
+        p.pre_scale = pre->scale; p.pre_shift = pre->shift; p.pre_act = pre->act;
+    }
     if (fold) p.fold = *fold;
     if (ep) {
         XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
@@ -1856,11 +1903,11 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
-    XV2_CHECK_ARG(out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
-    XV2_CHECK_ARG(esz_in(d) == 4 || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
+    XV2_CHECK_ARG(dry || out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
+    XV2_CHECK_ARG(dry || esz_in(d) == 4 || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
                                      (reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ohwi) & 15) == 0),
                   "conv2d_forward: bf16 operands must be 16-byte aligned with row strides that are multiples of 8");
-    XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
+    XV2_CHECK_ARG(dry || !(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
                   "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
     set_bnb(p, bnb);
@@ -1937,6 +1984,45 @@ extern "C" int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int
     f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
     return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
                              stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f);
+}
+
+// 1 if xv2_conv2d_forward_bn_pre() can run this convolution (the halo plan of XV2_MATH_F32X3), else 0
+extern "C" int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d) {
+    if (d->C1 != 0 || d->math != XV2_MATH_F32X3 || !bn_fold_enabled()) return 0;
+    int flag = 0;
+    float* fake_ws = reinterpret_cast<float*>(16);      // "a workspace is available": the plan may be split-K
+    if (conv_forward_impl(d, nullptr, d->C0, nullptr, 0, nullptr, nullptr, nullptr, d->Cout, nullptr, fake_ws, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, &flag) != XV2_OK)
+        return 0;
+    return flag;
+}
+
+// xv2_conv2d_forward_bn whose input is the RAW output y0 of the producing convolution: that layer's training-mode
+// BatchNorm + activation, z0 = act(y0 * pre_scale + pre_shift), is applied while the halo of y0 is staged into LDS (zero
+// padding stays zero) - z0 is never written to memory (model/layers.py:96-100 between the two convolutions of a
+// bottleneck / decoder block).  Same results, bit for bit, as xv2_bn_act_forward followed by xv2_conv2d_forward_bn.
+extern "C" int xv2_conv2d_forward_bn_pre(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
+                                         const float* pre_shift, int pre_act, const void* w_ohwi, void* y, int ldy,
+                                         float* stats_partials, float* workspace, int parts, int part_stride, double* sums,
+                                         double* scratch, double count, const float* gamma, const float* beta, float eps,
+                                         float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                                         float* scale, float* shift, void* stream) {
+    XV2_CHECK_ARG(stats_partials && scratch && sums && bn_fold_enabled(), "conv2d_forward_bn_pre: partials, scratch, sums; statistics fold on");
+    XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn_pre: parts=%d part_stride=%d", parts, part_stride);
+    XV2_CHECK_ARG(!mean || (invstd && scale && shift), "conv2d_forward_bn_pre: mean, invstd, scale and shift go together");
+    StatsFold f;
+    memset(&f, 0, sizeof(f));
+    f.on = 1;
+    f.S = parts;
+    f.part_stride = part_stride;
+    f.scratch = scratch;
+    f.sums = sums;
+    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
+    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
+    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
+    PreAct pre{pre_scale, pre_shift, pre_act};
+    return conv_forward_impl(d, (const float*)y0, ldy0, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)y, ldy, stats_partials,
+                             workspace, stream, nullptr, nullptr, nullptr, &f, &pre);
 }
 
 extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,

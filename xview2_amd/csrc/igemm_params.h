@@ -60,6 +60,13 @@ struct IgemmParams {
     const float* bnb_scale;
     const float* bnb_shift;
     int bnb_ldy, bnb_act;
+    // halo form only: the A operand is the RAW convolution output of the producing layer and that layer's training-mode
+    // BatchNorm + activation is applied while the halo is staged: a = act(y * pre_scale[c] + pre_shift[c]) inside the image,
+    // 0 in the padding (model/layers.py:96-100 BatchNorm + activation between two convolutions, never materialised)
+    const float* pre_scale;
+    const float* pre_shift;
+    int pre_act;
+    int* plan_halo;          // dry run: report whether the plan is the halo form (the only one with pre_*) and launch nothing
     long long* plan_tiles;   // dry run: report the M-tile count of the plan (0 = no fused BN-backward form) and launch nothing
     // in-launch fold of the BatchNorm statistics partials (bn_fold.h); the caller fills scratch / sums / S / part_stride /
     // fin and sets fold.on = 1, the launcher completes the plan (group size, tickets) for the tiling it picks

@@ -33,6 +33,11 @@ struct WgradParams {
     int tiles_n;  // column tiles per tap (Ctot / BN), or column tiles overall for SMALLC
     int fast;     // OW % 32 == 0 and operands < 2 GiB: scalar pixel decode + buffer loads
     unsigned bytesX0, bytesX1, bytesDY;
+    // all-taps F32X3 kernel only: X0 is the RAW output of the producing convolution and that layer's training-mode BatchNorm
+    // + activation is applied on load: x = act(X0 * pre_scale[c] + pre_shift[c]) inside the image, 0 in the padding
+    const float* pre_scale;
+    const float* pre_shift;
+    int pre_act;
     WTap taps[52];
 };
 
@@ -918,13 +923,28 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
     const bool x_ok = iw >= 0, x2 = tid < 16, x2_ok = x2 && iw2 < p.IW;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rd = zero, rx = zero, rx2 = zero;
+    // producer layer's BatchNorm + activation on the X operand (WgradParams::pre_*): this thread's four channels
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pre_scale) {
+        psc = *reinterpret_cast<const float4*>(p.pre_scale + xch + c4 * 4);
+        psf = *reinterpret_cast<const float4*>(p.pre_shift + xch + c4 * 4);
+    }
+    auto pre = [&](float4 v) {
+        if (p.pre_scale) {      // same arithmetic as bn_act_fwd_kernel
+            v.x = apply_act(__fmaf_rn(v.x, psc.x, psf.x), p.pre_act);
+            v.y = apply_act(__fmaf_rn(v.y, psc.y, psf.y), p.pre_act);
+            v.z = apply_act(__fmaf_rn(v.z, psc.z, psf.z), p.pre_act);
+            v.w = apply_act(__fmaf_rn(v.w, psc.w, psf.w), p.pre_act);
+        }
+        return v;
+    };
     auto load_dy = [&](int r) { rd = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch); };
     auto load_x = [&](int ih) {
         rx = zero;
         rx2 = zero;
         if ((unsigned)ih < (unsigned)p.IH) {
-            if (x_ok) rx = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch);
-            if (x2_ok) rx2 = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx);
+            if (x_ok) rx = pre(*reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch));
+            if (x2_ok) rx2 = pre(*reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx));
         }
     };
     auto put = [&](int off, const float4 v) {       // off: element offset inside a plane
@@ -1236,9 +1256,14 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t s
     return XV2_OK;
 }
 
+struct WgradPre {
+    const float* scale;
+    const float* shift;
+    int act;
+};
 static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, const float* x1, int ldx1,
                       const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
-                      hipStream_t stream) {
+                      hipStream_t stream, const WgradPre* pre = nullptr, int* plan_pre = nullptr) {
     xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3: the all-taps kernel has a split-bf16 variant; the other
     const bool x3 = dcopy.math == XV2_MATH_F32X3;      // weight-gradient kernels run the exact fp32 MFMA
     if (x3) dcopy.math = XV2_MATH_F32;
@@ -1247,10 +1272,17 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
     const WgradPlan pl = make_plan(d, x3);
     const bool hs = d->math == XV2_MATH_BF16_STORE;
+    if (plan_pre) {          // dry run: is this the all-taps F32X3 plan (the only one with a pre-activation form)?
+        *plan_pre = (pl.alltaps && x3 && d_in->C1 == 0) ? 1 : 0;
+        return XV2_OK;
+    }
+    XV2_CHECK_ARG(!pre || (pl.alltaps && x3 && !x1 && pre->scale && pre->shift),
+                  "backward_weight_pre: not the all-taps F32X3 plan (query _pre_supported), or two sources");
     XV2_CHECK_ARG(pl.smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "backward_weight: C0=%d C1=%d must be multiples of 32", d->C0, d->C1);
     WgradParams p;
     p.X0 = x0; p.X1 = x1; p.DY = dy; p.part = workspace;
+    p.pre_scale = pre ? pre->scale : nullptr; p.pre_shift = pre ? pre->shift : nullptr; p.pre_act = pre ? pre->act : 0;
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1; p.ldX0 = ldx0; p.ldX1 = ldx1; p.ldDY = lddy;
     p.Cout = d->Cout;
     p.IH = d->IH; p.IW = d->IW; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride;
@@ -1407,6 +1439,33 @@ extern "C" int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const vo
     XV2_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev, 0));
     return wgrad_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)dy, lddy, dw_oihw, cin_real, workspace,
                       (hipStream_t)side_stream);
+}
+
+// 1 if xv2_conv2d_backward_weight_pre_async() can run this layer (all-taps F32X3 plan, one source), else 0
+extern "C" int xv2_conv2d_backward_weight_pre_supported(const xv2_conv_desc* d) {
+    int flag = 0;
+    if (wgrad_impl(d, nullptr, d->C0, nullptr, 0, nullptr, d->Cout, nullptr, d->C0, nullptr, nullptr, nullptr, &flag) != XV2_OK) return 0;
+    return flag;
+}
+// xv2_conv2d_backward_weight_async whose X operand is the RAW output y0 of the producing convolution: z0 = act(y0 *
+// pre_scale + pre_shift) is formed on load (see xv2_conv2d_forward_bn_pre); same results bit for bit as with z0 in memory
+extern "C" int xv2_conv2d_backward_weight_pre_async(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
+                                                    const float* pre_shift, int pre_act, const void* dy, int lddy,
+                                                    float* dw_oihw, float* workspace, void* side_stream, void* stream) {
+    hipStream_t launch = (hipStream_t)stream;
+    if (side_stream && side_stream != stream) {
+        static thread_local hipEvent_t evs[64] = {};
+        int dev = 0;
+        XV2_CHECK_HIP(hipGetDevice(&dev));
+        XV2_CHECK_ARG(dev >= 0 && dev < 64, "backward_weight_pre_async: device index %d out of range", dev);
+        hipEvent_t& ev = evs[dev];
+        if (!ev) XV2_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        XV2_CHECK_HIP(hipEventRecord(ev, (hipStream_t)stream));
+        XV2_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev, 0));
+        launch = (hipStream_t)side_stream;
+    }
+    WgradPre pre{pre_scale, pre_shift, pre_act};
+    return wgrad_impl(d, (const float*)y0, ldy0, nullptr, 0, (const float*)dy, lddy, dw_oihw, d->C0, workspace, launch, &pre);
 }
 
 // conv_transpose: the equivalent conv `d` has input = the transposed conv's OUTPUT gradient (large

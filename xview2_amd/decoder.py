@@ -20,8 +20,8 @@ class ConvLayer(nn.Module):  # layers.py:89-100
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.batch_norm = nn.BatchNorm2d(out_channels, affine=True)
 
-    def forward(self, x0, x1=None):
-        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY)
+    def forward(self, x0, x1=None, lazy_out=False):
+        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY, lazy_out=lazy_out)
 
 
 class ConvBlock(nn.Module):  # layers.py:119-128
@@ -31,7 +31,8 @@ class ConvBlock(nn.Module):  # layers.py:119-128
         self.conv2 = ConvLayer(out_channels, out_channels)
 
     def forward(self, x0, x1=None):
-        return self.conv2(self.conv1(x0, x1))
+        # conv1's BatchNorm + LeakyReLU is applied in conv2's operand load (its output has no other consumer)
+        return self.conv2(self.conv1(x0, x1, lazy_out=True))
 
 
 class AttentionLayer(nn.Module):  # layers.py:68-77

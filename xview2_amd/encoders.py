@@ -34,10 +34,12 @@ class Bottleneck(nn.Module):
         # the block input has two consumers (conv1 and the shortcut): the shortcut reads conv1's pass-through alias,
         # so its gradient is added inside conv1's backward-data kernel rather than by a separate elementwise pass
         fuse = x.is_cuda and torch.is_grad_enabled() and x.requires_grad
+        # bn1 + ReLU is applied in conv2's operand load when conv2 is a stride-1 3x3 (its output has no other consumer)
+        lazy = self.conv2.stride == (1, 1) and self.conv2.groups == 1
         if fuse:
-            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True)
+            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True, lazy_out=lazy)
         else:
-            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
+            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, lazy_out=lazy)
         out = xnn.conv_bn_act(self.conv2, self.bn2, out, act=ops.ACT_RELU)
         idt = x if self.downsample is None else xnn.conv_bn_act(self.downsample[0], self.downsample[1], x)
         return xnn.conv_bn_act(self.conv3, self.bn3, out, act=ops.ACT_RELU, residual=idt)

@@ -60,7 +60,7 @@ class bn_split:
 FUSED_INFERENCE = True     # eval + no_grad: one launch per conv layer (tests switch it off to compare both forms)
 
 
-def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False):
+def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False, lazy_out=False):
     """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node.  passthrough=True returns (out, x0 alias):
     hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel."""
     if not bn.training and not torch.is_grad_enabled() and x0.is_cuda and FUSED_INFERENCE:
@@ -68,8 +68,9 @@ def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthro
         z = ops.conv_bn_act_infer(x0, x1, conv.weight, residual, _cfg(conv), ops.BnState(bn, False), act)
         return (z, x0) if passthrough else z
     bump_bn_counter(bn)
+    # lazy_out: the result feeds exactly ONE further conv_bn_act call and nothing else (see ops.ConvBnActFn.forward)
     return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
-                                 ops.BnState(bn, SYNC_BN), act, bn.training, passthrough)
+                                 ops.BnState(bn, SYNC_BN), act, bn.training, passthrough, lazy_out)
 
 
 def conv(conv_m, x0, x1=None):

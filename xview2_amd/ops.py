@@ -317,8 +317,29 @@ def _stats_scratch(C, device):
     return t
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None):
-    """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.  If `ihwo_out` is a list, the backward-data weight
+# Deferred BatchNorm apply: built, bit-identical (logits, every gradient, running statistics at 128^2 and
+# 1024^2; tests/test_model_gpu.py) and measured SLOWER on the cfg2 fp32 step - 27.39 -> 27.63 ms with 17 of the 63 apply launches
+# gone: the apply kernel it removes is HBM-bound and cheap (0.3 ms), the fused-multiply-add + activation it adds sit in the
+# operand loaders of the power-limited MFMA kernels (halo form, all-taps weight gradient), and the two layers of a pair
+# leave the one-call layer entry points.  Off by default; XV2_LAZY_BN=1 saves 0.75 GB of activations at 2 x 1024^2.
+LAZY_BN = os.environ.get("XV2_LAZY_BN", "0") != "0"
+
+
+def _apply_pre(y0, pre):
+    """materialise z0 = act(y0 * scale + shift) (the deferred BatchNorm apply of a lazy producer, see ConvBnActFn)"""
+    scale, shift, act = pre
+    C = y0.shape[-1]
+    z = torch.empty_like(y0)
+    call("xv2_bn_act_forward", y0, C, scale, shift, None, C, act, z, C, y0.numel() // C, C, _dt(y0))
+    return z
+
+
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None):
+    """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.
+    `pre` = (scale, shift, act): x0 is the RAW output of the producing convolution and that layer's BatchNorm + activation
+    is applied in this convolution's operand load (xv2_conv2d_forward_bn_pre) when the plan allows it - two more values are
+    returned then: the tensor that stands for the input in the backward pass (x0 itself, or the materialised z0) and whether
+    the deferred form ran.  If `ihwo_out` is a list, the backward-data weight
     packs are produced by the same repack launch and appended to it (one per group).  With `bn` (a BnState that
     does not synchronise across ranks) the statistics reduction also derives the BatchNorm coefficients in the
     same launch and the third return value is (mean, invstd, scale, shift).  `fused` = (scale, shift, residual, act):
@@ -342,6 +363,15 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         coeffs = (blob[0], blob[1], blob[2], blob[3])
         bn_stats_changed()
     stats_ok = True        # False: the M tiles do not split evenly over the S parts -> statistics taken from y afterwards
+    pre_used = False
+    if pre is not None:
+        d0 = _desc(N, IH, IW, C0t, C1t, Cout_t, g, OH, OW, half)
+        ok = (want_stats and fused is None and G == 1 and x1 is None and S == 1 and not half and
+              query("xv2_conv2d_forward_pre_supported", d0) == 1 and query("xv2_conv2d_forward_stats_tiles", d0) > 0)
+        if ok:
+            pre_used = True
+        else:
+            x0 = _apply_pre(x0, pre)
     w = weight.contiguous()
     if G > 1 and x1 is not None:
         raise RuntimeError("grouped convolution over a virtual concat is not supported")
@@ -372,6 +402,15 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             # convolution + statistics (+ coefficients) in one launch: the last blocks to arrive fold the tile partials
             og = gi * Coutg
             fin = [None] * 4 if coeffs is None else [Ptr(t, og) for t in coeffs]
+            if pre_used:
+                call("xv2_conv2d_forward_bn_pre", d, x0, C0t, pre[0], pre[1], pre[2], ohwi, Ptr(y, og), Cout_t,
+                     _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
+                     S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
+                     _off(bn.weight, og) if bn is not None else None, _off(bn.bias, og) if bn is not None else None,
+                     float(bn.eps) if bn is not None else 0.0, float(bn.momentum) if bn is not None else 0.0,
+                     _off(bn.running_mean, og) if coeffs is not None else None,
+                     _off(bn.running_var, og) if coeffs is not None else None, *fin)
+                continue
             call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
                  _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
                  S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
@@ -388,6 +427,8 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     assert cin_w <= C0g + C1t
     if want_stats and not stats_ok:
         sums, coeffs = None, None           # _bn_forward takes the statistics of each part from y
+    if pre is not None:
+        return y, sums, coeffs, x0, pre_used
     if bn is not None:
         return y, sums, coeffs
     return y, sums
@@ -528,6 +569,41 @@ def join_wgrad_stream():
     _join_queued = False
     if _wgrad_stream is not None:
         torch.cuda.current_stream().wait_stream(_wgrad_stream)
+
+
+def _conv_backward_weight_pre(y0, pre, dy, weight, g, wparam=None):
+    """weight gradient of a convolution whose input was the deferred BatchNorm + activation of y0 (xv2_conv2d_forward_bn_pre):
+    the X operand is formed on load when the plan allows it, else z0 is materialised for this call"""
+    global _join_queued
+    N, IH, IW, C0t = y0.shape
+    _, OH, OW, Cout_t = dy.shape
+    d = _desc(N, IH, IW, C0t, 0, Cout_t, g, OH, OW, False)
+    if g.groups != 1 or y0.dtype != torch.float32 or query("xv2_conv2d_backward_weight_pre_supported", d) != 1:
+        return _conv_backward_weight(_apply_pre(y0, pre), None, dy, weight, g, wparam)
+    side_ok = ASYNC_WGRAD and (WGRAD_SIDE == "all" or (WGRAD_SIDE == "3x3") == (g.kh * g.kw > 1))
+    out = grad_slot(weight if wparam is None else wparam) if side_ok else None
+    side = None
+    if out is not None:
+        if not _join_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+                _join_queued = True
+                side = _side_stream()
+            except RuntimeError:      # not inside a backward pass (direct call): stay synchronous
+                side = None
+        else:
+            side = _side_stream()
+    elif ASYNC_WGRAD and _wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(_wgrad_stream)      # a shared weight's earlier contribution (see below)
+    dw = out if out is not None else _grad_like(weight if wparam is None else wparam)
+    nbytes = query("xv2_conv2d_backward_weight_workspace", d)
+    ws = _side_workspace(nbytes, side, dy.device) if side is not None else _ws(nbytes, dy)
+    call("xv2_conv2d_backward_weight_pre_async", d, y0, C0t, pre[0], pre[1], pre[2], dy, Cout_t, dw, ws,
+         side.cuda_stream if side is not None else None)
+    if side is not None:
+        for t in (y0, dy, pre[0], pre[1]):
+            t.record_stream(side)
+    return dw
 
 
 def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
@@ -883,7 +959,7 @@ class ConvBnActFn(torch.autograd.Function):
     """z = act(BN(conv(cat(x0, x1), W)) [+ residual])  (one autograd node per conv layer)"""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training, passthrough=False):
+    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training, passthrough=False, lazy_out=False):
         """passthrough: also return x0 itself as a second output.  A caller whose x0 has a SECOND consumer (the
         residual shortcut of a bottleneck) feeds that consumer from this alias: its gradient then arrives here and
         the backward-data kernel adds onto it in its epilogue, instead of autograd summing two tensors afterwards.
@@ -892,6 +968,11 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.passthrough = passthrough
         x0_in = x0
+        # Deferred BatchNorm apply (model/layers.py:96-100 between two convolutions): a producer called
+        # with lazy_out=True returns its RAW convolution output y tagged with (scale, shift, act) instead of z; its one
+        # consumer - this function - applies them in the operand load of the halo kernel and of the weight gradient
+        # (or materialises z here when its plan has no such form).  The tag never leaves a pair of conv_bn_act calls.
+        pre = getattr(x0, "_xv2_lazy", None)
         ctx.src_rec = _bn_rec_of(x0, x0.shape[-1]) if (x1 is None and g.groups == 1) else None
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
@@ -901,13 +982,28 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.split = BN_SPLIT if (training and x0.shape[0] % BN_SPLIT == 0) else 1
         ctx.has_res = residual is not None
         fast = None
-        if LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
+        lazy = (lazy_out and LAZY_BN and training and not ctx.has_res and ctx.split == 1 and not _sync_group(bn) and
+                x0.dtype == torch.float32 and MATH_MODE == MATH_F32X3)
+        ctx.pre = None
+        if pre is not None and (not training or x1 is not None):
+            x0, pre = _apply_pre(x0, pre), None
+        if pre is None and not lazy and LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res)
         if fast is not None:
             y, z, zmask, stats = fast
+        elif pre is not None:
+            y, sums, coeffs, x0, used = _conv_forward(x0, None, weight, g, None, want_stats=True, ihwo_out=ctx.ihwo, bn=bn,
+                                                      pre=pre)
+            ctx.pre = pre if used else None
         else:
             y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
-        if fast is not None:
+        if fast is None and lazy and coeffs is not None:
+            # this layer's own apply is deferred to ITS consumer: hand out y with the coefficients attached
+            rows = y.numel() // y.shape[-1]
+            stats = (coeffs[0], coeffs[1], float(rows), coeffs[2], coeffs[3])
+            z, zmask = y, None
+            z._xv2_lazy = (coeffs[2], coeffs[3], act)
+        elif fast is not None:
             pass
         elif ctx.has_res:
             z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split)
@@ -917,7 +1013,10 @@ class ConvBnActFn(torch.autograd.Function):
         # the activation mask of the backward pass is recomputed from y unless a residual entered before it; then it
         # comes from the byte mask written next to z (or from z itself for shapes without a mask form)
         ctx.save_for_backward(x0, x1, weight, gamma, y, (zmask if zmask is not None else z) if ctx.has_res else None,
-                              stats[0], stats[1], stats[3], stats[4])
+                              stats[0], stats[1], stats[3], stats[4], *(ctx.pre[:2] if ctx.pre is not None else ()))
+        ctx.pre_act = ctx.pre[2] if ctx.pre is not None else 0
+        ctx.has_pre = ctx.pre is not None
+        ctx.pre = None
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
         ctx.wparam = weight
@@ -931,7 +1030,10 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, dpass=None):
-        x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
+        if ctx.has_pre:
+            x0, x1, weight, gamma, y, z, mean, invstd, scale, shift, psc, psf = ctx.saved_tensors
+        else:
+            x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
         g = ctx.g
         if dz is None:
             dz = torch.zeros_like(y)
@@ -954,10 +1056,15 @@ class ConvBnActFn(torch.autograd.Function):
         elif dpass is not None:
             dx0 = dpass
         ctx.ihwo = None
-        dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
+        if not ctx.needs_input_grad[2]:
+            dw = None
+        elif ctx.has_pre:
+            dw = _conv_backward_weight_pre(x0, (psc, psf, ctx.pre_act), dy, weight, g, ctx.wparam)
+        else:
+            dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam)
         ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
-                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None)
+                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None, None)
 
 
 class ConvFn(torch.autograd.Function):
