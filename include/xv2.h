@@ -94,6 +94,15 @@ int xv2_pack_weights_table(const int64_t* table, int n, int64_t total_tiles, voi
  * same stream whenever the packed weights change (xv2_presplit_table: all pairs of a device table [n][6] int64 =
  * {b_fp32, x3 (pointers), nrows, T, ctot, first block} in one launch, an entry owns xv2_presplit_blocks() blocks) and call
  * xv2_presplit_forget(b_fp32) before releasing either buffer (NULL: forget every pair).  XV2_PRESPLIT=0 ignores the pairs. */
+/* RGB stem (model/unet.py:45 enc_l1: the 7x7 / stride-2 convolution over the image) as a "band" convolution: a KH x KW
+ * (KW <= 8) kernel over the 4-channel image equals a KH x 1 kernel over 32 "channels" = the floats of eight consecutive
+ * pixels of a row.  xv2_pad_band copies the NHWC4 image into a zero-padded frame [N][IHp][IWp][4] (fp32 or bf16, image at
+ * (pad_top, pad_left)); xv2_pack_stem_band lays the weights out as [Cout][KH][8][4]; xv2_conv2d_forward* then runs the
+ * layer on the 32-channel kernels with the descriptor {IH = IHp, IW = IWp, C0 = 32, KH, KW = 1, stride, pad = 0, OH, OW}
+ * and ldx0 = 4 (IWp even, IWp >= stride * (OW - 1) + 8, IHp >= stride * (OH - 1) + KH). */
+int xv2_pad_band(const float* x4, int N, int H, int W, int pad_top, int pad_left, int IHp, int IWp, void* out,
+                 int dtype, void* stream);
+int xv2_pack_stem_band(const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_band, int dtype, void* stream);
 int xv2_presplit_supported(int nrows, int T, int ctot);
 size_t xv2_presplit_bytes(int nrows, int T, int ctot);
 int64_t xv2_presplit_blocks(int nrows, int T, int ctot);

@@ -12,7 +12,7 @@ CANDS = [(128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 2), 
 def main():
     filt = sys.argv[1:]
     dev = "cuda:0"
-    ops.PACK_CACHE = False
+    # (pack cache stays on: the pre-split weight planes of the halo kernels hang off its entries)
     if os.environ.get("XV2_MATH") == "0":
         ops.MATH_MODE = ops.MATH_F32
     adt = torch.bfloat16 if os.environ.get("XV2_MATH") == "2" else torch.float32

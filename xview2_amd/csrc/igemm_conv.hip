@@ -1904,7 +1904,9 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
     XV2_CHECK_ARG(dry || out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
-    XV2_CHECK_ARG(dry || esz_in(d) == 4 || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
+    // (band form of an RGB stem, xv2_pad_band: pixel stride 4 with an even pixel index on every access keeps 16-byte alignment)
+    const bool band = d->C0 == 32 && d->C1 == 0 && ldx0 == 4 && d->KW == 1 && d->stride == 2 && d->pad == 0 && d->IW % 2 == 0;
+    XV2_CHECK_ARG(dry || esz_in(d) == 4 || band || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
                                      (reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ohwi) & 15) == 0),
                   "conv2d_forward: bf16 operands must be 16-byte aligned with row strides that are multiples of 8");
     XV2_CHECK_ARG(dry || !(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),

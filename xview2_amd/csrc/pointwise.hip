@@ -858,6 +858,55 @@ extern "C" int xv2_normalize_u8_to_nhwc(const uint8_t* img_hwc, int csrc, int c0
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
+// ---- RGB stem as a "band" convolution ---------------------------------------------------------------------------------
+// A KH x KW (KW <= 8) convolution over the 4-channel image = a KH x 1 convolution over 32 "channels" = the 8 x 4 floats of
+// eight consecutive pixels of an input row: one contiguous 128-byte (fp32) / 64-byte (bf16) read per tap and output pixel.
+// The image is copied once into a zero-padded frame [N][H + 2 pad (+ slack)][IWp][4] so that no tap ever leaves it (the
+// implicit-GEMM kernels then run it as an ordinary 32-channel layer with pixel stride 4), the weights go to
+// [Cout][KH][8 px][4 ch] with zeros for kw >= KW and the padding channel.
+template <typename T>
+__global__ void pad_band_kernel(const float* __restrict__ x4, int N, int H, int W, int pt, int pl, int IHp, int IWp,
+                                T* __restrict__ out) {
+    const int64_t total = (int64_t)N * IHp * IWp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % IWp);
+        const int64_t r = i / IWp;
+        const int h = (int)(r % IHp), n = (int)(r / IHp);
+        const int ih = h - pt, iw = w - pl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = *reinterpret_cast<const float4*>(x4 + (((size_t)n * H + ih) * W + iw) * 4);
+        st4(out + (size_t)i * 4, v);
+    }
+}
+template <typename T>
+__global__ void pack_stem_band_kernel(const float* __restrict__ w_oihw, int Cout, int Cin, int KH, int KW,
+                                      T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (co, kh, px, c)
+    if (i >= Cout * KH * 32) return;
+    const int c = i & 3, px = (i >> 2) & 7, kh = (i >> 5) % KH, co = i / (32 * KH);
+    float v = 0.f;
+    if (c < Cin && px < KW) v = w_oihw[(((size_t)co * Cin + c) * KH + kh) * KW + px];
+    st1(out + i, v);
+}
+extern "C" int xv2_pad_band(const float* x4, int N, int H, int W, int pad_top, int pad_left, int IHp, int IWp, void* out,
+                            int dtype, void* stream) {
+    XV2_CHECK_ARG(x4 && out && N > 0 && IHp >= H + pad_top && IWp >= W + pad_left, "pad_band: bad geometry");
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pad_band_kernel<T>, dim3(grid_for((int64_t)N * IHp * IWp)), dim3(256), 0,
+                                                 (hipStream_t)stream, x4, N, H, W, pad_top, pad_left, IHp, IWp, (T*)out));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" int xv2_pack_stem_band(const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_band, int dtype,
+                                  void* stream) {
+    XV2_CHECK_ARG(w_oihw && w_band && Cin <= 4 && KW <= 8 && KH >= 1, "pack_stem_band: Cin=%d KW=%d", Cin, KW);
+    XV2_CHECK_DTYPE(dtype);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_stem_band_kernel<T>, dim3((unsigned)cdiv(Cout * KH * 32, 256)), dim3(256),
+                                                 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH, KW, (T*)w_band));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
 extern "C" int xv2_nhwc_to_nchw(const float* x, int ldx, int N, int C, int H, int W, float* y, void* stream) {
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * C * H * W)), dim3(256), 0,
                        (hipStream_t)stream, x, ldx, N, C, (int64_t)H * W, y);

@@ -323,6 +323,7 @@ def _stats_scratch(C, device):
 # operand loaders of the power-limited MFMA kernels (halo form, all-taps weight gradient), and the two layers of a pair
 # leave the one-call layer entry points.  Off by default; XV2_LAZY_BN=1 saves 0.75 GB of activations at 2 x 1024^2.
 LAZY_BN = os.environ.get("XV2_LAZY_BN", "0") != "0"
+STEM_BAND = os.environ.get("XV2_STEM_BAND", "1") != "0"      # RGB stem on the 32-channel kernels (xv2_pad_band); 0: gather kernel
 
 
 def _apply_pre(y0, pre):
@@ -363,6 +364,21 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         coeffs = (blob[0], blob[1], blob[2], blob[3])
         bn_stats_changed()
     stats_ok = True        # False: the M tiles do not split evenly over the S parts -> statistics taken from y afterwards
+    band_w = None
+    if (rgb and STEM_BAND and G == 1 and fused is None and ihwo_out is None and pre is None and 5 <= g.kw <= 8 and
+            g.stride == 2 and g.dil == 1 and (MATH_MODE == MATH_F32X3 or half)):
+        # RGB stem as a band convolution (xv2_pad_band): KH taps x 32 "channels" (8 pixels x 4) on the 32-channel kernels -
+        # split-bf16 / bf16 MFMA instead of the exact-fp32 gather kernel.  The backward pass keeps the image itself.
+        KH, Cin_w = g.kh, weight.shape[1]
+        IHp = max((OH - 1) * 2 + KH, IH + g.pad)
+        IWp = (max((OW - 1) * 2 + 8, IW + g.pad) + 1) // 2 * 2
+        bdt = torch.bfloat16 if half else torch.float32
+        xb = torch.empty((N, IHp, IWp, 4), dtype=bdt, device=x0.device)
+        call("xv2_pad_band", x0, N, IH, IW, g.pad, g.pad, IHp, IWp, xb, XV2_BF16 if half else XV2_F32)
+        band_w = torch.empty((Cout_t, KH, 32), dtype=bdt, device=x0.device)
+        call("xv2_pack_stem_band", weight.contiguous(), Cout_t, Cin_w, KH, g.kw, band_w, XV2_BF16 if half else XV2_F32)
+        x0, IH, IW, C0t = xb, IHp, IWp, 32
+        g = conv_cfg(KH, 1, 2, 0, 1, 1, g.math)
     pre_used = False
     if pre is not None:
         d0 = _desc(N, IH, IW, C0t, C1t, Cout_t, g, OH, OW, half)
@@ -379,7 +395,10 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     cin_w = w.shape[1]
     for gi in range(G):
         wg = w[gi * Coutg:(gi + 1) * Coutg]
-        ohwi, ihwo = _pack(wg, C0g + C1t, True, ihwo_out is not None, half)
+        if band_w is not None:
+            ohwi, ihwo = band_w, None
+        else:
+            ohwi, ihwo = _pack(wg, C0g + C1t, True, ihwo_out is not None, half)
         if ihwo_out is not None:
             ihwo_out.append(ihwo)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
@@ -411,7 +430,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
                      _off(bn.running_mean, og) if coeffs is not None else None,
                      _off(bn.running_var, og) if coeffs is not None else None, *fin)
                 continue
-            call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
+            call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
                  _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
                  S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
                  _off(bn.weight, og) if bn is not None else None, _off(bn.bias, og) if bn is not None else None,
@@ -419,7 +438,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
                  _off(bn.running_mean, og) if coeffs is not None else None,
                  _off(bn.running_var, og) if coeffs is not None else None, *fin)
         else:
-            call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), C0t, x1, C1t, ohwi,
+            call("xv2_conv2d_forward", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi,
                  None if bias is None else Ptr(bias, gi * Coutg), Ptr(y, gi * Coutg), Cout_t, None,
                  _ws(wsb, x0) if wsb else None)
             if want_stats:
@@ -462,6 +481,9 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     half = (STORAGE == torch.bfloat16) if rgb else x0.dtype == torch.bfloat16
     if x1 is not None and x1.dtype != x0.dtype:
         raise RuntimeError("convolution sources of different element types (%s, %s)" % (x0.dtype, x1.dtype))
+    if (rgb and STEM_BAND and ihwo_out is None and 5 <= g.kw <= 8 and g.stride == 2 and g.dil == 1 and
+            (MATH_MODE == MATH_F32X3 or half)):
+        return None      # the RGB stem runs as a band convolution (_conv_forward)
     ohwi, ihwo = _pack(weight.contiguous(), C0t + C1t, True, ihwo_out is not None, half)
     d = _desc(N, IH, IW, C0t, C1t, Cout, g, OH, OW, half)
     tiles = query("xv2_conv2d_forward_stats_tiles", d)
