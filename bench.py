@@ -617,8 +617,8 @@ def main():
                 "math": "f32x3: fp32 tensors and accumulation, each product = 6 bf16 MFMA products of exact 3-way bf16 "
                         "operand splits; peak = bf16 dense MFMA peak / 6 (the instruction stream's own bound); "
                         "achieved counts ALGORITHMIC fp32 flops (2*M*N*K); peak is quoted at the 2.4 GHz maximum clock - "
-                        "under this kernel the chip is power-limited to ~1.67 GHz effective (GRBM_GUI_ACTIVE, "
-                        "profiles/r02_pmc_clock_f32x3.txt), where the same bound is ~289 TFLOP/s" if x3 else
+                        "under these kernels the chip is power-limited to ~1.6 - 1.9 GHz effective (GRBM_GUI_ACTIVE, "
+                        "profiles/r03_pmc_halo.md), where the same bound is ~280 - 330 TFLOP/s" if x3 else
                         "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA",
                 "frac_of_fp32_mfma_peak_157.3": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if opt.precision == 32 else None,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -629,8 +629,10 @@ def main():
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                 "launches_timed": top["launches"],
-                "note": "since round 3 the unsplit launches of this kernel also fold their BatchNorm statistics (bn_fold.h; "
-                        "split-K slabs are summed by splitk_reduce_kernel, DESIGN.md section 4); "
+                "note": "'halo,wx3' = the round-3 form of the 3x3 / stride-1 forward and backward-data launches: 4 x 32 pixel patches, "
+                        "the halo of a 16-channel slice split and stored once for nine taps, weights pre-split once per step and "
+                        "streamed global -> LDS by DMA (DESIGN.md section 4); unsplit launches fold their BatchNorm statistics "
+                        "(bn_fold.h), split-K slabs are summed by splitk_reduce_kernel; "
                         "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
                         "(weight-gradient kernels co-scheduled on a side stream); 'isolated' = same kernel with every "
                         "launch alone on the chip; per_kernel/all_mfma_kernels: an extra untimed pass with every "
