@@ -1113,6 +1113,157 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t_kernel(const float* __rest
     for (int e = threadIdx.x; e < valid * T; e += 256) o[e] = sh[e];
 }
 
+// wgrad_alltaps_x3_kernel with a 64 co x 64 ci tile per block.  Why: that kernel's producer (load, three-way split, plane
+// stores of one dY row and one input row per row step) costs 30 % of its time (ablation) and it is redone by every
+// (co tile, ci tile) block of a strip - the dY row Ctot / 32 times, the input row Cout / 32 times.  With 64 x 64 tiles
+// the same row step feeds four times the MFMAs for twice the producer work: emulated (every second row step's producer
+// skipped) the 116-GFLOP decoder layers ran 16 - 20 % faster.  Each of the four waves owns a 32 x 32 quadrant for all nine
+// taps and both 16-pixel k-steps (144 accumulator VGPRs, no cross-wave fold in the epilogue); LDS rows are 64 channels =
+// 128 B with the 32-byte chunks of pixel column p stored at chunk ^ (p & 3) (conflict-free transpose reads and stores).
+constexpr int W64_PL = 2 * 32 * 64 + 4 * 34 * 64;                 // bf16 elements per plane: dY double buffer + X ring
+__device__ __forceinline__ int w64_off(int px, int c) { return px * 64 + ((((c >> 4) ^ (px & 3)) << 4) | (c & 15)); }
+__global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t planes64[];      // [3][W64_PL]: 76.8 KB
+    bf16_t* planes = planes64;
+    constexpr int PL = W64_PL;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;                            // co half / ci half of this wave's quadrant
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int co0 = tm * 64, cn0 = tn * 64;
+    const int chunks = p.ktiles, rows_per = p.kt_per_split;
+    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int tilesW = p.OW / 32;
+    const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
+    const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
+    const bool first = cn0 < p.C0;
+    const float* xsrc = first ? p.X0 : p.X1;
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+    // loads: 16 lanes x 16 bytes per pixel (64 channels); slot s = tid + 256 j: pixel s >> 4, channel quad s & 15
+    const int c4 = tid & 15, pxa = tid >> 4;                            // pixels pxa and pxa + 16; threads < 32 also 32 + (tid >> 4)
+    const float* dy0 = p.DY + ((size_t)n * p.OH * p.OW + ow0 + pxa) * p.ldDY + co0 + c4 * 4;
+    const size_t dy_pitch = (size_t)p.OW * p.ldDY;
+    const int iw = ow0 - 1 + pxa;
+    const float* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c4 * 4;
+    const size_t x_pitch = (size_t)p.IW * ldx;
+    const bool xok0 = iw >= 0, xok1 = true, x2 = tid < 32, xok2 = x2 && iw + 32 < p.IW;      // iw + 16 is always inside
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = zero;
+    if (p.pre_scale) {
+        psc = *reinterpret_cast<const float4*>(p.pre_scale + xch + c4 * 4);
+        psf = *reinterpret_cast<const float4*>(p.pre_shift + xch + c4 * 4);
+    }
+    auto pre = [&](float4 v) {
+        if (p.pre_scale) {
+            v.x = apply_act(__fmaf_rn(v.x, psc.x, psf.x), p.pre_act);
+            v.y = apply_act(__fmaf_rn(v.y, psc.y, psf.y), p.pre_act);
+            v.z = apply_act(__fmaf_rn(v.z, psc.z, psf.z), p.pre_act);
+            v.w = apply_act(__fmaf_rn(v.w, psc.w, psf.w), p.pre_act);
+        }
+        return v;
+    };
+    float4 rd0 = zero, rd1 = zero, rx0 = zero, rx1 = zero, rx2 = zero;
+    auto load_dy = [&](int r) {
+        rd0 = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch);
+        rd1 = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch + (size_t)16 * p.ldDY);
+    };
+    auto load_x = [&](int ih) {
+        rx0 = rx1 = rx2 = zero;
+        if ((unsigned)ih < (unsigned)p.IH) {
+            const float* xr = xa0 + (size_t)ih * x_pitch;
+            if (xok0) rx0 = pre(*reinterpret_cast<const float4*>(xr));
+            if (xok1) rx1 = pre(*reinterpret_cast<const float4*>(xr + (size_t)16 * ldx));
+            if (xok2) rx2 = pre(*reinterpret_cast<const float4*>(xr + (size_t)32 * ldx));
+        }
+    };
+    auto put = [&](int off, const float4 v) {
+        uint2 h, m, l;
+        split3x4(v, h, m, l);
+        *reinterpret_cast<uint2*>(planes + off) = h;
+        *reinterpret_cast<uint2*>(planes + PL + off) = m;
+        *reinterpret_cast<uint2*>(planes + 2 * PL + off) = l;
+    };
+    auto store_dy = [&](int buf) {
+        put(buf * 32 * 64 + w64_off(pxa, c4 * 4), rd0);
+        put(buf * 32 * 64 + w64_off(pxa + 16, c4 * 4), rd1);
+    };
+    auto store_x = [&](int ih) {
+        const int ring = 2 * 32 * 64 + ((ih + 4) & 3) * 34 * 64;
+        put(ring + w64_off(pxa, c4 * 4), rx0);
+        put(ring + w64_off(pxa + 16, c4 * 4), rx1);
+        if (x2) put(ring + w64_off(pxa + 32, c4 * 4), rx2);
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int frow = 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    auto frag = [&](const bf16_t* base, int px, int c) {       // transposed 16-pixel x 32-channel operand at (px, c)
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + w64_off(px, c)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + w64_off(px + 4, c)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    load_x(r0 - 1);
+    store_x(r0 - 1);
+    load_x(r0);
+    store_x(r0);
+    load_x(r0 + 1);
+    store_x(r0 + 1);
+    load_dy(r0);
+    store_dy(0);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            load_dy(r + 1);
+            load_x(r + 2);
+        }
+        const bf16_t* ab = planes + buf * 32 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pa = 16 * ks + frow, ca = wa * 32 + fcol;
+            const bf16x8 ah = frag(ab, pa, ca), am = frag(ab + PL, pa, ca), al = frag(ab + 2 * PL, pa, ca);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const bf16_t* row = planes + 2 * 32 * 64 + ((r - 1 + kh + 4) & 3) * 34 * 64;      // input row r-1+kh
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t = kh * 3 + kw, pb = pa + kw, cb = wb * 32 + fcol;
+                    const bf16x8 bh = frag(row, pb, cb), bm = frag(row + PL, pb, cb), bl = frag(row + 2 * PL, pb, cb);
+                    f32x16 c = acc[t];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up (144 + ~100 VGPRs)
+                }
+            }
+        }
+        if (more) {
+            store_dy(buf ^ 1);
+            store_x(r + 2);
+        }
+        __syncthreads();
+    }
+    // every wave writes its quadrant of the block's slab part[y][co][T][Ctot] (C layout of the 32x32 MFMA)
+    const size_t rowlen = (size_t)9 * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + wb * 32 + l31] = acc[t][r];
+        }
+}
+
 struct WgradPlan {
     int bm, bn, wk, splitk, kt_per, ktiles, tiles;
     bool smallc;
@@ -1158,14 +1309,22 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
         pl.bm = pl.bn = 32;
         pl.wk = 1;
         pl.tiles = (d->Cout / 32) * (Ctot / 32);
+        // split-bf16: 64 x 64 tiles (wgrad_alltaps64_x3_kernel) where the channel counts allow; XV2_WGRAD64=0: 32 x 32
+        static const int w64 = [] { const char* e = getenv("XV2_WGRAD64"); return e ? atoi(e) : 1; }();
+        const bool t64 = x3 && w64 && d->Cout % 64 == 0 && d->C0 % 64 == 0 && d->C1 % 64 == 0;
+        if (t64) {
+            pl.bm = pl.bn = 64;
+            pl.tiles = (d->Cout / 64) * (Ctot / 64);
+        }
         const int strips = d->N * (d->OW / 32);
         // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80),
         // 3 per CU for the split-bf16 one (134 VGPRs, 38 KB of LDS)
-        const int cap = wgrad_cap_override() ? wgrad_cap_override() : x3 ? 768 : d->math ? 1024 : 512;
+        const int cap = wgrad_cap_override() ? wgrad_cap_override() : t64 ? 512 : x3 ? 768 : d->math ? 1024 : 512;
         // row chunks per strip: the count that minimises (rounds of resident blocks) x (rows per chunk) x (time of one
         // row step with the CU full) + (slabs written by the kernel and re-read by the slab sum).  Row-step times measured
         // on the decoder layers: 2.4 us exact fp32, 2.25 us split-bf16, 0.8 us bf16; slab cost fitted on dec3 / l4 (bf16).
-        const double t_row = x3 ? 2.25 : d->math ? 0.8 : 2.4;
+        static const double trow64 = [] { const char* e = getenv("XV2_W64_TROW"); return e ? atof(e) : 7.0; }();
+        const double t_row = t64 ? trow64 : x3 ? 2.25 : d->math ? 0.8 : 2.4;      // (64 x 64: 4x the MFMAs per row step, two blocks per CU)
         const double slab_mb = 1e-6 * (double)d->Cout * 9.0 * Ctot * 4.0;
         const double slab_us = std::min(0.02 + 0.7 * slab_mb, 1.0 + 0.15 * slab_mb);   // per slab; small slabs sum in parallel
         const int maxchunks = std::max(1, d->OH / 8);
@@ -1314,7 +1473,12 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
         static const int kidx3 = prof_register("wgrad_alltaps_kernel<f32x3>");
         prof_begin(x3 ? kidx3 : hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
-        if (x3)
+        if (x3 && pl.bm == 64) {
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_alltaps64_x3_kernel),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W64_PL * 2);
+            XV2_CHECK_HIP(attr_rc);
+            hipLaunchKernelGGL(wgrad_alltaps64_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 3 * W64_PL * 2, stream, p);
+        } else if (x3)
             hipLaunchKernelGGL(wgrad_alltaps_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs && use_tr_wgrad())
             hipLaunchKernelGGL(wgrad_alltaps_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
