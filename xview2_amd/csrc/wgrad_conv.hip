@@ -1264,6 +1264,110 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
         }
 }
 
+// the same 64 x 64 tiling for bf16 storage (wgrad_alltaps_tr_kernel's big sibling): one bf16 plane, 16-byte loads and LDS
+// stores of 8 channels, one MFMA per (tap, k-step).  Emulated first (every second row step's producer skipped: -16 ... -31 %).
+__global__ void __launch_bounds__(256, 2) wgrad_alltaps64_tr_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t planes[W64_PL];      // 25.6 KB
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int co0 = tm * 64, cn0 = tn * 64;
+    const int chunks = p.ktiles, rows_per = p.kt_per_split;
+    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int tilesW = p.OW / 32;
+    const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
+    const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
+    const bool first = cn0 < p.C0;
+    const bf16_t* xsrc = reinterpret_cast<const bf16_t*>(first ? p.X0 : p.X1);
+    const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
+    // loads: 8 lanes x 16 bytes per pixel; every thread one dY element and one X element (pixels 0..31), threads < 16 pixels 32, 33
+    const int px = tid >> 3, c8 = tid & 7;
+    const bf16_t* dy0 = reinterpret_cast<const bf16_t*>(p.DY) + ((size_t)n * p.OH * p.OW + ow0 + px) * p.ldDY + co0 + c8 * 8;
+    const size_t dy_pitch = (size_t)p.OW * p.ldDY;
+    const int iw = ow0 - 1 + px;
+    const bf16_t* xa0 = xsrc + ((size_t)n * p.IH * p.IW + iw) * ldx + xch + c8 * 8;
+    const size_t x_pitch = (size_t)p.IW * ldx;
+    const bool xok = iw >= 0, x2 = tid < 16, x2ok = x2 && iw + 32 < p.IW;
+    const i32x4 zero = {0, 0, 0, 0};
+    i32x4 rd = zero, rx = zero, rx2 = zero;
+    auto load_dy = [&](int r) { rd = *reinterpret_cast<const i32x4*>(dy0 + (size_t)r * dy_pitch); };
+    auto load_x = [&](int ih) {
+        rx = zero;
+        rx2 = zero;
+        if ((unsigned)ih < (unsigned)p.IH) {
+            if (xok) rx = *reinterpret_cast<const i32x4*>(xa0 + (size_t)ih * x_pitch);
+            if (x2ok) rx2 = *reinterpret_cast<const i32x4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx);
+        }
+    };
+    auto store_dy = [&](int buf) { *reinterpret_cast<i32x4*>(planes + buf * 32 * 64 + w64_off(px, c8 * 8)) = rd; };
+    auto store_x = [&](int ih) {
+        bf16_t* ring = planes + 2 * 32 * 64 + ((ih + 4) & 3) * 34 * 64;
+        *reinterpret_cast<i32x4*>(ring + w64_off(px, c8 * 8)) = rx;
+        if (x2) *reinterpret_cast<i32x4*>(ring + w64_off(px + 32, c8 * 8)) = rx2;
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int frow = 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
+    auto frag = [&](const bf16_t* base, int fp, int c) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + w64_off(fp, c)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + w64_off(fp + 4, c)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    load_x(r0 - 1);
+    store_x(r0 - 1);
+    load_x(r0);
+    store_x(r0);
+    load_x(r0 + 1);
+    store_x(r0 + 1);
+    load_dy(r0);
+    store_dy(0);
+    __syncthreads();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            load_dy(r + 1);
+            load_x(r + 2);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pa = 16 * ks + frow;
+            const bf16x8 af = frag(planes + buf * 32 * 64, pa, wa * 32 + fcol);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const bf16_t* row = planes + 2 * 32 * 64 + ((r - 1 + kh + 4) & 3) * 34 * 64;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bf16x8 bf = frag(row, pa + kw, wb * 32 + fcol);
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[kh * 3 + kw], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            store_dy(buf ^ 1);
+            store_x(r + 2);
+        }
+        __syncthreads();
+    }
+    const size_t rowlen = (size_t)9 * p.Ctot;
+    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + wb * 32 + l31] = acc[t][r];
+        }
+}
+
 struct WgradPlan {
     int bm, bn, wk, splitk, kt_per, ktiles, tiles;
     bool smallc;
@@ -1306,41 +1410,53 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
         d->OW % 32 == 0 && d->OH == d->IH && d->OW == d->IW && d->Cout % 32 == 0 && d->C0 % 32 == 0 &&
         d->C1 % 32 == 0 && d->C0 > 0 && (d->Cout / 32) * (Ctot / 32) <= alltaps_max_tiles()) {
         pl.alltaps = true;
-        pl.bm = pl.bn = 32;
         pl.wk = 1;
-        pl.tiles = (d->Cout / 32) * (Ctot / 32);
-        // split-bf16: 64 x 64 tiles (wgrad_alltaps64_x3_kernel) where the channel counts allow; XV2_WGRAD64=0: 32 x 32
+        // split-bf16 / bf16 storage: 64 x 64 tiles (wgrad_alltaps64_*_kernel: half the producer work per FLOP) where the channel
+        // counts allow AND the cost model prefers them - layers with few tiles (ResNeSt's grouped 3x3 layers at 64^2 / 32^2) cannot
+        // fill the chip with a quarter of the blocks: resnest50 --precision 16 lost 0.75 ms per step with 64 x 64 everywhere.
+        // XV2_WGRAD64=0: always 32 x 32.
         static const int w64 = [] { const char* e = getenv("XV2_WGRAD64"); return e ? atoi(e) : 1; }();
-        const bool t64 = x3 && w64 && d->Cout % 64 == 0 && d->C0 % 64 == 0 && d->C1 % 64 == 0;
-        if (t64) {
-            pl.bm = pl.bn = 64;
-            pl.tiles = (d->Cout / 64) * (Ctot / 64);
-        }
+        const bool hs64 = d->math == XV2_MATH_BF16_STORE && use_tr_wgrad();
+        const bool can64 = (x3 || hs64) && w64 && d->Cout % 64 == 0 && d->C0 % 64 == 0 && d->C1 % 64 == 0;
         const int strips = d->N * (d->OW / 32);
-        // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs), 4 per CU for the bf16 variant (80),
-        // 3 per CU for the split-bf16 one (134 VGPRs, 38 KB of LDS)
-        const int cap = wgrad_cap_override() ? wgrad_cap_override() : t64 ? 512 : x3 ? 768 : d->math ? 1024 : 512;
-        // row chunks per strip: the count that minimises (rounds of resident blocks) x (rows per chunk) x (time of one
-        // row step with the CU full) + (slabs written by the kernel and re-read by the slab sum).  Row-step times measured
-        // on the decoder layers: 2.4 us exact fp32, 2.25 us split-bf16, 0.8 us bf16; slab cost fitted on dec3 / l4 (bf16).
-        static const double trow64 = [] { const char* e = getenv("XV2_W64_TROW"); return e ? atof(e) : 7.0; }();
-        const double t_row = t64 ? trow64 : x3 ? 2.25 : d->math ? 0.8 : 2.4;      // (64 x 64: 4x the MFMAs per row step, two blocks per CU)
+        static const double trow64 = [] { const char* e = getenv("XV2_W64_TROW"); return e ? atof(e) : 5.2; }();
         const double slab_mb = 1e-6 * (double)d->Cout * 9.0 * Ctot * 4.0;
         const double slab_us = std::min(0.02 + 0.7 * slab_mb, 1.0 + 0.15 * slab_mb);   // per slab; small slabs sum in parallel
         const int maxchunks = std::max(1, d->OH / 8);
-        int chunks = 1;
-        double best_cost = 0.0;
-        for (int c = 1; c <= maxchunks && c <= 64; ++c) {
-            const int rows = (int)cdiv(d->OH, c);
-            if ((int)cdiv(d->OH, rows) != c) continue;
-            const int64_t blocks = (int64_t)pl.tiles * strips * c;
-            const int nslab = strips * c;
-            const double cost = (double)cdiv(blocks, cap) * rows * t_row + (nslab + (nslab >= 64 ? 16 : 0)) * slab_us;
-            if (c == 1 || cost < best_cost) {
-                best_cost = cost;
-                chunks = c;
+        // row chunks per strip: the count that minimises (rounds of resident blocks) x (rows per chunk) x (time of one
+        // row step with the CU full) + (slabs written by the kernel and re-read by the slab sum).  Row-step times measured
+        // on the decoder layers: 2.4 us exact fp32, 2.25 us split-bf16, 0.8 us bf16 (32 x 32 tiles; 64 x 64: 5.2 / 1.15 us);
+        // resident blocks per chip: 2 per CU in fp32 (144 accumulator VGPRs) and for the 64 x 64 tiles, 4 per CU for the
+        // bf16 variant (80), 3 per CU for the split-bf16 one (134 VGPRs, 38 KB of LDS); slab cost fitted on dec3 / l4 (bf16).
+        auto plan_tiles = [&](bool t64, int& chunks_out) {
+            const int tiles = t64 ? (d->Cout / 64) * (Ctot / 64) : (d->Cout / 32) * (Ctot / 32);
+            const int cap = wgrad_cap_override() ? wgrad_cap_override() : t64 ? 512 : x3 ? 768 : d->math ? 1024 : 512;
+            // (64 x 64 row-step times fitted to the measured ratios on the 116-GFLOP layers: 0.86 split-bf16, ~0.7 bf16)
+            const double t_row = t64 ? (x3 ? trow64 : 0.22 * trow64) : x3 ? 2.25 : d->math ? 0.8 : 2.4;
+            double best_cost = 0.0;
+            chunks_out = 1;
+            for (int c = 1; c <= maxchunks && c <= 64; ++c) {
+                const int rows = (int)cdiv(d->OH, c);
+                if ((int)cdiv(d->OH, rows) != c) continue;
+                const int64_t blocks = (int64_t)tiles * strips * c;
+                const int nslab = strips * c;
+                const double cost = (double)cdiv(blocks, cap) * rows * t_row + (nslab + (nslab >= 64 ? 16 : 0)) * slab_us;
+                if (c == 1 || cost < best_cost) {
+                    best_cost = cost;
+                    chunks_out = c;
+                }
             }
+            return best_cost;
+        };
+        int chunks = 1, chunks64 = 1;
+        const double cost32 = plan_tiles(false, chunks);
+        bool t64 = false;
+        if (can64 && plan_tiles(true, chunks64) < cost32) {
+            t64 = true;
+            chunks = chunks64;
         }
+        pl.bm = pl.bn = t64 ? 64 : 32;
+        pl.tiles = t64 ? (d->Cout / 64) * (Ctot / 64) : (d->Cout / 32) * (Ctot / 32);
         pl.kt_per = (int)cdiv(d->OH, chunks);
         pl.ktiles = (int)cdiv(d->OH, pl.kt_per);
         pl.splitk = strips * pl.ktiles;
@@ -1480,6 +1596,8 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
             hipLaunchKernelGGL(wgrad_alltaps64_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 3 * W64_PL * 2, stream, p);
         } else if (x3)
             hipLaunchKernelGGL(wgrad_alltaps_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        else if (hs && use_tr_wgrad() && pl.bm == 64)
+            hipLaunchKernelGGL(wgrad_alltaps64_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs && use_tr_wgrad())
             hipLaunchKernelGGL(wgrad_alltaps_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs)
