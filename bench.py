@@ -188,7 +188,7 @@ def free_port():
 def self_launch(n):
     """--gpus N>1 outside a torchrun environment: become the launcher (the reference spawns its own ranks too)"""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and "--share-gpu" not in sys.argv:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible - refusing to report a %d-GPU number" % (n, have, n))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -417,6 +417,9 @@ def main():
                          "the step is GPU-bound; default is eager)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="debug: run the RCCL gradient/SyncBN collectives even with one rank (overhead probe)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug / test: all ranks share cuda:0 and gloo carries the device tensors (exercises the N>1 "
+                         "code path on a 1-GPU box; the line is marked and is NOT a scaling measurement)")
     opt = ap.parse_args()
 
     if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -428,7 +431,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
-    rank, local, world = xdist.init_from_env()
+    rank, local, world = xdist.init_from_env("gloo" if opt.share_gpu else None)
+    if opt.share_gpu:
+        local = 0
     if opt.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong rank count"
                          % (opt.gpus, world))
@@ -661,7 +666,9 @@ def main():
                                    "fp32 tensors, products as exact 3-way bf16 splits on the bf16 MFMA (6 MFMAs per product, "
                                    "fp32 accumulate; XV2_F32X3=0 selects the exact-fp32 MFMA)" if x3 else "fp32" if opt.precision == 32 else
                                    "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
-                   "global_batch": world * opt.batch, "parallelism": "dp%d" % world},
+                   "global_batch": world * opt.batch,
+                   "parallelism": "dp%d" % world + (" (ranks SHARE one GPU over gloo: code-path test, not a scaling "
+                                                    "measurement)" if opt.share_gpu else "")},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(model_tf, 2),
         "conv_roofline_frac_whole_step": round(

@@ -399,6 +399,18 @@ def test_bench_self_launches_two_ranks_over_rccl():
     assert line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench_path():
+    """the N > 1 path of bench.py end to end on the 1-GPU box: self-launch through torch.distributed.run, rendezvous on
+    127.0.0.1, SyncBatchNorm + bucketed gradient all-reduce in every step, barriers around the timed region, max over
+    ranks, ONE line from rank 0 (gloo carries the device tensors: RCCL refuses two ranks on one device).  With RCCL the
+    same code runs at round end (`test_bench_self_launches_two_ranks_over_rccl`, needs 2 GPUs)"""
+    r, line = _run_bench("--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--size", "256", "--no-cpu-baseline")
+    assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-500:])
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["global_batch"] == 4
+    assert line["value"] > 0 and line["scaling"] == "weak" and "SHARE" in line["config"]["parallelism"]
+
+
 def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size():
     """the default bench line at a reduced tile (256 x 256 so that the CPU oracle leg takes seconds): contract keys,
     the first-step parity block against the oracle and the resnest50 encoder-forward utilisation block"""
