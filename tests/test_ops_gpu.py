@@ -405,14 +405,17 @@ def test_conv_weight_gradient_bf16_math_mode(case):
     close(dw, dwr, 3e-4, "bf16 wgrad")
 
 
-@pytest.mark.parametrize("downsample", [False, True])
+@pytest.mark.parametrize("downsample", [False, True, "thin"])
 def test_bottleneck_shortcut_gradient_is_summed_in_the_dgrad_epilogue(downsample):
     """torchvision Bottleneck wiring: the block input feeds conv1 AND the shortcut.  With the pass-through alias the
     shortcut's gradient is accumulated by conv1's backward-data kernel (xv2_conv2d_backward_data_acc); the input
     gradient must equal torch autograd's sum of both paths (eval-mode BN keeps the comparison well conditioned)."""
     from xview2_amd import encoders
     torch.manual_seed(3)
-    inpl, planes, stride = (64, 32, 2) if downsample else (128, 32, 1)
+    # "thin": 256 -> 64 -> 256 over 66 045 pixels - conv1's backward-data (64 -> 256, accumulating) is the streaming kernel
+    thin = downsample == "thin"
+    downsample = False if thin else downsample
+    inpl, planes, stride = (256, 64, 1) if thin else (64, 32, 2) if downsample else (128, 32, 1)
     blk = encoders.Bottleneck(inpl, planes, stride, downsample).eval()
     for m in blk.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -420,7 +423,7 @@ def test_bottleneck_shortcut_gradient_is_summed_in_the_dgrad_epilogue(downsample
             m.running_var.uniform_(0.5, 1.5)
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.1)
-    x = torch.randn(2, inpl, 16, 16)
+    x = torch.randn(1, inpl, 255, 259) if thin else torch.randn(2, inpl, 16, 16)
     # reference: the same arithmetic in plain torch on the CPU
     xr = x.clone().requires_grad_(True)
 
@@ -438,7 +441,85 @@ def test_bottleneck_shortcut_gradient_is_summed_in_the_dgrad_epilogue(downsample
     out = blk(leaf * 1.0)
     out.backward(nhwc(dout))
     close(nchw(out), ref, 2e-5, "out")
-    close(nchw(leaf.grad), xr.grad, 5e-5, "dx")
+    if thin:
+        # 4 M activations: a handful of pre-activations sit within rounding of zero and their ReLU masks flip against the
+        # CPU evaluation (the tiled kernels show the same 4e-3 outliers, XV2_THIN=0); each flip moves one pixel's gradient
+        err = (nchw(leaf.grad).double() - xr.grad.double()).abs() / xr.grad.abs().max().item()
+        assert float((err > 5e-5).float().mean()) < 1e-3 and float(err.max()) < 5e-2
+    else:
+        close(nchw(leaf.grad), xr.grad, 5e-5, "dx")
+
+
+def _prof_kernel_names():
+    import ctypes
+    from xview2_amd import _capi
+    names = []
+    for kid in range(_capi.query("xv2_prof_num_kernels")):
+        tms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _capi.query("xv2_prof_summary", kid, ctypes.addressof(tms), ctypes.addressof(fl), ctypes.addressof(by),
+                    ctypes.addressof(n))
+        if n.value:
+            names.append(_capi.query("xv2_prof_kernel_name", kid).decode())
+    return names
+
+
+THIN_CASES = [   # 1x1 / stride 1, K * N <= 16384, >= 65536 pixels (ragged last tile: 255 * 259 = 515 * 128 + 125)
+    (1, 255, 259, 64, 0, 256, 1, 1, 0, 1, 1),
+    (1, 255, 259, 256, 0, 64, 1, 1, 0, 1, 1),
+    (1, 256, 256, 64, 0, 64, 1, 1, 0, 1, 1),
+    (1, 257, 256, 128, 0, 64, 1, 1, 0, 1, 1),
+    (2, 256, 130, 64, 0, 128, 1, 1, 0, 1, 1),
+]
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_thin_1x1_streaming_kernel_forward_statistics_and_backward_data(case, half):
+    """the HBM-bound 1x1 layers of the first encoder level (thin_conv.hip): forward with BatchNorm statistics and
+    backward-data against PyTorch fp32 under the gates of the tiled kernels, and the streaming kernel is what ran"""
+    from xview2_amd import _capi, ops
+    _capi.query("xv2_prof_enable", 1)
+    try:
+        if half:
+            test_bf16_storage_conv_bn_act_forward_backward(case)
+        else:
+            # as test_conv_bn_act_forward_backward, with the LeakyReLU derivative taken from the HIP path's own mask: among
+            # 17 M pre-activations some sit within rounding of zero (tests/test_conv_shapes_gpu.py does the same)
+            N, H, W, C0, C1, Cout, k, s, p, d, G = case
+            torch.manual_seed(sum(case))
+            x0 = torch.randn(N, C0, H, W)
+            w = torch.randn(Cout, C0, 1, 1) * (2.0 / C0) ** 0.5
+            gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
+            bnm = torch.nn.BatchNorm2d(Cout).to(dev())
+            with torch.no_grad():
+                bnm.weight.copy_(gamma)
+                bnm.bias.copy_(beta)
+            wg = w.to(dev()).requires_grad_(True)
+            a0 = nhwc(x0).requires_grad_(True)
+            z = ops.ConvBnActFn.apply(a0, None, wg, bnm.weight, bnm.bias, None, ops.conv_cfg(1, 1, 1, 0, 1, 1), ops.BnState(bnm),
+                                      ops.ACT_LEAKY, True)
+            dz = torch.randn(N, Cout, H, W)
+            z.backward(nhwc(dz))
+            zh = nchw(z)
+            xr, wr = x0.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            rm, rv = torch.zeros(Cout), torch.ones(Cout)
+            pre = F.batch_norm(F.conv2d(xr, wr), rm, rv, gr, br, True, 0.1, 1e-5)
+            close(zh, F.leaky_relu(pre, 0.01), 2e-4, "z")
+            close(bnm.running_mean, rm, 2e-4, "running_mean")
+            close(bnm.running_var, rv, 2e-4, "running_var")
+            (pre * torch.where(zh > 0, 1.0, 0.01)).backward(dz)
+            close(nchw(a0.grad), xr.grad, 5e-4, "dx")
+            close(wg.grad, wr.grad, 5e-4, "dw")
+            close(bnm.weight.grad, gr.grad, 5e-4, "dgamma")
+            close(bnm.bias.grad, br.grad, 5e-4, "dbeta")
+        torch.cuda.synchronize()
+        names = _prof_kernel_names()
+    finally:
+        _capi.query("xv2_prof_enable", 0)
+    mode = "bf16hbm" if half else "f32x3"
+    fwd, bwd = "thin1x1_kernel<%d,%d,%s>" % (case[3], case[5], mode), "thin1x1_kernel<%d,%d,%s>" % (case[5], case[3], mode)
+    assert fwd in names and bwd in names, names
 
 
 def test_table_driven_repack_matches_single_weight_pack():

@@ -1641,6 +1641,30 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     p.ksplit = ks;
     p.part = splitk_ws;
     p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);
+    if (ks == 1 && (bm == 128 || !p.stats) && !p.plan_halo && thin1x1_eligible(p, smallc)) {
+        // HBM-bound 1x1 layers: the streaming kernel (thin_conv.hip).  It writes the 128-row statistics partials of the
+        // BM = 128 plan and leaves their reduction to the separate launch (one device-scope hand-off per 128 rows would
+        // stall its barrier-free waves)
+        const StatsFold fold = p.fold;
+        p.fold.on = 0;
+        int rc = thin1x1_launch(p, stream);
+        if (rc || !fold.on) return rc;
+        const int64_t tiles = cdiv(maxM, 128);
+        XV2_CHECK_ARG(fold.S >= 1 && tiles % fold.S == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts",
+                      (long long)tiles, fold.S);
+        const int64_t tpp = tiles / fold.S;
+        for (int s = 0; s < fold.S && !rc; ++s) {
+            const float* ps = p.stats + (size_t)s * tpp * p.Nout * 2;
+            double* ss = fold.sums + (size_t)s * fold.part_stride * 2;
+            const size_t o = (size_t)s * fold.part_stride;
+            const BnFinalize& f = fold.fin;
+            rc = f.mean ? xv2_bn_reduce_finalize(ps, tpp, p.Nout, ss, fold.scratch, f.count, f.gamma, f.beta, f.eps, f.momentum,
+                                                 f.running_mean, f.running_var, f.mean + o, f.invstd + o, f.scale + o,
+                                                 f.shift + o, stream)
+                        : xv2_bn_reduce_stats(ps, tpp, p.Nout, ss, fold.scratch, stream);
+        }
+        return rc;
+    }
     if (ks == 1) {
         int mk = 0;
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);

@@ -82,4 +82,9 @@ constexpr int BK = 32;
 bool direct3x3_eligible(const IgemmParams& p, bool smallc);
 int direct3x3_launch(const IgemmParams& p, hipStream_t stream);
 
+// thin_conv.hip: 1x1 / stride 1 convolutions with K * N <= 16384 over >= 65536 pixels stream the pixels past weights that
+// stay in LDS (HBM-bound layers of the first encoder level); writes 128-row statistics partials, never folds them
+bool thin1x1_eligible(const IgemmParams& p, bool smallc);
+int thin1x1_launch(const IgemmParams& p, hipStream_t stream);
+
 }  // namespace xv2

@@ -1,0 +1,313 @@
+// Thin 1x1 convolutions: few channels on one side (K * N <= 16384), very many pixels - the first encoder level of the
+// ResNet / ResNeSt bottlenecks (model/unet.py:45-52 -> enc_l2: 64 -> 256, 256 -> 64, 64 -> 64 at 256 x 256 per image) and
+// their backward-data passes.  These layers move 170 - 200 MB per launch for 1 - 9 GFLOP: HBM-bound, and the tiled
+// implicit-GEMM kernel (one 128 x 128 tile per block: load, split, 4 - 16 MFMA stages, staged epilogue, all in sequence,
+// two blocks per CU) ran them at 2 TB/s.  Here the kernel is a stream:
+//   * the WHOLE weight matrix lives in LDS for the lifetime of the block ([plane][N][K + 8] bf16; fp32 tensors: the three
+//     bf16 planes of the exact 3-way split, made once per block),
+//   * every wave owns 128-pixel tiles (four 32-pixel MFMA row blocks) and needs no barrier after the weight staging:
+//     a lane loads the 8 consecutive channels of ITS pixel that the MFMA A operand wants straight from HBM into
+//     registers (32 contiguous bytes per lane and K step; fp32 tensors are split in registers), the next 64-channel slice
+//     is in flight while the current one is multiplied,
+//   * accumulators go to HBM directly (a wave store covers two full 128-byte lines), the BatchNorm statistics partials of
+//     the 128-row tile ([tile][N][2], the layout of the implicit-GEMM kernel with BM = 128) come out of the same registers.
+// Arithmetic is that of the kernels it replaces: XV2_MATH_F32X3 = six bf16 cross products per fp32 product in the same
+// order (igemm_conv.hip mfma_stage), XV2_MATH_BF16_STORE = bf16 tensors, bf16 MFMA, fp32 accumulation, statistics on
+// the values as stored.
+#include "igemm_params.h"
+#include <stdlib.h>
+
+namespace xv2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct ThinParams {
+    const void* A;        // [M][ldA] activations (fp32, or bf16 under XV2_MATH_BF16_STORE)
+    const void* B;        // [N][K] packed weights (same element type)
+    void* Out;            // [M][ldo]
+    float* stats;         // [tiles][N][2] or nullptr
+    int M, ldA, ldo, accum, tiles;
+    unsigned bytesA;
+};
+
+template <int K, int N, bool HS, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const ThinParams p) {
+    constexpr int P = HS ? 1 : 3;              // bf16 planes of the weights
+    constexpr int KP = K + 8;                  // LDS row pitch in bf16: (K + 8) / 2 dwords = 4 mod 32 -> conflict-free b128 reads
+    constexpr int NB = N / 32, KC = K / 64;
+    constexpr int PLANE = N * KP;
+    constexpr int ES = HS ? 2 : 4;             // bytes per tensor element
+    constexpr int NRAW = HS ? 4 : 8;           // 16-byte loads per lane and 64-channel slice
+    static_assert(K % 64 == 0 && N % 64 == 0, "64-channel slices, pairs of 32-column blocks");
+    extern __shared__ __attribute__((aligned(16))) __bf16 sw[];      // [P][N][KP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nw = gridDim.x * WAVES;
+    int tile = blockIdx.x * WAVES + wave;
+
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
+    // lane (l31, h) of a 32-pixel block owns pixel l31 and channels 16 * ks + 8 * h .. + 7 of every K step ks
+    auto issue = [&](int t, int sub, int kc, i32x4 (&r)[NRAW]) {
+        const int m = t * 128 + sub * 32 + l31;
+        const int off = m < p.M ? (m * p.ldA + kc * 64 + h * 8) * ES : (int)0x80000000;     // rows past M read zeros
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (HS) {
+                r[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off + ks * 32, 0, 0);
+            } else {
+                r[2 * ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off + ks * 64, 0, 0);
+                r[2 * ks + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off + ks * 64 + 16, 0, 0);
+            }
+        }
+    };
+    i32x4 rawn[NRAW];
+    if (tile < p.tiles) issue(tile, 0, 0, rawn);            // in flight under the weight staging
+
+    // ---- weights -> LDS (fp32: exact 3-way bf16 split, once per block)
+    // (all loads of a thread in flight before the first is used: one memory round trip, not one per 16 bytes)
+    constexpr int NT = WAVES * 64;
+    if constexpr (HS) {
+        constexpr int PER = N * K / 8 / NT;
+        static_assert(N * K / 8 % NT == 0, "whole passes");
+        const uint4* src = reinterpret_cast<const uint4*>(p.B);
+        uint4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) v[u] = src[tid + u * NT];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * NT, n = i / (K / 8), c8 = i - n * (K / 8);
+            *reinterpret_cast<uint4*>(sw + n * KP + c8 * 8) = v[u];
+        }
+    } else {
+        constexpr int PER = N * K / 4 / NT, CH = PER < 16 ? PER : 16;
+        static_assert(N * K / 4 % NT == 0 && PER % CH == 0, "whole passes");
+        const float4* src = reinterpret_cast<const float4*>(p.B);
+#pragma unroll 1
+        for (int u0 = 0; u0 < PER; u0 += CH) {
+            float4 v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = src[tid + (u0 + u) * NT];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = tid + (u0 + u) * NT, n = i / (K / 4), c4 = i - n * (K / 4);
+                uint2 q0, q1, q2;
+                split3x4(v[u], q0, q1, q2);
+                __bf16* d = sw + n * KP + c4 * 4;
+                *reinterpret_cast<uint2*>(d) = q0;
+                *reinterpret_cast<uint2*>(d + PLANE) = q1;
+                *reinterpret_cast<uint2*>(d + 2 * PLANE) = q2;
+            }
+        }
+    }
+    __syncthreads();
+
+    const __bf16* wl = sw + l31 * KP + 8 * h;              // this lane's B-operand row (column l31 of a 32-column block)
+    for (; tile < p.tiles; tile += nw) {
+        float s1[NB], s2[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll 1
+        for (int sub = 0; sub < 4; ++sub) {
+            // (acc[j][r]: pixel (r & 3) + 8 * (r >> 2) + 4 * h of the block, column 32 j + l31)
+            const int m0 = tile * 128 + sub * 32 + 4 * h;
+            const bool full = tile * 128 + sub * 32 + 32 <= p.M;
+            f32x16 acc[NB];
+            if (p.accum) {
+                // gradient of a tensor with a second consumer: the accumulators START from what the output holds (all
+                // loads of the block in flight at once, waited for by the first MFMA that uses them)
+                // (unconditional loads from rows clamped into the tensor, conversion in a second pass: a branch or a
+                // conversion next to each load makes the compiler wait for every load before issuing the next one)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = min(m0 + (r & 3) + 8 * (r >> 2), p.M - 1);
+                        const size_t at = (size_t)row * p.ldo + j * 32 + l31;
+                        if constexpr (HS)       // the dword that holds this lane's column and its neighbour's
+                            acc[j][r] = __uint_as_float(reinterpret_cast<const unsigned*>(p.Out)[at >> 1]);
+                        else
+                            acc[j][r] = reinterpret_cast<const float*>(p.Out)[at];
+                    }
+                if constexpr (HS) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned u = __float_as_uint(acc[j][r]);
+                            acc[j][r] = __uint_as_float((l31 & 1) ? (u & 0xffff0000u) : (u << 16));
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            }
+#pragma unroll(KC > 2 ? 1 : KC)      // K = 256: rolled (unrolled, the weight fragments of all four slices stay live: 512 registers)
+            for (int kc = 0; kc < KC; ++kc) {
+                // A operand of this slice: xa[ks][plane]
+                bf16x8 xa[4][P];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if constexpr (HS) {
+                        xa[ks][0] = __builtin_bit_cast(bf16x8, rawn[ks]);
+                    } else {
+                        uint2 a0, a1, a2, b0, b1, b2;
+                        split3x4(__builtin_bit_cast(float4, rawn[2 * ks]), a0, a1, a2);
+                        split3x4(__builtin_bit_cast(float4, rawn[2 * ks + 1]), b0, b1, b2);
+                        xa[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                        xa[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+                        xa[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+                    }
+                }
+                {   // the next slice (of this block of pixels, of the next block, or of the wave's next tile) goes in flight
+                    int nt = tile, ns = sub, nk = kc + 1;
+                    if (nk == KC) {
+                        nk = 0;
+                        if (++ns == 4) {
+                            ns = 0;
+                            nt += nw;
+                        }
+                    }
+                    if (nt < p.tiles) issue(nt, ns, nk, rawn);
+                }
+#pragma unroll
+                for (int jp = 0; jp < NB; jp += 2) {       // two independent accumulator chains
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf16x8 wb[2][P];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int q = 0; q < P; ++q)
+                                wb[jj][q] = *reinterpret_cast<const bf16x8*>(wl + q * PLANE + (jp + jj) * 32 * KP + kc * 64 + ks * 16);
+                        if constexpr (HS) {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj)
+                                acc[jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[ks][0], wb[jj][0], acc[jp + jj], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 6; ++t) {      // smallest terms first, as in igemm_conv.hip
+                                const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
+                                const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+#pragma unroll
+                                for (int jj = 0; jj < 2; ++jj)
+                                    acc[jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[ks][qa], wb[jj][qb], acc[jp + jj], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (kc == KC - 1) {
+                        // ---- these two column blocks are complete: their statistics and stores go out under the MFMAs
+                        // of the next pair
+#pragma unroll
+                        for (int j = jp; j < jp + 2; ++j) {
+                            if constexpr (HS) {
+                                unsigned short* o = reinterpret_cast<unsigned short*>(p.Out) + (size_t)m0 * p.ldo + j * 32 + l31;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int dr = (r & 3) + 8 * (r >> 2);
+                                    if (full || m0 + dr < p.M) {
+                                        const bf16_t sv = f32_to_bf16(acc[j][r]);
+                                        o[(size_t)dr * p.ldo] = sv;
+                                        const float fv = bf16_to_f32(sv);         // statistics on the value as stored
+                                        s1[j] += fv;
+                                        s2[j] += fv * fv;
+                                    }
+                                }
+                            } else {
+                                float* o = reinterpret_cast<float*>(p.Out) + (size_t)m0 * p.ldo + j * 32 + l31;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int dr = (r & 3) + 8 * (r >> 2);
+                                    if (full || m0 + dr < p.M) {
+                                        const float v = acc[j][r];
+                                        o[(size_t)dr * p.ldo] = v;
+                                        s1[j] += v;
+                                        s2[j] += v * v;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float a = s1[j] + __shfl_xor(s1[j], 32, 64), b = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (h == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * N + j * 32 + l31) * 2) = make_float2(a, b);
+            }
+        }
+    }
+}
+
+static bool thin_enabled() {      // XV2_THIN=0: these layers stay on the tiled implicit-GEMM kernel (A/B runs)
+    static const bool on = [] { const char* e = getenv("XV2_THIN"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+template <int K, int N, bool HS, int WAVES>
+static int thin_launch_one(const ThinParams& q, const char* name, double flops, double abytes, hipStream_t stream) {
+    constexpr size_t smem = (size_t)(HS ? 1 : 3) * N * (K + 8) * 2;
+    auto kern = thin1x1_kernel<K, N, HS, WAVES>;
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    XV2_CHECK_HIP(attr_rc);
+    static const int kid = prof_register(name);
+    const int blocks = (int)cdiv(q.tiles, WAVES);
+    prof_begin(kid, flops, abytes, stream);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, stream, q);
+    prof_end(stream);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+// shapes with an instantiation: fp32 tensors need 3 planes in LDS (6 (K + 8) N bytes <= 160 KB), bf16 tensors one
+static bool thin_shape(int K, int N, int math) {
+    (void)math;     // one set for both modes (fp32 tensors: 6 (K + 8) N bytes of LDS <= 160 KB)
+    return (K == 64 && (N == 64 || N == 128 || N == 256)) || (K == 128 && N == 64) || (K == 256 && N == 64);
+}
+
+bool thin1x1_eligible(const IgemmParams& p, bool smallc) {
+    if (!thin_enabled() || smallc || (p.math != XV2_MATH_F32X3 && p.math != XV2_MATH_BF16_STORE)) return false;
+    if (p.ncls != 1 || p.T != 1 || p.s_in != 1 || p.C1 != 0 || p.A1 || p.Out1 || p.N0 != p.Nout) return false;
+    if (p.bias || p.ep_scale || p.bnb_y || p.pre_scale || p.ksplit != 1 || p.sk_tickets) return false;
+    const ClassInfo& c = p.cls[0];
+    if (c.ntaps != 1 || c.tap0 != 0 || p.taps[0].dh != 0 || p.taps[0].dw != 0 || p.taps[0].slot != 0) return false;
+    if (c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl || c.OHl != p.IH || c.OWl != p.IW) return false;
+    if (!thin_shape(p.Ctot, p.Nout, p.math) || c.M < 65536) return false;
+    const int es = p.math == XV2_MATH_BF16_STORE ? 2 : 4;
+    if ((reinterpret_cast<uintptr_t>(p.A0) | reinterpret_cast<uintptr_t>(p.B)) & 15) return false;
+    if ((p.ldA0 * es) % 16 != 0 || (long long)c.M * p.ldo0 * es >= (1ll << 31)) return false;
+    return true;
+}
+
+int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
+    ThinParams q;
+    q.A = p.A0; q.B = p.B; q.Out = p.Out0; q.stats = p.stats;
+    q.M = p.cls[0].M; q.ldA = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1;
+    q.tiles = (int)cdiv(q.M, 128);
+    q.bytesA = p.bytesA0;
+    const int K = p.Ctot, N = p.Nout;
+    const bool hs = p.math == XV2_MATH_BF16_STORE;
+    const double es = hs ? 2.0 : 4.0;
+    const double flops = 2.0 * q.M * (double)N * K, abytes = es * ((double)q.M * (K + N) + (double)K * N);
+#define XV2_THIN_CASE(KK, NN)                                                                                        \
+    if (K == KK && N == NN)                                                                                          \
+        return hs ? thin_launch_one<KK, NN, true, 2>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream) \
+                  : thin_launch_one<KK, NN, false, 4>(q, "thin1x1_kernel<" #KK "," #NN ",f32x3>", flops, abytes, stream);
+    XV2_THIN_CASE(64, 64)
+    XV2_THIN_CASE(64, 128)
+    XV2_THIN_CASE(64, 256)
+    XV2_THIN_CASE(128, 64)
+    XV2_THIN_CASE(256, 64)
+#undef XV2_THIN_CASE
+    set_error("thin1x1: no instantiation for K=%d N=%d", K, N);
+    return XV2_EINVAL;
+}
+
+}  // namespace xv2
