@@ -707,24 +707,27 @@ def test_bf16_storage_stem_residual_convt_pool_head():
     old = ops.STORAGE
     ops.set_storage_dtype(torch.bfloat16)
     try:
-        # RGB stem: fp32 image in, bf16 activations out
-        x = torch.randn(2, 3, 40, 36)
-        w = torch.randn(64, 3, 7, 7) * 0.1
-        wr = w.clone().requires_grad_(True)
-        bnr = torch.nn.BatchNorm2d(64)
-        pre = bnr(F.conv2d(x, wr, None, 2, 3))
-        dz = r16(torch.randn_like(pre))
-        bng = torch.nn.BatchNorm2d(64).to(dev())
-        a = ops.nchw_to_nhwc(x.to(dev()), 4)
-        wg = w.to(dev()).requires_grad_(True)
-        z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, None, ops.conv_cfg(7, 7, 2, 3), ops.BnState(bng),
-                                  ops.ACT_RELU, True)
-        assert z.dtype == torch.bfloat16
-        z.backward(hnhwc(dz))
-        zh = nchw(z.float())
-        bf16_close(zh, F.relu(pre), 2e-2, "stem z")
-        (pre * (zh > 0).float()).backward(dz)
-        bf16_close(wg.grad, wr.grad, 3e-2, "stem dw")
+        # RGB stems: fp32 image in, bf16 activations out - the torchvision 7x7 / stride 2 stem (a band convolution,
+        # ops.STEM_BAND) and the first 3x3 / stride 2 convolution of the ResNeSt deep stem (32 or 64 outputs; gather kernel -
+        # as a band convolution it measured 0.194 -> 0.099 ms alone and nothing on the cfg3 step: frame copy + weight pack)
+        for co, k, pad in ((64, 7, 3), (32, 3, 1), (64, 3, 1)):
+            x = torch.randn(2, 3, 40, 36)
+            w = torch.randn(co, 3, k, k) * (0.1 if k == 7 else 0.3)
+            wr = w.clone().requires_grad_(True)
+            bnr = torch.nn.BatchNorm2d(co)
+            pre = bnr(F.conv2d(x, wr, None, 2, pad))
+            dz = r16(torch.randn_like(pre))
+            bng = torch.nn.BatchNorm2d(co).to(dev())
+            a = ops.nchw_to_nhwc(x.to(dev()), 4)
+            wg = w.to(dev()).requires_grad_(True)
+            z = ops.ConvBnActFn.apply(a, None, wg, bng.weight, bng.bias, None, ops.conv_cfg(k, k, 2, pad), ops.BnState(bng),
+                                      ops.ACT_RELU, True)
+            assert z.dtype == torch.bfloat16
+            z.backward(hnhwc(dz))
+            zh = nchw(z.float())
+            bf16_close(zh, F.relu(pre), 2e-2, "stem z %d" % k)
+            (pre * (zh > 0).float()).backward(dz)
+            bf16_close(wg.grad, wr.grad, 3e-2, "stem dw %d" % k)
     finally:
         ops.set_storage_dtype(old)
     # residual + ReLU tail with the byte mask, bf16 residual gradient
