@@ -1262,6 +1262,93 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         if (c < Nout) {
             float4 bv = make_float4(0, 0, 0, 0);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + c);
+            float4 sc = make_float4(1, 1, 1, 1), sf = make_float4(0, 0, 0, 0);      // inference epilogue coefficients: once per thread
+            if (ep_scale) {
+                sc = *reinterpret_cast<const float4*>(ep_scale + c);
+                sf = *reinterpret_cast<const float4*>(ep_shift + c);
+            }
+            // the row's tail: statistics, bias / inference epilogue, (accumulating) store of the summed row `a`
+            auto finish_row = [&](int r, float4 a, bool have_old, float4 old_v) {
+                {      // statistics on the values as they will be stored
+                    const float4 q = make_float4(Elem<OT>::round(a.x), Elem<OT>::round(a.y), Elem<OT>::round(a.z), Elem<OT>::round(a.w));
+                    s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+                    s2.x += q.x * q.x; s2.y += q.y * q.y; s2.z += q.z * q.z; s2.w += q.w * q.w;
+                }
+                a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+                if (ep_scale) {
+                    a.x = __fmaf_rn(a.x, sc.x, sf.x); a.y = __fmaf_rn(a.y, sc.y, sf.y);
+                    a.z = __fmaf_rn(a.z, sc.z, sf.z); a.w = __fmaf_rn(a.w, sc.w, sf.w);
+                    if (ep_res) {
+                        const float4 rr = ld4(ep_res + (size_t)r * ep_ldres + c);
+                        a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
+                    }
+                    a.x = apply_act(a.x, ep_act); a.y = apply_act(a.y, ep_act);
+                    a.z = apply_act(a.z, ep_act); a.w = apply_act(a.w, ep_act);
+                }
+                OT* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
+                if (accum & (c < N0 ? 1 : 2)) {
+                    const float4 old = have_old ? old_v : ld4(o);
+                    a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
+                }
+                st4(o, a);
+            };
+            // ksplit <= 8: ALL eight rows of this thread (5 - 8 slabs: four at a time) and all their slabs in flight at once (up to 32 loads of 16 bytes,
+            // slab count as a compile-time constant: no branch between the loads), then the sums in the fixed slab order -
+            // one memory round trip per block instead of one per pair of rows.  These grids are a block or two per CU,
+            // i.e. latency-bound (ISA of the rolled loop: every pair of rows ended in s_waitcnt vmcnt(0))
+            auto all_rows = [&](auto ksc) {
+                constexpr int KS = decltype(ksc)::value;
+                constexpr int NR = KS <= 4 ? SPLITK_ROWS / 4 : SPLITK_ROWS / 8;      // 5 - 8 slabs: two batches of four rows
+                const bool acc = (accum & (c < N0 ? 1 : 2)) != 0;
+#pragma unroll 1
+              for (int rb = r0 + ty; rb < r0 + SPLITK_ROWS; rb += 4 * NR) {
+                float4 t[NR][KS], olds[NR];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int rr = min(rb + 4 * i, M - 1);
+#pragma unroll
+                    for (int z = 0; z < KS; ++z) t[i][z] = *reinterpret_cast<const float4*>(part + z * slab + (size_t)rr * Nout + c);
+                }
+                if (acc) {        // what an accumulating store adds to: in flight with the slabs
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        const int rr = min(rb + 4 * i, M - 1);
+                        olds[i] = ld4(c < N0 ? out0 + (size_t)rr * ldo0 + c : out1 + (size_t)rr * ldo1 + (c - N0));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) olds[i] = make_float4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int r = rb + 4 * i;
+                    if (r < M) {
+                        float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+                        for (int z = 0; z < KS; ++z) {
+                            a.x += t[i][z].x; a.y += t[i][z].y; a.z += t[i][z].z; a.w += t[i][z].w;
+                        }
+                        finish_row(r, a, true, olds[i]);
+                    }
+                }
+              }
+            };
+            const bool rolled = (accum & 0x100) != 0;      // XV2_SK_ALLROWS=0 (A/B runs): the rolled loop
+            if (ksplit == 2 && !rolled) {
+                all_rows(std::integral_constant<int, 2>{});
+            } else if (ksplit == 3 && !rolled) {
+                all_rows(std::integral_constant<int, 3>{});
+            } else if (ksplit == 4 && !rolled) {
+                all_rows(std::integral_constant<int, 4>{});
+            } else if (ksplit == 5 && !rolled) {
+                all_rows(std::integral_constant<int, 5>{});
+            } else if (ksplit == 6 && !rolled) {
+                all_rows(std::integral_constant<int, 6>{});
+            } else if (ksplit == 7 && !rolled) {
+                all_rows(std::integral_constant<int, 7>{});
+            } else if (ksplit == 8 && !rolled) {
+                all_rows(std::integral_constant<int, 8>{});
+            } else {
 #pragma unroll 2
             for (int r = r0 + ty; r < min(r0 + SPLITK_ROWS, M); r += 4) {
                 // all slabs of the row in flight at once (ksplit <= 8), then the fixed-order sum
@@ -1280,30 +1367,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                     const float4 v = *reinterpret_cast<const float4*>(part + z * slab + (size_t)r * Nout + c);
                     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                 }
-                {      // statistics on the values as they will be stored
-                    const float4 q = make_float4(Elem<OT>::round(a.x), Elem<OT>::round(a.y), Elem<OT>::round(a.z), Elem<OT>::round(a.w));
-                    s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
-                    s2.x += q.x * q.x; s2.y += q.y * q.y; s2.z += q.z * q.z; s2.w += q.w * q.w;
-                }
-                a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
-                if (ep_scale) {
-                    const float4 sc = *reinterpret_cast<const float4*>(ep_scale + c);
-                    const float4 sf = *reinterpret_cast<const float4*>(ep_shift + c);
-                    a.x = __fmaf_rn(a.x, sc.x, sf.x); a.y = __fmaf_rn(a.y, sc.y, sf.y);
-                    a.z = __fmaf_rn(a.z, sc.z, sf.z); a.w = __fmaf_rn(a.w, sc.w, sf.w);
-                    if (ep_res) {
-                        const float4 rr = ld4(ep_res + (size_t)r * ep_ldres + c);
-                        a.x += rr.x; a.y += rr.y; a.z += rr.z; a.w += rr.w;
-                    }
-                    a.x = apply_act(a.x, ep_act); a.y = apply_act(a.y, ep_act);
-                    a.z = apply_act(a.z, ep_act); a.w = apply_act(a.w, ep_act);
-                }
-                OT* o = c < N0 ? out0 + (size_t)r * ldo0 + c : out1 + (size_t)r * ldo1 + (c - N0);
-                if (accum & (c < N0 ? 1 : 2)) {
-                    const float4 old = ld4(o);
-                    a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
-                }
-                st4(o, a);
+                finish_row(r, a, false, make_float4(0, 0, 0, 0));
+            }
             }
         }
         if (stats) {
@@ -1739,13 +1804,14 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (rc) return rc;
         const int M = p.cls[0].M;
         const dim3 rgrid((unsigned)cdiv(M, SPLITK_ROWS), (unsigned)cdiv(p.Nout, 256));
+        static const int rolled = [] { const char* e = getenv("XV2_SK_ALLROWS"); return (e && atoi(e) == 0) ? 0x100 : 0; }();
         if (p.math == XV2_MATH_BF16_STORE)
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
-                               p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum,
+                               p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum | rolled,
                                p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
-                               p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum, p.ep_scale, p.ep_shift,
+                               p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum | rolled, p.ep_scale, p.ep_shift,
                                p.ep_res, p.ep_ldres, p.ep_act, fold);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
