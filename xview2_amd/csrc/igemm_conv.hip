@@ -1596,6 +1596,20 @@ __device__ __forceinline__ void presplit_block(const float* __restrict__ src, __
     const int half = (k0 >> 3) ^ ((r >> 2) & 1);
     const float* sp = src + (size_t)(unit * 64 + r) * T * ctot + cs * 16 + k0;
     __bf16* dp = dst + ((size_t)unit * T * nsl + cs) * 3072 + r * 16 + half * 8 + (k0 & 7);
+    if (T == 9) {        // (the only supported tap count) all nine taps in flight: one memory round trip per block, not three
+        float4 v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)u * ctot);
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            uint2 pk[3];
+            split3x4(v[u], pk[0], pk[1], pk[2]);
+            __bf16* d = dp + (size_t)u * nsl * 3072;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * 1024) = pk[q];
+        }
+        return;
+    }
     for (int t0 = 0; t0 < T; t0 += 3) {        // three taps in flight
         float4 v[3];
 #pragma unroll
