@@ -36,6 +36,9 @@ def pretty(mangled):
         if "ILb1ELb1E" in mangled:
             return "direct3x3_n32_kernel<bf16hbm>"
         return "direct3x3_n32_kernel<bf16>" if "ILb1E" in mangled else "direct3x3_n32_kernel"
+    m = re.match(r"_ZN3xv2\d+thin1x1_kernelILi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    if m:
+        return "thin1x1_kernel<%s,%s,%s>" % (m.group(1), m.group(2), "bf16hbm" if m.group(3) == "1" else "f32x3")
     m = re.match(r"_ZN3xv2\d+wgrad_tr_kernelILi(\d+)ELi(\d+)E", mangled)
     if m:
         return "wgrad_tr_kernel<%s,%s,bf16hbm>" % (m.group(1), m.group(2))
