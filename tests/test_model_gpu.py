@@ -571,7 +571,10 @@ def test_fused_inference_path_is_bit_identical_to_the_unfused_eval_forward(name)
                                          ("post_siameseEnc_resnet50", 4, 64),
                                          # 160 x 160, B = 2: the /32 level has M = 4 * 25 = 100 rows, 50 per pass - no
                                          # statistics tile (64 / 128 rows) ends on the pass boundary
-                                         ("post_siameseEnc_resnet50", 2, 160), ("post_siamese_coral", 1, 160)])
+                                         ("post_siameseEnc_resnet50", 2, 160), ("post_siamese_coral", 1, 160),
+                                         # 512 x 512, B = 2: the /4 level has 4 * 128 * 128 = 65 536 rows - the streaming 1x1
+                                         # kernel (thin_conv.hip) with its 128-row statistics tiles split over the two passes
+                                         ("post_siameseEnc_resnet50", 2, 512)])
 def test_batched_siamese_passes_equal_two_sequential_passes(name, B, size):
     """SiameseUNet runs its shared-weight U-Net on the pre and the post image (model/unet.py:232-233).  The default
     here sends both through as ONE batch of 2B with per-part BatchNorm statistics (ops.BN_SPLIT); it must reproduce
