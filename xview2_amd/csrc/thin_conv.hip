@@ -32,21 +32,27 @@ struct ThinParams {
     unsigned bytesA;
 };
 
-template <int K, int N, bool HS, int WAVES>
+// SUBS = 32-pixel row blocks per wave: 4 = a wave owns a whole 128-pixel tile (no barrier at all); 2 = the block's WAVES = 2
+// waves share one tile (bf16 tensors: the single weight plane leaves room for four such blocks per CU, i.e. twice the waves
+// and loads in flight per CU), their statistics meet in LDS behind one barrier per tile
+template <int K, int N, bool HS, int WAVES, int SUBS>
 __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const ThinParams p) {
     constexpr int P = HS ? 1 : 3;              // bf16 planes of the weights
     constexpr int KP = K + 8;                  // LDS row pitch in bf16: (K + 8) / 2 dwords = 4 mod 32 -> conflict-free b128 reads
-    constexpr int NB = N / 32, KC = K / 64;
+    constexpr int NB = N / 32, KC = K / 64, KCU = KC > 2 ? 1 : KC;
     constexpr int PLANE = N * KP;
     constexpr int ES = HS ? 2 : 4;             // bytes per tensor element
     constexpr int NRAW = HS ? 4 : 8;           // 16-byte loads per lane and 64-channel slice
+    constexpr int WPT = 4 / SUBS;              // waves per 128-pixel tile
     static_assert(K % 64 == 0 && N % 64 == 0, "64-channel slices, pairs of 32-column blocks");
-    extern __shared__ __attribute__((aligned(16))) __bf16 sw[];      // [P][N][KP]
+    static_assert(SUBS == 4 || (SUBS == 2 && WAVES == WPT), "a tile is one wave's, or exactly the block's");
+    extern __shared__ __attribute__((aligned(16))) __bf16 sw[];      // [P][N][KP], then (WPT > 1) [WPT][N][2] floats
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int nw = gridDim.x * WAVES;
-    int tile = blockIdx.x * WAVES + wave;
+    const int nw = gridDim.x * WAVES / WPT;              // tiles in flight chip-wide
+    int tile = (blockIdx.x * WAVES + wave) / WPT;
+    const int sub0 = (wave % WPT) * SUBS;                // this wave's first row block inside the tile
 
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
     // lane (l31, h) of a 32-pixel block owns pixel l31 and channels 16 * ks + 8 * h .. + 7 of every K step ks
@@ -64,7 +70,7 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
         }
     };
     i32x4 rawn[NRAW];
-    if (tile < p.tiles) issue(tile, 0, 0, rawn);            // in flight under the weight staging
+    if (tile < p.tiles) issue(tile, sub0, 0, rawn);         // in flight under the weight staging
 
     // ---- weights -> LDS (fp32: exact 3-way bf16 split, once per block)
     // (all loads of a thread in flight before the first is used: one memory round trip, not one per 16 bytes)
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
 #pragma unroll
         for (int j = 0; j < NB; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll 1
-        for (int sub = 0; sub < 4; ++sub) {
+        for (int sub = sub0; sub < sub0 + SUBS; ++sub) {
             // (acc[j][r]: pixel (r & 3) + 8 * (r >> 2) + 4 * h of the block, column 32 j + l31)
             const int m0 = tile * 128 + sub * 32 + 4 * h;
             const bool full = tile * 128 + sub * 32 + 32 <= p.M;
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
             }
-#pragma unroll(KC > 2 ? 1 : KC)      // K = 256: rolled (unrolled, the weight fragments of all four slices stay live: 512 registers)
+#pragma unroll KCU      // K = 256: rolled (unrolled, the weight fragments of all four slices stay live: 512 registers)
             for (int kc = 0; kc < KC; ++kc) {
                 // A operand of this slice: xa[ks][plane]
                 bf16x8 xa[4][P];
@@ -167,8 +173,8 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
                     int nt = tile, ns = sub, nk = kc + 1;
                     if (nk == KC) {
                         nk = 0;
-                        if (++ns == 4) {
-                            ns = 0;
+                        if (++ns == sub0 + SUBS) {
+                            ns = sub0;
                             nt += nw;
                         }
                     }
@@ -236,10 +242,31 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
             }
         }
         if (p.stats) {
+            if constexpr (WPT == 1) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const float a = s1[j] + __shfl_xor(s1[j], 32, 64), b = s2[j] + __shfl_xor(s2[j], 32, 64);
-                if (h == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * N + j * 32 + l31) * 2) = make_float2(a, b);
+                for (int j = 0; j < NB; ++j) {
+                    const float a = s1[j] + __shfl_xor(s1[j], 32, 64), b = s2[j] + __shfl_xor(s2[j], 32, 64);
+                    if (h == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)tile * N + j * 32 + l31) * 2) = make_float2(a, b);
+                }
+            } else {
+                // the tile's waves meet in LDS (wave order = row order: a fixed sum)
+                float2* red = reinterpret_cast<float2*>(sw + P * PLANE);        // [WPT][N]
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float a = s1[j] + __shfl_xor(s1[j], 32, 64), b = s2[j] + __shfl_xor(s2[j], 32, 64);
+                    if (h == 0) red[(wave % WPT) * N + j * 32 + l31] = make_float2(a, b);
+                }
+                __syncthreads();
+                for (int c = tid; c < N; c += WAVES * 64) {
+                    float2 a = red[c];
+#pragma unroll
+                    for (int w = 1; w < WPT; ++w) {
+                        a.x += red[w * N + c].x;
+                        a.y += red[w * N + c].y;
+                    }
+                    *reinterpret_cast<float2*>(p.stats + ((size_t)tile * N + c) * 2) = a;
+                }
+                __syncthreads();
             }
         }
     }
@@ -250,15 +277,16 @@ static bool thin_enabled() {      // XV2_THIN=0: these layers stay on the tiled 
     return on;
 }
 
-template <int K, int N, bool HS, int WAVES>
+template <int K, int N, bool HS, int WAVES, int SUBS>
 static int thin_launch_one(const ThinParams& q, const char* name, double flops, double abytes, hipStream_t stream) {
-    constexpr size_t smem = (size_t)(HS ? 1 : 3) * N * (K + 8) * 2;
-    auto kern = thin1x1_kernel<K, N, HS, WAVES>;
+    constexpr int WPT = 4 / SUBS;
+    constexpr size_t smem = (size_t)(HS ? 1 : 3) * N * (K + 8) * 2 + (WPT > 1 ? (size_t)WPT * N * 8 : 0);
+    auto kern = thin1x1_kernel<K, N, HS, WAVES, SUBS>;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     XV2_CHECK_HIP(attr_rc);
     static const int kid = prof_register(name);
-    const int blocks = (int)cdiv(q.tiles, WAVES);
+    const int blocks = (int)cdiv((int64_t)q.tiles * WPT, WAVES);
     prof_begin(kid, flops, abytes, stream);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, stream, q);
     prof_end(stream);
@@ -296,10 +324,13 @@ int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
     const bool hs = p.math == XV2_MATH_BF16_STORE;
     const double es = hs ? 2.0 : 4.0;
     const double flops = 2.0 * q.M * (double)N * K, abytes = es * ((double)q.M * (K + N) + (double)K * N);
+    // bf16 tensors: two waves per tile (XV2_THIN_SUBS=4: one wave per tile, A/B runs)
+    static const bool wide = [] { const char* e = getenv("XV2_THIN_SUBS"); return !(e && atoi(e) == 4); }();
 #define XV2_THIN_CASE(KK, NN)                                                                                        \
     if (K == KK && N == NN)                                                                                          \
-        return hs ? thin_launch_one<KK, NN, true, 2>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream) \
-                  : thin_launch_one<KK, NN, false, 4>(q, "thin1x1_kernel<" #KK "," #NN ",f32x3>", flops, abytes, stream);
+        return hs ? (wide ? thin_launch_one<KK, NN, true, 2, 2>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream)  \
+                          : thin_launch_one<KK, NN, true, 2, 4>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream)) \
+                  : thin_launch_one<KK, NN, false, 4, 4>(q, "thin1x1_kernel<" #KK "," #NN ",f32x3>", flops, abytes, stream);
     XV2_THIN_CASE(64, 64)
     XV2_THIN_CASE(64, 128)
     XV2_THIN_CASE(64, 256)
