@@ -418,28 +418,42 @@ __global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict
     s = wave_sum(s);
     if (lane == 0) y[wid] = s + (b ? b[o] : 0.f);
 }
-// dx[n][c] = sum_o dy[n][o] * w[o][c]: block = 64 columns x 4 output lanes, each lane with 4 independent chains
-// (the one-thread-per-element form was a 1024-deep dependent load chain: 110 us for a 1 MFLOP product)
+// dx[n][c] = sum_o dy[n][o] * w[o][c]: block = 16 columns x 16 output lanes, each lane with 8 independent chains
+// (the one-thread-per-element form was a 1024-deep dependent load chain: 110 us for a 1 MFLOP product; 64 columns x 4 lanes
+// x 4 chains still walked Cout / 16 = 32 .. 128 dependent rounds on a grid of 4 - 8 blocks: 10.5 us per launch, 32 launches per
+// resnest50 step, 264 per resnest200 step.  Now Cout / 128 rounds on 4x the blocks)
+constexpr int LB_COLS = 16, LB_LANES = 16;
 __global__ void __launch_bounds__(256) linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                                              float* __restrict__ dx, int N, int Cin, int Cout) {
     __shared__ float sh[256];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx, n = blockIdx.y;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int tx = threadIdx.x % LB_COLS, ty = threadIdx.x / LB_COLS;
+    const int c = blockIdx.x * LB_COLS + tx, n = blockIdx.y;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
     if (c < Cin) {
         const float* g = dy + (size_t)n * Cout;
         int o = ty;
-        for (; o + 12 < Cout; o += 16) {
-            s0 += g[o] * w[(size_t)o * Cin + c];
-            s1 += g[o + 4] * w[(size_t)(o + 4) * Cin + c];
-            s2 += g[o + 8] * w[(size_t)(o + 8) * Cin + c];
-            s3 += g[o + 12] * w[(size_t)(o + 12) * Cin + c];
+        for (; o + 7 * LB_LANES < Cout; o += 8 * LB_LANES) {
+            float gv[8], wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                gv[k] = g[o + k * LB_LANES];
+                wv[k] = w[(size_t)(o + k * LB_LANES) * Cin + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += gv[k] * wv[k];
         }
-        for (; o < Cout; o += 4) s0 += g[o] * w[(size_t)o * Cin + c];
+        for (; o < Cout; o += LB_LANES) s[0] += g[o] * w[(size_t)o * Cin + c];
     }
-    sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    sh[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (ty == 0 && c < Cin) dx[(size_t)n * Cin + c] = (sh[tx] + sh[64 + tx]) + (sh[128 + tx] + sh[192 + tx]);
+    if (ty == 0 && c < Cin) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < LB_LANES; ++q) a += sh[q * LB_COLS + tx];      // fixed order
+        dx[(size_t)n * Cin + c] = a;
+    }
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                      float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout) {
@@ -1012,7 +1026,7 @@ extern "C" int xv2_linear_backward(const float* x, const float* w, const float* 
                                    int N, int Cin, int Cout, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(Cin, 64), N), dim3(256), 0, st, w, dy, dx, N, Cin,
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(Cin, LB_COLS), N), dim3(256), 0, st, w, dy, dx, N, Cin,
                            Cout);
         XV2_CHECK_LAUNCH();
     }
