@@ -134,6 +134,31 @@ int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int ldx0, cons
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                           float* shift, void* stream);
+/* xv2_conv2d_forward_bn that also APPLIES the BatchNorm it has just derived - z = act(y * scale + shift [+ residual]),
+ * optionally the byte mask of z > 0 - inside the same launch (model/layers.py:89-100 conv -> norm -> activation as ONE
+ * launch in training mode; the bottleneck convolutions of the encoders, model/unet.py:45-52).  Every block keeps its output
+ * tile in registers, waits at a gate (device-scope flag per column tile) until the last blocks to arrive have folded the
+ * statistics and written the coefficients, and then normalises the tile from the registers - y rounded to the storage type
+ * first, so z equals xv2_bn_act_forward[_mask] on the stored y bit for bit.  Blocks that wait hold their CU slots: the form
+ * is taken only when the whole grid is resident at once (the kernel's occupancy x 256 CUs; split-K plans gate their slab-sum
+ * launch instead) - otherwise the call behaves exactly like xv2_conv2d_forward_bn.  *applied (HOST int) tells which: 1 = z
+ * (and zmask) were written, 0 = the caller still has to run xv2_bn_act_forward[_mask].  Single-process training-mode
+ * BatchNorm only (mean .. shift required).  OPT-IN (XV2_COOP=1 or xv2_set_coop_blocks(n > 0)): exact, and measured SLOWER
+ * than the two launches on MI355X - cfg2 fp32 26.66 -> 27.07 ms, cfg3 18.3 -> 20.3 ms per step: the hand-off is ~10 dependent
+ * device-scope round trips that every block of the grid sits through (profiles/r04_gated_ab.md).  xv2_set_coop_blocks(n) /
+ * XV2_COOP_BLOCKS cap the gated grid (processes SHARING one GPU must keep their combined gated grids within the chip: two
+ * partly resident gated launches would wait for each other; a block that waits longer than 4 s traps). */
+int xv2_conv2d_forward_bn_act(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                              const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
+                              int parts, int part_stride, double* sums, double* scratch, double count,
+                              const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                              float* shift, const void* residual, int ldr, int act, void* z, int ldz,
+                              uint8_t* zmask, int* applied, void* stream);
+/* cap on the grid of gated launches (blocks); n > 0 also switches them on; 0: off; < 0: back to XV2_COOP / XV2_COOP_BLOCKS */
+int xv2_set_coop_blocks(int blocks);
+/* number of gated launches this process has issued (tests assert which form ran) */
+int64_t xv2_coop_count(void);
 /* BatchNorm + activation of the PRODUCING layer applied in this convolution's operand load (model/layers.py:96-100: the
  * BatchNorm + activation between the two convolutions of a bottleneck / decoder block): `y0` is the
  * RAW output of the producing convolution, z0 = act(y0 * pre_scale[c] + pre_shift[c]) (training-mode coefficients, as

@@ -1,0 +1,207 @@
+"""Gated launches (include/xv2.h: xv2_conv2d_forward_bn_act): the BatchNorm a convolution launch derives is applied by that
+same launch.  The gated form must equal the two-launch form (xv2_conv2d_forward_bn + xv2_bn_act_forward[_mask]) bit for bit -
+outputs, byte masks, coefficients, running statistics - and the tests assert WHICH form ran (xv2_coop_count)."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _lib():
+    from xview2_amd import _lib
+    return _lib.lib()
+
+
+class gated:
+    """with gated(False): the two-launch forms; with gated(True): the gated forms, opt-in (measured slower, include/xv2.h),
+    capped at the share of the chip this process may hold (tests/gpu_lock.py) - the whole chip for `gpu_exclusive` tests"""
+    full = False
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        import os
+        from xview2_amd import ops
+        self.old = ops.COOP_APPLY
+        ops.COOP_APPLY = self.on
+        cap = (1 << 30) if (gated.full or not os.environ.get("PYTEST_XDIST_WORKER")) else int(os.environ.get("XV2_COOP_BLOCKS", "40"))
+        _lib().xv2_set_coop_blocks(cap if self.on else 0)
+        self.n0 = _lib().xv2_coop_count()
+        return self
+
+    def count(self):
+        return _lib().xv2_coop_count() - self.n0
+
+    def __exit__(self, *exc):
+        from xview2_amd import ops
+        torch.cuda.synchronize()
+        ops.COOP_APPLY = self.old
+        _lib().xv2_set_coop_blocks(-1)
+
+
+# N, H, W, C0, C1, Cout, k, stride, pad, groups, residual, act
+SMALL = [
+    (2, 16, 16, 64, 0, 64, 3, 1, 1, 1, False, "relu"),        # 4 x 1 tiles
+    (2, 16, 16, 256, 0, 1024, 1, 1, 0, 1, True, "relu"),      # residual + byte mask, 8 column tiles
+    (2, 12, 20, 64, 32, 128, 3, 1, 1, 1, False, "leaky"),     # virtual concat, ragged last tile (480 rows)
+    (1, 9, 7, 128, 0, 128, 3, 2, 1, 1, False, "relu"),        # stride 2, 20 rows
+    (2, 8, 8, 512, 0, 512, 3, 1, 1, 1, True, "relu"),         # deep K, 128 rows: split-K plan -> the slab-sum launch is gated
+    (2, 16, 16, 512, 0, 256, 1, 1, 0, 1, False, "none"),
+    (2, 16, 32, 64, 0, 128, 3, 1, 1, 2, False, "relu"),       # grouped (split attention's radix-2 convolution)
+    (4, 8, 32, 64, 0, 64, 3, 1, 1, 1, False, "relu"),         # halo plan (W % 32 == 0, H % 4 == 0)
+]
+BIG = [
+    (2, 64, 64, 256, 0, 256, 3, 1, 1, 1, False, "relu"),      # l3.conv2 of cfg2: 64 x 2 tiles
+    (2, 64, 64, 1024, 0, 256, 1, 1, 0, 1, False, "relu"),     # l3.conv1: split-K, 256 slab-sum blocks
+    (2, 64, 64, 256, 0, 1024, 1, 1, 0, 1, True, "relu"),      # l3.conv3: 64 x 8 = 512 tiles
+    (2, 128, 128, 128, 0, 128, 3, 1, 1, 1, False, "relu"),    # l2.conv2: 256 tiles, halo plan
+    (2, 32, 32, 512, 0, 1024, 3, 1, 1, 2, False, "relu"),     # resnest l4 radix convolution, grouped
+]
+
+
+def _run_raw(case, dtype, split=1, g=None):
+    from xview2_amd import nn as xnn, ops
+    N, H, W, C0, C1, Cout, k, s, p, G, has_res, act = case
+    torch.manual_seed(sum(case[:10]))
+    conv = nn.Conv2d(C0 + C1, Cout, k, s, p, groups=G, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(Cout).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn(N, H, W, C0, device=DEV).to(dtype)
+    x1 = torch.randn(N, H, W, C1, device=DEV).to(dtype) if C1 else None
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = torch.randn(N, OH, OW, Cout, device=DEV).to(dtype) if has_res else None
+    old = ops.STORAGE
+    ops.set_storage_dtype(dtype)
+    try:
+        with xnn.bn_split(split):
+            bn.train()
+            x0.requires_grad_(True)
+            z = xnn.conv_bn_act(conv, bn, x0, x1, act=ops.ACTS[act], residual=res)
+            node = z.grad_fn
+            saved = [t.clone() if t is not None else None for t in node.saved_tensors]
+            n = g.count() if g is not None else 0
+    finally:
+        ops.set_storage_dtype(old)
+    return z.detach().clone(), saved, bn.running_mean.clone(), bn.running_var.clone(), n
+
+
+def _run(case, dtype, on, split=1):
+    with gated(on) as g:
+        return _run_raw(case, dtype, split, g)
+
+
+def _same(a, b, what):
+    assert (a is None) == (b is None), what
+    if a is not None:
+        assert a.dtype == b.dtype and a.shape == b.shape, (what, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), "%s differs (max |d| = %g)" % (what, (a.double() - b.double()).abs().max().item())
+
+
+def _check(case, dtype, split=1, expect_gated=True):
+    z0, s0, rm0, rv0, n0 = _run(case, dtype, False, split)
+    z1, s1, rm1, rv1, n1 = _run(case, dtype, True, split)
+    assert n0 == 0
+    if expect_gated:
+        assert n1 >= 1, "the gated form did not run"
+    _same(z0, z1, "z")
+    assert len(s0) == len(s1)
+    for i, (a, b) in enumerate(zip(s0, s1)):       # x0, x1, weight, gamma, y, z / mask, mean, invstd, scale, shift
+        _same(a, b, "saved[%d]" % i)
+    _same(rm0, rm1, "running_mean")
+    _same(rv0, rv1, "running_var")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", SMALL)
+def test_gated_bn_apply_equals_two_launch_form(case, dtype):
+    _check(case, dtype)
+
+
+@pytest.mark.parametrize("case", [SMALL[0], SMALL[1], SMALL[4]])
+def test_gated_bn_apply_split_batch(case):
+    """two independent BatchNorm batches back to back (the Siamese pre / post passes): per-part coefficients"""
+    case = (4,) + case[1:]
+    _check(case, torch.float32, split=2)
+    _check(case, torch.bfloat16, split=2)
+
+
+@pytest.mark.gpu_exclusive
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", BIG)
+def test_gated_bn_apply_full_size_layers(case, dtype):
+    """grids of 128 .. 512 blocks: the test is alone on the GPU (tests/gpu_lock.py); whether a plan is gated depends on its
+    tiling against the kernel's occupancy, so only equality is asserted"""
+    gated.full = True
+    try:
+        _check(case, dtype, expect_gated=False)
+    finally:
+        gated.full = False
+
+
+def test_gated_grid_above_the_cap_takes_the_two_launch_form():
+    """a grid that is not resident at once must NOT be gated: cap 4 blocks, 8 x 8 tiles"""
+    from xview2_amd import ops
+    case = (2, 32, 16, 256, 0, 1024, 1, 1, 0, 1, False, "relu")
+    z0 = _run(case, torch.float32, False)[0]
+    old = ops.COOP_APPLY
+    ops.COOP_APPLY = True
+    _lib().xv2_set_coop_blocks(4)
+    try:
+        n0 = _lib().xv2_coop_count()
+        z1 = _run_raw(case, torch.float32)[0]
+        assert _lib().xv2_coop_count() == n0
+    finally:
+        ops.COOP_APPLY = old
+        _lib().xv2_set_coop_blocks(-1)
+    _same(z0, z1, "z")
+
+
+@pytest.mark.parametrize("enc", ["resnet50", "resnest50"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_training_step_is_bit_identical_with_and_without_gated_launches(enc, dtype):
+    from types import SimpleNamespace
+    from xview2_amd import criterion, networks, ops
+    from xview2_amd.weights import deterministic_init_
+    a = SimpleNamespace(encoder=enc, dilation=1, ppm=False, aspp=False, no_skip=False, interpolate=False,
+                        attention=False, dec_interp=False, deep_supervision=False, loss_str="dice+focal",
+                        dmg_model="siamese", type="pre")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    y = (torch.rand(2, 64, 64, generator=g) > 0.7).to(torch.uint8).to(DEV)
+    out = []
+    old = ops.STORAGE
+    ops.set_storage_dtype(dtype)
+    try:
+        for on in (False, True):
+            torch.manual_seed(0)
+            m = networks.UNetLoc(a)
+            deterministic_init_(m, 1)
+            m.to(DEV).train()
+            with gated(on) as gt:
+                logits = m(x)
+                loss = criterion.Loss(a)(logits, y)
+                loss.backward()
+                n = gt.count()
+            ops.join_wgrad_stream()
+            torch.cuda.synchronize()
+            out.append((loss.detach().clone(), logits.detach().clone(),
+                        {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                        {k: b.clone() for k, b in m.named_buffers()}, n))
+    finally:
+        ops.set_storage_dtype(old)
+    (l0, p0, g0, b0, n0), (l1, p1, g1, b1, n1) = out
+    assert n0 == 0 and n1 > 20, (n0, n1)
+    _same(l0, l1, "loss")
+    _same(p0, p1, "logits")
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        _same(g0[k], g1[k], "grad " + k)
+    for k in b0:
+        _same(b0[k], b1[k], "buffer " + k)

@@ -27,8 +27,8 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "xv2_common.h"), os.path.join(CSRC, "igemm_params.h"),
-                                                      os.path.join(_HERE, "..", "include", "xv2.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
+        os.path.join(_HERE, "..", "include", "xv2.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -80,6 +80,7 @@ def lib():
             getattr(_lib, name).restype = ctypes.c_size_t
         _lib.xv2_conv2d_forward_stats_tiles.restype = ctypes.c_int64
         _lib.xv2_conv2d_forward_stats_tile_rows.restype = ctypes.c_int64
+        _lib.xv2_coop_count.restype = ctypes.c_int64
     return _lib
 
 

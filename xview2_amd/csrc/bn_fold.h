@@ -43,8 +43,9 @@ __device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1
     const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
     const float sc = g * (float)is;
     const float msc = (float)m * sc;
-    f.scale[out_off + c] = sc;
-    f.shift[out_off + c] = b - msc;
+    // (write-through: with a gate - see StatsFold::gate - the other blocks of this launch read them right away)
+    __hip_atomic_store(f.scale + out_off + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f.shift + out_off + c, b - msc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f.running_mean) {
         const double vc = var * f.count;
         const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;
@@ -66,6 +67,12 @@ struct StatsFold {
     int part_stride;      // channels between the outputs (sums, coefficients) of consecutive parts (>= C: channel groups)
     int on;               // 0: no in-launch fold (partials only)
     BnFinalize fin;       // outputs of part s at offset s * part_stride
+    // Gate (optional): EVERY block of the launch waits, after its tile's fold duties, until the column tile's sums /
+    // coefficients are final, and then goes on to USE them (BatchNorm apply out of the accumulators: no second launch,
+    // no re-read of the convolution output).  The whole grid must be resident at once - the launcher checks the grid
+    // against the kernel's occupancy (coop_capacity) and falls back to the two-launch form otherwise.
+    unsigned* gate;       // [ntn][2]: flag (0 -> 1 when column tile tn is final), departures; zero between launches
+    int gate_n;           // blocks waiting per column tile
 };
 
 // host: group size so that level 1 and level 2 are balanced and S * ngroups rows fit the scratch (XV2_BN_SCRATCH_ROWS)
@@ -89,7 +96,37 @@ static inline bool stats_fold_plan(StatsFold& f, int64_t tiles, int S, int ntn, 
 static inline int stats_fold_tickets(const StatsFold& f) { return f.S * f.ngroups * f.ntn + f.ntn; }
 
 unsigned* take_tickets(int n);      // norm_act.hip: zero-initialised device pool, handed out round-robin
+int coop_capacity(const void* kern, int threads, size_t smem);   // igemm_conv.hip: blocks of `kern` the chip holds at once
+int coop_block_cap();               // igemm_conv.hip: XV2_COOP_BLOCKS / xv2_set_coop_blocks cap on gated grids
 bool bn_fold_enabled();             // norm_act.hip: XV2_BN_FOLD=0 restores the separate reduction launches (A/B runs)
+
+// ---- gate: a launch-wide "the reduction is final" hand-off between blocks that are all resident -------------------------
+// coop_open: called by ONE thread of the finishing block after that block's result stores were issued write-through and
+// drained (s_waitcnt vmcnt(0) + barrier).  coop_wait: called by ONE thread of every waiting block (the finisher included);
+// returns once the flag is up, having executed an agent-scope acquire; the last block to leave re-arms the gate (both
+// words back to zero: the pool they come from is shared by later launches).  A block that waits longer than ~4 s (the
+// grid was not resident at once: a planning bug, or several processes crowding one GPU) traps instead of hanging the box.
+__device__ __forceinline__ void coop_open(unsigned* gate) {
+    __hip_atomic_store(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coop_wait(unsigned* gate, int nblocks) {
+    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const unsigned long long t0 = wall_clock64();          // 100 MHz
+        while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 400000000ull) __builtin_trap();
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const unsigned prev = __hip_atomic_fetch_add(gate + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)(nblocks - 1)) {       // everybody has seen the flag
+        __hip_atomic_store(gate + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ float coop_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // write-through store of one (s1, s2) partial
 __device__ __forceinline__ void fold_store(float* p, float s1, float s2) {
@@ -194,11 +231,16 @@ __device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* pa
             const double a = ok ? fold_rows(f.scratch + (size_t)sp * f.ngroups * stride + i, stride, f.ngroups) : 0.0;
             const double other = __shfl_xor(a, 1, 64);
             if (!ok) continue;
-            if (f.sums) f.sums[(size_t)sp * f.part_stride * 2 + i] = a;
+            if (f.sums) __hip_atomic_store(f.sums + (size_t)sp * f.part_stride * 2 + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f.f0 && !which) f.f0[c] = (float)a;
             if (f.f1 && which) f.f1[c] = (float)a;
             if (f.fin.mean && !which) bn_finalize_channel(f.fin, c, a, other, sp * f.part_stride);
         }
+    }
+    if (f.gate) {         // the column tile is final: let the waiting blocks of this launch go on
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) coop_open(f.gate + 2 * tn);
     }
 }
 

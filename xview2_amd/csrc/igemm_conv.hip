@@ -1234,13 +1234,74 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         return;
     }
     // the tile rows are reduced (and the BatchNorm coefficients derived) by the last blocks to arrive: bn_fold.h
-    if (do_stats && p.fold.on) stats_fold_tile<float, false>(p.fold, p.stats, tm, tn, n0, BN, rowoff);
+    if (do_stats && p.fold.on) stats_fold_tile<float, false>(p.fold, p.stats, tm, tn, n0, BN, reinterpret_cast<int*>(red));
+    // ---- BatchNorm apply in the same launch (IgemmParams::cz): wait at the gate until this column tile's coefficients are
+    // final, then normalise + (residual) + activate the tile out of the accumulators.  The grid is resident at once
+    // (launcher: coop_capacity), so every block arrives.
+    if (do_stats && p.fold.on && p.fold.gate && p.cz) {
+        if (tid == 0) coop_wait(p.fold.gate + 2 * tn, p.fold.gate_n);
+        __syncthreads();
+        // (everything below is derived from a laundered copy of the thread index: nothing of this pass may be computed ahead
+        // of - and kept live across - the fold, whose 64 registers of loads in flight set the kernel's register count)
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        constexpr int F4R = BN / 4;
+        const int part_off = (tm / p.fold.tiles_per_part) * p.fold.part_stride;
+        const int ccol = n0 + (t2 % F4R) * 4;             // this thread's 4 columns (256 % F4R == 0: the same in every pass)
+        float4 sc, sf;
+        {
+            const float* ps = p.fold.fin.scale + part_off + ccol;
+            const float* pf = p.fold.fin.shift + part_off + ccol;
+            sc = make_float4(coop_load(ps), coop_load(ps + 1), coop_load(ps + 2), coop_load(ps + 3));
+            sf = make_float4(coop_load(pf), coop_load(pf + 1), coop_load(pf + 2), coop_load(pf + 3));
+        }
+        const int c4n = p.Nout >> 2;
+        // The tile is NOT kept in the accumulators across the wait (64 live registers under the fold's 64 would cost the
+        // bf16 kernels their third block per CU): one staging pass (NH == 1) leaves the whole tile in LDS, where it still is;
+        // with two passes (bf16 storage) a thread re-reads the 8 bytes per element it has just stored (L2-hot, and exactly
+        // "y as stored").
+#pragma unroll 1
+        for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll 2
+            for (int e = t2; e < HROWS * F4R; e += 256) {
+                const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
+                const int off = rowoff[row];
+                if (off < 0) continue;
+                const int col = n0 + c;
+                float4 v;
+                if constexpr (NH == 1) {
+                    v = *reinterpret_cast<const float4*>(Cs + row * CLD + c);
+                    v = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));   // y as stored
+                } else {
+                    v = ld4(reinterpret_cast<const OT*>(p.Out0) + (size_t)off * p.ldo0 + col);
+                }
+                v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
+                v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
+                if (p.cres) {
+                    const float4 r = ld4(reinterpret_cast<const OT*>(p.cres) + (size_t)off * p.cldres + col);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                v.x = apply_act(v.x, p.cact); v.y = apply_act(v.y, p.cact);
+                v.z = apply_act(v.z, p.cact); v.w = apply_act(v.w, p.cact);
+                st4(reinterpret_cast<OT*>(p.cz) + (size_t)off * p.cldz + col, v);
+                if (p.cmask)
+                    p.cmask[(size_t)off * c4n + (col >> 2)] =
+                        (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+            }
+        }
+    }
 }
 
 // Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
 // for 32-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.  (32 rows, all slabs
 // of a row in flight: 64-row tiles left a 128-block grid latency-bound - cfg3 bf16 20.5 -> 19.2 ms; 16 rows: slower)
 constexpr int SPLITK_ROWS = 32;
+struct CoopApply {        // IgemmParams::cz .. cact for the slab-sum kernel
+    void* z;
+    const void* res;
+    unsigned char* mask;
+    int ldz, ldres, act;
+};
 template <typename OT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M,
                                                              int Nout, const float* __restrict__ bias,
@@ -1250,7 +1311,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              const float* __restrict__ ep_scale,
                                                              const float* __restrict__ ep_shift,
                                                              const OT* __restrict__ ep_res, int ep_ldres, int ep_act,
-                                                             const StatsFold fold) {
+                                                             const StatsFold fold, const CoopApply ca) {
     __shared__ float sh[256 * 8];
     __shared__ int fold_flag;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -1394,6 +1455,45 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
             __syncthreads();
             // (the grid covers the columns exactly once: gridDim.y = ceil(Nout / 256), one pass of this loop per block)
             if (fold.on) stats_fold_tile<float>(fold, stats, blockIdx.x, blockIdx.y, cb, min(256, Nout - cb), &fold_flag);
+            // BatchNorm apply in the same launch (IgemmParams::cz): every block waits until its column tile's coefficients
+            // are final and normalises the 32 rows it has just written (a thread re-reads its own stores: y as stored)
+            if (fold.on && fold.gate && ca.z) {
+                if (threadIdx.x == 0) coop_wait(fold.gate + 2 * blockIdx.y, fold.gate_n);
+                __syncthreads();
+                if (c < Nout) {
+                    const int part_off = ((int)blockIdx.x / fold.tiles_per_part) * fold.part_stride;
+                    const float* ps = fold.fin.scale + part_off + c;
+                    const float* pf = fold.fin.shift + part_off + c;
+                    const float4 sc = make_float4(coop_load(ps), coop_load(ps + 1), coop_load(ps + 2), coop_load(ps + 3));
+                    const float4 sf = make_float4(coop_load(pf), coop_load(pf + 1), coop_load(pf + 2), coop_load(pf + 3));
+                    constexpr int NRW = SPLITK_ROWS / 4;
+                    float4 yv[NRW], rv[NRW];
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) {
+                        const int rr = min(r0 + ty + 4 * i, M - 1);
+                        yv[i] = ld4(out0 + (size_t)rr * ldo0 + c);
+                        rv[i] = ca.res ? ld4(reinterpret_cast<const OT*>(ca.res) + (size_t)rr * ca.ldres + c) : make_float4(0, 0, 0, 0);
+                    }
+                    const int c4n = Nout >> 2;
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) {
+                        const int r = r0 + ty + 4 * i;
+                        if (r >= M) continue;
+                        float4 v = yv[i];
+                        v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
+                        v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
+                        if (ca.res) {
+                            v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+                        }
+                        v.x = apply_act(v.x, ca.act); v.y = apply_act(v.y, ca.act);
+                        v.z = apply_act(v.z, ca.act); v.w = apply_act(v.w, ca.act);
+                        st4(reinterpret_cast<OT*>(ca.z) + (size_t)r * ca.ldz + c, v);
+                        if (ca.mask)
+                            ca.mask[(size_t)r * c4n + (c >> 2)] =
+                                (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+                    }
+                }
+            }
         }
     }
 }
@@ -1401,6 +1501,36 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, bool HIN, int WGM, bool HALO = false>
 constexpr size_t igemm_smem_bytes() {
     return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1, HALO>() * 4 + BM * 4 + 4 * BN * 2 * 4;
+}
+
+// ---- launches whose blocks wait for each other (StatsFold::gate) --------------------------------------------------------
+// Such a grid must be RESIDENT at once: blocks that wait at the gate hold their CU slots, a block that was never dispatched
+// would never arrive.  coop_capacity = what the chip holds of this kernel when it has the chip to itself (other kernels only
+// delay a launch - they finish without waiting for us - as long as no second gated launch is in flight: the library gates
+// launches of the COMPUTE stream only).
+// MEASURED A LOSS, hence OPT-IN (XV2_COOP=1, or xv2_set_coop_blocks(n > 0)): same box, gated vs two launches - cfg2 fp32 26.66 ->
+// 27.07 ms, cfg2 --precision 16 14.09 -> 14.58, cfg3 18.3 -> 20.3 ms, resnest50 encoder forward 6.42 -> 6.76 (fp32) / 4.95 -> 5.58
+// ms (bf16): the hand-off chain (partials -> group ticket -> group fold -> top ticket -> fold + coefficients -> gate -> acquire ->
+// coefficient loads) is ~10 dependent device-scope round trips of 1 - 2.5 us each, paid by EVERY block of the grid while it
+// holds its CU; a kernel boundary plus the streaming apply kernel costs less than that on MI355X (profiles/r04_gated_ab.md).
+// XV2_COOP_BLOCKS caps the grid (processes that share one GPU - the test suite's workers - must keep their combined gated grids
+// below the chip's capacity).
+static int g_coop_blocks = -1;      // xv2_set_coop_blocks(): cap on gated grids; > 0 also switches the gated forms on; -1 = env
+long long g_coop_count = 0;         // gated launches issued so far (xv2_coop_count: tests assert WHICH form ran)
+static bool coop_enabled() {
+    static const int v = [] { const char* e = getenv("XV2_COOP"); return e ? atoi(e) : 0; }();
+    return v != 0 || g_coop_blocks > 0;
+}
+int coop_block_cap() {
+    static const int envcap = [] { const char* e = getenv("XV2_COOP_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
+    return g_coop_blocks >= 0 ? g_coop_blocks : envcap;
+}
+int coop_capacity(const void* kern, int threads, size_t smem) {
+    int nb = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, smem) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    // blocks go to the 8 XCDs round-robin: whole blocks per CU, whole CUs per XCD
+    return nb * (cus / 8) * 8;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
@@ -1429,6 +1559,17 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
         flops += 2.0 * (double)q.cls[c].M * q.Nout * kreal;
     }
     const int grid = maxtiles * (q.Nout / BN);
+    if (q.cz && q.ksplit == 1) {
+        // BatchNorm apply behind the gate: only if the whole grid is resident at once
+        static const int cap = coop_capacity(reinterpret_cast<const void*>(kern), 256, smem);
+        if (coop_enabled() && q.fold.on && q.fold.gate && q.ncls == 1 && grid <= std::min(cap, coop_block_cap())) {
+            if (q.coop_applied) *q.coop_applied = 1;
+            ++g_coop_count;
+        } else {
+            q.cz = nullptr;
+            q.fold.gate = nullptr;
+        }
+    }
     // algorithmic bytes: input pixels x channels + weights + output, each once
     const double ein = (HS && !SMALLC) ? 2.0 : 4.0, eout = HS ? 2.0 : 4.0;
     double abytes = ein * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
@@ -1571,6 +1712,12 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
                   "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, p.fold.S);
     f.tickets = take_tickets(stats_fold_tickets(f));
     XV2_CHECK_ARG(f.tickets, "conv2d_forward_bn: ticket pool allocation failed");
+    f.gate = nullptr;
+    f.gate_n = (int)tiles;
+    if (p.cz && f.fin.mean && coop_enabled()) {       // BatchNorm apply in the same launch: the launcher of the kernel decides
+        f.gate = take_tickets(2 * ntn);
+        XV2_CHECK_ARG(f.gate, "conv2d_forward_bn: ticket pool allocation failed");
+    }
     p.fold = f;
     return XV2_OK;
 }
@@ -1710,6 +1857,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             return XV2_OK;
         }
         XV2_CHECK_ARG(!p.pre_scale, "conv2d_forward_bn_pre: the direct 3x3 plan has no pre-activation form");
+        p.cz = nullptr;
         return direct3x3_launch(p, stream);
     }
     if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
@@ -1726,6 +1874,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         // stall its barrier-free waves)
         const StatsFold fold = p.fold;
         p.fold.on = 0;
+        p.cz = nullptr;
         int rc = thin1x1_launch(p, stream);
         if (rc || !fold.on) return rc;
         const int64_t tiles = cdiv(maxM, 128);
@@ -1793,6 +1942,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         }
         XV2_CHECK_ARG(!p.pre_scale || (halo && !halo16), "conv2d_forward_bn_pre: this shape is not planned as the halo form");
         if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8) {
+            p.cz = nullptr;       // (no gated apply behind the in-launch slab sum)
             // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
             // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
             const int64_t ntiles = cdiv(maxM, 128) * (p.Nout / 128);
@@ -1806,8 +1956,23 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         }
         // split-K: the slab-sum kernel takes the statistics (64-row tiles, 256-column tiles) and folds them
         if (int rc = complete_fold(p, cdiv(maxM, SPLITK_ROWS), (int)cdiv(p.Nout, 256))) return rc;
-        const StatsFold fold = p.fold;
+        StatsFold fold = p.fold;
         p.fold.on = 0;
+        CoopApply ca{p.cz, p.cres, p.cmask, p.cldz, p.cldres, p.cact};
+        p.cz = nullptr;           // (the GEMM launch writes slabs; the slab-sum launch below is the one that applies)
+        {
+            const long long rblocks = (long long)cdiv(p.cls[0].M, SPLITK_ROWS) * cdiv(p.Nout, 256);
+            static const int cap_f = coop_capacity(reinterpret_cast<const void*>(splitk_reduce_kernel<float>), 256, 0);
+            static const int cap_h = coop_capacity(reinterpret_cast<const void*>(splitk_reduce_kernel<bf16_t>), 256, 0);
+            const int cap = std::min(p.math == XV2_MATH_BF16_STORE ? cap_h : cap_f, coop_block_cap());
+            if (coop_enabled() && ca.z && fold.on && fold.gate && !p.Out1 && rblocks <= cap) {
+                if (p.coop_applied) *p.coop_applied = 1;
+                ++g_coop_count;
+            } else {
+                ca.z = nullptr;
+                fold.gate = nullptr;
+            }
+        }
         int rc = (halo && halo16)              ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
                  : p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
                  : (halo && p.Bx3)             ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
@@ -1822,11 +1987,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (p.math == XV2_MATH_BF16_STORE)
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum | rolled,
-                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold);
+                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold, ca);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum | rolled, p.ep_scale, p.ep_shift,
-                               p.ep_res, p.ep_ldres, p.ep_act, fold);
+                               p.ep_res, p.ep_ldres, p.ep_act, fold, ca);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -1910,6 +2075,7 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bnb_ldy = p.bnb_act = 0;
     p.plan_tiles = nullptr;
     p.plan_halo = nullptr;
+    p.cz = nullptr; p.cres = nullptr; p.cmask = nullptr; p.cldz = p.cldres = p.cact = 0; p.coop_applied = nullptr;
     p.pre_scale = p.pre_shift = nullptr;
     p.pre_act = 0;
     memset(&p.fold, 0, sizeof(p.fold));
@@ -1977,15 +2143,30 @@ struct PreAct {           // IgemmParams::pre_*
     const float* shift;
     int act;
 };
+struct CoopArgs {         // IgemmParams::cz ..: BatchNorm apply in the same launch
+    void* z;
+    int ldz;
+    const void* res;
+    int ldres, act;
+    unsigned char* mask;
+    int* applied;
+};
 
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
                              long long* plan = nullptr, const StatsFold* fold = nullptr, const PreAct* pre = nullptr,
-                             int* plan_halo = nullptr) {
+                             int* plan_halo = nullptr, const CoopArgs* coop = nullptr) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    if (coop && coop->z) {
+        XV2_CHECK_ARG(fold && fold->fin.mean && out_aligned(d, coop->z, coop->ldz) &&
+                          (!coop->res || out_aligned(d, coop->res, coop->ldres)) && coop->applied,
+                      "conv2d_forward_bn_act: coefficients, aligned z / residual rows and the `applied` flag are required");
+        p.cz = coop->z; p.cldz = coop->ldz; p.cres = coop->res; p.cldres = coop->ldres; p.cact = coop->act;
+        p.cmask = coop->mask; p.coop_applied = coop->applied;
+    }
     p.plan_tiles = plan;
     p.plan_halo = plan_halo;
     const bool dry = plan_halo != nullptr;
@@ -2091,6 +2272,43 @@ extern "C" int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int
     return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
                              stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f);
 }
+
+extern "C" int xv2_conv2d_forward_bn_act(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
+                                         const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
+                                         int parts, int part_stride, double* sums, double* scratch, double count,
+                                         const float* gamma, const float* beta, float eps, float momentum,
+                                         float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                         float* shift, const void* residual, int ldr, int act, void* z, int ldz,
+                                         uint8_t* zmask, int* applied, void* stream) {
+    XV2_CHECK_ARG(applied && z && mean && invstd && scale && shift, "conv2d_forward_bn_act: z, the coefficient outputs and `applied` are required");
+    *applied = 0;
+    XV2_CHECK_ARG(stats_partials && scratch && sums, "conv2d_forward_bn_act: partials, scratch and sums are required");
+    XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn_act: parts=%d part_stride=%d", parts, part_stride);
+    XV2_CHECK_ARG(!zmask || (ldz == d->Cout && act != XV2_ACT_SIGMOID), "conv2d_forward_bn_act: the mask form needs dense rows and a ReLU-type activation");
+    if (!bn_fold_enabled())
+        return xv2_conv2d_forward_bn(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, parts, part_stride, sums,
+                                     scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                                     scale, shift, stream);
+    StatsFold f;
+    memset(&f, 0, sizeof(f));
+    f.on = 1;
+    f.S = parts;
+    f.part_stride = part_stride;
+    f.scratch = scratch;
+    f.sums = sums;
+    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
+    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
+    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
+    CoopArgs ca{z, ldz, residual, ldr, act, zmask, applied};
+    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
+                             stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f, nullptr, nullptr, &ca);
+}
+
+extern "C" int xv2_set_coop_blocks(int blocks) {
+    g_coop_blocks = blocks;
+    return XV2_OK;
+}
+extern "C" int64_t xv2_coop_count(void) { return g_coop_count; }
 
 // 1 if xv2_conv2d_forward_bn_pre() can run this convolution (the halo plan of XV2_MATH_F32X3), else 0
 extern "C" int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d) {

@@ -71,6 +71,15 @@ struct IgemmParams {
     // in-launch fold of the BatchNorm statistics partials (bn_fold.h); the caller fills scratch / sums / S / part_stride /
     // fin and sets fold.on = 1, the launcher completes the plan (group size, tickets) for the tiling it picks
     StatsFold fold;
+    // Training-mode BatchNorm APPLY in the same launch (fold.on, fold.fin and fold.gate set, ksplit == 1 in the GEMM kernel or
+    // the slab-sum kernel of a split-K plan): once the coefficients are final every block forms
+    // z = act(y * scale + shift [+ res]) from the tile it still holds - y rounded to the storage type first, so the result
+    // equals xv2_bn_act_forward on the stored y bit for bit (model/layers.py:93-100).  cz == nullptr: off.
+    void* cz;
+    const void* cres;
+    unsigned char* cmask;    // optional byte mask of z > 0 (xv2_bn_act_forward_mask), dense rows of Nout / 4 bytes
+    int cldz, cldres, cact;
+    int* coop_applied;       // host: set to 1 by the launcher when the plan took the in-launch apply
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

@@ -16,11 +16,13 @@ extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, i
                                        float* scale, float* shift, const void* residual, int ldr, int act, void* z,
                                        int ldz, uint8_t* zmask, int dtype, void* stream) {
     // convolution + statistics + coefficients: ONE launch (the last blocks to arrive fold the tile partials, bn_fold.h)
+    // (+ the BatchNorm apply behind a gate in that same launch when its grid is resident at once: xv2_conv2d_forward_bn_act)
     (void)tiles;
-    int rc = xv2_conv2d_forward_bn(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
-                                   scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                                   scale, shift, stream);
-    if (rc) return rc;
+    int applied = 0;
+    int rc = xv2_conv2d_forward_bn_act(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
+                                       scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                                       scale, shift, residual, ldr, act, z, ldz, zmask, &applied, stream);
+    if (rc || applied) return rc;
     const int64_t npix = (int64_t)d->N * d->OH * d->OW;
     if (zmask)
         return xv2_bn_act_forward_mask(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, d->Cout, zmask, dtype, stream);

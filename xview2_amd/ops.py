@@ -13,6 +13,11 @@ import torch.distributed as dist
 
 from ._capi import ConvDesc, Ptr, call, query
 
+
+def ctypes_addr(obj):
+    import ctypes
+    return ctypes.addressof(obj)
+
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACTS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
 LOSS_DICE, LOSS_FOCAL, LOSS_CE, LOSS_MSE, LOSS_CORAL = 1, 2, 4, 8, 16
@@ -335,7 +340,21 @@ def _apply_pre(y0, pre):
     return z
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None):
+# BatchNorm apply inside the convolution launch (xv2_conv2d_forward_bn_act: blocks wait at a gate for the coefficients): exact,
+# tested, and measured SLOWER than the two-launch form on every configuration (cfg3 18.3 -> 20.3 ms; include/xv2.h) - opt-in
+COOP_APPLY = os.environ.get("XV2_COOP", "0") != "0"
+_applied_flag = None
+
+
+def _applied():
+    global _applied_flag
+    if _applied_flag is None:
+        import ctypes
+        _applied_flag = ctypes.c_int(0)
+    return _applied_flag
+
+
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None, apply=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.
     `pre` = (scale, shift, act): x0 is the RAW output of the producing convolution and that layer's BatchNorm + activation
     is applied in this convolution's operand load (xv2_conv2d_forward_bn_pre) when the plan allows it - two more values are
@@ -345,7 +364,9 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
     does not synchronise across ranks) the statistics reduction also derives the BatchNorm coefficients in the
     same launch and the third return value is (mean, invstd, scale, shift).  `fused` = (scale, shift, residual, act):
     inference form, the folded BatchNorm / residual / activation run in the convolution epilogue and y IS the
-    activated output (xv2_conv2d_forward_fused)."""
+    activated output (xv2_conv2d_forward_fused).  `apply` = {"residual", "act", "want_mask"}: training mode, the
+    BatchNorm this launch derives is also APPLIED by it when its grid is resident at once (xv2_conv2d_forward_bn_act);
+    on success apply["z"] (and apply["zmask"]) hold the activated output - the caller skips its apply pass."""
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     Cout_t = weight.shape[0]
@@ -433,6 +454,25 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
                      _off(bn.running_mean, og) if coeffs is not None else None,
                      _off(bn.running_var, og) if coeffs is not None else None, *fin)
                 continue
+            if apply is not None and coeffs is not None and COOP_APPLY and (gi == 0 or apply.get("n") == gi):
+                # ... and the apply behind the gate of the same launch (every group must take it, else the caller applies)
+                if gi == 0:
+                    apply["z"] = torch.empty_like(y)
+                    apply["zmask"] = None
+                    if apply["want_mask"] and G == 1 and _mask_ok(Cout_t, apply["act"], half):
+                        apply["zmask"] = torch.empty((N * OH * OW * (Cout_t // 4),), dtype=torch.uint8, device=x0.device)
+                    apply["residual"] = _same(apply["residual"], y)
+                    apply["n"] = 0
+                res, flag = apply["residual"], _applied()
+                call("xv2_conv2d_forward_bn_act", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
+                     _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
+                     S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
+                     _off(bn.weight, og), _off(bn.bias, og), float(bn.eps), float(bn.momentum),
+                     _off(bn.running_mean, og), _off(bn.running_var, og), *fin,
+                     None if res is None else Ptr(res, og), Cout_t, apply["act"], Ptr(apply["z"], og), Cout_t, apply["zmask"],
+                     ctypes_addr(flag))
+                apply["n"] += flag.value
+                continue
             call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
                  _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
                  S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
@@ -447,6 +487,9 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             if want_stats:
                 stats_ok = False
     assert cin_w <= C0g + C1t
+    if apply is not None and not (apply.get("n") == G and stats_ok):
+        apply.pop("z", None)
+        apply.pop("zmask", None)
     if want_stats and not stats_ok:
         sums, coeffs = None, None           # _bn_forward takes the statistics of each part from y
     if pre is not None:
@@ -1005,7 +1048,7 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.ihwo = [] if need_dx else None
         ctx.split = BN_SPLIT if (training and x0.shape[0] % BN_SPLIT == 0) else 1
         ctx.has_res = residual is not None
-        fast = None
+        fast = ap = None
         lazy = (lazy_out and LAZY_BN and training and not ctx.has_res and ctx.split == 1 and not _sync_group(bn) and
                 x0.dtype == torch.float32 and MATH_MODE == MATH_F32X3)
         ctx.pre = None
@@ -1020,8 +1063,14 @@ class ConvBnActFn(torch.autograd.Function):
                                                       pre=pre)
             ctx.pre = pre if used else None
         else:
-            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn)
-        if fast is None and lazy and coeffs is not None:
+            if training and COOP_APPLY and not lazy and not _sync_group(bn):
+                ap = {"residual": residual, "act": act, "want_mask": ctx.has_res}
+            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn, apply=ap)
+        if ap is not None and "z" in ap and coeffs is not None:
+            # the convolution launch(es) applied the BatchNorm they derived (grouped / split-batch layers: xv2_conv2d_forward_bn_act)
+            z, zmask = ap["z"], ap["zmask"]
+            stats = (coeffs[0], coeffs[1], float(y.numel() // y.shape[-1] // ctx.split), coeffs[2], coeffs[3])
+        elif fast is None and lazy and coeffs is not None:
             # this layer's own apply is deferred to ITS consumer: hand out y with the coefficients attached
             rows = y.numel() // y.shape[-1]
             stats = (coeffs[0], coeffs[1], float(rows), coeffs[2], coeffs[3])
