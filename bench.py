@@ -91,9 +91,10 @@ def cpu_model_name():
 
 
 def cpu_baseline(a, size, batch, seed, timed_steps=3):
-    """fwd+loss+bwd+AdamW steps of the CPU oracle at the SAME shape, batch and weights (bounded sample: one warm-up
-    step, then the median of `timed_steps`).  The warm-up step starts from the weights and batch the HIP path's
-    first step sees, so its loss / logits / gradients are the full-size parity reference (second return value)."""
+    """fwd+loss+bwd steps of the CPU oracle at the SAME shape, batch and weights (bounded sample: one warm-up step, then
+    the median of `timed_steps`); the optimizer step is timed SEPARATELY and reported beside it (SURVEY 8d / BASELINE.md 4:
+    the CPU step is fwd + loss + bwd).  The warm-up step starts from the weights and batch the HIP path's first step sees,
+    so its loss / logits / gradients are the full-size parity reference (second return value)."""
     from oracle import torch_ref
     from xview2_amd.weights import deterministic_init_
     torch.manual_seed(0)
@@ -103,7 +104,7 @@ def cpu_baseline(a, size, batch, seed, timed_steps=3):
     x, y = synthetic_batch(a, batch, size, seed, "cpu")
     opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.0)
     loss_fn = torch_ref.Loss(a)
-    times, ref = [], None
+    times, opt_times, ref = [], [], None
     for it in range(1 + timed_steps):
         opt.zero_grad()
         t0 = time.time()
@@ -114,14 +115,18 @@ def cpu_baseline(a, size, batch, seed, timed_steps=3):
             p0 = pred[0] if isinstance(pred, list) else pred
             ref = {"loss": float(loss), "logits": p0.detach().clone(),
                    "grads": {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}}
-        opt.step()
         times.append(time.time() - t0)
+        t1 = time.time()
+        opt.step()
+        opt_times.append(time.time() - t1)
     dt = statistics.median(times[1:]) if timed_steps else times[0]
+    dt_opt = statistics.median(opt_times[1:]) if timed_steps else opt_times[0]
     return {"value": batch / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "cpu": cpu_model_name(),
-            "sample": "PyTorch-CPU oracle, %s %dx%dx%d fp32 training step (fwd+loss+bwd+AdamW): 1 warm-up step, then the "
-                      "median of %d steps" % (a.encoder, batch, size, size, timed_steps),
-            "seconds": dt, "seconds_all": [round(t, 3) for t in times], "loss": ref["loss"]}, ref
+            "sample": "PyTorch-CPU oracle, %s %dx%dx%d fp32 training step (fwd+loss+bwd; AdamW timed separately: "
+                      "optimizer_seconds): 1 warm-up step, then the median of %d steps" % (a.encoder, batch, size, size, timed_steps),
+            "seconds": dt, "seconds_all": [round(t, 3) for t in times], "optimizer_seconds": round(dt_opt, 4),
+            "loss": ref["loss"]}, ref
 
 
 def parity_block(ref, hip, precision, size=1024):
@@ -558,6 +563,7 @@ def main():
         loss = run()
     barrier()
     dt = time.time() - t0
+    xdist.check_peer_exchange()      # one-shot SyncBatchNorm exchange (XV2_SYNCBN=auto / oneshot): a timed-out exchange is an error
     if hip_first is None and world == 1 and graphed is None and opt.warmup == 0:
         sys.stderr.write("no warm-up step: the parity block needs the first step outside the timed region\n")
     rows, iso = [], []
@@ -668,7 +674,12 @@ def main():
                                    "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
                    "global_batch": world * opt.batch,
                    "parallelism": "dp%d" % world + (" (ranks SHARE one GPU over gloo: code-path test, not a scaling "
-                                                    "measurement)" if opt.share_gpu else "")},
+                                                    "measurement)" if opt.share_gpu else ""),
+                   "grad_buckets": len(reducer.buckets),
+                   "syncbn": ("none" if world == 1 else
+                              "one-shot peer exchange" if xdist._peer_exchange is not None else
+                              "all_reduce per BatchNorm (%s)" % ("gloo" if opt.share_gpu else "RCCL") +
+                              ("; one-shot exchange unavailable, downgraded" if xdist._peer_exchange_off else ""))},
         "loss": float(loss.detach()), "launch": "hipGraph" if graphed is not None else "eager",
         "model_tflops": round(model_tf, 2),
         "conv_roofline_frac_whole_step": round(

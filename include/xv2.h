@@ -65,7 +65,13 @@ typedef struct xv2_conv_desc {
  * matrix-pipe time for fp32-level accuracy.  Covers the implicit-GEMM kernel (forward, backward-data, transposed
  * convolution) and the two main weight-gradient kernels (all-taps 3x3, transpose-read 1x1 / strided); the direct 3x3
  * kernel, the RGB stem and odd-shaped weight-gradient layers run their exact-fp32 forms under this mode.  This is the
- * mode the host layer uses for fp32 tensors by default (XV2_F32X3=0 in the environment selects XV2_MATH_F32). */
+ * mode the host layer uses for fp32 tensors by default (XV2_F32X3=0 in the environment selects XV2_MATH_F32).
+ * NON-FINITE OPERANDS: the split of +-Inf is h = Inf, m = bf16(Inf - Inf) = NaN, so an operand element that is +-Inf (or NaN)
+ * makes every output it contributes to NaN, where the exact-fp32 MFMA (and torch) would propagate +-Inf through products
+ * with non-zero finite values.  Both are already-diverged training states; finite inputs are unaffected (every finite fp32
+ * splits exactly, including denormals and values whose bf16 rounding overflows to Inf: bf16 has fp32's exponent range, a
+ * finite fp32 rounds to a finite bf16 or to Inf only above 0x7f7f8000 ~ 3.39e38, where h = Inf again yields NaN).  Callers
+ * that must keep Inf semantics select XV2_MATH_F32. */
 #define XV2_MATH_F32X3 3
 
 /* element type of activation tensors for the non-convolution entry points (`dtype` arguments) */
@@ -522,9 +528,15 @@ int xv2_prof_record(int i, int* kid, double* ms, double* flops, double* algorith
  * each rank stores its vector straight into every peer's buffer over xGMI (write-through 8-byte stores + a sequence-number
  * flag), waits for the `world` flags of its own buffer and adds the rows in RANK order (identical bits on every rank).
  * `seq` counts the exchanges of the job (same value on every rank); `peers_dev` = device array of the `world` mapped base
- * pointers (own buffer at index `rank`); `timeout_flag` (device int) becomes non-zero if a peer never arrived. */
+ * pointers (own buffer at index `rank`); `timeout_flag` (device int) becomes non-zero if a peer never arrived within the
+ * spin limit (xv2_xchg_set_spin_limit polls, default 2^26 ~ seconds) - from then on every exchange writes NaN instead of a
+ * sum of stale rows (a failed exchange must be loud: NaN statistics -> NaN loss; the collective library would have waited).
+ * xv2_xchg_alloc: *finegrained = 1 if the runtime granted fine-grained device memory (coherent across GPUs while kernels
+ * run), 0 if it fell back to ordinary device memory - usable only when all ranks share ONE device; a caller on a multi-GPU
+ * node must then stay with the collective library (xview2_amd.dist.stats_all_reduce_ does). */
 size_t xv2_xchg_bytes(int world, size_t row_doubles);
-int xv2_xchg_alloc(int world, size_t row_doubles, void** base_out, unsigned char* handle64);
+int xv2_xchg_alloc(int world, size_t row_doubles, void** base_out, unsigned char* handle64, int* finegrained);
+int xv2_xchg_set_spin_limit(unsigned polls);
 int xv2_xchg_open(const unsigned char* handle64, void** peer_base);
 int xv2_xchg_close(void* peer_base);
 int xv2_xchg_free(void* base);

@@ -104,7 +104,19 @@ def _same(a, b, what):
         assert torch.equal(a, b), "%s differs (max |d| = %g)" % (what, (a.double() - b.double()).abs().max().item())
 
 
+def _fits_worker_cap(case):
+    """under xdist a worker may gate at most XV2_COOP_BLOCKS blocks (tests/gpu_lock.py): the smallest tiling a plan can pick
+    is 64 x 64, so larger problems need not take the gated form there"""
+    import os
+    if gated.full or not os.environ.get("PYTEST_XDIST_WORKER"):
+        return True
+    N, H, W, C0, C1, Cout, k, s, p, G = case[:10]
+    M = N * ((H + 2 * p - k) // s + 1) * ((W + 2 * p - k) // s + 1)
+    return -(-M // 64) * -(-(Cout // G) // 64) <= int(os.environ.get("XV2_COOP_BLOCKS", "40"))
+
+
 def _check(case, dtype, split=1, expect_gated=True):
+    expect_gated = expect_gated and _fits_worker_cap(case)
     z0, s0, rm0, rv0, n0 = _run(case, dtype, False, split)
     z1, s1, rm1, rv1, n1 = _run(case, dtype, True, split)
     assert n0 == 0

@@ -132,11 +132,11 @@ def test_hipgraph_replay_matches_eager_steps():
     assert res["eager"][2] == res["graph"][2] == 5
 
 
-def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=False):
-    """one of two processes sharing cuda:0 (gloo carries the device tensors): a SyncBatchNorm + bucketed-reducer
-    training step of the HIP path on this rank's half of a global batch of 4"""
+def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=False, total=4):
+    """one of `world` processes sharing cuda:0 (gloo carries the device tensors): a SyncBatchNorm + bucketed-reducer
+    training step of the HIP path on this rank's share of a global batch of `total`"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK="0", XV2_COOP="0")
     if exact_fp32:
         os.environ["XV2_F32X3"] = "0"        # read when xview2_amd.ops is imported (spawned process: not yet)
     import torch.distributed as dist
@@ -148,15 +148,16 @@ def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=F
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         a = ARGS(encoder=encoder, loss_str="ce", type="pre")
-        x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
+        x, y = model_input(a, batch=total).cuda(), labels(a, batch=total).cuda()
         torch.manual_seed(0)
         m = networks.UNetLoc(a)
         deterministic_init_(m, 1)
         m.cuda().train()
         opt = FlatAdamW(m.parameters(), lr=1e-3)
-        red = xdist.GradReducer(opt, bucket_bytes=16 << 20)
-        assert red.enabled and xnn.SYNC_BN
-        xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
+        red = xdist.GradReducer(opt) if world > 2 else xdist.GradReducer(opt, bucket_bytes=16 << 20)
+        assert red.enabled and xnn.SYNC_BN and (world == 2 or len(red.buckets) >= 8)
+        per = total // world
+        xs, ys = x[per * rank:per * (rank + 1)], y[per * rank:per * (rank + 1)]
         opt.zero_grad()
         red.prepare()
         logits = m(xs)
@@ -170,9 +171,36 @@ def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=F
         key = "unet.enc_l2.1.0.bn1.running_var" if encoder == "resnet50" else "unet.enc_l2.1.0.conv2.bn1.running_var"
         torch.save((rank, float(loss.detach()), logits.detach().cpu(), g, sd[key].cpu(),
                     sd["unet.enc_l1.1.running_mean"].cpu(), opt.flat_p.cpu()), os.path.join(outdir, "rank%d.pt" % rank))
+        with open(os.path.join(outdir, "transport%d.txt" % rank), "w") as fh:
+            fh.write("oneshot" if xdist._peer_exchange is not None else ("downgraded" if xdist._peer_exchange_off else "collective"))
+        xdist.reset_peer_exchange()
     finally:
         xnn.SYNC_BN = False
         dist.destroy_process_group()
+
+
+def _spawn(target, world, args, timeout=900):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0, "rank process exit code %s" % p.exitcode
+
+
+@pytest.mark.parametrize("world,total", [(4, 4), (8, 8)])
+def test_many_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path, world, total):
+    """the same equivalence at world 4 and 8 (one image per rank): SyncBatchNorm statistics over the global batch, >= 8
+    gradient buckets, every rank ends with identical gradients and parameters"""
+    _spawn(_two_rank_worker, world, (str(tmp_path), "resnet50", False, total))
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    _compare_with_global_batch(res, "resnet50", False, total)
 
 
 @pytest.mark.parametrize("encoder,exact_fp32", [("resnet50", False), ("resnest50", False), ("resnest50", True)])
@@ -207,14 +235,14 @@ def test_two_ranks_with_syncbn_equal_one_process_with_the_global_batch(tmp_path,
         ops.MATH_MODE = old_mode
 
 
-def _compare_with_global_batch(res, encoder, exact_fp32):
+def _compare_with_global_batch(res, encoder, exact_fp32, total=4):
     from tests.golden.cases import ARGS, labels, model_input
     from xview2_amd import criterion, networks
     from xview2_amd.optim import FlatAdamW
     from xview2_amd.weights import deterministic_init_
     # single process, global batch
     a = ARGS(encoder=encoder, loss_str="ce", type="pre")
-    x, y = model_input(a, batch=4).cuda(), labels(a, batch=4).cuda()
+    x, y = model_input(a, batch=total).cuda(), labels(a, batch=total).cuda()
     torch.manual_seed(0)
     m = networks.UNetLoc(a)
     deterministic_init_(m, 1)
@@ -232,10 +260,11 @@ def _compare_with_global_batch(res, encoder, exact_fp32):
 
     def rel(u, v):
         return float((u.double() - v.double()).abs().max()) / max(float(v.double().abs().max()), 1e-12)
-    assert abs(0.5 * (res[0][1] + res[1][1]) - float(loss)) <= 1e-5 * abs(float(loss))
-    both = torch.cat([res[0][2], res[1][2]], 0)
-    assert rel(both, logits.detach().cpu()) <= 1e-4                      # batch statistics were global on both ranks
-    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][6], res[1][6])   # ranks end up identical
+    assert abs(sum(r[1] for r in res) / len(res) - float(loss)) <= 1e-5 * abs(float(loss))
+    both = torch.cat([r[2] for r in res], 0)
+    assert rel(both, logits.detach().cpu()) <= 1e-4                      # batch statistics were global on every rank
+    for r in res[1:]:
+        assert torch.equal(res[0][3], r[3]) and torch.equal(res[0][6], r[6])   # ranks end up identical
     key = "unet.enc_l2.1.0.bn1.running_var" if encoder == "resnet50" else "unet.enc_l2.1.0.conv2.bn1.running_var"
     assert rel(res[0][4], sd[key].cpu()) <= (1e-5 if encoder == "resnet50" else 1e-3)
     gr = res[0][3]
@@ -309,7 +338,7 @@ def _peer_exchange_worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_one_shot_peer_exchange_sums_in_rank_order_under_uneven_load(tmp_path, world):
     """include/xv2.h xv2_xchg_allreduce (the SyncBatchNorm statistics exchange without a collective call): `world`
     processes on cuda:0 map each other's exchange buffers over hipIpc; 300 exchanges of 1 .. 4096 doubles must equal the
@@ -328,40 +357,57 @@ def test_one_shot_peer_exchange_sums_in_rank_order_under_uneven_load(tmp_path, w
         assert p.exitcode == 0
     for r in range(world):
         rank, bad, seq = torch.load(os.path.join(str(tmp_path), "px%d.pt" % r), weights_only=False)
-        assert rank == r and bad == 0 and seq == 300
+        assert rank == r and bad == 0 and seq == 300 + 8      # 8 handshake exchanges at construction
 
 
-def _two_rank_worker_oneshot(rank, world, port, outdir, encoder):
-    os.environ["XV2_SYNCBN"] = "oneshot"
-    _two_rank_worker(rank, world, port, outdir, encoder)
+def _syncbn_worker(rank, world, port, outdir, encoder, mode, total, fail):
+    os.environ["XV2_SYNCBN"] = mode
+    if fail:
+        os.environ["XV2_XCHG_TEST_FAIL"] = fail
+    _two_rank_worker(rank, world, port, outdir, encoder, False, total)
 
 
-def test_one_shot_syncbn_equals_the_collective_path_bit_for_bit(tmp_path):
-    """the two-rank SyncBatchNorm training step with XV2_SYNCBN=oneshot (statistics exchanged by xv2_xchg_allreduce) must
-    reproduce the run whose statistics travel through torch.distributed.all_reduce: loss, logits, gradients, running
-    statistics, updated parameters - every bit (both sum two fp64 rows in rank order)"""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    res = {}
-    for mode, target in (("rccl", _two_rank_worker), ("oneshot", _two_rank_worker_oneshot)):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        out = tmp_path / mode
-        out.mkdir()
-        procs = [ctx.Process(target=target, args=(r, 2, port, str(out), "resnest50")) for r in range(2)]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join(timeout=600)
-            assert p.exitcode == 0
-        res[mode] = [torch.load(os.path.join(str(out), "rank%d.pt" % r), weights_only=False) for r in range(2)]
-    for r in range(2):
-        a, b = res["rccl"][r], res["oneshot"][r]
-        assert a[1] == b[1]
-        for u, v in zip(a[2:], b[2:]):
+def _syncbn_run(tmp_path, tag, world, encoder, mode, total, fail=None):
+    out = tmp_path / tag
+    out.mkdir()
+    _spawn(_syncbn_worker, world, (str(out), encoder, mode, total, fail))
+    res = [torch.load(os.path.join(str(out), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    transports = {open(os.path.join(str(out), "transport%d.txt" % r)).read() for r in range(world)}
+    assert len(transports) == 1, transports          # the ranks agree on the transport
+    return res, transports.pop()
+
+
+def _same_results(a, b):
+    for ra, rb in zip(a, b):
+        assert ra[1] == rb[1]
+        for u, v in zip(ra[2:], rb[2:]):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("world,encoder,total", [(2, "resnest50", 4), (4, "resnet50", 4)])
+def test_one_shot_syncbn_equals_the_collective_path_bit_for_bit(tmp_path, world, encoder, total):
+    """the SyncBatchNorm training step with XV2_SYNCBN=oneshot (statistics exchanged by xv2_xchg_allreduce) must reproduce
+    the run whose statistics travel through torch.distributed.all_reduce: loss, logits, gradients, running statistics,
+    updated parameters - every bit (both add the fp64 rows in rank order); XV2_SYNCBN=auto takes the same path after its
+    handshake"""
+    ref, t0 = _syncbn_run(tmp_path, "rccl", world, encoder, "rccl", total)
+    one, t1 = _syncbn_run(tmp_path, "oneshot", world, encoder, "oneshot", total)
+    assert (t0, t1) == ("collective", "oneshot")
+    _same_results(ref, one)
+    if world == 2:
+        auto, t2 = _syncbn_run(tmp_path, "auto", world, encoder, "auto", total)
+        assert t2 == "oneshot"
+        _same_results(ref, auto)
+
+
+@pytest.mark.parametrize("stage", ["alloc", "map", "handshake"])
+def test_auto_syncbn_downgrades_to_the_collective_path_when_any_rank_cannot_build_the_exchange(tmp_path, stage):
+    """XV2_SYNCBN=auto: rank 1 fails one stage of the peer exchange's construction (injected) - EVERY rank must drop to
+    torch.distributed.all_reduce together (no hang, no exception) and the step must equal the collective run bit for bit"""
+    ref, _ = _syncbn_run(tmp_path, "rccl", 3, "resnet50", "rccl", 3)
+    got, transport = _syncbn_run(tmp_path, "auto", 3, "resnet50", "auto", 3, fail="%s:1" % stage)
+    assert transport == "downgraded"
+    _same_results(ref, got)
 
 
 def _run_bench(*argv, timeout=900):

@@ -11,7 +11,7 @@ from . import _lib
 
 _CT = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
-    "float": ctypes.c_float, "double": ctypes.c_double, "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float, "double": ctypes.c_double, "uint64_t": ctypes.c_uint64, "unsigned": ctypes.c_uint,
 }
 
 

@@ -1941,7 +1941,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             return XV2_OK;
         }
         XV2_CHECK_ARG(!p.pre_scale || (halo && !halo16), "conv2d_forward_bn_pre: this shape is not planned as the halo form");
-        if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8) {
+        if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8 &&
+            2 * cdiv(maxM, 128) * (p.Nout / 128) <= (1 << 16)) {      // (two tickets per tile from a pool of 65536)
             p.cz = nullptr;       // (no gated apply behind the in-launch slab sum)
             // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
             // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form

@@ -376,18 +376,27 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
 // ticket counters for reduce_stats_kernel: a zero-initialised device pool handed out round-robin; every user
 // returns its counters to zero, so concurrent launches on different streams never share a live ticket.
 unsigned* take_tickets(int n) {
-    static unsigned* pool = nullptr;
-    static size_t cursor = 0;
-    static std::mutex mu;
+    // one pool per device (a host thread may drive several devices; the counters must live on the device that launches)
     constexpr size_t POOL = 1 << 16;
+    constexpr int MAXDEV = 16;
+    static unsigned* pool[MAXDEV] = {};
+    static size_t cursor[MAXDEV] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (n <= 0 || (size_t)n > POOL || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;   // callers check
     std::lock_guard<std::mutex> lk(mu);
-    if (!pool) {
-        if (hipMalloc(&pool, POOL * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(pool, 0, POOL * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (!pool[dev]) {
+        unsigned* p = nullptr;
+        if (hipMalloc(&p, POOL * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, POOL * sizeof(unsigned)) != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        pool[dev] = p;
     }
-    if (cursor + (size_t)n > POOL) cursor = 0;
-    unsigned* p = pool + cursor;
-    cursor += (size_t)n;
+    if (cursor[dev] + (size_t)n > POOL) cursor[dev] = 0;
+    unsigned* p = pool[dev] + cursor[dev];
+    cursor[dev] += (size_t)n;
     return p;
 }
 

@@ -18,9 +18,12 @@
 
 namespace xv2 {
 
+static unsigned g_xchg_spins = 1u << 26;      // polls (~0.1 us apart) before an exchange gives up on a peer: xv2_xchg_set_spin_limit
+
 struct XchgArgs {
     double* vals;
     int n, world, rank;
+    unsigned spins;
     unsigned long long row;       // doubles per row
     unsigned long long seq;
     unsigned long long* const* peers;   // device array: base pointer of every rank's exchange buffer (own included)
@@ -49,27 +52,39 @@ __global__ void __launch_bounds__(256) xchg_allreduce_kernel(const XchgArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: the payload left this GPU
     __syncthreads();
-    if (tid < a.world)
+    if (tid < a.world) {
+        // release at SYSTEM scope ahead of the flag: whatever a cache level of this GPU may still hold of the payload is
+        // written back before a peer can see the sequence number (the stores above are write-through already; the fence is
+        // the architectural guarantee for memory the runtime could only give us coarse-grained)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __hip_atomic_store(xchg_flag(a.peers[tid], a.world, a.row, slot, a.rank), epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // 2. all rows of my own buffer have arrived
     if (tid < a.world) {
         unsigned long long* f = xchg_flag(a.peers[a.rank], a.world, a.row, slot, tid);
         bool ok = false;
-        for (unsigned spin = 0; spin < (1u << 26); ++spin) {
+        for (unsigned spin = 0; spin < a.spins; ++spin) {
             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) {
                 ok = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
         }
-        if (!ok) *a.timeout = 1 + tid;      // a peer never arrived: the host reports it, the sums are garbage
+        if (!ok) *a.timeout = 1 + tid;      // a peer never arrived: PeerExchange.check() reports it ...
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope
     }
     __syncthreads();
+    // ... and the result is POISONED, not a sum of stale rows: NaN statistics turn the loss into NaN at once, where a
+    // half-right BatchNorm would let the replicas drift apart silently (RCCL would simply have waited)
+    const bool timed_out = __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     // 3. rank-ordered sum, in place
     unsigned long long* mine = a.peers[a.rank];
     for (int i = tid; i < a.n; i += 256) {
+        if (timed_out) {
+            a.vals[i] = __longlong_as_double(0x7ff8000000000000ll);
+            continue;
+        }
         double s = 0.0;
         for (int r = 0; r < a.world; ++r)
             s += __longlong_as_double((long long)__hip_atomic_load(xchg_row(mine, a.world, a.row, slot, r) + i,
@@ -86,14 +101,17 @@ extern "C" size_t xv2_xchg_bytes(int world, size_t row_doubles) {
     return ((size_t)2 * world * row_doubles + (size_t)2 * world) * sizeof(double);
 }
 
-extern "C" int xv2_xchg_alloc(int world, size_t row_doubles, void** base_out, unsigned char* handle64) {
-    XV2_CHECK_ARG(world >= 1 && world <= 64 && row_doubles > 0 && base_out && handle64, "xchg_alloc: bad arguments");
+extern "C" int xv2_xchg_alloc(int world, size_t row_doubles, void** base_out, unsigned char* handle64, int* finegrained) {
+    XV2_CHECK_ARG(world >= 1 && world <= 64 && row_doubles > 0 && base_out && handle64 && finegrained, "xchg_alloc: bad arguments");
     const size_t bytes = xv2_xchg_bytes(world, row_doubles);
     void* p = nullptr;
-    // fine-grained (uncached at device scope) memory is what in-kernel cross-GPU signalling needs; plain device memory
-    // is the fallback (enough for ranks that share one GPU)
+    // fine-grained (coherent across GPUs while kernels run) memory is what in-kernel cross-GPU signalling needs.  Plain
+    // (coarse-grained) device memory is only coherent between kernels that run on the SAME GPU: *finegrained = 0 tells the
+    // caller, who may go on only if all ranks share one device and must use the collective library otherwise
+    *finegrained = 1;
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
         (void)hipGetLastError();
+        *finegrained = 0;
         XV2_CHECK_HIP(hipMalloc(&p, bytes));
     }
     XV2_CHECK_HIP(hipMemset(p, 0, bytes));
@@ -132,7 +150,13 @@ extern "C" int xv2_xchg_allreduce(double* vals, int n, const void* peers_dev, in
     a.vals = vals; a.n = n; a.world = world; a.rank = rank; a.row = row_doubles; a.seq = seq;
     a.peers = reinterpret_cast<unsigned long long* const*>(peers_dev);
     a.timeout = timeout_flag;
+    a.spins = g_xchg_spins;
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+extern "C" int xv2_xchg_set_spin_limit(unsigned polls) {
+    g_xchg_spins = polls ? polls : (1u << 26);
     return XV2_OK;
 }

@@ -6,8 +6,8 @@ sync_batchnorm=gpus > 1), main.py:106-107).
   gradient has been written, the bucket slice is all-reduced (SUM) on a side HIP stream, fenced by events, so
   the collective overlaps with the rest of backward.  The 1/world averaging is folded into the optimizer
   kernel (grad_scale), no extra pass.
-* xGMI is point-to-point (7 links per GPU): buckets are large (default 64 MiB) so each RCCL call is
-  bandwidth- not latency-bound; there is no per-parameter collective.
+* xGMI is point-to-point (7 links per GPU): buckets are large (64 MiB, but at least 8 per step so that the last one is a
+  small share of the gradients) so each RCCL call is bandwidth- not latency-bound; there is no per-parameter collective.
 * SyncBatchNorm: xview2_amd.nn.SYNC_BN makes every BN all-reduce its (sum, sum-of-squares) in forward and
   (sum g, sum g*xhat) in backward - same statistics as torch.nn.SyncBatchNorm.
 """
@@ -53,8 +53,16 @@ def init_from_env(backend=None):
 
 
 class GradReducer:
-    def __init__(self, optimizer, bucket_bytes=64 << 20, sync_bn=True, overlap=True):
+    MIN_BUCKETS = 8          # buckets per step at least: the LAST one (stem side) cannot overlap with anything, keep it small
+
+    def __init__(self, optimizer, bucket_bytes=None, sync_bn=True, overlap=True):
+        # default bucket: 64 MiB (bandwidth-bound RCCL calls over the point-to-point xGMI links), but never fewer than
+        # MIN_BUCKETS buckets per step - cfg2's 164 MB of gradients would otherwise travel as 3 collectives, the last third
+        # of them behind the end of backward; floor 1 MiB
         self.opt = optimizer
+        if bucket_bytes is None:
+            # (a bucket closes once it HOLDS the cap, i.e. overshoots by up to one parameter tensor: aim for 1.5 x MIN_BUCKETS)
+            bucket_bytes = max(1 << 20, min(64 << 20, 4 * optimizer.total * 2 // (3 * self.MIN_BUCKETS)))
         from . import ops
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.enabled = self.world > 1 or (ops.FORCE_COLLECTIVES and dist.is_initialized())
@@ -138,7 +146,34 @@ class GradReducer:
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
         self.handles = []
+        # one-shot SyncBatchNorm exchange: a timed-out exchange poisons its results with NaN (loud by itself); every ~4000
+        # exchanges (tens of steps) the host also reads the flag and names the rank
+        check_peer_exchange(every=4000)
         return 1.0 / self.world
+
+
+class PeerExchangeUnavailable(RuntimeError):
+    """the one-shot exchange cannot be used by this job (every rank raises it together): use the collective library"""
+
+
+def _all_ok(ok, group=None):
+    """True iff `ok` holds on EVERY rank (one MIN all-reduce through the process group, on the device the backend wants)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def _device_identity():
+    """(host, physical device) of this rank's current device"""
+    import socket
+    d = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(d)
+    ident = getattr(props, "uuid", None)
+    if ident is not None:
+        return (socket.gethostname(), str(ident))
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+    return (socket.gethostname(), "%s/%s" % (getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?")), vis, d)
 
 
 class PeerExchange:
@@ -146,35 +181,94 @@ class PeerExchange:
     exchange as ONE single-block launch on the compute stream - every rank stores its vector straight into its peers'
     exchange buffers (hipIpc-mapped, xGMI stores) and adds the rows in rank order - instead of one RCCL collective
     (~20-30 us of launch + ring latency) per BatchNorm layer and direction.  All ranks must live on one node.
-    Opt-in: XV2_SYNCBN=oneshot (the default keeps torch.distributed.all_reduce = RCCL: the peer path could only be
-    developed with ranks sharing ONE GPU here - tests/test_dist_gpu.py - never on a multi-GPU box)."""
+
+    Construction is COLLECTIVE and all-or-nothing: allocation, handle exchange, peer mapping and a bounded handshake
+    (`verify` exchanges of known vectors under a short spin limit, results checked against the rank-ordered host sum) each
+    end in an agreement round; if ANY rank failed ANY stage, every rank releases what it holds and raises
+    PeerExchangeUnavailable - `stats_all_reduce_` then stays with torch.distributed (XV2_SYNCBN=auto).  Coarse-grained
+    exchange memory (the runtime refused fine-grained) is accepted only when all ranks share ONE device.
+    Developed with ranks sharing one GPU (tests/test_dist_gpu.py, world 2 .. 8); it has never met an xGMI link, hence
+    the default transport stays RCCL and `auto` verifies before it trusts."""
     ROW = 2 * 2 * 4096          # doubles per row: S <= 2 parts x [C <= 4096][2]
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, verify=8):
         import ctypes
         from ._lib import lib
         self.lib = lib()
+        self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        base = ctypes.c_void_p()
+        self.base, self.peers, self.peers_dev, self.timeout, self.seq = None, [], None, None, 0
+        self.exchanges_since_check = 0
+        fail = os.environ.get("XV2_XCHG_TEST_FAIL")           # test hook: "stage:rank" makes that rank fail that stage
+        fail = tuple(fail.split(":")) if fail else None
+
+        def stage(name, fn):
+            ok, err = True, None
+            try:
+                if fail is not None and fail[0] == name and int(fail[1]) == self.rank:
+                    raise RuntimeError("injected failure (XV2_XCHG_TEST_FAIL)")
+                fn()
+            except Exception as e:  # noqa: BLE001  (whatever went wrong, the ranks must agree on it)
+                ok, err = False, e
+            if not _all_ok(ok, group):
+                self.close()
+                raise PeerExchangeUnavailable("one-shot SyncBatchNorm exchange unavailable: stage '%s' failed on %s"
+                                              % (name, "this rank: %s" % err if err is not None else "another rank"))
+
         handle = (ctypes.c_ubyte * 64)()
-        self._check(self.lib.xv2_xchg_alloc(self.world, ctypes.c_size_t(self.ROW), ctypes.byref(base), handle))
-        self.base = base.value
-        handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle), group=group)
-        self.peers = []
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                self.peers.append(self.base)
-                continue
-            pb = ctypes.c_void_p()
-            buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
-            self._check(self.lib.xv2_xchg_open(buf, ctypes.byref(pb)))
-            self.peers.append(pb.value)
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.peers_dev = torch.tensor(self.peers, dtype=torch.int64).to(dev)
-        self.timeout = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.seq = 0
+        fine = ctypes.c_int(0)
+
+        def alloc():
+            base = ctypes.c_void_p()
+            self._check(self.lib.xv2_xchg_alloc(self.world, ctypes.c_size_t(self.ROW), ctypes.byref(base), handle,
+                                                ctypes.byref(fine)))
+            self.base = base.value
+        stage("alloc", alloc)
+        infos = [None] * self.world
+        dist.all_gather_object(infos, (bytes(handle), int(fine.value), _device_identity()), group=group)
+        self.finegrained = all(i[1] for i in infos)
+        self.one_device = len({i[2] for i in infos}) == 1
+
+        def coherent():
+            if not self.finegrained and not self.one_device:
+                raise RuntimeError("the runtime granted only coarse-grained exchange memory and the ranks sit on different GPUs")
+        stage("memory", coherent)
+
+        def open_peers():
+            for r, (h, _, _) in enumerate(infos):
+                if r == self.rank:
+                    self.peers.append(self.base)
+                    continue
+                pb = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                self._check(self.lib.xv2_xchg_open(buf, ctypes.byref(pb)))
+                self.peers.append(pb.value)
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self.peers_dev = torch.tensor(self.peers, dtype=torch.int64).to(dev)
+            self.timeout = torch.zeros(1, dtype=torch.int32, device=dev)
+        stage("map", open_peers)
         dist.barrier(group=group)            # every rank has mapped every buffer before the first store
+
+        def handshake():
+            # bounded: ~2^21 polls (a fraction of a second) instead of the production limit; known vectors, checked on the host
+            self.lib.xv2_xchg_set_spin_limit(1 << 21)
+            try:
+                for k in range(verify):
+                    n = (1, 7, 512, self.ROW, 64, 4096, 3, 1000)[k % 8]
+                    rows = [torch.arange(n, dtype=torch.float64) * (0.5 + r) + (k + 1) * 0.125 * (r + 1) for r in range(self.world)]
+                    want = rows[0].clone()
+                    for r in range(1, self.world):
+                        want += rows[r]
+                    t = rows[self.rank].cuda()
+                    self.all_reduce_(t)
+                    got = t.cpu()                      # synchronises
+                    if int(self.timeout.item()) or not torch.equal(got, want):
+                        raise RuntimeError("handshake exchange %d of %d doubles returned %s" % (
+                            k, n, "a timeout" if int(self.timeout.item()) else "a wrong sum"))
+            finally:
+                self.lib.xv2_xchg_set_spin_limit(0)
+        if verify:
+            stage("handshake", handshake)
 
     def _check(self, rc):
         if rc != 0:
@@ -188,19 +282,28 @@ class PeerExchange:
             raise RuntimeError("PeerExchange.all_reduce_: contiguous fp64 tensor of <= %d elements expected" % self.ROW)
         call("xv2_xchg_allreduce", t, t.numel(), self.peers_dev, self.world, self.rank, self.ROW, self.seq, self.timeout)
         self.seq += 1
+        self.exchanges_since_check += 1
         return t
 
     def check(self):
-        """host-side: did any exchange give up waiting for a peer? (synchronises)"""
+        """host-side: did any exchange give up waiting for a peer? (synchronises; the kernel has poisoned every result
+        since with NaN, this names the rank)"""
+        self.exchanges_since_check = 0
         v = int(self.timeout.item())
         if v:
-            raise RuntimeError("peer exchange timed out waiting for rank %d" % (v - 1))
+            raise RuntimeError("peer exchange timed out waiting for rank %d (results since then are NaN)" % (v - 1))
 
     def close(self):
+        """unmap the peers' buffers and free this rank's own (all ranks, after their last exchange has completed)"""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         for r, pb in enumerate(self.peers):
             if r != self.rank and pb:
                 self.lib.xv2_xchg_close(ctypes_voidp(pb))
         self.peers = []
+        if self.base:
+            self.lib.xv2_xchg_free(ctypes_voidp(self.base))
+            self.base = None
 
 
 def ctypes_voidp(v):
@@ -209,20 +312,47 @@ def ctypes_voidp(v):
 
 
 _peer_exchange = None
+_peer_exchange_off = False        # auto mode: construction failed once - stay with the collective library
+
+
+def syncbn_transport():
+    """XV2_SYNCBN = rccl (default: torch.distributed.all_reduce) | auto (the one-shot peer exchange if its collective
+    construction and handshake succeed on every rank, else RCCL - with one warning) | oneshot (the peer exchange or an error)"""
+    return os.environ.get("XV2_SYNCBN", "rccl")
 
 
 def stats_all_reduce_(t):
-    """SUM all-reduce of a BatchNorm statistics vector (fp64, in place): RCCL by default, the one-shot peer exchange with
-    XV2_SYNCBN=oneshot"""
-    global _peer_exchange
-    if os.environ.get("XV2_SYNCBN", "rccl") == "oneshot" and t.is_cuda and t.numel() <= PeerExchange.ROW:
+    """SUM all-reduce of a BatchNorm statistics vector (fp64, in place)"""
+    global _peer_exchange, _peer_exchange_off
+    mode = syncbn_transport()
+    if mode in ("oneshot", "auto") and not _peer_exchange_off and t.is_cuda and t.numel() <= PeerExchange.ROW:
         if _peer_exchange is None:
-            _peer_exchange = PeerExchange()
-        return _peer_exchange.all_reduce_(t)
+            try:
+                _peer_exchange = PeerExchange()
+            except PeerExchangeUnavailable as e:
+                if mode == "oneshot":
+                    raise
+                _peer_exchange_off = True
+                if dist.get_rank() == 0:
+                    import warnings
+                    warnings.warn("%s - SyncBatchNorm statistics travel through torch.distributed.all_reduce instead" % e)
+        if _peer_exchange is not None:
+            return _peer_exchange.all_reduce_(t)
     dist.all_reduce(t)
     return t
 
 
+def check_peer_exchange(every=0):
+    """raise if an exchange has timed out; `every` > 0: only once that many exchanges have been issued since the last check
+    (the check synchronises the stream).  GradReducer.finish calls it every few steps, trainers at the end of an epoch."""
+    if _peer_exchange is not None and _peer_exchange.exchanges_since_check >= max(every, 1):
+        _peer_exchange.check()
+
+
 def reset_peer_exchange():
-    global _peer_exchange
+    """release the exchange buffers and mappings (collective: every rank, after its last exchange)"""
+    global _peer_exchange, _peer_exchange_off
+    if _peer_exchange is not None:
+        _peer_exchange.close()
     _peer_exchange = None
+    _peer_exchange_off = False

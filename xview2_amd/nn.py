@@ -65,6 +65,11 @@ def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthro
     hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel."""
     if not bn.training and not torch.is_grad_enabled() and x0.is_cuda and FUSED_INFERENCE:
         # inference: BatchNorm folded into the convolution epilogue (xv2_conv2d_forward_fused), no autograd node
+        tag = getattr(x0, "_xv2_lazy", None)
+        if tag is not None:
+            # XV2_LAZY_BN with a partially frozen network: the producer (BatchNorm in train mode) handed out its RAW
+            # convolution output tagged with its coefficients - materialise its BatchNorm + activation before convolving
+            x0 = ops._apply_pre(x0, tag)
         z = ops.conv_bn_act_infer(x0, x1, conv.weight, residual, _cfg(conv), ops.BnState(bn, False), act)
         return (z, x0) if passthrough else z
     bump_bn_counter(bn)

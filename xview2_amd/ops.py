@@ -1616,7 +1616,16 @@ class DeviceImage:
     def __getitem__(self, idx):
         if not isinstance(idx, tuple):
             idx = (idx,)
-        u8 = self.u8[idx[0]] if not isinstance(idx[0], int) else self.u8[idx[0]:idx[0] + 1]
+        if isinstance(idx[0], int):
+            # (the reference's batch["image"][i] drops the batch dimension; a DeviceImage is always a batch, so an integer
+            # index selects the one-image batch [i % N : i % N + 1] - negative indices count from the end, out of range raises)
+            n = self.u8.shape[0]
+            if not -n <= idx[0] < n:
+                raise IndexError("DeviceImage index %d out of range for a batch of %d" % (idx[0], n))
+            i = idx[0] % n
+            u8 = self.u8[i:i + 1]
+        else:
+            u8 = self.u8[idx[0]]
         c0, nch = self.c0, self.nch
         if len(idx) > 1:
             sl = idx[1]

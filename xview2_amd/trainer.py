@@ -94,6 +94,7 @@ class Trainer:
                 self.global_step += 1
                 if self.log_every and self.rank == 0 and self.global_step % self.log_every == 0:
                     print("epoch %d step %d loss %.5f" % (epoch, self.global_step, float(loss)))
+            xdist.check_peer_exchange()          # one-shot SyncBatchNorm exchange: a timed-out exchange is an error, per epoch
             score = self.validate(model, datamodule)
             if self.checkpointing:
                 ckdir = os.path.join(self.root, "checkpoints")
@@ -101,6 +102,8 @@ class Trainer:
                 if score is not None and (self.best_score is None or score >= self.best_score):
                     self.best_score = score
                     self.save_checkpoint(model, os.path.join(ckdir, "best.ckpt"), epoch, optimizer)
+        if self.world > 1:
+            xdist.reset_peer_exchange()          # unmap the peers' exchange buffers, free this rank's own
         return model
 
     @torch.no_grad()
