@@ -629,7 +629,11 @@ BLOCK_CASES = [("pre_resnest50", 2, 32), ("pre_resnest50_dil2", 2, 32), ("pre_re
                ("post_siamese_resnest50_ds", 2, 32), ("post_siamese_resnest101", 2, 32),
                ("post_fused_resnest50_attn_ds", 2, 32), ("post_fused_resnest200_attn_ds", 2, 32),
                ("post_fused_resnest200_attn_ds", 4, 32), ("pre_resnet50", 2, 32),
-               ("pre_resnest50", 2, 16), ("post_fused_resnest200_attn_ds", 2, 16), ("post_fused_resnest200_attn_ds", 4, 16)]
+               ("pre_resnest50", 2, 16), ("post_fused_resnest200_attn_ds", 2, 16), ("post_fused_resnest200_attn_ds", 4, 16),
+               # cfg4's / cfg5's own models against the oracle at 256 x 256 (the 64 x 64 tiles of the rows
+               # above put every layer on a one- or two-tile launch; at 256 x 256 the /4 level has 8192 rows, split-K and
+               # multi-tile statistics folds run) - a fourth field gives the tile size
+               ("post_siamese_resnest101", 2, 32, 256), ("post_fused_resnest200_attn_ds", 2, 32, 256)]
 
 
 def _nchw_cpu(t):
@@ -643,15 +647,17 @@ def _rms_rel(a, b):
     return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("name,batch,precision", BLOCK_CASES, ids=["%s-b%d-p%d" % c for c in BLOCK_CASES])
-def test_blockwise_teacher_forced_parity(name, batch, precision):
+@pytest.mark.parametrize("case", BLOCK_CASES, ids=["%s-b%d-p%d" % c[:3] + ("-s%d" % c[3] if len(c) > 3 else "") for c in BLOCK_CASES])
+def test_blockwise_teacher_forced_parity(case):
     from oracle import torch_ref
     from xview2_amd import criterion, ops
+    name, batch, precision = case[:3]
+    size = case[3] if len(case) > 3 else 64
     a = ARGS(**MODEL_CASES[name])
     ora, hip = build_pair(a)
     ora.train()
     hip.train()
-    x, y = model_input(a, batch=batch), labels(a, batch=batch)
+    x, y = model_input(a, batch=batch, size=size), labels(a, batch=batch, size=size)
     names = [n for n, m in hip.named_modules() if type(m).__name__ in FORCED_CLASSES]
     omods = dict(ora.named_modules())
     assert len(names) >= 10 and all(n in omods and type(omods[n]).__name__ in FORCED_CLASSES for n in names)
@@ -707,7 +713,8 @@ def test_blockwise_teacher_forced_parity(name, batch, precision):
     worst_rms = max(e[1] for e in errs)
     lrel = max(rel(h, o) for h, o in zip(ph, po))
     loss_rel = abs(float(loss_h) - float(loss_o)) / max(abs(float(loss_o)), 1e-12)
-    row = {"case": name, "batch": batch, "mode": "train, block-by-block from HIP inputs, precision %d" % precision,
+    row = {"case": name + ("" if size == 64 else " @%d" % size), "batch": batch,
+           "mode": "train, block-by-block from HIP inputs, precision %d" % precision,
            "branch": "every block 1e-3 + logits 1e-3 + exact argmax" if precision == 32 else "bf16: per-block rms, loss 1e-2",
            "blocks": len(errs), "block_max_rel": worst[0], "block_max_rel_at": worst[2], "block_max_rms_rel": worst_rms,
            "hip_vs_cpu32": lrel, "loss_hip": float(loss_h), "loss_cpu32": float(loss_o), "loss_rel": loss_rel}
