@@ -367,16 +367,18 @@ int xv2_bn_act_backward(const void* dz, int lddz, const void* z, int ldz, const 
                         float* dbeta, float* workspace, int dtype, void* stream);
 
 /* ---- pooling / resampling ----------------------------------------------------------------- */
-/* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order) */
+/* nn.MaxPool2d(3,2,1) (model/unet.py:81); idx = argmax tap (first maximum in scan order).  Backward passes of the pooling
+ * layers: accumulate != 0 ADDS the gradient onto what dx already holds - the gradient of the input's other consumer (the
+ * decoder's skip connection, model/unet.py:150-170) - instead of a separate elementwise sum. */
 int xv2_maxpool3x3s2_forward(const void* x, int N, int H, int W, int C, void* y, uint8_t* idx,
                              int dtype, void* stream);
 int xv2_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, int N, int H, int W, int C,
-                              void* dx, int dtype, void* stream);
+                              void* dx, int accumulate, int dtype, void* stream);
 /* nn.AvgPool2d(k, s, pad, count_include_pad) (ResNeSt avd / avg_down shortcuts) */
 int xv2_avgpool_forward(const void* x, int N, int H, int W, int C, int k, int s, int pad,
                         int count_include_pad, int OH, int OW, void* y, int dtype, void* stream);
 int xv2_avgpool_backward(const void* dy, int N, int H, int W, int C, int k, int s, int pad,
-                         int count_include_pad, int OH, int OW, void* dx, int dtype, void* stream);
+                         int count_include_pad, int OH, int OW, void* dx, int accumulate, int dtype, void* stream);
 /* F.adaptive_avg_pool2d(x, bins) (model/layers.py:14; bins=1 is the split-attention GAP) */
 int xv2_adaptive_avgpool_forward(const float* x, int ldx, int N, int H, int W, int C, int bins,
                                  float* y, void* stream);

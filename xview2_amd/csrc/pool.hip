@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dy,
                                                            const uint8_t* __restrict__ idx, int N, int H, int W,
-                                                           int C, int OH, int OW, T* __restrict__ dx) {
+                                                           int C, int OH, int OW, T* dx, int accumulate) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,6 +67,10 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
         const int ih = (int)(q % H);
         const int n = (int)(q / H);
         float a[4] = {0, 0, 0, 0};
+        if (accumulate) {      // dx already holds the gradient of the input's OTHER consumer (a skip connection): add onto it
+            const float4 old = ld4(dx + (((int64_t)n * H + ih) * W + iw) * C + c);
+            a[0] = old.x; a[1] = old.y; a[2] = old.z; a[3] = old.w;
+        }
         // windows with oh*2-1 <= ih <= oh*2+1
         const int oh0 = ih >> 1, oh1 = (ih + 1) >> 1;
         const int ow0 = iw >> 1, ow1 = (iw + 1) >> 1;
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(256) avgpool_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const T* __restrict__ dy, int N, int H, int W, int C,
                                                            int k, int s, int pad, int incl, int OH, int OW,
-                                                           T* __restrict__ dx) {
+                                                           T* dx, int accumulate) {
     const int C4 = C >> 2;
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -145,6 +149,7 @@ __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const T* __restrict__ 
         ow0 = ow0 <= 0 ? 0 : (ow0 + s - 1) / s;
         const int ow1 = min((iw + pad) / s, OW - 1);
         float4 a = make_float4(0, 0, 0, 0);
+        if (accumulate) a = ld4(dx + (((int64_t)n * H + ih) * W + iw) * C + c);      // see maxpool_bwd_kernel
         for (int oh = oh0; oh <= oh1; ++oh) {
             int lo, hi;
             const float dh = avg_divisor(oh, k, s, pad, H, incl, lo, hi);
@@ -320,12 +325,12 @@ extern "C" int xv2_maxpool3x3s2_forward(const void* x, int N, int H, int W, int 
     return XV2_OK;
 }
 extern "C" int xv2_maxpool3x3s2_backward(const void* dy, const uint8_t* idx, int N, int H, int W, int C, void* dx,
-                                         int dtype, void* stream) {
+                                         int accumulate, int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
     XV2_CHECK_DTYPE(dtype);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
-                                                 (hipStream_t)stream, (const T*)dy, idx, N, H, W, C, OH, OW, (T*)dx));
+                                                 (hipStream_t)stream, (const T*)dy, idx, N, H, W, C, OH, OW, (T*)dx, accumulate));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -340,12 +345,12 @@ extern "C" int xv2_avgpool_forward(const void* x, int N, int H, int W, int C, in
     return XV2_OK;
 }
 extern "C" int xv2_avgpool_backward(const void* dy, int N, int H, int W, int C, int k, int s, int pad,
-                                    int count_include_pad, int OH, int OW, void* dx, int dtype, void* stream) {
+                                    int count_include_pad, int OH, int OW, void* dx, int accumulate, int dtype, void* stream) {
     XV2_CHECK_ARG(C % 4 == 0, "avgpool: C=%d must be a multiple of 4", C);
     XV2_CHECK_DTYPE(dtype);
     XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(grid_for((int64_t)N * H * W * C / 4)), dim3(256), 0,
                                                  (hipStream_t)stream, (const T*)dy, N, H, W, C, k, s, pad,
-                                                 count_include_pad, OH, OW, (T*)dx));
+                                                 count_include_pad, OH, OW, (T*)dx, accumulate));
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

@@ -20,8 +20,9 @@ class ConvLayer(nn.Module):  # layers.py:89-100
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.batch_norm = nn.BatchNorm2d(out_channels, affine=True)
 
-    def forward(self, x0, x1=None, lazy_out=False):
-        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY, lazy_out=lazy_out)
+    def forward(self, x0, x1=None, lazy_out=False, passthrough=0):
+        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY, lazy_out=lazy_out,
+                               passthrough=passthrough)
 
 
 class ConvBlock(nn.Module):  # layers.py:119-128
@@ -41,9 +42,10 @@ class AttentionLayer(nn.Module):  # layers.py:68-77
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1, bias=False)
         self.batch_norm = nn.BatchNorm2d(out_channels, affine=True)
 
-    def forward(self, x, act=ops.ACT_NONE):
+    def forward(self, x, act=ops.ACT_NONE, passthrough=0):
         if self.conv.out_channels >= 32:
-            return xnn.conv_bn_act(self.conv, self.batch_norm, x, act=act)
+            return xnn.conv_bn_act(self.conv, self.batch_norm, x, act=act, passthrough=passthrough)
+        assert not passthrough
         # psi: 1 output channel -> narrow head kernel + stand-alone BN (+ fused sigmoid)
         y = xnn.head_conv(self.conv, x, nchw_out=False)
         return xnn.bn_act(self.batch_norm, y, act=act)
@@ -82,7 +84,14 @@ class UpsampleBlock(nn.Module):  # layers.py:131-168
         if self.skip_channels == 0:
             return self.conv_block(out)
         if self.attention:
-            r = ops.AddReluFn.apply(self.conv_o(out), self.conv_s(skip))
+            # `out` and `skip` each feed the gate AND the convolution block: the block side reads the alias the gate's 1x1
+            # convolution publishes of its input, so the two gradients are summed in that convolution's backward-data epilogue
+            if self.conv_o.conv.out_channels >= 32 and xnn.want_aliases(out, skip):
+                o, out = self.conv_o(out, passthrough=1)
+                sk, skip = self.conv_s(skip, passthrough=1)
+            else:
+                o, sk = self.conv_o(out), self.conv_s(skip)
+            r = ops.AddReluFn.apply(o, sk)
             gate = self.psi(r, act=ops.ACT_SIGMOID)
             skip = ops.GateMulFn.apply(skip, gate)
         return self.conv_block(out, skip)
@@ -142,10 +151,22 @@ class FusionBlock(nn.Module):  # layers.py:103-116
         self.conv_pre = ConvLayer(2 * channels, channels)
         self.conv_post = ConvLayer(2 * channels, channels)
 
+    input_aliases = None      # encoder side: what the OTHER consumers of this block's inputs should read (xnn.stage_with_input_alias)
+
     def forward(self, pre, post, dec_pre=None, dec_post=None, last_dec=False):
-        pre = self.pre_conv(pre, dec_pre) if dec_pre is not None or last_dec else self.pre_conv(pre)
-        post = self.post_conv(post, dec_post) if dec_post is not None or last_dec else self.post_conv(post)
-        return self.conv_pre(pre, post), self.conv_post(pre, post)   # virtual cat([pre, post], 1)
+        if dec_pre is not None or last_dec:
+            pre, post = self.pre_conv(pre, dec_pre), self.post_conv(post, dec_post)
+        else:
+            # encoder stages: the fused features entering here also feed the decoder's fusion blocks (skip connections)
+            pre, a_pre = xnn.stage_with_input_alias(self.pre_conv, pre)
+            post, a_post = xnn.stage_with_input_alias(self.post_conv, post)
+            self.input_aliases = (a_pre, a_post)
+        # virtual cat([pre, post], 1) feeds BOTH fusion convolutions: the second one reads the aliases the first one publishes of
+        # its two sources - the gradients of `pre` and `post` are then summed in the first one's backward-data epilogue
+        if xnn.want_aliases(pre, post):
+            f_pre, pre, post = self.conv_pre(pre, post, passthrough=3)
+            return f_pre, self.conv_post(pre, post)
+        return self.conv_pre(pre, post), self.conv_post(pre, post)
 
 
 class OutputBlock(nn.Module):  # layers.py:171-189; NHWC features in, NCHW logits out (what Model consumes)

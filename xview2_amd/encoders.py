@@ -30,6 +30,8 @@ class Bottleneck(nn.Module):
             self.downsample = xnn.Numbered(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False),
                                            nn.BatchNorm2d(planes * 4))
 
+    alias_request, alias_out = False, None      # xnn.stage_with_input_alias
+
     def forward(self, x):
         # the block input has two consumers (conv1 and the shortcut): the shortcut reads conv1's pass-through alias,
         # so its gradient is added inside conv1's backward-data kernel rather than by a separate elementwise pass
@@ -41,23 +43,35 @@ class Bottleneck(nn.Module):
         else:
             out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, lazy_out=lazy)
         out = xnn.conv_bn_act(self.conv2, self.bn2, out, act=ops.ACT_RELU)
-        idt = x if self.downsample is None else xnn.conv_bn_act(self.downsample[0], self.downsample[1], x)
+        if self.downsample is None:
+            idt = x
+        elif fuse and self.alias_request:
+            # a THIRD consumer of the block input (the decoder's skip connection) reads the shortcut convolution's alias: its
+            # gradient is summed in that convolution's backward-data epilogue (for the stride-2 shortcut also instead of the
+            # memset of the pixels no tap reaches)
+            idt, self.alias_out = xnn.conv_bn_act(self.downsample[0], self.downsample[1], x, passthrough=True)
+        else:
+            idt = xnn.conv_bn_act(self.downsample[0], self.downsample[1], x)
         return xnn.conv_bn_act(self.conv3, self.bn3, out, act=ops.ACT_RELU, residual=idt)
 
 
 class _Pool(nn.Module):
     """parameter-free pooling placeholders keep the numbering of nn.Sequential children"""
+    alias_request, alias_out = False, None      # xnn.stage_with_input_alias
 
     def __init__(self, fn):
         super().__init__()
         self.fn = fn
 
     def forward(self, x):
-        return self.fn(x)
+        if self.alias_request and xnn.want_aliases(x):
+            y, self.alias_out = self.fn(x, True)
+            return y
+        return self.fn(x, False)
 
 
 def _maxpool():
-    return _Pool(lambda x: ops.MaxPool3x3s2Fn.apply(x))
+    return _Pool(lambda x, alias: ops.MaxPool3x3s2Fn.apply(x, alias))
 
 
 class ResNet(nn.Module):
@@ -124,9 +138,12 @@ class StBottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
 
+    alias_request, alias_out = False, None      # xnn.stage_with_input_alias
+
     def forward(self, x):
         # conv1's pass-through alias feeds the shortcut (see Bottleneck.forward): one gradient sum less per block
-        if x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        fuse = x.is_cuda and torch.is_grad_enabled() and x.requires_grad
+        if fuse:
             out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True)
         else:
             out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
@@ -136,8 +153,17 @@ class StBottleneck(nn.Module):
         idt = x
         if self.downsample is not None:
             k = self.downsample.pool_k
-            pooled = x if k == 1 else ops.AvgPoolFn.apply(x, k, k, 0, True, False)
-            idt = xnn.conv_bn_act(self.downsample[1], self.downsample[2], pooled)
+            want = fuse and self.alias_request       # the decoder's skip connection reads the shortcut's alias (Bottleneck.forward)
+            if k == 1:
+                pooled = x
+            elif want:
+                pooled, self.alias_out = ops.AvgPoolFn.apply(x, k, k, 0, True, False, True)
+            else:
+                pooled = ops.AvgPoolFn.apply(x, k, k, 0, True, False)
+            if want and k == 1:
+                idt, self.alias_out = xnn.conv_bn_act(self.downsample[1], self.downsample[2], pooled, passthrough=True)
+            else:
+                idt = xnn.conv_bn_act(self.downsample[1], self.downsample[2], pooled)
         return xnn.conv_bn_act(self.conv3, self.bn3, out, act=ops.ACT_RELU, residual=idt)
 
 

@@ -64,10 +64,16 @@ class _EncoderMixin:
         return chn
 
     def _encode(self, x, suffix=""):
+        # every stage output has two consumers - the next stage and the decoder (skip connection / fusion block): the feature
+        # handed out is the ALIAS the next stage publishes of its input, so that the two gradients are summed inside that
+        # stage's first backward kernels instead of by an elementwise pass (xnn.stage_with_input_alias)
         feats = []
-        for i in range(5):
-            x = getattr(self, "enc_l%d%s" % (i + 1, suffix))(x)
-            feats.append(x)
+        x = getattr(self, "enc_l1%s" % suffix)(x)
+        for i in range(1, 5):
+            y, alias = xnn.stage_with_input_alias(getattr(self, "enc_l%d%s" % (i + 1, suffix)), x)
+            feats.append(alias)
+            x = y
+        feats.append(x)
         return feats
 
 
@@ -210,7 +216,11 @@ class _Fused(nn.Module, _EncoderMixin):
         pre, post = _pre(data), _post(data)
         feats = []
         for i in range(5):
-            pre, post = getattr(self, "fusion_block%d" % (i + 1))(pre, post)
+            fb = getattr(self, "fusion_block%d" % (i + 1))
+            pre, post = fb(pre, post)
+            if i > 0:      # the previous level's fused features: hand out the aliases this level's stages published of them
+                feats[i - 1] = fb.input_aliases
+            fb.input_aliases = None
             feats.append((pre, post))
         return feats
 

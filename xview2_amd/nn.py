@@ -61,8 +61,10 @@ FUSED_INFERENCE = True     # eval + no_grad: one launch per conv layer (tests sw
 
 
 def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False, lazy_out=False):
-    """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node.  passthrough=True returns (out, x0 alias):
-    hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel."""
+    """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node.  passthrough=True (or 1) returns (out, x0 alias):
+    hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel; 2 = alias of x1,
+    3 = (out, x0 alias, x1 alias)."""
+    passthrough = int(passthrough) & (3 if x1 is not None else 1)
     if not bn.training and not torch.is_grad_enabled() and x0.is_cuda and FUSED_INFERENCE:
         # inference: BatchNorm folded into the convolution epilogue (xv2_conv2d_forward_fused), no autograd node
         tag = getattr(x0, "_xv2_lazy", None)
@@ -71,11 +73,24 @@ def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthro
             # convolution output tagged with its coefficients - materialise its BatchNorm + activation before convolving
             x0 = ops._apply_pre(x0, tag)
         z = ops.conv_bn_act_infer(x0, x1, conv.weight, residual, _cfg(conv), ops.BnState(bn, False), act)
-        return (z, x0) if passthrough else z
+        return _with_aliases(z, x0, x1, passthrough)
     bump_bn_counter(bn)
     # lazy_out: the result feeds exactly ONE further conv_bn_act call and nothing else (see ops.ConvBnActFn.forward)
     return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
                                  ops.BnState(bn, SYNC_BN), act, bn.training, passthrough, lazy_out)
+
+
+def _with_aliases(z, x0, x1, passthrough):
+    if passthrough == 3:
+        return z, x0, x1
+    if passthrough == 2:
+        return z, x1
+    return (z, x0) if passthrough else z
+
+
+def want_aliases(*xs):
+    """pass-through aliases only matter (and only work) when gradients flow: every tensor on the device and differentiable"""
+    return torch.is_grad_enabled() and all(x is not None and x.is_cuda and x.requires_grad for x in xs)
 
 
 def conv(conv_m, x0, x1=None):
@@ -118,6 +133,29 @@ class Chain(Numbered):
         for m in self._modules.values():
             x = m(x)
         return x
+
+
+# A tensor with TWO consumers (an encoder stage's output: the next stage and the decoder's skip connection,
+# model/unet.py:150-170) costs autograd an elementwise sum of the two gradients - unless the consumer that runs its backward
+# LAST adds its contribution onto the other one's gradient inside its own kernel.  The first layers of a stage can do that
+# (ops.ConvBnActFn / MaxPool3x3s2Fn / AvgPoolFn with passthrough): asked to, the stage's first block publishes an ALIAS of its
+# input; the other consumers read the alias, their gradient reaches the block's first layers as `dpass` and is summed in the
+# backward-data epilogue / pooling backward.  Blocks keep returning a single tensor (forward hooks, nn.Sequential semantics):
+# the alias travels through two attributes of the block.
+def stage_with_input_alias(stage, x):
+    """-> (stage(x), tensor that x's OTHER consumers should read): the alias published by the stage's first block, or x"""
+    first = stage
+    while isinstance(first, Chain) and len(first) > 0:
+        first = first[0]
+    if not (want_aliases(x) and hasattr(first, "alias_request")):
+        return stage(x), x
+    first.alias_request = True
+    try:
+        y = stage(x)
+    finally:
+        first.alias_request = False
+    alias, first.alias_out = first.alias_out, None
+    return y, (alias if alias is not None else x)
 
 
 def to_nhwc_image(x_nchw):

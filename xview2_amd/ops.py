@@ -557,7 +557,7 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
     the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
     that produced source 0 - its BatchNorm-backward statistics are taken in the same epilogue when the plan allows."""
@@ -569,9 +569,12 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
     if add_to0 is not None and not (add_to0.is_contiguous() and tuple(add_to0.shape) == (N, IH, IW, C0t)
                                     and add_to0.dtype == dy.dtype):
         raise RuntimeError("backward_data: accumulation target has the wrong layout")
+    if add_to1 is not None and not (C1t and add_to1.is_contiguous() and tuple(add_to1.shape) == (N, IH, IW, C1t)
+                                    and add_to1.dtype == dy.dtype and G == 1):
+        raise RuntimeError("backward_data: accumulation target of the second source has the wrong layout")
     half = dy.dtype == torch.bfloat16
     dx0 = add_to0 if add_to0 is not None else _act((N, IH, IW, C0t), dy)
-    dx1 = _act((N, IH, IW, C1t), dy) if C1t else None
+    dx1 = add_to1 if add_to1 is not None else (_act((N, IH, IW, C1t), dy) if C1t else None)
     for gi in range(G):
         if ihwo_packs:
             ihwo = ihwo_packs[gi]
@@ -579,7 +582,7 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
             _, ihwo = _pack(w[gi * Coutg:(gi + 1) * Coutg], C0g + C1t, False, True, half)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
-        acc = 1 if add_to0 is not None else 0
+        acc = (1 if add_to0 is not None else 0) | (2 if add_to1 is not None else 0)
         if bnrec is not None and G == 1 and C1t == 0 and not half:
             tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
             if tiles > 0:
@@ -1033,8 +1036,11 @@ class ConvBnActFn(torch.autograd.Function):
         The alias must have exactly one consumer whose gradient tensor is not shared with anybody else."""
         _need_cuda(x0)
         ctx.set_materialize_grads(False)
+        passthrough = int(passthrough)          # bit 0: alias of x0, bit 1: alias of x1 (True = 1: x0 only)
+        if x1 is None:
+            passthrough &= 1
         ctx.passthrough = passthrough
-        x0_in = x0
+        x0_in, x1_in = x0, x1
         # Deferred BatchNorm apply (VERDICT r02 item 8; model/layers.py:96-100 between two convolutions): a producer called
         # with lazy_out=True returns its RAW convolution output y tagged with (scale, shift, act) instead of z; its one
         # consumer - this function - applies them in the operand load of the halo kernel and of the weight gradient
@@ -1097,12 +1103,18 @@ class ConvBnActFn(torch.autograd.Function):
         if FUSE_BN_BWD and not ctx.has_res:
             ctx.rec = _BnRec(y, stats[0], stats[1], stats[3], stats[4], act)
             z._xv2_bnrec = ctx.rec
+        if passthrough == 3:
+            return z, x0_in, x1_in
+        if passthrough == 2:
+            return z, x1_in
         if passthrough:
             return z, x0_in
         return z
 
     @staticmethod
-    def backward(ctx, dz, dpass=None):
+    def backward(ctx, dz, *dps):
+        dpass = dps[0] if ctx.passthrough & 1 else None
+        dpass1 = (dps[1] if ctx.passthrough == 3 else dps[0]) if ctx.passthrough & 2 else None
         if ctx.has_pre:
             x0, x1, weight, gamma, y, z, mean, invstd, scale, shift, psc, psf = ctx.saved_tensors
         else:
@@ -1110,24 +1122,32 @@ class ConvBnActFn(torch.autograd.Function):
         g = ctx.g
         if dz is None:
             dz = torch.zeros_like(y)
-        dpass = _same(dpass, y)
+        dpass, dpass1 = _same(dpass, y), _same(dpass1, y)
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
                                                ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec,
                                                ctx.split)
         ctx.rec = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            acc = None
-            if dpass is not None and g.groups == 1 and dpass.is_contiguous():
+            acc = acc1 = None
+            if dpass is not None and g.groups == 1 and dpass.is_contiguous() and tuple(dpass.shape) == tuple(x0.shape):
                 acc, dpass = dpass, None          # summed inside the backward-data epilogue
+            if (dpass1 is not None and g.groups == 1 and dpass1.is_contiguous() and x1 is not None
+                    and tuple(dpass1.shape) == tuple(x1.shape)):
+                acc1, dpass1 = dpass1, None
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
-                                           ctx.src_rec if dpass is None else None)
+                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1)
             ctx.src_rec = None
             if dpass is not None:
                 dx0 = dx0 + dpass
-        elif dpass is not None:
-            dx0 = dpass
+            if dpass1 is not None:
+                dx1 = dx1 + dpass1
+        else:
+            if dpass is not None:
+                dx0 = dpass
+            if dpass1 is not None:
+                dx1 = dpass1
         ctx.ihwo = None
         if not ctx.needs_input_grad[2]:
             dw = None
@@ -1239,6 +1259,7 @@ class HeadConvFn(torch.autograd.Function):
         call("xv2_head_conv_forward", x, Cin, N * H * W, H * W, Cin, Cout, w2, bias, y, 1 if nchw_out else 0, _dt(x))
         ctx.save_for_backward(x, w2)
         ctx.nchw, ctx.has_bias, ctx.wshape = nchw_out, bias is not None, weight.shape
+        ctx.params = (weight, bias)      # their gradients go straight into the flat gradient buffer (grad_slot)
         return y
 
     @staticmethod
@@ -1248,8 +1269,10 @@ class HeadConvFn(torch.autograd.Function):
         N, H, W, Cin = x.shape
         Cout = w2.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w2)
-        db = _f32((Cout,), x) if ctx.has_bias else None
+        pw, pb = ctx.params
+        ctx.params = None
+        dw = _grad_like(pw).view(Cout, Cin) if pw.is_contiguous() else torch.empty_like(w2)
+        db = _grad_like(pb) if ctx.has_bias else None
         ws = _ws(query("xv2_head_conv_backward_workspace", N * H * W, Cin, Cout), x)
         call("xv2_head_conv_backward", x, Cin, dy, N * H * W, H * W, Cin, Cout, w2, 1 if ctx.nchw else 0, dx, Cin,
              dw, db, ws, _dt(x))
@@ -1278,10 +1301,22 @@ class BnActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, dres, None, None, None
 
 
+def _acc_target(dpass, like_shape, like):
+    """the pass-through alias's gradient if the kernel can add onto it in place (same layout and element type), else None"""
+    if dpass is not None and dpass.is_contiguous() and tuple(dpass.shape) == tuple(like_shape) and dpass.dtype == like.dtype:
+        return dpass
+    return None
+
+
 class MaxPool3x3s2Fn(torch.autograd.Function):
+    """passthrough=True: also return x itself as a second output (see ConvBnActFn.forward): x's OTHER consumer - the decoder's
+    skip connection - reads that alias, its gradient arrives here and the backward kernel adds onto it in place"""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, passthrough=False):
         _need_cuda(x)
+        ctx.set_materialize_grads(False)
+        x_in = x
         x = x.contiguous()
         N, H, W, C = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -1290,21 +1325,29 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         call("xv2_maxpool3x3s2_forward", x, N, H, W, C, y, idx, _dt(x))
         ctx.save_for_backward(idx)
         ctx.shape = (N, H, W, C)
-        return y
+        return (y, x_in) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         (idx,) = ctx.saved_tensors
         N, H, W, C = ctx.shape
-        dx = _act(ctx.shape, dy)
-        call("xv2_maxpool3x3s2_backward", dy.contiguous(), idx, N, H, W, C, dx, _dt(dy))
-        return dx
+        if dy is None:
+            return dpass, None
+        dy = dy.contiguous()
+        acc = _acc_target(dpass, ctx.shape, dy)
+        dx = acc if acc is not None else _act(ctx.shape, dy)
+        call("xv2_maxpool3x3s2_backward", dy, idx, N, H, W, C, dx, 1 if acc is not None else 0, _dt(dy))
+        if dpass is not None and acc is None:
+            dx = dx + _same(dpass, dx)
+        return dx, None
 
 
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, s, pad, ceil_mode, count_include_pad):
+    def forward(ctx, x, k, s, pad, ceil_mode, count_include_pad, passthrough=False):
         _need_cuda(x)
+        ctx.set_materialize_grads(False)
+        x_in = x
         x = x.contiguous()
         N, H, W, C = x.shape
 
@@ -1318,14 +1361,20 @@ class AvgPoolFn(torch.autograd.Function):
         y = _act((N, OH, OW, C), x)
         call("xv2_avgpool_forward", x, N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW, y, _dt(x))
         ctx.cfg = (N, H, W, C, k, s, pad, 1 if count_include_pad else 0, OH, OW)
-        return y
+        return (y, x_in) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         N, H, W, C, k, s, pad, inc, OH, OW = ctx.cfg
-        dx = _act((N, H, W, C), dy)
-        call("xv2_avgpool_backward", dy.contiguous(), N, H, W, C, k, s, pad, inc, OH, OW, dx, _dt(dy))
-        return dx, None, None, None, None, None
+        if dy is None:
+            return dpass, None, None, None, None, None, None
+        dy = dy.contiguous()
+        acc = _acc_target(dpass, (N, H, W, C), dy)
+        dx = acc if acc is not None else _act((N, H, W, C), dy)
+        call("xv2_avgpool_backward", dy, N, H, W, C, k, s, pad, inc, OH, OW, dx, 1 if acc is not None else 0, _dt(dy))
+        if dpass is not None and acc is None:
+            dx = dx + _same(dpass, dx)
+        return dx, None, None, None, None, None, None
 
 
 class AdaptiveAvgPoolFn(torch.autograd.Function):
