@@ -522,6 +522,20 @@ int xv2_prof_summary(int kid, double* total_ms, double* total_flops, double* tot
 int xv2_prof_num_records(void);
 int xv2_prof_record(int i, int* kid, double* ms, double* flops, double* algorithmic_bytes);
 
+/* ---- training-time augmentation of the uint8 tiles on the device ---------------------------------------
+ * The albumentations recipe the reference's datasets apply to the uint8 tile before A.Normalize()
+ * (data_loading/pytorch_loader.py:57-63,77-91): CropNonEmptyMaskIfExists(512, 512), HorizontalFlip, VerticalFlip, GaussNoise,
+ * RandomBrightnessContrast.  The random DECISIONS are drawn on the host; this launch moves the bytes - crop origin + flips as a
+ * gather, the Gaussian field from a counter-based generator (splitmix64 of seed and element index, Box-Muller in fp64; the
+ * same field on host and device), brightness / contrast as a 256-entry table per image - for image and mask together.
+ * params: [N][16] int32 in device memory = {src, H, W, y0, x0, hflip, vflip, noise[2], sigma[2] (float bits), seed_lo[2],
+ * seed_hi[2], lut bits}; src_img / src_mask: device arrays of device pointers to the source tiles (uint8 [H][W][C] /
+ * [H][W]; src_mask may be NULL), row `src` of them belongs to the sample; luts [N][2][256]; outputs img [N][h][w][C] and
+ * mask [N][h][w].  C = 3 (pre) or 6 (pre | post: the two images draw their own noise and table).  Bit-exact against
+ * xview2_amd.data_loading.device_aug.apply_params_numpy (tests/test_augment_gpu.py). */
+int xv2_augment_u8(const void* params, const void* src_img, const void* src_mask, const uint8_t* luts, int N, int C,
+                   int h, int w, uint8_t* img, uint8_t* mask, void* stream);
+
 /* ---- SyncBatchNorm statistics exchange without a collective library call ------------------------------------------
  * (reference: Trainer(sync_batchnorm=gpus > 1), main.py:106 - torch.nn.SyncBatchNorm exchanges <= 32 KB per BatchNorm
  * layer and direction, 126 ... 606 times per step).  Every rank allocates one exchange buffer (xv2_xchg_alloc returns

@@ -95,21 +95,47 @@ def test_training_samples_follow_the_index_and_always_contain_buildings(tree):
 
 
 def test_geometric_augmentations_move_image_and_mask_together():
+    from xview2_amd.data_loading import device_aug as da
     pl._rng_holder["rng"] = np.random.default_rng(0)
     img = np.zeros((64, 64, 3), np.uint8)
     mask = np.zeros((64, 64), np.uint8)
     img[5:9, 50:60] = 200
     mask[5:9, 50:60] = 1
-    for axis in (0, 1):
-        a, b = pl.flip(img, mask, axis, p=1.0)
+    base = {"H": 64, "W": 64, "h": 64, "w": 64, "y0": 0, "x0": 0, "hflip": False, "vflip": False, "noise": [None], "lut": [None]}
+    for key in ("hflip", "vflip"):
+        a, b = da.apply_params_numpy(img, mask, dict(base, **{key: True}))
         assert np.array_equal(a[:, :, 0] > 0, b > 0)
         assert not np.array_equal(b, mask)
     big_i, big_m = pl.random_scale(np.tile(img, (10, 10, 1)), np.tile(mask, (10, 10)), p=1.0)
     assert big_i.shape[:2] == big_m.shape and 640 <= big_m.shape[0] <= 832
-    lut = pl.random_brightness_contrast(img, p=1.0)
-    assert lut.dtype == np.uint8 and lut.shape == img.shape
-    noisy = pl.gauss_noise(np.full((32, 32, 3), 128, np.uint8), p=1.0)
-    assert noisy.dtype == np.uint8 and 2.0 < noisy.astype(np.float32).std() < 9.0       # sigma in [sqrt10, sqrt50]
+    flat = np.full((32, 32, 3), 128, np.uint8)
+    noisy, _ = da.apply_params_numpy(flat, np.zeros((32, 32), np.uint8),
+                                     dict(base, H=32, W=32, h=32, w=32, noise=[(30.0 ** 0.5, 12345)]))
+    assert noisy.dtype == np.uint8 and 4.5 < noisy.astype(np.float32).std() < 6.5       # sigma = sqrt(30) = 5.48
+
+
+def test_decisions_follow_the_reference_recipe():
+    """device_aug.draw_params: probabilities and ranges of pytorch_loader.py:57-63 (0.33 / 0.33 flips, GaussNoise p = 0.1 with
+    var in (10, 50), RandomBrightnessContrast p = 0.2 with limits 0.2), crop windows that contain a foreground pixel"""
+    from xview2_amd.data_loading import device_aug as da
+    rng = np.random.default_rng(3)
+    mask = np.zeros((1024, 1024), np.uint8)
+    mask[700:720, 100:130] = 1
+    n = 4000
+    ps = [da.draw_params(rng, mask, 2) for _ in range(n)]
+    assert abs(sum(p["hflip"] for p in ps) / n - 0.33) < 0.03 and abs(sum(p["vflip"] for p in ps) / n - 0.33) < 0.03
+    nz = [q for p in ps for q in p["noise"]]
+    assert abs(sum(q is not None for q in nz) / len(nz) - 0.1) < 0.02
+    assert all(10.0 <= q[0] ** 2 <= 50.0 for q in nz if q is not None)
+    luts = [q for p in ps for q in p["lut"]]
+    assert abs(sum(q is not None for q in luts) / len(luts) - 0.2) < 0.03
+    for p in ps[:200]:
+        assert 0 <= p["y0"] <= 512 and 0 <= p["x0"] <= 512
+        assert mask[p["y0"]:p["y0"] + 512, p["x0"]:p["x0"] + 512].any()
+    f = da.hash_normal_field(99, 1 << 20, 3.0)                 # the counter-based Gaussian field: moments of N(0, 9)
+    assert abs(float(f.mean())) < 0.02 and abs(float(f.std()) - 3.0) < 0.02
+    assert abs(float((np.abs(f) < 3.0).mean()) - 0.6827) < 0.003
+    assert np.array_equal(f[:1000], da.hash_normal_field(99, 1000, 3.0))      # element i depends on (seed, i) only
 
 
 def test_build_index_flags_classes_like_generate_idx(tree):

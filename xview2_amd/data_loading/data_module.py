@@ -31,6 +31,89 @@ class _OnDevice:
             yield out
 
 
+class DeviceAugLoader:
+    """Training loader with the augmentation ON THE DEVICE (include/xv2.h xv2_augment_u8).
+
+    Every tile is decoded once (PIL, a small thread pool running ahead of the consumer) and then lives in HBM as uint8
+    (device_aug.DeviceTileCache: xBD's training set is 20 GB of 288); per sample the host only draws the decisions
+    (device_aug.draw_params - the same stream, in the same order, as the worker path of pytorch_loader._TrainBase._augment,
+    so both paths deliver the same bytes from the same seed) and ONE launch per batch crops, flips, adds the noise and applies
+    the brightness / contrast tables to image and mask; the result goes to the network as an ops.DeviceImage.  RandomScale
+    (p = 0.2, bicubic) stays on the host: the tile comes back from the cache, is zoomed and cropped there and travels as a
+    one-off 512 x 512 source.  Sampling = DataLoader(shuffle=True, drop_last=True) / DistributedSampler semantics."""
+
+    def __init__(self, dataset, batch_size, device, rank=0, world_size=1, seed=0, threads=4, shuffle=True):
+        from .device_aug import DeviceAugmenter, DeviceTileCache
+        self.ds, self.bs, self.device = dataset, int(batch_size), torch.device(device)
+        self.rank, self.world, self.seed, self.epoch, self.shuffle = rank, world_size, seed, 0, shuffle
+        self.cache = DeviceTileCache(self.device)
+        self.aug = DeviceAugmenter(self.cache)
+        self.rows, self.host_masks = {}, {}
+        self.threads = max(1, int(threads))
+        self.rng = None
+
+    def __len__(self):
+        return (len(self.ds) // self.world) // self.bs
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _order(self):
+        import numpy as np
+        n = len(self.ds)
+        order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        per = n // self.world                      # (DistributedSampler pads; drop_last training can simply truncate)
+        return [int(i) for i in order[self.rank:per * self.world:self.world]]
+
+    def _row(self, i, pending):
+        k = self.ds.key(i)
+        if k not in self.rows:
+            img, lbl = pending.pop(i).result() if i in pending else self.ds.load(i)
+            self.rows[k] = self.cache.add(img, lbl)
+            self.host_masks[k] = lbl
+        return self.rows[k], self.host_masks[k]
+
+    def __iter__(self):
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        from . import pytorch_loader as pl
+        from .device_aug import draw_params
+        from ..ops import DeviceImage
+        if self.rng is None:
+            self.rng = pl._rng()                   # the stream the worker path would consume (seed_worker / the module default)
+        order = self._order()
+        ahead = 4 * self.bs
+        with ThreadPoolExecutor(self.threads) as pool:
+            pending = {}
+
+            def prefetch(pos):
+                for j in order[pos:pos + ahead]:
+                    if self.ds.key(j) not in self.rows and j not in pending:
+                        pending[j] = pool.submit(self.ds.load, j)
+            for b in range(len(order) // self.bs):
+                prefetch(b * self.bs)
+                plist, rows, extra = [], [], []
+                for i in order[b * self.bs:(b + 1) * self.bs]:
+                    row, mask = self._row(i, pending)
+                    s = pl.draw_scale(self.rng)
+                    if s is None:
+                        plist.append(draw_params(self.rng, mask, self.cache.imgs[row].shape[2] // 3))
+                        rows.append(row)
+                        continue
+                    # zoomed sample: resize on the host, crop there, upload the window as a one-off source tile
+                    img, zmask = pl.apply_scale(self.cache.imgs[row].cpu().numpy(), mask, s)
+                    p = draw_params(self.rng, zmask, img.shape[2] // 3)
+                    y0, x0 = p["y0"], p["x0"]
+                    win = np.ascontiguousarray(img[y0:y0 + p["h"], x0:x0 + p["w"]])
+                    wm = np.ascontiguousarray(zmask[y0:y0 + p["h"], x0:x0 + p["w"]])
+                    p.update(H=p["h"], W=p["w"], y0=0, x0=0)
+                    extra.append((torch.from_numpy(win).to(self.device), torch.from_numpy(wm).to(self.device)))
+                    plist.append(p)
+                    rows.append(len(self.cache) + len(extra) - 1)
+                img, mask = self.aug(plist, rows, extra)
+                yield {"image": DeviceImage(img), "mask": mask}
+
+
 class DataModule:
     def __init__(self, args, device="cuda", rank=0, world_size=1):
         self.args, self.device, self.rank, self.world_size = args, device, rank, world_size
@@ -62,7 +145,15 @@ class DataModule:
 
     def train_dataloader(self):
         if getattr(self, "_train", None) is None:
-            self._train = self._loader(self.train_path, True, self.train_loader_kwargs)
+            # augmentation on the device, tiles resident in HBM (DeviceAugLoader); XV2_DEVICE_AUG=0, --autoaugment (a PIL policy)
+            # or the host-normalise switch keep the reference's worker pipeline
+            if (self.raw_u8 and os.environ.get("XV2_DEVICE_AUG", "1") != "0" and
+                    not getattr(self.args, "autoaugment", False)):
+                ds = fetch_pytorch_loader(self.train_path, self.args.type, True, {"batch_size": 1}, False, True).dataset
+                self._train = DeviceAugLoader(ds, self.args.batch_size, self.device, self.rank, self.world_size,
+                                              seed=getattr(self.args, "seed", 0) or 0, threads=max(2, self.args.num_workers))
+            else:
+                self._train = self._loader(self.train_path, True, self.train_loader_kwargs)
         return self._train
 
     def val_dataloader(self):

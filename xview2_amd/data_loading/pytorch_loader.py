@@ -100,11 +100,20 @@ def build_index(train_path, out_csv=None):
 
 
 # ---- augmentations (albumentations 0.5 recipes named in pytorch_loader.py:57-63) ---------------------------------
+def draw_scale(rng, p=0.2, scale_limit=(0.0, 0.3)):
+    """the decision of A.RandomScale(p=0.2, scale_limit=(0, 0.3)): None, or the zoom factor"""
+    if rng.random() >= p:
+        return None
+    return 1.0 + rng.uniform(*scale_limit)
+
+
 def random_scale(img, mask, p=0.2, scale_limit=(0.0, 0.3)):
     """A.RandomScale(p=0.2, scale_limit=(0, 0.3), interpolation=cv2.INTER_CUBIC); masks use nearest"""
-    if _rng().random() >= p:
-        return img, mask
-    s = 1.0 + _rng().uniform(*scale_limit)
+    s = draw_scale(_rng(), p, scale_limit)
+    return (img, mask) if s is None else apply_scale(img, mask, s)
+
+
+def apply_scale(img, mask, s):
     h, w = mask.shape[:2]
     nh, nw = int(round(h * s)), int(round(w * s))
     chans = [np.asarray(Image.fromarray(np.ascontiguousarray(img[:, :, i:i + 3])).resize((nw, nh), Image.BICUBIC))
@@ -113,6 +122,8 @@ def random_scale(img, mask, p=0.2, scale_limit=(0.0, 0.3)):
     return np.concatenate(chans, 2), mask
 
 
+# crop / flips / noise / brightness-contrast: decisions drawn by device_aug.draw_params (same order and probabilities as
+# pytorch_loader.py:77-91), bytes moved by device_aug.apply_params_numpy here or by ONE launch on the GPU (xv2_augment_u8)
 def crop_non_empty_mask_if_exists(img, mask, height=512, width=512):
     """A.CropNonEmptyMaskIfExists(p=1): a window around a random foreground pixel, else a random window"""
     H, W = mask.shape[:2]
@@ -127,29 +138,6 @@ def crop_non_empty_mask_if_exists(img, mask, height=512, width=512):
         y0 = int(_rng().integers(0, H - height + 1))
         x0 = int(_rng().integers(0, W - width + 1))
     return img[y0:y0 + height, x0:x0 + width], mask[y0:y0 + height, x0:x0 + width]
-
-
-def flip(img, mask, axis, p=0.33):
-    if _rng().random() >= p:
-        return img, mask
-    return np.ascontiguousarray(np.flip(img, axis)), np.ascontiguousarray(np.flip(mask, axis))
-
-
-def gauss_noise(img, p=0.1, var_limit=(10.0, 50.0)):
-    if _rng().random() >= p:
-        return img
-    sigma = _rng().uniform(*var_limit) ** 0.5
-    noisy = img.astype(np.float32) + _rng().normal(0.0, sigma, img.shape).astype(np.float32)
-    return np.clip(noisy, 0, 255).astype(np.uint8)
-
-
-def random_brightness_contrast(img, p=0.2, limit=0.2):
-    if _rng().random() >= p:
-        return img
-    alpha = 1.0 + _rng().uniform(-limit, limit)
-    beta = _rng().uniform(-limit, limit)
-    lut = np.clip(np.arange(256, dtype=np.float32) * alpha + beta * 255.0, 0, 255).astype(np.uint8)
-    return lut[img]
 
 
 def normalize(img):
@@ -191,14 +179,11 @@ class _TrainBase(Dataset):
             mask = np.asarray(out[1])
             img = np.concatenate([np.asarray(p) for p in (out[0],) + tuple(out[2:])], 2)
             return _finish(img, mask, self.raw_u8)
+        from .device_aug import apply_params_numpy, draw_params
         img, mask = random_scale(img, mask)
-        img, mask = crop_non_empty_mask_if_exists(img, mask)
-        img, mask = flip(img, mask, 1)      # HorizontalFlip
-        img, mask = flip(img, mask, 0)      # VerticalFlip
-        parts = [img[:, :, i:i + 3] for i in range(0, img.shape[2], 3)]
-        parts = [gauss_noise(p) for p in parts]                 # drawn per image, like two A.GaussNoise calls
-        parts = [random_brightness_contrast(p) for p in parts]
-        return _finish(np.concatenate(parts, 2), mask, self.raw_u8)
+        prm = draw_params(_rng(), mask, img.shape[2] // 3)      # crop, hflip, vflip, noise per image, brightness per image
+        img, mask = apply_params_numpy(img, mask, prm)          # (data_module.DeviceAugLoader: the same bytes in one GPU launch)
+        return _finish(img, mask, self.raw_u8)
 
 
 class TrainPreDataset(_TrainBase):  # pytorch_loader.py:53-94
@@ -210,9 +195,15 @@ class TrainPreDataset(_TrainBase):  # pytorch_loader.py:53-94
     def __len__(self):
         return len(self.idx)
 
+    def key(self, i):
+        return self.idx[i]
+
+    def load(self, i):
+        """the decoded, un-augmented tile of sample i: (uint8 [H, W, 3] in B,G,R order, uint8 mask)"""
+        return load_pair(self.imgs_pre[self.idx[i]], self.lbls_pre[self.idx[i]])
+
     def __getitem__(self, i):
-        img, lbl = load_pair(self.imgs_pre[self.idx[i]], self.lbls_pre[self.idx[i]])
-        return self._augment(img, lbl)
+        return self._augment(*self.load(i))
 
 
 class TrainPostDataset(_TrainBase):  # pytorch_loader.py:97-148
@@ -231,11 +222,18 @@ class TrainPostDataset(_TrainBase):  # pytorch_loader.py:97-148
     def __len__(self):
         return len(self.idx)
 
-    def __getitem__(self, i):
+    def key(self, i):
+        return self.idx[i]
+
+    def load(self, i):
+        """the decoded, un-augmented pair of sample i: (uint8 [H, W, 6] = pre | post in B,G,R order, uint8 post mask)"""
         k = self.idx[i]
         img_pre, _ = load_pair(self.imgs_pre[k], self.lbls_pre[k])
         img_post, lbl = load_pair(self.imgs_post[k], self.lbls_post[k])
-        return self._augment(np.concatenate((img_pre, img_post), 2), lbl)
+        return np.concatenate((img_pre, img_post), 2), lbl
+
+    def __getitem__(self, i):
+        return self._augment(*self.load(i))
 
 
 class TestDataset(Dataset):  # pytorch_loader.py:151-171
