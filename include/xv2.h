@@ -209,11 +209,12 @@ int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int ldd
  * partials[tile][C0][2] = (sum g, sum g * xhat), g = dx * act'(bn_y * scale + shift), xhat = (bn_y - mean) * invstd -
  * what xv2_bn_act_backward_reduce would compute with a separate pass over dz and y.  Only layers WITHOUT a residual
  * before the activation.  `*_bn_tiles` returns the tile count of the plan, or 0 if the shape has no fused form
- * (stride 2, two sources, split-K plan, bf16 math): then use the plain calls.  Fold the partials with
+ * (stride 2, two sources, split-K plan, the 32-channel direct plan outside XV2_MATH_F32, XV2_MATH_BF16): then use the plain
+ * calls.  All storage types since round 4 (bf16: g from the ROUNDED dx, y read as stored).  Fold the partials with
  * xv2_bn_backward_reduce_partials (scratch as for xv2_bn_reduce_stats). */
 int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace);
-int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
-                                float* dx0, int lddx0, int accumulate, const float* bn_y, int ld_bn_y,
+int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ihwo,
+                                void* dx0, int lddx0, int accumulate, const void* bn_y, int ld_bn_y,
                                 const float* bn_mean, const float* bn_invstd, const float* bn_scale,
                                 const float* bn_shift, int bn_act, float* partials, float* workspace,
                                 void* stream);

@@ -593,21 +593,25 @@ def test_f1_device_counts_match_the_reference_bookkeeping(task, loss_str):
     assert torch.equal(torch.as_tensor(d[0]), torch.as_tensor(c[0]))
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 3), (1, 64, 64, 32, 32, 3), (2, 16, 16, 128, 256, 1)])
-def test_bn_backward_statistics_taken_in_the_consumer_dgrad_epilogue(shape):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 3), (1, 64, 64, 32, 32, 3), (2, 16, 16, 128, 256, 1), (2, 32, 32, 256, 128, 3)])
+def test_bn_backward_statistics_taken_in_the_consumer_dgrad_epilogue(shape, dtype):
     """xv2_conv2d_backward_data_bn (opt-in, ops.FUSE_BN_BWD): conv+BN+ReLU -> conv+BN+ReLU; the first layer's
     (sum g, sum g*xhat) come out of the second layer's backward-data epilogue.  Gradients must match the default
     path (separate column-reduction pass) to rounding."""
     from xview2_amd import ops
     N, H, W, C0, C1, k = shape
     torch.manual_seed(7)
-    x = torch.randn(N, H, W, C0, device=dev())
+    x = torch.randn(N, H, W, C0, device=dev()).to(dtype)
     w1 = (torch.randn(C1, C0, k, k, device=dev()) * 0.1)
     w2 = (torch.randn(C1, C1, k, k, device=dev()) * 0.1)
-    dz = torch.randn(N, H, W, C1, device=dev())
+    dz = torch.randn(N, H, W, C1, device=dev()).to(dtype)
     res = {}
+    from xview2_amd import _capi
+    fused_launches = 0
     for fuse in (False, True):
         ops.FUSE_BN_BWD = fuse
+        ops.set_storage_dtype(dtype)
         try:
             bn1, bn2 = torch.nn.BatchNorm2d(C1).to(dev()), torch.nn.BatchNorm2d(C1).to(dev())
             a = x.clone().requires_grad_(True)
@@ -615,12 +619,20 @@ def test_bn_backward_statistics_taken_in_the_consumer_dgrad_epilogue(shape):
             g = ops.conv_cfg(k, k, 1, k // 2)
             h = ops.ConvBnActFn.apply(a, None, p1, bn1.weight, bn1.bias, None, g, ops.BnState(bn1), ops.ACT_RELU, True)
             z = ops.ConvBnActFn.apply(h, None, p2, bn2.weight, bn2.bias, None, g, ops.BnState(bn2), ops.ACT_LEAKY, True)
+            rec = getattr(h, "_xv2_bnrec", None)
             z.backward(dz)
             res[fuse] = (a.grad.clone(), p1.grad.clone(), bn1.weight.grad.clone(), bn1.bias.grad.clone(), p2.grad.clone())
+            if fuse:
+                d = ops._desc(N, H, W, C1, 0, C1, g, H, W, dtype == torch.bfloat16)
+                fused_launches = _capi.query("xv2_conv2d_backward_data_bn_tiles", d, 0, 1)
+                assert rec is not None
         finally:
             ops.FUSE_BN_BWD = False
+            ops.set_storage_dtype(None)
+    if shape in ((2, 32, 64, 64, 64, 3), (2, 16, 16, 128, 256, 1)):      # (the others: direct 32-channel plan / split-K plan)
+        assert fused_launches > 0, "the fused form was not planned for this shape: the test compared nothing"
     for name, u, v in zip(("dx", "dw1", "dgamma1", "dbeta1", "dw2"), res[True], res[False]):
-        close(u, v, 2e-5, name)
+        close(u, v, 2e-5 if dtype == torch.float32 else 1e-2, name)
     assert torch.equal(res[True][4], res[False][4])        # the second layer itself is untouched
 
 

@@ -1039,6 +1039,17 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             }
         }
     }
+    // BN-backward statistics of the producer layer (see IgemmParams::bnb_*): a thread keeps ONE group of 4 channels through
+    // every staging pass (256 % (BN / 4) == 0), so its coefficients are loaded once and its sums run over the whole tile
+    const bool bnb = p.bnb_y && !(p.ksplit > 1);
+    float4 bmu = make_float4(0, 0, 0, 0), bis = bmu, bsc = bmu, bsf = bmu, bs1 = bmu, bs2 = bmu;
+    if (bnb) {
+        const int bc = n0 + (tid % (BN / 4)) * 4;
+        bmu = *reinterpret_cast<const float4*>(p.bnb_mean + bc);
+        bis = *reinterpret_cast<const float4*>(p.bnb_invstd + bc);
+        bsc = *reinterpret_cast<const float4*>(p.bnb_scale + bc);
+        bsf = *reinterpret_cast<const float4*>(p.bnb_shift + bc);
+    }
 #pragma unroll
   for (int hh = 0; hh < NH; ++hh) {
     if (NH == 1 || (wm * WTM) / HROWS == hh) {
@@ -1093,17 +1104,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         constexpr int F4R = BN / 4;
         float* slab = (p.ksplit > 1 && !(skf && sk_reducer)) ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
         const size_t slab_elems = (size_t)ci.M * p.Nout;
-        // BN-backward statistics of the producer layer (see IgemmParams::bnb_*): a thread keeps ONE group of 4
-        // channels through the loop (256 % F4R == 0), so its coefficients are loaded once
-        const bool bnb = p.bnb_y && !slab;
-        float4 bmu = make_float4(0, 0, 0, 0), bis = bmu, bsc = bmu, bsf = bmu, bs1 = bmu, bs2 = bmu;
-        if (bnb) {
-            const int bc = n0 + (tid % F4R) * 4;
-            bmu = *reinterpret_cast<const float4*>(p.bnb_mean + bc);
-            bis = *reinterpret_cast<const float4*>(p.bnb_invstd + bc);
-            bsc = *reinterpret_cast<const float4*>(p.bnb_scale + bc);
-            bsf = *reinterpret_cast<const float4*>(p.bnb_shift + bc);
-        }
 #pragma unroll 4
         for (int e = tid; e < HROWS * F4R; e += 256) {
             const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
@@ -1166,8 +1166,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             st4(o, v);
-            if (bnb) {      // (fp32 storage only: the *_bn_tiles queries return 0 otherwise)
-                const float4 yv = *reinterpret_cast<const float4*>(p.bnb_y + (size_t)off * p.bnb_ldy + col);
+            if (bnb) {      // y in the storage type; g = the value as STORED (what the BatchNorm backward will read)
+                const float4 yv = ld4(reinterpret_cast<const OT*>(p.bnb_y) + (size_t)off * p.bnb_ldy + col);
+                v = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));
                 const float gx = v.x * act_grad_from_pre(__fmaf_rn(yv.x, bsc.x, bsf.x), p.bnb_act);
                 const float gy = v.y * act_grad_from_pre(__fmaf_rn(yv.y, bsc.y, bsf.y), p.bnb_act);
                 const float gz = v.z * act_grad_from_pre(__fmaf_rn(yv.z, bsc.z, bsf.z), p.bnb_act);
@@ -1177,7 +1178,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 bs2.z += gz * ((yv.z - bmu.z) * bis.z); bs2.w += gw * ((yv.w - bmu.w) * bis.w);
             }
         }
-        if (bnb) {
+        if (bnb && hh == NH - 1) {
             __syncthreads();                       // every thread is done reading Cs: reuse it for the fold
             float* sb = smem + tid * 8;
             sb[0] = bs1.x; sb[1] = bs1.y; sb[2] = bs1.z; sb[3] = bs1.w;
@@ -1632,7 +1633,7 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
         if (bn == 128 && nkt >= 16) {
             static const int ks_max_h = [] { const char* e = getenv("XV2_KSPLIT_MAX"); return e ? atoi(e) : 8; }();
             for (int ks = 2; ks <= ks_max_h && nkt / ks >= 8; ++ks) {
-                const double c = cost(cdiv(M, 128) * ntn * ks, 128.0, (double)cdiv(nkt, ks) + slab_cost(4.0), 1.0);
+                const double c = cost(cdiv(M, 128) * ntn * ks, 128.0, (double)cdiv(nkt, ks) + slab_cost(12.0), 1.0);
                 if (c < best * 0.95) {
                     best = c;
                     bm = 128;
@@ -1664,7 +1665,9 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
             const double per = (double)cdiv(nkt, ks);
             // + ~6 K-tiles worth of work per block for writing / re-reading the fp32 slab (3 measured against the
             // split-bf16 form's 64-row alternative on the short-K 1x1 layers)
-            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + slab_cost(math == XV2_MATH_F32X3 ? 3.0 : 6.0));
+            // (round 4, whole-step sweeps of XV2_SLAB_COST - profiles/r04_gated_ab.md: the isolated-kernel fit of 3 / 4 K-tiles
+            //  left out what the slab-sum LAUNCH costs the step; 9 / 12 measured 1 - 1.5 % faster on cfg2 fp32, cfg2 p16 and cfg3)
+            const double c = rounds(blocks128 * ks, cap128) * 128.0 * (per + slab_cost(math == XV2_MATH_F32X3 ? 9.0 : 6.0));
             if (c < best * 0.95) {
                 best = c;
                 bm = 128;
@@ -1843,8 +1846,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     if (p.plan_tiles) {      // dry run for the fused BN-backward statistics: which tiling would this launch use?
         *p.plan_tiles = 0;
         if (p.ncls != 1 || smallc || p.Out1) return XV2_OK;
-        if (direct3x3_eligible(p, smallc)) {
-            *p.plan_tiles = p.cls[0].M / 128;
+        if (direct3x3_eligible(p, smallc)) {      // (the direct kernel takes them in its exact-fp32 form only)
+            *p.plan_tiles = p.math == XV2_MATH_F32 ? p.cls[0].M / 128 : 0;
             return XV2_OK;
         }
         pick_tile(maxM, p.Nout, smallc, splitk_ws ? p.cls[0].nkt : 0, p.math, bm, bn, ks);
@@ -2453,7 +2456,7 @@ extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* 
 static float* const kPlanPtr = reinterpret_cast<float*>(64);   // dry runs never dereference operands
 
 extern "C" int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace) {
-    if (d->stride != 1 || d->C1 != 0 || d->math != 0) return 0;
+    if (d->stride != 1 || d->C1 != 0 || d->math == XV2_MATH_BF16) return 0;
     long long tiles = 0;
     if (dgrad_impl(d, kPlanPtr, d->Cout, kPlanPtr, kPlanPtr, d->C0, nullptr, 0, has_workspace ? kPlanPtr : nullptr, nullptr,
                    accumulate, nullptr, &tiles) != XV2_OK)
@@ -2461,8 +2464,8 @@ extern "C" int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int
     return tiles;
 }
 
-extern "C" int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
-                                           float* dx0, int lddx0, int accumulate, const float* bn_y, int ld_bn_y,
+extern "C" int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ihwo,
+                                           void* dx0, int lddx0, int accumulate, const void* bn_y, int ld_bn_y,
                                            const float* bn_mean, const float* bn_invstd, const float* bn_scale,
                                            const float* bn_shift, int bn_act, float* partials, float* workspace,
                                            void* stream) {
@@ -2471,8 +2474,9 @@ extern "C" int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const float* 
     XV2_CHECK_ARG(bn_y && bn_mean && bn_invstd && bn_scale && bn_shift && partials && ld_bn_y % 4 == 0 &&
                       (reinterpret_cast<uintptr_t>(bn_y) & 15) == 0,
                   "backward_data_bn: BatchNorm operands missing or misaligned");
-    BnbArgs b{bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
-    return dgrad_impl(d, dy, lddy, w_ihwo, dx0, lddx0, nullptr, 0, workspace, (hipStream_t)stream, accumulate, &b);
+    BnbArgs b{(const float*)bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
+    return dgrad_impl(d, (const float*)dy, lddy, (const float*)w_ihwo, (float*)dx0, lddx0, nullptr, 0, workspace,
+                      (hipStream_t)stream, accumulate, &b);
 }
 
 extern "C" int64_t xv2_conv_transpose2d_backward_data_bn_tiles(const xv2_conv_desc* d) {

@@ -583,7 +583,8 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
         acc = (1 if add_to0 is not None else 0) | (2 if add_to1 is not None else 0)
-        if bnrec is not None and G == 1 and C1t == 0 and not half:
+        if (bnrec is not None and G == 1 and C1t == 0 and add_to1 is None and bnrec.y.dtype == dy.dtype and
+                dy.numel() // Cout_t * C0t <= FUSE_BN_BWD_MAX):
             tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
             if tiles > 0:
                 part = _f32((tiles, C0t, 2), dy)
@@ -837,6 +838,7 @@ ZMASK = os.environ.get("XV2_ZMASK", "1") != "0"
 # but measured 0.3 ms/step SLOWER on cfg2 (the extra read of y lengthens the serial epilogue of big-activation
 # layers by about what the separate HBM-speed pass cost, and there are 8x more partial rows to fold): off by default.
 FUSE_BN_BWD = os.environ.get("XV2_FUSE_BN_BWD", "0") != "0"
+FUSE_BN_BWD_MAX = int(float(os.environ.get("XV2_FUSE_BN_BWD_MAX", "1e12")))      # only tensors of at most this many elements
 
 
 class _BnRec:
@@ -966,8 +968,7 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
         dg, db = (dgamma, dbeta) if h == 0 else tmp      # the parameter gradients are the LOCAL sums over all parts
         s2 = Ptr(sums2, oc * 2)
         if pre is not None:
-            scratch = torch.empty((64 * C * 2,), dtype=torch.float64, device=y.device)
-            call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, scratch)
+            call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, _stats_scratch(C, y.device))
         elif masked:
             call("xv2_bn_act_backward_reduce_mask", Ptr(dz, o), C, Ptr(z, h * rows * (C // 4)), Ptr(y, o), C,
                  Ptr(mean, oc), Ptr(invstd, oc), act, rows, C, s2, dg, db, ws, dt)
