@@ -316,9 +316,14 @@ _peer_exchange_off = False        # auto mode: construction failed once - stay w
 
 
 def syncbn_transport():
-    """XV2_SYNCBN = rccl (default: torch.distributed.all_reduce) | auto (the one-shot peer exchange if its collective
-    construction and handshake succeed on every rank, else RCCL - with one warning) | oneshot (the peer exchange or an error)"""
-    return os.environ.get("XV2_SYNCBN", "rccl")
+    """XV2_SYNCBN = auto (default: the one-shot peer exchange if its collective construction and its verified handshake succeed
+    on EVERY rank, else torch.distributed.all_reduce = RCCL, with one warning) | rccl (the collective library, no attempt) |
+    oneshot (the peer exchange or an error).  Why auto is the default although the exchange has never met an xGMI link: the
+    alternative is 2 x 126 (cfg2) ... 2 x 606 (cfg5) latency-bound collectives per step on the compute stream; construction is
+    all-or-nothing across the ranks (any failure anywhere -> every rank stays with RCCL), the handshake compares 8 exchanges of
+    1 .. 16384 doubles with the rank-ordered host sum under a short spin limit, and a later timeout poisons its result with
+    NaN instead of hanging or drifting."""
+    return os.environ.get("XV2_SYNCBN", "auto")
 
 
 def stats_all_reduce_(t):
