@@ -78,6 +78,14 @@ def test_reference_construction_errors_are_kept():
         networks.get_decoder([64, 256, 512, 1024, 2048], 3, False)
     m = networks.get_dmg_unet(ARGS(type="post", dmg_model="fused", ppm=True, dec_interp=True, loss_str="ce"))
     assert not any("ppm" in k for k in m.state_dict()) and m.dec_l1_pre.skip_channels == 0
+    # mse / coral combined with other terms: the reference constructs the Loss and dies in its first forward with a
+    # RuntimeError (shape mismatch inside nn.MSELoss / CORAL, model/loss.py:92-99) - same timing, same exception type here
+    import torch
+    from xview2_amd import criterion
+    for combo in ("coral+ce", "mse+dice"):
+        loss = criterion.Loss(ARGS(type="post", loss_str=combo))
+        with pytest.raises(RuntimeError):
+            loss(torch.zeros(1, 4, 8, 8), torch.ones(1, 8, 8, dtype=torch.uint8))
 
 
 def test_cli_flags_match_reference_defaults():

@@ -272,6 +272,46 @@ def test_exact_fp32_mfma_mode_and_split_bf16_mode_agree(name, batch):
                 "grad_global_diff_between_modes": gerr})
 
 
+def test_interpolate_head_training_step_parity():
+    """--interpolate in TRAINING mode (model/layers.py:186-188: the logits are resized to the hard-coded 512 x 512 of the
+    training crops, whatever the feature size): forward, loss and every gradient against the oracle, fp64 as the yardstick"""
+    from oracle import torch_ref
+    from xview2_amd import criterion
+    a = ARGS(**MODEL_CASES["pre_resnet50_interpolate"])
+    ora, hip = build_pair(a)
+    ora64 = copy.deepcopy(ora).double().train()
+    ora.train()
+    hip.train()
+    x, y = model_input(a, batch=2, size=128), labels(a, batch=2, size=512)
+    po = ora(x)
+    lo = torch_ref.compute_loss(torch_ref.Loss(a), po, y, a.deep_supervision)
+    lo.backward()
+    pq = ora64(x.double())
+    lq = torch_ref.compute_loss(torch_ref.Loss(a), pq, y, a.deep_supervision)
+    lq.backward()
+    ph = hip(x.to(DEV))
+    lh = criterion.compute_loss(criterion.Loss(a), ph, y.to(DEV), a.deep_supervision)
+    lh.backward()
+    torch.cuda.synchronize()
+    assert tuple(ph.shape) == tuple(po.shape) == (2, 2, 512, 512)
+    cond = rel(po, pq)
+    assert rel(ph, pq) <= max(1e-3, 3.0 * cond), (rel(ph, pq), cond)
+    assert abs(float(lh) - float(lo)) <= 1e-3 * max(1.0, abs(float(lo)))
+    go = {k: p.grad for k, p in ora.named_parameters() if p.grad is not None}
+    gq = {k: p.grad for k, p in ora64.named_parameters() if p.grad is not None}
+    gh = {k: p.grad for k, p in hip.named_parameters() if p.grad is not None}
+    assert set(gh) == set(go)
+    num_h = sum(float((gh[k].double().cpu() - gq[k]).pow(2).sum()) for k in gq)
+    num_o = sum(float((go[k].double() - gq[k]).pow(2).sum()) for k in gq)
+    den = sum(float(gq[k].pow(2).sum()) for k in gq)
+    eh, eo = (num_h / den) ** 0.5, (num_o / den) ** 0.5
+    log_parity({"case": "pre_resnet50_interpolate (train, logits resized to 512)", "batch": 2, "mode": "train",
+                "cond_cpu32_vs_f64": cond, "hip_vs_f64": rel(ph, pq), "hip_vs_cpu32": rel(ph, po), "loss_hip": float(lh),
+                "loss_cpu32": float(lo), "grad_global_err_hip_vs_f64": eh, "grad_global_err_cpu32_vs_f64": eo,
+                "grad_tensors": len(gq), "branch": "logits max(1e-3, 3 x cond) vs f64; whole gradient within 3 x cpu32's error"})
+    assert eh <= 3.0 * eo + 1e-3, (eh, eo)
+
+
 @pytest.mark.parametrize("name", ["pre_resnet50", "pre_resnest50", "post_siamese_resnest50_ds",
                                   "post_fused_resnest50_attn_ds", "pre_resnet50_interpolate"])
 def test_eval_forward_parity(name):

@@ -23,13 +23,20 @@ class Loss(nn.Module):
         for n in self.names:
             if n not in ("dice", "focal", "ce", "ohem", "mse", "coral"):
                 raise KeyError(n)
-        if ("mse" in self.names or "coral" in self.names) and len(self.names) > 1:
-            # the reference special-cases loss_str == "mse" (float targets) and its coral head has 3 logits:
-            # neither composes with the softmax-based terms
-            raise ValueError("mse / coral cannot be combined with other loss terms")
+        # The reference special-cases loss_str == "mse" (float targets, model/loss.py:92-94) and builds the 3-logit coral head
+        # only for loss_str == "coral" (model/unet.py:21-26): combined with other terms both fail in the reference's FIRST
+        # forward with a RuntimeError (nn.MSELoss on [M, 4] logits against [M] long labels: "The size of tensor a (4) must match
+        # the size of tensor b (M)"; CORAL's [M, 4] logits against its [M, 3] levels: "... tensor a (4) ... tensor b (3) ...").
+        # Same here: construction succeeds, the first forward raises RuntimeError.
+        self.unsupported_combo = ("mse" in self.names or "coral" in self.names) and len(self.names) > 1
 
     def forward(self, y_pred, y_true, label_stride=1):
         """y_pred NCHW logits; y_true [N, H*label_stride, W*label_stride] uint8/long labels."""
+        if self.unsupported_combo:
+            bad = "mse" if "mse" in self.names else "coral"
+            raise RuntimeError("--loss_str %s: the size of tensor a (%d) must match the size of tensor b (%s) at non-singleton "
+                               "dimension 1 (%s does not compose with other loss terms: model/loss.py:92-99 fails the same way)"
+                               % (self.loss_str, y_pred.shape[1], "3" if bad == "coral" else "M", bad))
         if self.names[0] in ("mse", "coral"):
             bits = ops.LOSS_MSE if self.names[0] == "mse" else ops.LOSS_CORAL
             return ops.LossFn.apply(y_pred, y_true, bits, self.post, label_stride)
