@@ -361,6 +361,23 @@ int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, co
                             float* running_mean, float* running_var, float* mean, float* invstd,
                             float* scale, float* shift, const void* residual, int ldr, int act, void* z,
                             int ldz, uint8_t* zmask, int dtype, void* stream);
+/* xv2_splat_tail_forward / _backward = the op-level sequence of split attention's tail (xv2_splat_gap_forward, xv2_linear_forward,
+ *   xv2_bn_rows_forward, xv2_linear_forward, xv2_rsoftmax_forward, xv2_splat_apply_forward; backward: their twins in reverse) behind
+ *   one call: 10 calls less per ResNeSt block and direction (cfg5 runs 132 blocks per pass and is bound by the host's call
+ *   rate).  parts = BatchNorm batches back to back in the N rows (N / parts <= 64 rows each); every intermediate vector is
+ *   passed explicitly (the caller owns what the backward pass needs); workspace: xv2_splat_gap_workspace(N, hw, C). */
+int xv2_splat_tail_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1, const float* b1,
+                           const float* gamma1, const float* beta1, float eps, float momentum,
+                           float* running_mean, float* running_var, int train, int parts, const float* w2,
+                           const float* b2, float* gap, float* h1, float* a1, float* mean1, float* invstd1,
+                           float* scale1, float* shift1, float* logits, float* att, void* out, float* workspace,
+                           int dtype, void* stream);
+int xv2_splat_tail_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter,
+                            const float* gap, const float* h1, const float* a1, const float* mean1,
+                            const float* invstd1, const float* gamma1, const float* w1, const float* w2,
+                            const float* att, int train, int parts, float* datt, float* dlogits, float* da1,
+                            float* dh1, float* dgap, float* dw2, float* db2, float* dgamma1, float* dbeta1,
+                            float* dw1, float* db1, void* dx, float* workspace, int dtype, void* stream);
 int xv2_bn_act_backward(const void* dz, int lddz, const void* z, int ldz, const uint8_t* zmask, const void* y,
                         int ldy, const float* mean, const float* invstd, const float* gamma,
                         const float* scale, const float* shift, int act, double count, void* dy, int lddy,

@@ -13,9 +13,13 @@ ap.add_argument("--type", default="pre")
 ap.add_argument("--dmg_model", default="siamese")
 ap.add_argument("--precision", type=int, default=32)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--attention", action="store_true")
+ap.add_argument("--ppm", action="store_true")
+ap.add_argument("--deep_supervision", action="store_true")
 o = ap.parse_args()
 bench.set_precision(o.precision)
-a = bench.make_args(o.encoder, o.type, "dice" if o.type == "pre" else "focal+dice", o.dmg_model)
+a = bench.make_args(o.encoder, o.type, "dice" if o.type == "pre" else "focal+dice", o.dmg_model, attention=o.attention, ppm=o.ppm,
+                    deep_supervision=o.deep_supervision)
 m = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
 deterministic_init_(m, 1); m.cuda().train()
 opt = FlatAdamW(m.parameters()); lf = criterion.Loss(a)
@@ -37,9 +41,11 @@ torch.cuda.synchronize()
 t2 = time.time()
 print("1024x1024: enqueue %.2f ms/step, total %.2f ms/step" % ((t1 - t0) * 100, (t2 - t0) * 100))
 if o.profile:
+    torch.autograd.set_multithreading_enabled(False)      # backward in THIS thread: cProfile sees the Python backward functions
+    for _ in range(2): step(xs, ys)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(5): step(xs, ys)
     torch.cuda.synchronize()
     pr.disable()
-    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)

@@ -48,3 +48,51 @@ extern "C" int xv2_bn_act_backward(const void* dz, int lddz, const void* z, int 
     return xv2_bn_act_backward_apply(dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2, count, act, 1,
                                      dy, lddy, dres, lddres, npix, C, dtype, stream);
 }
+
+// Split attention's tail (ResNeSt SplAtConv2d: gap -> fc1 -> bn1 -> ReLU -> fc2 -> rSoftMax -> sum_r att_r * x_r, reference
+// call site model/unet.py:52) as ONE call each way: exactly the launches of the op-level sequence (xv2_splat_gap_forward,
+// xv2_linear_forward, xv2_bn_rows_forward, xv2_linear_forward, xv2_rsoftmax_forward, xv2_splat_apply_forward / their backward
+// twins), same order, same stream - bit-identical.  A resnest200 fused model (cfg5) runs 132 of these blocks per pass and its
+// step is bound by the HOST's call rate (134 ms to enqueue 8050 calls, scripts/host_time.py): 10 calls less per block and
+// direction.  Single-process BatchNorm over <= 64 rows only (xv2_bn_rows_*); SyncBatchNorm keeps the op-level calls around its
+// exchange.  vec: one fp32 buffer of 2 * (N * C + 2 * N * inter + N * 2C) floats is NOT implied - every vector is passed
+// explicitly so that the caller decides what it saves for the backward pass.
+extern "C" int xv2_splat_tail_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1, const float* b1,
+                                      const float* gamma1, const float* beta1, float eps, float momentum,
+                                      float* running_mean, float* running_var, int train, int parts, const float* w2,
+                                      const float* b2, float* gap, float* h1, float* a1, float* mean1, float* invstd1,
+                                      float* scale1, float* shift1, float* logits, float* att, void* out, float* workspace,
+                                      int dtype, void* stream) {
+    int rc = xv2_splat_gap_forward(x, N, hw, C, gap, workspace, dtype, stream);
+    if (rc) return rc;
+    rc = xv2_linear_forward(gap, w1, b1, h1, N, C, inter, stream);
+    if (rc) return rc;
+    rc = xv2_bn_rows_forward(h1, N / parts, inter, parts, gamma1, beta1, eps, momentum, running_mean, running_var, train,
+                             XV2_ACT_RELU, mean1, invstd1, scale1, shift1, a1, stream);
+    if (rc) return rc;
+    rc = xv2_linear_forward(a1, w2, b2, logits, N, inter, 2 * C, stream);
+    if (rc) return rc;
+    rc = xv2_rsoftmax_forward(logits, att, N, C, stream);
+    if (rc) return rc;
+    return xv2_splat_apply_forward(x, att, N, hw, C, out, dtype, stream);
+}
+
+extern "C" int xv2_splat_tail_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter,
+                                       const float* gap, const float* h1, const float* a1, const float* mean1,
+                                       const float* invstd1, const float* gamma1, const float* w1, const float* w2,
+                                       const float* att, int train, int parts, float* datt, float* dlogits, float* da1,
+                                       float* dh1, float* dgap, float* dw2, float* db2, float* dgamma1, float* dbeta1,
+                                       float* dw1, float* db1, void* dx, float* workspace, int dtype, void* stream) {
+    int rc = xv2_splat_apply_backward(x, att, dout, nullptr, N, hw, C, nullptr, datt, workspace, dtype, stream);
+    if (rc) return rc;
+    rc = xv2_rsoftmax_backward(att, datt, dlogits, N, C, stream);
+    if (rc) return rc;
+    rc = xv2_linear_backward(a1, w2, dlogits, da1, dw2, db2, N, inter, 2 * C, stream);
+    if (rc) return rc;
+    rc = xv2_bn_rows_backward(da1, a1, h1, mean1, invstd1, gamma1, N / parts, inter, parts, XV2_ACT_RELU, train, dh1, dgamma1,
+                              dbeta1, stream);
+    if (rc) return rc;
+    rc = xv2_linear_backward(gap, w1, dh1, dgap, dw1, db1, N, C, inter, stream);
+    if (rc) return rc;
+    return xv2_splat_apply_backward(x, att, dout, dgap, N, hw, C, dx, nullptr, workspace, dtype, stream);
+}

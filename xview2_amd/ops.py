@@ -1467,6 +1467,7 @@ class GateMulFn(torch.autograd.Function):
 # fat blocks walk 128..256-long dependent load chains where the op-by-op kernels spread the same work over the chip -
 # so it stays opt-in (XV2_FUSED_SPLAT=1).
 FUSED_SPLAT = os.environ.get("XV2_FUSED_SPLAT", "0") != "0"
+SPLAT_TAIL = os.environ.get("XV2_SPLAT_TAIL", "1") != "0"      # the op-level tail behind one ABI call each way (xv2_splat_tail_*)
 
 
 class SplitAttentionFn(torch.autograd.Function):
@@ -1486,6 +1487,7 @@ class SplitAttentionFn(torch.autograd.Function):
         gap, att = _f32((N, C), x), _f32((N, C2), x)
         ctx.fused = (FUSED_SPLAT and not (training and (_sync_group(bn1) or BN_SPLIT > 1)) and b1 is not None and
                      query("xv2_splat_att_supported", N, C, inter) == 1)
+        ctx.tail = False
         if ctx.fused:
             h1, a1 = _f32((N, inter), x), _f32((N, inter), x)
             mean1, invstd1 = _f32((inter,), x), _f32((inter,), x)
@@ -1499,6 +1501,29 @@ class SplitAttentionFn(torch.autograd.Function):
             call("xv2_splat_apply_forward", x, att, N, hw, C, out, _dt(x))
             ctx.save_for_backward(x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att)
             ctx.training = training
+            ctx.shapes = (w1.shape, w2.shape)
+            ctx.params = (w1, b1, w2, b2, bn1.weight, bn1.bias)
+            return out
+        S = BN_SPLIT if (training and N % BN_SPLIT == 0) else 1
+        ctx.tail = (LAYER_CALLS and SPLAT_TAIL and BN_ROWS and N // S <= 64 and not (training and _sync_group(bn1)))
+        if ctx.tail:
+            # the whole tail behind ONE ABI call (xv2_splat_tail_forward: the same six launches): the step of a deep ResNeSt
+            # model is bound by the host's call rate; the small vectors live in one allocation
+            sizes = (N * C, N * inter, N * inter, S * inter, S * inter, S * inter, S * inter, N * C2, N * C2)
+            blob = _f32((sum(sizes),), x)
+            parts, o = [], 0
+            for n in sizes:
+                parts.append(blob[o:o + n])
+                o += n
+            gap, h1, a1, mean1, invstd1, scale1, shift1, logits, att = parts
+            out = _act((N, H, W, C), x)
+            if training:
+                bn_stats_changed()
+            call("xv2_splat_tail_forward", x, N, hw, C, inter, w1m, b1, bn1.weight, bn1.bias, float(bn1.eps),
+                 float(bn1.momentum), bn1.running_mean, bn1.running_var, 1 if training else 0, S, w2m, b2, gap, h1, a1,
+                 mean1, invstd1, scale1, shift1, logits, att, out, _persist("splat", query("xv2_splat_gap_workspace", N, hw, C) // 4 + 16, x.device), _dt(x))
+            ctx.save_for_backward(x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att)
+            ctx.training, ctx.split = training, S
             ctx.shapes = (w1.shape, w2.shape)
             ctx.params = (w1, b1, w2, b2, bn1.weight, bn1.bias)
             return out
@@ -1538,6 +1563,32 @@ class SplitAttentionFn(torch.autograd.Function):
             call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws, _dt(x))
             s1, s2 = ctx.shapes
             return dx, dw1.reshape(s1), db1, dg1, dbe1, dw2.reshape(s2), db2, None, None
+        if ctx.tail:
+            x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
+            dout = _same(dout, x).contiguous()
+            N, H, W, C2 = x.shape
+            C, hw = C2 // 2, H * W
+            inter = w1m.shape[0]
+            pw1, pb1, pw2, pb2, pg1, pbe1 = ctx.params
+            ctx.params = None
+            dw1, dw2 = _grad_like(pw1), _grad_like(pw2)
+            db1 = _grad_like(pb1) if pb1 is not None else _f32((inter,), x)
+            db2 = _grad_like(pb2) if pb2 is not None else _f32((C2,), x)
+            dg1, dbe1 = _grad_like(pg1), _grad_like(pbe1)
+            sizes = (N * C2, N * C2, N * inter, N * inter, N * C)
+            blob = _f32((sum(sizes),), x)
+            parts, o = [], 0
+            for n in sizes:
+                parts.append(blob[o:o + n])
+                o += n
+            datt, dlogits, da1, dh1, dgap = parts
+            dx = torch.empty_like(x)
+            call("xv2_splat_tail_backward", x, dout, N, hw, C, inter, gap, h1, a1, mean1, invstd1, g1, w1m, w2m, att,
+                 1 if ctx.training else 0, ctx.split, datt, dlogits, da1, dh1, dgap, dw2, db2, dg1, dbe1, dw1, db1, dx,
+                 _persist("splat", query("xv2_splat_gap_workspace", N, hw, C) // 4 + 16, x.device), _dt(x))
+            s1, s2 = ctx.shapes
+            return dx, dw1.reshape(s1), (db1 if pb1 is not None else None), dg1, dbe1, dw2.reshape(s2), \
+                (db2 if pb2 is not None else None), None, None
         x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att, scale1, shift1 = ctx.saved_tensors
         dout = _same(dout, x).contiguous()
         N, H, W, C2 = x.shape
