@@ -21,7 +21,10 @@ class ConvDesc(ctypes.Structure):
                 ("N", "IH", "IW", "C0", "C1", "Cout", "KH", "KW", "stride", "pad", "dil", "OH", "OW", "math")]
 
     def key(self):
-        return tuple(getattr(self, f[0]) for f in self._fields_)
+        k = self.__dict__.get("_k")      # ops._desc memoises descriptors and stores the field tuple with them
+        if k is None:
+            k = self.__dict__["_k"] = tuple(getattr(self, f[0]) for f in self._fields_)
+        return k
 
 
 class Ptr:
@@ -101,13 +104,15 @@ _TO_C = {
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+# (the device query behind torch.cuda.current_device() without its Python-level lazy-init check: once per launch)
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream_handle():
     """hipStream_t of torch's current stream (the raw-handle query is ~10x cheaper than building a Stream object, and
     this runs once per launch: ~1000 times per training step)"""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -140,11 +145,14 @@ def query_cache_clear():
 def query(name, *args):
     """Value-returning helper (workspace sizes, tile counts): no stream argument.  Pure functions of a convolution
     descriptor are memoised (the same ~100 geometries recur every step)."""
-    if len(args) >= 1 and isinstance(args[0], ConvDesc) and all(isinstance(a, int) for a in args[1:]):
-        key = (name, args[0].key()) + tuple(args[1:])
+    if args and type(args[0]) is ConvDesc:
+        d = args[0]
+        key = (name, d.__dict__.get("_k") or d.key()) + args[1:]
         v = _query_cache.get(key)
-        if v is None:
+        if v is not None:
+            return v
+        if all(isinstance(a, int) for a in args[1:]):
             v = _func(name)(*[_conv(a) for a in args])
             _query_cache[key] = v
-        return v
+            return v
     return _func(name)(*[_conv(a) for a in args])

@@ -121,8 +121,21 @@ def _desc(N, IH, IW, C0, C1, Cout, g, OH, OW, half=False):
     if half:
         math = MATH_BF16_STORE
     else:
-        math = getattr(g, "math", None) if getattr(g, "math", None) is not None else MATH_MODE
-    return ConvDesc(N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW, math)
+        math = g.math if getattr(g, "math", None) is not None else MATH_MODE
+    # (descriptors are immutable and recur every step: one object per geometry, with its field tuple for the plan-query memo -
+    #  a cfg5 step builds ~1800 of them and asks ~3000 plan questions, all on the host's critical path)
+    k = (N, IH, IW, C0, C1, Cout, g.kh, g.kw, g.stride, g.pad, g.dil, OH, OW, math)
+    d = _desc_cache.get(k)
+    if d is None:
+        if len(_desc_cache) > 65536:
+            _desc_cache.clear()
+        d = ConvDesc(*k)
+        d.__dict__["_k"] = k
+        _desc_cache[k] = d
+    return d
+
+
+_desc_cache = {}
 
 
 # ------------------------------------------------------------------------------------------------
