@@ -255,6 +255,11 @@ int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,
                                  const void* w_ihwo, void* y, int ldy, void* stream);
 int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
                                        const void* w_ohwi, void* dx, int lddx, void* stream);
+/* the same with accumulate != 0: the gradient is ADDED onto what dx holds (the transposed convolution's input also feeds a
+ * deep-supervision head, model/unet.py:193-197: no elementwise sum of the two gradients); workspace as for xv2_conv2d_forward
+ * of the same descriptor (may be NULL: no split-K plan then) */
+int xv2_conv_transpose2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi,
+                                           void* dx, int lddx, int accumulate, float* workspace, void* stream);
 int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const void* x, int ldx,
                                          const void* dy, int lddy, float* dw, float* workspace,
                                          void* stream);

@@ -2160,10 +2160,11 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
                              long long* plan = nullptr, const StatsFold* fold = nullptr, const PreAct* pre = nullptr,
-                             int* plan_halo = nullptr, const CoopArgs* coop = nullptr) {
+                             int* plan_halo = nullptr, const CoopArgs* coop = nullptr, int accumulate = 0) {
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    p.accum = accumulate & 1;      // ADD the result onto what y holds (the gradient of the tensor's other consumer)
     if (coop && coop->z) {
         XV2_CHECK_ARG(fold && fold->fin.mean && out_aligned(d, coop->z, coop->ldz) &&
                           (!coop->res || out_aligned(d, coop->res, coop->ldres)) && coop->applied,
@@ -2511,6 +2512,12 @@ extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
                                                   const void* w_ohwi, void* dx, int lddx, void* stream) {
     return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
+}
+
+extern "C" int xv2_conv_transpose2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi,
+                                                      void* dx, int lddx, int accumulate, float* workspace, void* stream) {
+    return conv_forward_impl(d, (const float*)dy, lddy, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)dx, lddx, nullptr,
+                             workspace, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, accumulate);
 }
 
 // ---- pre-split weights (see PresplitEntry) ---------------------------------------------------------------------------

@@ -56,8 +56,8 @@ class ConvTranspose(nn.Module):  # layers.py:80-86
         super().__init__()
         self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2, bias=False)
 
-    def forward(self, x):
-        return ops.ConvTranspose2x2Fn.apply(x, self.conv.weight)
+    def forward(self, x, passthrough=False):
+        return ops.ConvTranspose2x2Fn.apply(x, self.conv.weight, passthrough)
 
 
 class UpsampleBlock(nn.Module):  # layers.py:131-168
@@ -75,10 +75,14 @@ class UpsampleBlock(nn.Module):  # layers.py:131-168
             self.conv_s = AttentionLayer(skip_channels, att)
             self.psi = AttentionLayer(att, 1)
 
+    alias_request, alias_out = False, None      # xnn.stage_with_input_alias: `inputs` also feeds a deep-supervision head
+
     def forward(self, inputs, skip):
         if self.dec_interp:
             y = xnn.conv(self.conv, inputs)
             out = ops.BilinearFn.apply(y, 2 * y.shape[1], 2 * y.shape[2])
+        elif self.alias_request and xnn.want_aliases(inputs):
+            out, self.alias_out = self.conv_tranpose(inputs, True)
         else:
             out = self.conv_tranpose(inputs)
         if self.skip_channels == 0:
@@ -155,7 +159,10 @@ class FusionBlock(nn.Module):  # layers.py:103-116
 
     def forward(self, pre, post, dec_pre=None, dec_post=None, last_dec=False):
         if dec_pre is not None or last_dec:
-            pre, post = self.pre_conv(pre, dec_pre), self.post_conv(post, dec_post)
+            # decoder side: the previous level's fused features may also feed a deep-supervision head
+            pre, a_pre = xnn.stage_with_input_alias(self.pre_conv, pre, dec_pre)
+            post, a_post = xnn.stage_with_input_alias(self.post_conv, post, dec_post)
+            self.input_aliases = (a_pre, a_post)
         else:
             # encoder stages: the fused features entering here also feed the decoder's fusion blocks (skip connections)
             pre, a_pre = xnn.stage_with_input_alias(self.pre_conv, pre)

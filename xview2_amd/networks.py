@@ -51,7 +51,11 @@ def _decode(owner, dilation, no_skip, encs, prefix="dec_l%d"):
     x, decs = encs[4], {}
     for lvl in range(_FIRST_LEVEL[dilation], 5):
         skip = None if (no_skip or lvl == 4) else encs[3 - lvl]
-        x = getattr(owner, prefix % (lvl + 1))(x, skip)
+        # the previous level's output also feeds a deep-supervision head (unet.py:193-197): the head reads the alias this level's
+        # transposed convolution publishes of its input (xnn.stage_with_input_alias)
+        x, alias = xnn.stage_with_input_alias(getattr(owner, prefix % (lvl + 1)), x, skip)
+        if lvl - 1 in decs:
+            decs[lvl - 1] = alias
         decs[lvl] = x
     return decs[4], decs[3], decs[2]
 
@@ -249,6 +253,9 @@ class FusedUNet(_Fused):  # unet.py:320-376
                 pre, post = fb(pre, post, f[3 - i][0], f[3 - i][1])
             else:
                 pre, post = fb(pre, post, last_dec=True)
+            if i > 0:      # the previous level's fused features as the deep-supervision heads should read them
+                decs[i - 1] = fb.input_aliases
+            fb.input_aliases = None
             decs.append((pre, post))
         return self.output_block(concat(*decs[4]), concat(*decs[3]), concat(*decs[2]))
 

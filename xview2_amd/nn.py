@@ -142,16 +142,16 @@ class Chain(Numbered):
 # input; the other consumers read the alias, their gradient reaches the block's first layers as `dpass` and is summed in the
 # backward-data epilogue / pooling backward.  Blocks keep returning a single tensor (forward hooks, nn.Sequential semantics):
 # the alias travels through two attributes of the block.
-def stage_with_input_alias(stage, x):
-    """-> (stage(x), tensor that x's OTHER consumers should read): the alias published by the stage's first block, or x"""
+def stage_with_input_alias(stage, x, *more):
+    """-> (stage(x, *more), tensor that x's OTHER consumers should read): the alias published by the stage's first block, or x"""
     first = stage
     while isinstance(first, Chain) and len(first) > 0:
         first = first[0]
     if not (want_aliases(x) and hasattr(first, "alias_request")):
-        return stage(x), x
+        return stage(x, *more), x
     first.alias_request = True
     try:
-        y = stage(x)
+        y = stage(x, *more)
     finally:
         first.alias_request = False
     alias, first.alias_out = first.alias_out, None

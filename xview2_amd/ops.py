@@ -1216,9 +1216,13 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
     """nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, passthrough=False):
+        """passthrough: also return x itself (see ConvBnActFn.forward): x's other consumer - a deep-supervision head - reads
+        the alias and its gradient is summed in this layer's backward-data epilogue"""
         _need_cuda(x)
+        ctx.set_materialize_grads(False)
         ctx.src_rec = _bn_rec_of(x, x.shape[-1])
+        x_in = x
         x = x.contiguous()
         N, H, W, Cin = x.shape
         Cout = weight.shape[1]
@@ -1231,19 +1235,31 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.d = d
         ctx.wparam = weight
-        return y
+        return (y, x_in) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, weight = ctx.saved_tensors
+        if dy is None:
+            return dpass, None, None
         dy = _same(dy, x).contiguous()
         d = ctx.d
         Cin, Cout = weight.shape[0], weight.shape[1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
             ohwi, _ = _pack(weight.contiguous(), Cout, True, False, x.dtype == torch.bfloat16)
-            dx = torch.empty_like(x)
+            acc = _acc_target(_same(dpass, x), x.shape, x)
             rec, ctx.src_rec = ctx.src_rec, None
+            if acc is not None:      # summed onto the other consumer's gradient in the epilogue
+                dx = acc
+                wsb = query("xv2_conv2d_forward_workspace", d)
+                call("xv2_conv_transpose2d_backward_data_acc", d, dy, Cout, ohwi, dx, Cin, 1, _ws(wsb, dy) if wsb else None)
+                if ctx.needs_input_grad[1]:
+                    dw = _grad_like(ctx.wparam)
+                    ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+                    call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
+                return dx, dw, None
+            dx = torch.empty_like(x)
             tiles = query("xv2_conv_transpose2d_backward_data_bn_tiles", d) if (rec is not None and x.dtype == torch.float32) else 0
             if tiles > 0:      # the producer layer's BatchNorm-backward statistics ride along in the epilogue
                 part = _f32((tiles, Cin, 2), x)
@@ -1256,7 +1272,9 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
             dw = _grad_like(ctx.wparam)
             ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
             call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
-        return dx, dw
+        if dpass is not None and dx is not None:
+            dx = dx + _same(dpass, dx)
+        return dx, dw, None
 
 
 class HeadConvFn(torch.autograd.Function):
