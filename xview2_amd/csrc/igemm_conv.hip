@@ -1871,14 +1871,15 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     p.ksplit = ks;
     p.part = splitk_ws;
     p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);
-    if (ks == 1 && (bm == 128 || !p.stats) && !p.plan_halo && thin1x1_eligible(p, smallc)) {
+    const bool stem7 = ks == 1 && !p.plan_halo && stem7x7_eligible(p, smallc);
+    if (stem7 || (ks == 1 && (bm == 128 || !p.stats) && !p.plan_halo && thin1x1_eligible(p, smallc))) {
         // HBM-bound 1x1 layers: the streaming kernel (thin_conv.hip).  It writes the 128-row statistics partials of the
         // BM = 128 plan and leaves their reduction to the separate launch (one device-scope hand-off per 128 rows would
-        // stall its barrier-free waves)
+        // stall its barrier-free waves).  The 7x7 RGB stem (stem_conv.hip) does the same with its two rows per patch.
         const StatsFold fold = p.fold;
         p.fold.on = 0;
         p.cz = nullptr;
-        int rc = thin1x1_launch(p, stream);
+        int rc = stem7 ? stem7x7_launch(p, stream) : thin1x1_launch(p, stream);
         if (rc || !fold.on) return rc;
         const int64_t tiles = cdiv(maxM, 128);
         XV2_CHECK_ARG(fold.S >= 1 && tiles % fold.S == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts",

@@ -96,4 +96,9 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream);
 bool thin1x1_eligible(const IgemmParams& p, bool smallc);
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream);
 
+// stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
+// patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them
+bool stem7x7_eligible(const IgemmParams& p, bool smallc);
+int stem7x7_launch(const IgemmParams& p, hipStream_t stream);
+
 }  // namespace xv2
