@@ -100,5 +100,7 @@ int thin1x1_launch(const IgemmParams& p, hipStream_t stream);
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them
 bool stem7x7_eligible(const IgemmParams& p, bool smallc);
 int stem7x7_launch(const IgemmParams& p, hipStream_t stream);
+int stem7x7_wgrad_slabs(const xv2_conv_desc* d);      // slabs [64][49][4] its weight-gradient twin writes (0: not its layer)
+int stem7x7_wgrad_launch(const xv2_conv_desc* d, const float* x, const float* dy, int lddy, float* part, hipStream_t stream);
 
 }  // namespace xv2

@@ -173,6 +173,128 @@ __global__ void __launch_bounds__(256, 2) stem7x7_kernel(const StemParams p) {
     }
 }
 
+// ---- weight gradient of the same layer: dW[co][tap][c] = sum over pixels of dY[px][co] * X[2 oy + ky][2 ox + kx][c] --------------
+// GEMM view: 64 output channels x 196 (tap, channel) columns (padded to 224), K = every output pixel of the batch (524 288).
+// Persistent blocks; per 8 x 32 output patch the input patch is staged in LDS exactly as in the forward kernel; the four waves
+// SPLIT THE COLUMNS (wave w: column tiles 2w, 2w + 1; tile 7 does not exist) and each walks ALL 256 pixels of the patch, two
+// per MFMA (the wave halves supply the two k values): A = dY read straight from HBM (a lane owns one output channel: two
+// coalesced 128-byte rows per instruction, a row of 32 pixels prefetched while the previous one is multiplied), B = the
+// input pixel of (tap, channel) of the lane's column out of LDS.  Accumulators live across ALL patches of the block - no
+// per-patch reduction - and leave as one slab [64][49][4] per block, summed by the weight-gradient slab kernels.
+struct StemWgradParams {
+    const float* x;        // [N][IH][IW][4]
+    const float* dy;       // [N][OH][OW][lddy]
+    float* part;           // [gridDim.x][64][49][4]
+    int N, IH, IW, OH, OW, lddy, patches, tiles_w, tiles_h;
+    unsigned bytesX, bytesDY;
+};
+
+__global__ void __launch_bounds__(256, 2) stem7x7_wgrad_kernel(const StemWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* patch = reinterpret_cast<float4*>(smem);               // [21][69]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.bytesX, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.bytesDY, 0x00020000);
+    const int per = (p.patches + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = min(p0 + per, p.patches);
+    float* slab = p.part + (size_t)blockIdx.x * 64 * 196;
+    // this lane's two columns: n = 32 * (2 wave + q) + l31 -> tap n / 4 (clamped into the kernel for the padding columns,
+    // whose sums are never stored), channel n % 4; +8 floats for the odd pixel of a pair (2 input pixels further)
+    int boff[2];
+    bool bval[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = 32 * (2 * wave + q) + l31;
+        const int tap = min(n >> 2, 48), c = n & 3;
+        boff[q] = ((tap / 7) * S_IW + tap % 7) * 4 + c + 8 * h;
+        bval[q] = n < 196;
+    }
+    const bool two = wave < 3;      // wave 3 owns column tile 6 only
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+
+    constexpr int NL = (S_PATCH + 255) / 256;
+    i32x4 pr[NL];
+    auto pload = [&](int pt) {
+        const int tw = pt % p.tiles_w, th = (pt / p.tiles_w) % p.tiles_h, n = pt / (p.tiles_w * p.tiles_h);
+        const int ih0 = th * S_PH * 2 - 3, iw0 = tw * S_PW * 2 - 3;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * 256;
+            const int r = e / S_IW, c = e - r * S_IW;
+            const int ih = ih0 + r, iw = iw0 + c;
+            const bool ok = e < S_PATCH && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            pr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (int)((((size_t)n * p.IH + ih) * p.IW + iw) * 16) : (int)0x80000000, 0, 0);
+        }
+    };
+    auto pstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * 256;
+            if (e < S_PATCH) *reinterpret_cast<i32x4*>(patch + e) = pr[j];
+        }
+    };
+    // dY of one patch row: 16 pixel pairs x 2 channel tiles per lane (pixel 2 kk + h, channel 32 i + l31)
+    float ar[2][2][16];
+    auto aload = [&](int pt, int oy, float (&a)[2][16]) {
+        const int tw = pt % p.tiles_w, th = (pt / p.tiles_w) % p.tiles_h, n = pt / (p.tiles_w * p.tiles_h);
+        const int base = ((((n * p.OH + th * S_PH + oy) * p.OW + tw * S_PW + h) * p.lddy) + l31) * 4;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            a[0][kk] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, base + kk * 2 * p.lddy * 4, 0, 0));
+            a[1][kk] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsD, base + kk * 2 * p.lddy * 4 + 128, 0, 0));
+        }
+    };
+    if (p0 < p1) {
+        pload(p0);
+        aload(p0, 0, ar[0]);
+        pstore();
+    }
+    __syncthreads();
+    const float* pf = reinterpret_cast<const float*>(patch);
+    for (int pt = p0; pt < p1; ++pt) {
+        if (pt + 1 < p1) pload(pt + 1);
+#pragma unroll
+        for (int oy = 0; oy < S_PH; ++oy) {
+            // next row of dY in flight (the next patch's first row behind the last one)
+            if (oy + 1 < S_PH) aload(pt, oy + 1, ar[(oy + 1) & 1]);
+            else if (pt + 1 < p1) aload(pt + 1, 0, ar[(oy + 1) & 1]);
+            const float (&a)[2][16] = ar[oy & 1];
+            const float* pb = pf + (2 * oy * S_IW) * 4;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float b0 = pb[boff[0] + kk * 16];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][kk], b0, acc[1][0], 0, 0, 0);
+                if (two) {
+                    const float b1 = pb[boff[1] + kk * 16];
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][kk], b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][kk], b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                       // every wave is done reading the patch
+        if (pt + 1 < p1) pstore();
+        __syncthreads();
+    }
+    // slab [co][49][4]: accumulator row = output channel 32 i + (r & 3) + 8 (r >> 2) + 4 h, column = n
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (!bval[q] || (q == 1 && !two)) continue;
+        const int n = 32 * (2 * wave + q) + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(size_t)(32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * 196 + n] = acc[i][q][r];
+    }
+}
+
 static bool stem_enabled() {      // XV2_STEM7=0: the implicit-GEMM kernel (A/B runs)
     static const int v = [] { const char* e = getenv("XV2_STEM7"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -219,6 +341,37 @@ int stem7x7_launch(const IgemmParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(stem7x7_kernel<true>, dim3(grid), dim3(256), S_SMEM, stream, q);
     else
         hipLaunchKernelGGL(stem7x7_kernel<false>, dim3(grid), dim3(256), S_SMEM, stream, q);
+    prof_end(stream);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+
+// plan: slabs the weight-gradient kernel writes for this geometry (0 = not this kernel's layer)
+int stem7x7_wgrad_slabs(const xv2_conv_desc* d) {
+    static const int on = [] { const char* e = getenv("XV2_STEM7W"); return e ? atoi(e) : 1; }();
+    if (!on || !stem_enabled() || d->C0 != 4 || d->C1 != 0 || d->Cout != 64 || d->KH != 7 || d->KW != 7 || d->stride != 2 ||
+        d->pad != 3 || d->dil != 1 || d->math == XV2_MATH_BF16_STORE || d->math == XV2_MATH_BF16)
+        return 0;
+    if (d->OH % S_PH != 0 || d->OW % S_PW != 0 || d->OH * 2 != d->IH || d->OW * 2 != d->IW) return 0;
+    if ((long long)d->N * d->IH * d->IW * 16 >= (1ll << 31) || (long long)d->N * d->OH * d->OW * 64 * 4 >= (1ll << 31)) return 0;
+    const int patches = d->N * (d->OH / S_PH) * (d->OW / S_PW);
+    return std::min(patches, 512);
+}
+
+int stem7x7_wgrad_launch(const xv2_conv_desc* d, const float* x, const float* dy, int lddy, float* part, hipStream_t stream) {
+    static const int kid = prof_register("stem7x7_wgrad_kernel<rgb>");
+    StemWgradParams q;
+    q.x = x; q.dy = dy; q.part = part;
+    q.N = d->N; q.IH = d->IH; q.IW = d->IW; q.OH = d->OH; q.OW = d->OW; q.lddy = lddy;
+    q.tiles_w = d->OW / S_PW; q.tiles_h = d->OH / S_PH;
+    q.patches = d->N * q.tiles_w * q.tiles_h;
+    q.bytesX = (unsigned)((size_t)d->N * d->IH * d->IW * 16);
+    q.bytesDY = (unsigned)((size_t)d->N * d->OH * d->OW * lddy * 4);
+    const int grid = stem7x7_wgrad_slabs(d);
+    XV2_CHECK_ARG(grid > 0 && lddy >= 64, "stem7x7_wgrad: not the 7x7 / stride-2 RGB stem");
+    const double M = (double)d->N * d->OH * d->OW;
+    prof_begin(kid, 2.0 * M * 64.0 * 49.0 * 3.0, 4.0 * ((double)d->N * d->IH * d->IW * 3.0 + M * 64.0) + 4.0 * 64 * 49 * 3, stream);
+    hipLaunchKernelGGL(stem7x7_wgrad_kernel, dim3(grid), dim3(256), (size_t)S_PATCH * 16, stream, q);
     prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;

@@ -1368,9 +1368,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_tr_kernel(const WgradP
         }
 }
 
+// stem_conv.hip
+int stem7x7_wgrad_slabs(const xv2_conv_desc* d);
+int stem7x7_wgrad_launch(const xv2_conv_desc* d, const float* x, const float* dy, int lddy, float* part, hipStream_t stream);
+
 struct WgradPlan {
     int bm, bn, wk, splitk, kt_per, ktiles, tiles;
     bool smallc;
+    bool stem7;        // stem_conv.hip: the 7x7 / stride-2 RGB stem from an LDS-resident input patch
     bool alltaps;      // wgrad_alltaps_kernel: ktiles = row chunks per strip, kt_per = rows per chunk
     int nslab;         // partial slabs the MFMA kernel writes
     int groups;        // > 0: two-level slab sum with this many intermediate slabs
@@ -1404,8 +1409,17 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
     const int Ctot = d->C0 + d->C1;
     pl.smallc = (d->C0 == 4 && d->C1 == 0);
     pl.alltaps = false;
+    pl.stem7 = false;
     pl.groups = 0;
     const int T = d->KH * d->KW;
+    if (const int slabs = stem7x7_wgrad_slabs(d)) {
+        pl.stem7 = true;
+        pl.bm = pl.bn = 64;
+        pl.wk = pl.splitk = pl.kt_per = pl.ktiles = pl.tiles = 1;
+        pl.nslab = slabs;
+        if (pl.nslab >= 64) pl.groups = 16;
+        return pl;
+    }
     if (!pl.smallc && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 &&
         d->OW % 32 == 0 && d->OH == d->IH && d->OW == d->IW && d->Cout % 32 == 0 && d->C0 % 32 == 0 &&
         d->C1 % 32 == 0 && d->C0 > 0 && (d->Cout / 32) * (Ctot / 32) <= alltaps_max_tiles()) {
@@ -1582,7 +1596,9 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
             p.taps[kh * d->KW + kw].dw = (short)(kw * d->dil - d->pad);
         }
     int rc;
-    if (pl.alltaps) {
+    if (pl.stem7) {
+        rc = stem7x7_wgrad_launch(d, x0, dy, lddy, workspace, stream);
+    } else if (pl.alltaps) {
         static const int kid = prof_register("wgrad_alltaps_kernel");
         static const int kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
         static const int kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
