@@ -2507,16 +2507,19 @@ extern "C" int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, con
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,
                                             const void* w_ihwo, void* y, int ldy, void* stream) {
     XV2_CHECK_ARG(d->C1 == 0, "conv_transpose2d: single output tensor expected");
+    if (const int rc = thin_convT_forward(d, x, ldx, w_ihwo, y, ldy, (hipStream_t)stream); rc >= 0) return rc;      // thin_conv.hip
     return dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
                                                   const void* w_ohwi, void* dx, int lddx, void* stream) {
+    if (const int rc = thin_convT_backward_data(d, dy, lddy, w_ohwi, dx, lddx, 0, (hipStream_t)stream); rc >= 0) return rc;
     return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi,
                                                       void* dx, int lddx, int accumulate, float* workspace, void* stream) {
+    if (const int rc = thin_convT_backward_data(d, dy, lddy, w_ohwi, dx, lddx, accumulate, (hipStream_t)stream); rc >= 0) return rc;
     return conv_forward_impl(d, (const float*)dy, lddy, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)dx, lddx, nullptr,
                              workspace, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, accumulate);
 }

@@ -95,6 +95,11 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream);
 // stay in LDS (HBM-bound layers of the first encoder level); writes 128-row statistics partials, never folds them
 bool thin1x1_eligible(const IgemmParams& p, bool smallc);
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream);
+// the same streaming kernel for nn.ConvTranspose2d(64 -> 32, 2, 2) at >= 65536 small-grid pixels (the 1024^2 decoder level):
+// forward = four 32-column blocks scattered to the four big-grid pixels, backward-data = K gathered from them.  -1: other shape
+int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, hipStream_t stream);
+int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi, void* dx, int lddx,
+                             int accumulate, hipStream_t stream);
 
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them

@@ -30,13 +30,26 @@ struct ThinParams {
     float* stats;         // [tiles][N][2] or nullptr
     int M, ldA, ldo, accum, tiles;
     unsigned bytesA;
+    int W;                // MODE 1 / 2: width of the SMALL grid of the 2x2 / stride-2 transposed convolution (W % 32 == 0)
 };
+
+// MODE 1 / 2: nn.ConvTranspose2d(k = 2, s = 2) (model/layers.py:80-86) of the 1024^2 decoder level, forward and backward-data.
+// Small-grid pixel m = (n H + h) W + w and tap t = 2 i + j  <->  big-grid pixel (n 2H + 2h + i) 2W + 2w + j:
+__device__ __forceinline__ int ct_pixel(int m, int W, int t) {
+    const int q = m / W;
+    return 4 * q * W + 2 * (m - q * W) + (t >> 1) * 2 * W + (t & 1);
+}
 
 // SUBS = 32-pixel row blocks per wave: 4 = a wave owns a whole 128-pixel tile (no barrier at all); 2 = the block's WAVES = 2
 // waves share one tile (bf16 tensors: the single weight plane leaves room for four such blocks per CU, i.e. twice the waves
 // and loads in flight per CU), their statistics meet in LDS behind one barrier per tile
-template <int K, int N, bool HS, int WAVES, int SUBS>
+// MODE 0: 1x1 convolution.  MODE 1: transposed-convolution FORWARD, 64 -> 32 channels = a 1x1 GEMM with N = 4 taps x 32 columns
+// whose 32-column blocks are the four output pixels of an input pixel (each store is still a full 128-byte line); the packed
+// weight rows (channel-major, tap-minor) are re-ordered tap-major while they are staged.  MODE 2: its backward-data = the
+// 2x2 / stride-2 convolution 32 -> 64: K = 4 taps x 32 channels GATHERED from the four big-grid pixels of a small-grid pixel.
+template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0>
 __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const ThinParams p) {
+    static_assert(MODE == 0 || (MODE == 1 && K == 64 && N == 128) || (MODE == 2 && K == 128 && N == 64), "transposed-convolution shapes");
     constexpr int P = HS ? 1 : 3;              // bf16 planes of the weights
     constexpr int KP = K + 8;                  // LDS row pitch in bf16: (K + 8) / 2 dwords = 4 mod 32 -> conflict-free b128 reads
     constexpr int NB = N / 32, KC = K / 64, KCU = KC > 2 ? 1 : KC;
@@ -58,6 +71,21 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
     // lane (l31, h) of a 32-pixel block owns pixel l31 and channels 16 * ks + 8 * h .. + 7 of every K step ks
     auto issue = [&](int t, int sub, int kc, i32x4 (&r)[NRAW]) {
         const int m = t * 128 + sub * 32 + l31;
+        if constexpr (MODE == 2) {
+            // slice kc = taps 2 kc, 2 kc + 1 (big-grid row 2h + kc): K step ks -> tap 2 kc + (ks >> 1), channels 16 (ks & 1) + 8 h ..
+            const int pix = ct_pixel(m < p.M ? m : 0, p.W, 2 * kc);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = m < p.M ? ((pix + (ks >> 1)) * p.ldA + (ks & 1) * 16 + h * 8) * ES : (int)0x80000000;
+                if constexpr (HS) {
+                    r[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+                } else {
+                    r[2 * ks] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+                    r[2 * ks + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off + 16, 0, 0);
+                }
+            }
+            return;
+        }
         const int off = m < p.M ? (m * p.ldA + kc * 64 + h * 8) * ES : (int)0x80000000;     // rows past M read zeros
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -84,7 +112,8 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
         for (int u = 0; u < PER; ++u) v[u] = src[tid + u * NT];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int i = tid + u * NT, n = i / (K / 8), c8 = i - n * (K / 8);
+            const int i = tid + u * NT, ng = i / (K / 8), c8 = i - ng * (K / 8);
+            const int n = MODE == 1 ? (ng & 3) * 32 + (ng >> 2) : ng;      // packed row = channel * 4 + tap -> LDS row tap * 32 + channel
             *reinterpret_cast<uint4*>(sw + n * KP + c8 * 8) = v[u];
         }
     } else {
@@ -98,7 +127,8 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
             for (int u = 0; u < CH; ++u) v[u] = src[tid + (u0 + u) * NT];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int i = tid + (u0 + u) * NT, n = i / (K / 4), c4 = i - n * (K / 4);
+                const int i = tid + (u0 + u) * NT, ng = i / (K / 4), c4 = i - ng * (K / 4);
+                const int n = MODE == 1 ? (ng & 3) * 32 + (ng >> 2) : ng;
                 uint2 q0, q1, q2;
                 split3x4(v[u], q0, q1, q2);
                 __bf16* d = sw + n * KP + c4 * 4;
@@ -210,27 +240,32 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
                         // of the next pair
 #pragma unroll
                         for (int j = jp; j < jp + 2; ++j) {
+                            // MODE 1: column block j = tap j: the rows of this 32-pixel block (one small-grid row: W % 32 == 0) go to
+                            // every second big-grid pixel of row 2h + (j >> 1)
+                            const size_t obase = MODE == 1 ? ((size_t)ct_pixel(tile * 128 + sub * 32, p.W, j) + 8 * h) * p.ldo + l31
+                                                           : (size_t)m0 * p.ldo + j * 32 + l31;
+                            const size_t ostep = MODE == 1 ? 2 * (size_t)p.ldo : (size_t)p.ldo;
                             if constexpr (HS) {
-                                unsigned short* o = reinterpret_cast<unsigned short*>(p.Out) + (size_t)m0 * p.ldo + j * 32 + l31;
+                                unsigned short* o = reinterpret_cast<unsigned short*>(p.Out) + obase;
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
                                     const int dr = (r & 3) + 8 * (r >> 2);
                                     if (full || m0 + dr < p.M) {
                                         const bf16_t sv = f32_to_bf16(acc[j][r]);
-                                        o[(size_t)dr * p.ldo] = sv;
+                                        o[(size_t)dr * ostep] = sv;
                                         const float fv = bf16_to_f32(sv);         // statistics on the value as stored
                                         s1[j] += fv;
                                         s2[j] += fv * fv;
                                     }
                                 }
                             } else {
-                                float* o = reinterpret_cast<float*>(p.Out) + (size_t)m0 * p.ldo + j * 32 + l31;
+                                float* o = reinterpret_cast<float*>(p.Out) + obase;
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
                                     const int dr = (r & 3) + 8 * (r >> 2);
                                     if (full || m0 + dr < p.M) {
                                         const float v = acc[j][r];
-                                        o[(size_t)dr * p.ldo] = v;
+                                        o[(size_t)dr * ostep] = v;
                                         s1[j] += v;
                                         s2[j] += v * v;
                                     }
@@ -277,11 +312,11 @@ static bool thin_enabled() {      // XV2_THIN=0: these layers stay on the tiled 
     return on;
 }
 
-template <int K, int N, bool HS, int WAVES, int SUBS>
+template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0>
 static int thin_launch_one(const ThinParams& q, const char* name, double flops, double abytes, hipStream_t stream) {
     constexpr int WPT = 4 / SUBS;
     constexpr size_t smem = (size_t)(HS ? 1 : 3) * N * (K + 8) * 2 + (WPT > 1 ? (size_t)WPT * N * 8 : 0);
-    auto kern = thin1x1_kernel<K, N, HS, WAVES, SUBS>;
+    auto kern = thin1x1_kernel<K, N, HS, WAVES, SUBS, MODE>;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     XV2_CHECK_HIP(attr_rc);
@@ -317,7 +352,7 @@ bool thin1x1_eligible(const IgemmParams& p, bool smallc) {
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
     ThinParams q;
     q.A = p.A0; q.B = p.B; q.Out = p.Out0; q.stats = p.stats;
-    q.M = p.cls[0].M; q.ldA = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1;
+    q.M = p.cls[0].M; q.ldA = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1; q.W = 0;
     q.tiles = (int)cdiv(q.M, 128);
     q.bytesA = p.bytesA0;
     const int K = p.Ctot, N = p.Nout;
@@ -339,6 +374,53 @@ int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
 #undef XV2_THIN_CASE
     set_error("thin1x1: no instantiation for K=%d N=%d", K, N);
     return XV2_EINVAL;
+}
+
+// ---- nn.ConvTranspose2d(64 -> 32, k = 2, s = 2) of the 1024^2 decoder level (model/layers.py:80-86), forward and backward-data:
+// 402 MB for 8.6 GFLOP each - the tiled kernel ran them at 0.18 / 0.14 ms, 2 - 3x their HBM floor.  `d` = the equivalent
+// 2x2 / stride-2 convolution (C0 = 32 big-grid channels, Cout = 64 small-grid channels).  Return -1: not this kernel's shape.
+static bool thin_ct_shape(const xv2_conv_desc* d, int ld_small, int ld_big, const void* a, const void* b, const void* c) {
+    static const bool on = [] { const char* e = getenv("XV2_THIN_CT"); return !(e && atoi(e) == 0); }();
+    if (!on || !thin_enabled() || (d->math != XV2_MATH_F32X3 && d->math != XV2_MATH_BF16_STORE)) return false;
+    if (d->C0 != 32 || d->C1 != 0 || d->Cout != 64 || d->KH != 2 || d->KW != 2 || d->stride != 2 || d->pad != 0 || d->dil != 1) return false;
+    if (d->OW % 32 != 0 || d->IH != 2 * d->OH || d->IW != 2 * d->OW || (long long)d->N * d->OH * d->OW < 65536) return false;
+    const long long es = d->math == XV2_MATH_BF16_STORE ? 2 : 4;
+    if ((long long)d->N * d->IH * d->IW * ld_big * es >= (1ll << 31) || (long long)d->N * d->OH * d->OW * ld_small * es >= (1ll << 31)) return false;
+    if ((ld_small * es) % 16 != 0 || (ld_big * es) % 16 != 0) return false;
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, hipStream_t stream) {
+    if (!thin_ct_shape(d, ldx, ldy, x, w_ihwo, y)) return -1;
+    ThinParams q;
+    q.A = x; q.B = w_ihwo; q.Out = y; q.stats = nullptr;
+    q.M = d->N * d->OH * d->OW; q.ldA = ldx; q.ldo = ldy; q.accum = 0; q.W = d->OW;
+    q.tiles = (int)cdiv(q.M, 128);
+    const bool hs = d->math == XV2_MATH_BF16_STORE;
+    const double es = hs ? 2.0 : 4.0;
+    q.bytesA = (unsigned)((double)q.M * ldx * es);
+    const double flops = 2.0 * q.M * 128.0 * 64.0, abytes = es * ((double)q.M * (64 + 128) + 64.0 * 128);
+    return hs ? thin_launch_one<64, 128, true, 2, 2, 1>(q, "thin_convT_fwd<64,32,bf16hbm>", flops, abytes, stream)
+              : thin_launch_one<64, 128, false, 4, 4, 1>(q, "thin_convT_fwd<64,32,f32x3>", flops, abytes, stream);
+}
+
+int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi, void* dx, int lddx,
+                             int accumulate, hipStream_t stream) {
+    if (!thin_ct_shape(d, lddx, lddy, dy, w_ohwi, dx)) return -1;
+    // (fp32 tensors: the K = 128 gather form needs 338 + 82 registers and ran at 0.283 ms against 0.14 ms of the tiled kernel -
+    //  measured, profiles/r04_gated_ab.md; bf16 storage only, XV2_THIN_CT=2 forces it for A/B runs)
+    static const bool force = [] { const char* e = getenv("XV2_THIN_CT"); return e && atoi(e) == 2; }();
+    if (d->math != XV2_MATH_BF16_STORE && !force) return -1;
+    ThinParams q;
+    q.A = dy; q.B = w_ohwi; q.Out = dx; q.stats = nullptr;
+    q.M = d->N * d->OH * d->OW; q.ldA = lddy; q.ldo = lddx; q.accum = accumulate & 1; q.W = d->OW;
+    q.tiles = (int)cdiv(q.M, 128);
+    const bool hs = d->math == XV2_MATH_BF16_STORE;
+    const double es = hs ? 2.0 : 4.0;
+    q.bytesA = (unsigned)((double)d->N * d->IH * d->IW * lddy * es);
+    const double flops = 2.0 * q.M * 128.0 * 64.0, abytes = es * ((double)q.M * (64 + 128) + 64.0 * 128);
+    return hs ? thin_launch_one<128, 64, true, 2, 2, 2>(q, "thin_convT_bwd<32,64,bf16hbm>", flops, abytes, stream)
+              : thin_launch_one<128, 64, false, 4, 4, 2>(q, "thin_convT_bwd<32,64,f32x3>", flops, abytes, stream);
 }
 
 }  // namespace xv2
