@@ -152,6 +152,46 @@ def test_cfg2_conv_transpose_at_true_size(shape):
     close(wg.grad, wr.grad, 5e-4, "convT dw")
 
 
+def test_conv_transpose_1024_level_bf16_and_pass_through_alias():
+    """ConvTranspose2d(64 -> 32) at 2 x 512 x 512 -> 1024 x 1024 under bf16 storage (the streaming kernel's scatter / gather forms,
+    csrc/thin_conv.hip MODE 1 / 2) against fp32 PyTorch on the bf16-rounded operands, and the pass-through alias: the gradient of
+    the input's other consumer is summed in the backward-data launch (xv2_conv_transpose2d_backward_data_acc)"""
+    from xview2_amd import ops
+    Cin, Cout, H = 64, 32, 512
+    torch.manual_seed(5)
+    x = torch.randn(B, Cin, H, H).bfloat16().float()
+    w = (torch.randn(Cin, Cout, 2, 2) * (1.0 / Cin) ** 0.5)
+    dy = torch.randn(B, Cout, 2 * H, 2 * H).bfloat16().float()
+    other = torch.randn(B, Cin, H, H).bfloat16().float()          # the other consumer's gradient of x
+    xr, wr = x.clone().requires_grad_(True), w.bfloat16().float().clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2)
+    (yr * dy).sum().backward()
+    old = ops.STORAGE
+    ops.set_storage_dtype(torch.bfloat16)
+    try:
+        a = nhwc(x).bfloat16().requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        y, alias = ops.ConvTranspose2x2Fn.apply(a, wg, True)
+        (y.float() * nhwc(dy)).sum().backward(retain_graph=True)
+        torch.cuda.synchronize()
+        g_plain = a.grad.clone()
+        a.grad = None
+        wg.grad = None
+        ((y.float() * nhwc(dy)).sum() + (alias.float() * nhwc(other)).sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_storage_dtype(old)
+
+    def bclose(u, v, tol, what):
+        u, v = u.double(), v.double()
+        err = float((u - v).abs().max()) / max(float(v.abs().max()), 1e-12)
+        assert err <= tol, "%s: %.3e" % (what, err)
+    bclose(nchw(y.float()), yr.detach(), 2e-2, "convT bf16 y")
+    bclose(nchw(g_plain.float()), xr.grad, 2e-2, "convT bf16 dx")
+    bclose(nchw(a.grad.float()), xr.grad + other, 2e-2, "convT bf16 dx + other consumer")
+    bclose(wg.grad.cpu(), wr.grad, 2e-2, "convT bf16 dw")
+
+
 def test_cfg2_stem_and_head_at_true_size():
     from xview2_amd import ops
     torch.manual_seed(99)
