@@ -116,6 +116,27 @@ int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int ctot, void* 
 int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream);
 int xv2_presplit_forget(const void* b_fp32);
 
+/* F16X2 - the two-plane form of XV2_MATH_F32X3 (same tensors, same accumulation, half the matrix instructions): an operand x is
+ * scaled by a power of two s taken from the tensor's max |x| (|x * s| < 2^15) and split as x * s = h + m, h = fp16(x * s),
+ * m = fp16(x * s - h): 22 significant bits for every element within 2^18 of the maximum, an absolute error of 2^-39 of the maximum
+ * below that; each product is three v_mfma_f32_32x32x16_f16 (h*h, h*m, m*h; the dropped m*m <= 2^-22) with fp32 accumulation and
+ * the epilogue multiplies by 1 / (s_a * s_b) - exact.  Measured against an fp64 convolution it is as close as an fp32 one
+ * (scripts/chk_f16x2.py); F.conv2d on the reference's GPU path defaults to TF32, 2^-11.  The mode needs the operands' maxima:
+ *   - a tensor's maximum lives in 64 uint32 "slots" (bit patterns of |x|; the maximum of the 64 is the tensor's), written with
+ *     atomicMax by the kernel that PRODUCES the tensor (xv2_bn_act_forward_amax, ...) or by xv2_tensor_amax (zeroes the slots
+ *     first, then one pass over x); a producer that cannot know the maximum leaves the consumer on the three-plane bf16 form;
+ *   - xv2_amax_ctx(a0, a1) names the slots of the activation sources x0 / x1 (dy for the backward passes) for the convolution
+ *     calls of THIS host thread that follow, until it is called again (NULL, NULL clears; always clear after the call);
+ *   - xv2_presplit_weights_f16 takes the maximum of a packed fp32 weight operand into `amax_slots` and writes the two scaled fp16
+ *     planes ([nrows/64][T][ctot/16][2][64][16], xv2_presplit_f16_bytes) and remembers the pair like xv2_presplit_weights.
+ * A convolution whose plan is the halo form and whose three maxima are known runs as F16X2, every other one as F32X3; a value
+ * above the recorded maximum (a slot that is stale) overflows to Inf / NaN - loud, never a silently wrong finite result.
+ * XV2_F16X2=0 in the environment keeps every launch on the three-plane form. */
+int xv2_amax_ctx(const void* amax_a0, const void* amax_a1);
+int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* stream);
+size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot);
+int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream);
+
 /* y = conv2d(cat(x0,x1), w) [+ bias]; replaces F.conv2d.  If `stats` != NULL the kernel also
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]
  * (tile count = xv2_conv2d_forward_stats_tiles(d)), consumed by xv2_bn_reduce_stats. */

@@ -44,3 +44,15 @@ for ms, gf, mb, name, i in rows:
     b[k][0] += ms; b[k][1] += gf
 for k in ("<60", "<80", "<100", "<120", ">=120"):
     print("TF %-6s time %.2f ms  %.0f GF" % (k, b[k][0], b[k][1]))
+# distance of every launch from its own bound: max(flops / 210 TFLOP/s [the isolated rate of the best 3x3 launches],
+# algorithmic bytes / 5 TB/s [the streaming BatchNorm passes' rate]) - sorted by the time above that bound
+if os.environ.get("XV2_PROF_EXCESS") == "1":
+    ex = []
+    for ms, gf, mb, name, i in rows:
+        tr = max(gf / 210.0, mb / 5000.0)
+        ex.append((ms - tr, ms, tr, gf, mb, name, i))
+    ex.sort(reverse=True)
+    print("sum of time above the per-launch bound: %.2f ms of %.2f" % (sum(e[0] for e in ex), tot))
+    for e in ex[:70]:
+        print("#%3d %-46s %7.3f ms  bound %6.3f  excess %6.3f   %7.2f GF %7.1f MB  %s" % (
+            e[6], e[5], e[1], e[2], e[0], e[3], e[4], "flops" if e[3] / 210.0 > e[4] / 5000.0 else "bytes"))

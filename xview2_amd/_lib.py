@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("XV2_LIB", os.path.join(_HERE, "libxv2.so"))
 SOURCES = ["errors.cpp", "igemm_conv.hip", "direct_conv.hip", "thin_conv.hip", "stem_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
            "loss_optim.hip", "xchg.hip", "augment.hip", "layer_entry.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("XV2_EXTRA_FLAGS", "").split()
 
 
 def _stale():
@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     """Compile every kernel for gfx950 and link libxv2.so (cross-compiles without a GPU)."""
     if not force and not _stale():
         return LIB_PATH
-    objdir = os.path.join(_HERE, "build")
+    objdir = os.environ.get("XV2_OBJDIR", os.path.join(_HERE, "build"))
     os.makedirs(objdir, exist_ok=True)
 
     def cc(src):
@@ -76,7 +76,7 @@ def lib():
         for name in ("xv2_conv2d_backward_weight_workspace", "xv2_conv2d_forward_workspace",
                      "xv2_conv2d_backward_data_workspace", "xv2_head_conv_backward_workspace",
                      "xv2_bn_tensor_stats_workspace", "xv2_bn_backward_workspace", "xv2_splat_gap_workspace",
-                     "xv2_loss_workspace", "xv2_xchg_bytes"):
+                     "xv2_loss_workspace", "xv2_xchg_bytes", "xv2_presplit_f16_bytes"):
             getattr(_lib, name).restype = ctypes.c_size_t
         _lib.xv2_conv2d_forward_stats_tiles.restype = ctypes.c_int64
         _lib.xv2_conv2d_forward_stats_tile_rows.restype = ctypes.c_int64

@@ -108,9 +108,10 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // optimizer step) and goes global -> LDS with direct-to-LDS buffer loads: no registers, no split, no ds_write for it.
 // PMC had shown the plane stores as the most expensive producer step in clock; emulated first (garbage data): -12 %.
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
-          bool HALO = false, bool BX3 = false>
+          bool HALO = false, bool BX3 = false, int NPL = 3>
 __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!BX3 || HALO, "pre-split weights: halo form only");
+    static_assert(NPL == 3 || (NPL == 2 && BX3), "two fp16 planes (F16X2): halo form with pre-split weights");
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     static_assert(!HALO || ((X3 || (HS && !SMALLC)) && BM == 128), "halo form: F32X3 or bf16 storage, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -476,15 +477,18 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         // 16) SQ_LDS_BANK_CONFLICT counted 2.1e7 cycles per launch, 8 % of the kernel; consecutive rows: 0.
         constexpr int LDK = 24, HWD = PW + 2, HUSE = PW + 2, NHP = ((PH + 2) * HWD + 7) / 8 * 8;      // 204 -> 208 LDS rows
         constexpr int PLA = NHP * LDK;                                   // halo plane [240][24] bf16
-        constexpr int PLB = BN * LDK, STB = 3 * PLB;                     // weight stage: three planes [BN][24]
+        constexpr int PLB = BN * LDK, STB = NPL * PLB;                   // weight stage: NPL planes [BN][24]
         constexpr int HL = (NHP * 4 + 255) / 256;                        // 16-byte halo loads per thread (4, a quarter idle)
-        static_assert((size_t)(3 * PLA + 2 * STB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + weight stages fit the operand buffers");
-        __bf16* sa = reinterpret_cast<__bf16*>(smem);                    // [3][NHPP][LDK]
-        __bf16* sbw = sa + 3 * PLA;                                      // [2][3][BN][LDK]
+        static_assert((size_t)(NPL * PLA + 2 * STB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + weight stages fit the operand buffers");
+        __bf16* sa = reinterpret_cast<__bf16*>(smem);                    // [NPL][NHPP][LDK]
+        __bf16* sbw = sa + NPL * PLA;                                    // [2][NPL][BN][LDK]
         // BX3: ring of three weight stages, each [BN / 64 units][3 planes][64 rows][16] bf16 with the two 16-byte halves of a
         // row swapped on rows 4..7 mod 8 (conflict-free 16-byte fragment reads without padding), 1 KB per DMA instruction
-        constexpr int STBX = 3 * BN * 16;                                // elements per pre-split weight stage
-        static_assert(!BX3 || (size_t)(3 * PLA + 3 * STBX) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + three weight stages fit");
+        constexpr int STBX = NPL * BN * 16;                              // elements per pre-split weight stage
+        static_assert(!BX3 || (size_t)(NPL * PLA + 3 * STBX) * 2 <= (size_t)MAIN_FLOATS * 4, "halo + three weight stages fit");
+        // F16X2: scale of the activation operand (a power of two from the producer's recorded maximum)
+        float sA = 1.f;
+        if constexpr (NPL == 2) sA = amax_scale(amax_exponent(p.amaxA0, p.amaxA1));
         const int ntp = ci.ntaps;                                        // 9
         // split-K ranges are whole 32-channel chunks (kt_per_split % ntaps == 0, igemm_launch)
         const int cs_begin = 2 * (kt_begin / ntp), cs_end = 2 * (kt_end / ntp);      // 16-channel slices
@@ -508,8 +512,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + 1) * HWD + l31 + 1;
         float4 hraw[HL], rbb[BROWS], rbb1[BROWS];
         float4 hsc = make_float4(1.f, 1.f, 1.f, 1.f), hsf = make_float4(0.f, 0.f, 0.f, 0.f);      // pre_scale / pre_shift of hraw's slice
-        uint2 pkb[BROWS][3], pkh[HL][3];
-        bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
+        uint2 pkb[BROWS][NPL], pkh[HL][NPL];
+        bf16x8 fa0[MR][NPL], fb0[NR][NPL], fa1[MR][NPL], fb1[NR][NPL];
         auto hload = [&](int cs) {
             const int cc = (cs >> 1) * BK + (cs & 1) * 16;
             const bool first = cc < p.C0;
@@ -537,7 +541,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                     v.z = apply_act(__fmaf_rn(v.z, hsc.z, hsf.z), p.pre_act);
                     v.w = apply_act(__fmaf_rn(v.w, hsc.w, hsf.w), p.pre_act);
                 }
-                split3x4(v, pkh[j][0], pkh[j][1], pkh[j][2]);
+                if constexpr (NPL == 2) split2hx4(v, sA, pkh[j][0], pkh[j][1]);
+                else split3x4(v, pkh[j][0], pkh[j][1], pkh[j][NPL - 1]);
             }
         };
         auto hstore = [&]() {
@@ -548,9 +553,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             for (int j = 0; j < HL; ++j)
                 if (hrow[j] >= 0) {
                     __bf16* d = sa + hrow[j] * LDK + (tid & 3) * 4;
-                    *reinterpret_cast<uint2*>(d) = pkh[j][0];
-                    *reinterpret_cast<uint2*>(d + PLA) = pkh[j][1];
-                    *reinterpret_cast<uint2*>(d + 2 * PLA) = pkh[j][2];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2*>(d + q * PLA) = pkh[j][q];
                 }
         };
         // taps are the 3 x 3 neighbourhood in slot order, (dh, dw) = sgn * (t / 3 - 1, t % 3 - 1) with sgn = +1 (forward) or
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         };
         auto bsplit = [&](const float4 (&xb)[BROWS]) {
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) split3x4(xb[j], pkb[j][0], pkb[j][1], pkb[j][2]);
+            for (int j = 0; j < BROWS; ++j) split3x4(xb[j], pkb[j][0], pkb[j][1], pkb[j][NPL - 1]);
         };
         auto bstore = [&](int buf) {
 #if XV2_HABL & 4
@@ -576,13 +580,12 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 const int rr = r0 + RPP * j;
                 if (BN % RPP == 0 || rr < BN) {
                     __bf16* d = sbw + buf * STB + rr * LDK + c4 * 4;
-                    *reinterpret_cast<uint2*>(d) = pkb[j][0];
-                    *reinterpret_cast<uint2*>(d + PLB) = pkb[j][1];
-                    *reinterpret_cast<uint2*>(d + 2 * PLB) = pkb[j][2];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2*>(d + q * PLB) = pkb[j][q];
                 }
             }
         };
-        auto read_a = [&](int tp, bf16x8 (&fa)[MR][3]) {
+        auto read_a = [&](int tp, bf16x8 (&fa)[MR][NPL]) {
             const int th = tp / 3;
 #if XV2_HABL & 2
             const int toff = 0;
@@ -590,31 +593,44 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             const int toff = sgn * ((th - 1) * HWD + (tp - th * 3 - 1));
 #endif
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NPL; ++q)
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
                     fa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * PLA + (abase[i] + toff) * LDK + 8 * h);
         };
-        auto read_b = [&](int buf, bf16x8 (&fb)[NR][3]) {
+        auto read_b = [&](int buf, bf16x8 (&fb)[NR][NPL]) {
 #if XV2_HABL & 8
             const __bf16* b = sbw + buf * STB + l31 * 8 + 256 * h;      // conflict-free by construction (wrong data)
 #else
             const __bf16* b = sbw + buf * STB + (wn * WTN + l31) * LDK + 8 * h;
 #endif
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NPL; ++q)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * PLB + j * 32 * LDK);
         };
-        auto mfma_stage = [&](const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3]) {
+        auto mfma_stage = [&](const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL]) {
+            if constexpr (NPL == 2) {        // fp16 planes: m*h, h*m, h*h
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][t == 0 ? 1 : 0]),
+                                                                               __builtin_bit_cast(f16x8, fb[j][t == 1 ? 1 : 0]),
+                                                                               acc[i][j], 0, 0, 0);
+                return;
+            }
+#pragma unroll
+            for (int t = XV2_T0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
-                        const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+                        const int qa = t == 0 ? NPL - 1 : (t == 2 || t == 3) ? 1 : 0;
+                        const int qb = t == 1 ? NPL - 1 : (t == 2 || t == 4) ? 1 : 0;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
                     }
         };
@@ -623,8 +639,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         // is split and replaces the halo in LDS - nobody reads it any more: the A fragments of the last tap were fetched one
         // iteration earlier - and the first tap's A fragments are read behind the barrier.
         // (tp, cs = tap and slice of stage st, by value: as captured loop state they ended up in scratch memory)
-        auto iter = [&](int st, const int tp, const int cs, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3],
-                        bf16x8 (&na)[MR][3], bf16x8 (&nb)[NR][3], float4 (&xb)[BROWS], float4 (&yb)[BROWS]) {
+        auto iter = [&](int st, const int tp, const int cs, const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL],
+                        bf16x8 (&na)[MR][NPL], bf16x8 (&nb)[NR][NPL], float4 (&xb)[BROWS], float4 (&yb)[BROWS]) {
             const bool last = tp == ntp - 1;
             const bool more = st + 1 < s_end;
             if (more) {
@@ -637,8 +653,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
             for (int j = 0; j < BROWS; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pkb[j][q].x), "+v"(pkb[j][q].y));
-            constexpr int NMFMA = 6 * MR * NR, NRD = 3 * (MR + NR);
+                for (int q = 0; q < NPL; ++q) asm volatile("" : "+v"(pkb[j][q].x), "+v"(pkb[j][q].y));
+            constexpr int NMFMA = (6 - XV2_T0) * MR * NR, NRD = NPL * (MR + NR);
 #pragma unroll
             for (int g = 0; g < NMFMA; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -667,25 +683,25 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
                 for (int u = 0; u < CPW; ++u) {
                     const int chunk = (wave * CPW + u) % NCH;
-                    const int unit = chunk / 6, cq = chunk - unit * 6;
-                    const int goff = (((tn * (BN / 64) + unit) * p.T + tp) * nsl + cs) * 6144 + cq * 1024 + lane * 16;
+                    const int unit = chunk / (2 * NPL), cq = chunk - unit * (2 * NPL);
+                    const int goff = (((tn * (BN / 64) + unit) * p.T + tp) * nsl + cs) * (2048 * NPL) + cq * 1024 + lane * 16;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rsX, (__attribute__((address_space(3))) void*)(sbw + buf * STBX + unit * 3072 + cq * 512), 16, goff, 0, 0, 0);
+                        rsX, (__attribute__((address_space(3))) void*)(sbw + buf * STBX + unit * (1024 * NPL) + cq * 512), 16, goff, 0, 0, 0);
                 }
             };
-            auto read_bx = [&](int buf, bf16x8 (&fb)[NR][3]) {
+            auto read_bx = [&](int buf, bf16x8 (&fb)[NR][NPL]) {
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     const int row = wn * WTN + j * 32 + l31, unit = row >> 6, r = row & 63;
-                    const __bf16* b = sbw + buf * STBX + unit * 3072 + r * 16 + ((h ^ ((r >> 2) & 1)) * 8);
+                    const __bf16* b = sbw + buf * STBX + unit * (1024 * NPL) + r * 16 + ((h ^ ((r >> 2) & 1)) * 8);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * 1024);
+                    for (int q = 0; q < NPL; ++q) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * 1024);
                 }
             };
             // iteration st (ring slot bc = st % 3): fragments of st in (fa, fb); (na, nb) receive st+1; the DMA of st+2 (issued
             // one iteration ago) must have landed by the barrier, the DMA of st+3 is issued here into the slot of st
-            auto iterx = [&](int st, const int tp, const int cs, const int bc, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3],
-                             bf16x8 (&na)[MR][3], bf16x8 (&nb)[NR][3]) {
+            auto iterx = [&](int st, const int tp, const int cs, const int bc, const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL],
+                             bf16x8 (&na)[MR][NPL], bf16x8 (&nb)[NR][NPL]) {
                 const bool last = tp == ntp - 1;
                 const bool more = st + 1 < s_end;
                 if (more) {
@@ -702,7 +718,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 }
                 if (pf) {
                     if constexpr (CPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if constexpr (CPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -828,7 +845,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             // smallest terms first (l*h, h*l, m*m, m*h, h*m, h*h); the accumulator tiles interleave, so dependent MFMAs
             // are MR*NR issues apart
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = XV2_T0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -854,7 +871,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
                 for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
             // per MFMA slot (32 cycles): one fragment read of the next stage while there are any, ~4 split VALU
-            constexpr int NMFMA = 6 * MR * NR, NRD = 3 * (MR + NR);
+            constexpr int NMFMA = (6 - XV2_T0) * MR * NR, NRD = 3 * (MR + NR);
 #pragma unroll
             for (int g = 0; g < NMFMA; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -988,6 +1005,15 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
     if (acc[0][0][0] == 123.456f) p.Out0[0] = 1.f;
     return;
 #endif
+    if constexpr (NPL == 2) {      // F16X2: undo the operand scales (powers of two: exact)
+        const float ia = amax_inv(amax_exponent(p.amaxA0, p.amaxA1)), ib = amax_inv(amax_exponent(p.amaxB));
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * ia * ib;
+    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // The tile is staged through LDS (the A/B buffers are free now) so that global stores are 16 bytes per lane
     // and cover whole 128..512-byte output rows: for the K<=256 1x1 convolutions the dword-store epilogue was
@@ -1535,10 +1561,10 @@ int coop_capacity(const void* kern, int threads, size_t smem) {
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
-          bool HALO = false, bool BX3 = false>
+          bool HALO = false, bool BX3 = false, int NPL = 3>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
     constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM, HALO>();
-    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO, BX3>;
+    auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO, BX3, NPL>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1547,7 +1573,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? (HALO ? "c32,bf16hbm,halo" : "c32,bf16hbm") : (X3 ? (HALO ? (BX3 ? "c32,f32x3,halo,wx3" : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? (HALO ? "c32,bf16hbm,halo" : "c32,bf16hbm") : (X3 ? (HALO ? (BX3 ? (NPL == 2 ? "c32,f16x2,halo,wx2" : "c32,f32x3,halo,wx3") : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -1731,9 +1757,34 @@ static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
 struct PresplitEntry {
     const void* x3;
     int nrows, T, ctot;
+    const unsigned* amax = nullptr;      // F16X2 entries: the 64 maximum slots the two fp16 planes were scaled with
 };
 static std::mutex g_presplit_mu;
 static std::unordered_map<const void*, PresplitEntry> g_presplit;
+static std::unordered_map<const void*, PresplitEntry> g_presplit2;      // packed fp32 operand -> two scaled fp16 planes (F16X2)
+
+// F16X2 operand maxima of the NEXT convolution call of this thread (xv2_amax_ctx): consumed by fill_common()
+struct AmaxCtx {
+    const unsigned* a0 = nullptr;
+    const unsigned* a1 = nullptr;
+};
+static thread_local AmaxCtx t_amax;
+static bool f16x2_enabled() {      // XV2_F16X2=0: every launch on the three-plane bf16 form
+    static const int v = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+// max |x| of a tensor into 64 slots (zeroed by the caller): the weight operands' maxima, and the test harness
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ slots) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) m = __uint_as_float(0x7fc00000u);      // NaN stays loud
+    }
+    amax_record(slots, m, red);
+}
 
 // one block = one (64-row unit, 16-channel slice), all taps: 256 threads = 64 rows x 4 channel quads, so that every plane of
 // a (tap, slice) is written as ONE contiguous 2 KB run (the first version wrote 32-byte pieces 6 KB apart: 210 us per cfg2
@@ -1776,6 +1827,35 @@ __device__ __forceinline__ void presplit_block(const float* __restrict__ src, __
             }
     }
 }
+// the same image with TWO fp16 planes of w * s (F16X2; 2048 elements per (unit, tap, slice)), s from the operand's recorded maximum
+__global__ void __launch_bounds__(256) presplit2h_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
+                                                         int T, int ctot, const unsigned* __restrict__ amax) {
+    const float s = amax_scale(amax_exponent(amax));
+    const int nsl = ctot / 16;
+    const int64_t nb = (int64_t)(nrows / 64) * nsl;
+    const int r = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 4;
+    const int half = (k0 >> 3) ^ ((r >> 2) & 1);
+    for (int64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+        const int cs = (int)(blk % nsl), unit = (int)(blk / nsl);
+        const float* sp = src + (size_t)(unit * 64 + r) * T * ctot + cs * 16 + k0;
+        __bf16* dp = dst + ((size_t)unit * T * nsl + cs) * 2048 + r * 16 + half * 8 + (k0 & 7);
+        for (int t0 = 0; t0 < T; t0 += 3) {
+            float4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (t0 + u < T) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)(t0 + u) * ctot);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (t0 + u < T) {
+                    uint2 pk[2];
+                    split2hx4(v[u], s, pk[0], pk[1]);
+                    __bf16* d = dp + (size_t)(t0 + u) * nsl * 2048;
+                    *reinterpret_cast<uint2*>(d) = pk[0];
+                    *reinterpret_cast<uint2*>(d + 1024) = pk[1];
+                }
+        }
+    }
+}
 __global__ void __launch_bounds__(256) presplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
                                                        int T, int ctot) {
     const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
@@ -1798,6 +1878,18 @@ static bool presplit_lookup(const void* b, int nrows, int T, int ctot, const voi
     auto it = g_presplit.find(b);
     if (it == g_presplit.end() || it->second.nrows != nrows || it->second.T != T || it->second.ctot != ctot) return false;
     *x3 = it->second.x3;
+    return true;
+}
+// F16X2 for this launch: the operand maxima of both sides are known and the weights exist as two scaled fp16 planes
+static bool f16x2_ready(IgemmParams& p) {
+    if (!f16x2_enabled() || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1) || p.pre_scale) return false;
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    auto it = g_presplit2.find(p.B);
+    if (it == g_presplit2.end() || it->second.nrows != p.Nout || it->second.T != p.T || it->second.ctot != p.Ctot) return false;
+    p.Bx3 = reinterpret_cast<const float*>(it->second.x3);
+    p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 4);
+    p.amaxB = it->second.amax;
+    p.npl = 2;
     return true;
 }
 
@@ -1912,6 +2004,9 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         }
         XV2_CHECK_ARG(!p.pre_scale || halo1, "conv2d_forward_bn_pre: this shape is not planned as the halo form (query _pre_supported)");
         if (halo1) {
+            if (f16x2_ready(p))
+                return bn == 128 ? launch_one<128, 128, 2, 2, false, true, false, true, true, true, 2>(p, stream)
+                                 : launch_one<128, 64, 2, 2, false, true, false, true, true, true, 2>(p, stream);
             const void* x3 = nullptr;
             if (presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
                 p.Bx3 = reinterpret_cast<const float*>(x3);
@@ -1932,7 +2027,8 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
                 p.kt_per_split = 9 * cps;
                 p.ksplit = nks;
                 const void* x3 = nullptr;
-                if (!halo16 && presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
+                if (!halo16 && f16x2_ready(p)) {
+                } else if (!halo16 && presplit_enabled() && presplit_lookup(p.B, p.Nout, p.T, p.Ctot, &x3)) {
                     p.Bx3 = reinterpret_cast<const float*>(x3);
                     p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 6);
                 }
@@ -1980,6 +2076,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         }
         int rc = (halo && halo16)              ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
                  : p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                 : (halo && p.npl == 2)        ? launch_one<128, 128, 2, 2, false, true, false, true, true, true, 2>(p, stream)
                  : (halo && p.Bx3)             ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
                  : halo                        ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
@@ -2070,6 +2167,10 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.sk_tickets = nullptr;
     p.Bx3 = nullptr;
     p.bytesBx3 = 0;
+    p.npl = 3;
+    p.amaxA0 = t_amax.a0;      // (sticky until the caller clears it: plan queries run through here too)
+    p.amaxA1 = t_amax.a1;
+    p.amaxB = nullptr;
     p.ksplit = 1;
     p.cin_real = 3;
     p.math = d->math;
@@ -2548,6 +2649,38 @@ extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int c
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
+extern "C" int xv2_amax_ctx(const void* amax_a0, const void* amax_a1) {
+    t_amax.a0 = static_cast<const unsigned*>(amax_a0);
+    t_amax.a1 = static_cast<const unsigned*>(amax_a1);
+    return XV2_OK;
+}
+extern "C" int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* stream) {
+    XV2_CHECK_ARG(x && slots && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "tensor_amax: n %% 4 == 0, 16-byte aligned");
+    XV2_CHECK_HIP(hipMemsetAsync(slots, 0, AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream));
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::min<long long>(cdiv(n4, 1024), 1024)), dim3(256), 0, (hipStream_t)stream, x,
+                       (size_t)n4, static_cast<unsigned*>(slots));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+extern "C" size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot) { return (size_t)nrows * T * ctot * 4; }
+extern "C" int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream) {
+    XV2_CHECK_ARG(b_fp32 && x2 && amax_slots && xv2_presplit_supported(nrows, T, ctot), "presplit_f16: unsupported operand %d x %d x %d",
+                  nrows, T, ctot);
+    XV2_CHECK_ARG(((uintptr_t)x2 & 15) == 0 && xv2_presplit_f16_bytes(nrows, T, ctot) < (1ull << 31), "presplit_f16: alignment / size");
+    if (int rc = xv2_tensor_amax(b_fp32, (long long)nrows * T * ctot, amax_slots, stream)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_presplit_mu);
+        PresplitEntry e{x2, nrows, T, ctot};
+        e.amax = static_cast<const unsigned*>(amax_slots);
+        g_presplit2[b_fp32] = e;
+    }
+    const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
+    hipLaunchKernelGGL(presplit2h_kernel, dim3((unsigned)std::min<int64_t>(nb, 16384)), dim3(256), 0, (hipStream_t)stream, b_fp32,
+                       reinterpret_cast<__bf16*>(x2), nrows, T, ctot, static_cast<const unsigned*>(amax_slots));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
 extern "C" int64_t xv2_presplit_blocks(int nrows, int T, int ctot) { (void)T; return (int64_t)(nrows / 64) * (ctot / 16); }
 // every registered pair of a device table in one launch (after the optimizer step); rows as in presplit_table_kernel
 extern "C" int xv2_presplit_table(const int64_t* table, int n, int64_t total_blocks, void* stream) {
@@ -2558,7 +2691,12 @@ extern "C" int xv2_presplit_table(const int64_t* table, int n, int64_t total_blo
 }
 extern "C" int xv2_presplit_forget(const void* b_fp32) {
     std::lock_guard<std::mutex> lk(g_presplit_mu);
-    if (b_fp32) g_presplit.erase(b_fp32);
-    else g_presplit.clear();
+    if (b_fp32) {
+        g_presplit.erase(b_fp32);
+        g_presplit2.erase(b_fp32);
+    } else {
+        g_presplit.clear();
+        g_presplit2.clear();
+    }
     return XV2_OK;
 }

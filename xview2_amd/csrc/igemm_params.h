@@ -33,6 +33,12 @@ struct IgemmParams {
     unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
     const float* Bx3;                   // halo form: B pre-split into three bf16 planes (xv2_presplit_weights), or nullptr
     unsigned bytesBx3;
+    // F16X2 (xv2_common.h): npl == 2 - Bx3 holds TWO fp16 planes scaled by the maximum recorded in amaxB, the A operand is
+    // scaled by the maximum of amaxA0 / amaxA1 (64 slots each, written by the tensor's producer); npl == 3: bf16 planes, no scale
+    int npl;
+    const unsigned* amaxA0;
+    const unsigned* amaxA1;
+    const unsigned* amaxB;
     int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
     int ldA0, ldA1;
     int IH, IW;        // spatial size of A

@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
                 bl[j] = frag(bb + 2 * PL + (16 * ks) * SB + j * 32, SB);
             }
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = XV2_T0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
         for (int j = 0; j < APASS + BPASS; ++j)
 #pragma unroll
             for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
-        constexpr int NMFMA = 2 * 6 * MR * NR;
+        constexpr int NMFMA = 2 * (6 - XV2_T0) * MR * NR;
 #pragma unroll
         for (int g = 0; g < NMFMA; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1006,9 +1006,11 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
                 if ((t & 1) != odd) continue;          // wave-uniform
                 const bf16x8 bh = frag(row + kw * 32), bm = frag(row + kw * 32 + PL), bl = frag(row + kw * 32 + 2 * PL);
                 f32x16 c = acc[t >> 1];
+#if XV2_T0 == 0
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+#endif
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
                 acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
@@ -1235,9 +1237,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
                     const int t = kh * 3 + kw, pb = pa + kw, cb = wb * 32 + fcol;
                     const bf16x8 bh = frag(row, pb, cb), bm = frag(row + PL, pb, cb), bl = frag(row + 2 * PL, pb, cb);
                     f32x16 c = acc[t];
+#if XV2_T0 == 0
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);

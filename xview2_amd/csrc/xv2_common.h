@@ -140,6 +140,59 @@ __device__ __forceinline__ void split3x4(const float4 v, uint2& h, uint2& m, uin
     split3x2(v.z, v.w, h.y, m.y, l.y);
 }
 
+// Scaled-fp16 pair ("F16X2", the two-plane form of the F32X3 kernels): x * s = h + m with h = fp16(x * s), m = fp16(x * s - h),
+// s a power of two taken from the tensor's max |x| so that |x * s| < 2^15.  11 + 11 significant bits: every element within 2^18
+// of the tensor's maximum is represented to 2^-22 relative, smaller ones to 2^-39 of the maximum; three fp16 MFMAs per product
+// (h*h, h*m, m*h; the dropped m*m is <= 2^-22) instead of six bf16 ones.  The maximum comes from the PRODUCER of the tensor
+// (64 slots of |x| bit patterns, atomicMax per block) - without it a launch stays on the three-plane bf16 form, which needs no
+// range information.  A value above the recorded maximum (a stale slot) would overflow to Inf and is therefore loud.
+__device__ __forceinline__ void split2hx2(float a, float b, unsigned& h, unsigned& m) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    const h2 hh = __builtin_convertvector(v, h2);
+    const f2 r = v - __builtin_convertvector(hh, f2);        // exact
+    const h2 mm = __builtin_convertvector(r, h2);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, mm);
+}
+__device__ __forceinline__ void split2hx4(const float4 v, float s, uint2& h, uint2& m) {
+    split2hx2(v.x * s, v.y * s, h.x, m.x);
+    split2hx2(v.z * s, v.w * s, h.y, m.y);
+}
+constexpr int AMAX_SLOTS = 64;
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+// biased exponent of the recorded maximum, clamped so that both the scale and its inverse are normal numbers
+__device__ __forceinline__ int amax_exponent(const unsigned* slots, const unsigned* slots1 = nullptr) {
+    unsigned v = slots[threadIdx.x & 63];
+    if (slots1) v = max(v, slots1[threadIdx.x & 63]);
+    v = wave_max_u(v);
+    const int e = (int)((v >> 23) & 0xffu);
+    return __builtin_amdgcn_readfirstlane(min(max(e, 16), 240));
+}
+__device__ __forceinline__ float amax_scale(int e) { return __uint_as_float((unsigned)(268 - e) << 23); }      // |x| * s < 2^15
+__device__ __forceinline__ float amax_inv(int e) { return __uint_as_float((unsigned)(e - 14) << 23); }
+// block-level record of max |x| (bits of |x| order like the values; NaN / Inf order above every finite number)
+__device__ __forceinline__ void amax_record(unsigned* slots, float local_abs_max, float* smem4) {
+    unsigned v = wave_max_u(__float_as_uint(local_abs_max) & 0x7fffffffu);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned*>(smem4)[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) v = max(v, reinterpret_cast<unsigned*>(smem4)[w]);
+        unsigned* d = slots + (blockIdx.x & (AMAX_SLOTS - 1));
+        if (v > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#ifndef XV2_T0
+#define XV2_T0 0   // emulation switch: 3 drops the three smallest product terms of the F32X3 kernels
+#endif
 #define XV2_CHECK_DTYPE(dt) XV2_CHECK_ARG((dt) == XV2_F32 || (dt) == XV2_BF16, "unknown activation dtype %d", (int)(dt))
 // run `call` with T bound to the storage type named by dtype
 #define XV2_DISPATCH_DTYPE(dt, ...)             \
