@@ -20,16 +20,16 @@ def run(f16):
     keep = []
     if f16:
         x2 = torch.empty((query("xv2_presplit_f16_bytes", Co, 9, C0 + C1) // 2,), dtype=torch.float16, device="cuda")
-        sw = torch.zeros(64, dtype=torch.int32, device="cuda")
+        sw = torch.zeros(2048, dtype=torch.int32, device="cuda")
         call("xv2_presplit_weights_f16", ohwi, Co, 9, C0 + C1, x2, sw)
-        s0 = torch.zeros(64, dtype=torch.int32, device="cuda")
+        s0 = torch.zeros(2048, dtype=torch.int32, device="cuda")
         call("xv2_tensor_amax", x0, x0.numel(), s0)
         s1 = None
         if x1 is not None:
-            s1 = torch.zeros(64, dtype=torch.int32, device="cuda")
+            s1 = torch.zeros(2048, dtype=torch.int32, device="cuda")
             call("xv2_tensor_amax", x1, x1.numel(), s1)
         keep = [x2, sw, s0, s1]
-        call("xv2_amax_ctx", s0, s1)
+        query("xv2_amax_ctx", s0, s1, None, None)
     try:
         y = ops._conv_forward(x0, x1, w, g, None, True)[0]
         torch.cuda.synchronize()
@@ -39,7 +39,7 @@ def run(f16):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 20
     finally:
-        call("xv2_amax_ctx", None, None)
+        query("xv2_amax_ctx", None, None, None, None)
         query("xv2_presplit_forget", ohwi.data_ptr()) if f16 else None
     return y, dt, keep
 

@@ -116,8 +116,23 @@ def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
 
+_amax_pending = None
+
+
+def set_amax(a0=None, a1=None, dy=None, out=None):
+    """F16X2 operand maxima (include/xv2.h xv2_amax_ctx) of the NEXT launching call: device addresses of 64-slot arrays
+    or None.  Handed to the library right before that call; the library clears the context when a convolution /
+    BatchNorm-apply entry point returns, so it serves exactly one layer."""
+    global _amax_pending
+    _amax_pending = (a0, a1, dy, out) if (a0 or a1 or dy or out) else None
+
+
 def call(name, *args):
     """Status-returning entry point on the current torch stream (stream argument appended)."""
+    global _amax_pending
+    if _amax_pending is not None:
+        (_funcs.get("xv2_amax_ctx") or _func("xv2_amax_ctx"))(*_amax_pending)
+        _amax_pending = None
     f = _funcs.get(name) or _func(name)
     get = _TO_C.get
     conv = []

@@ -245,3 +245,6 @@ __device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* pa
 }
 
 }  // namespace xv2
+
+// igemm_conv.hip: max |x| on top of what the 64 F16X2 slots hold (no zeroing) - producers without a recording kernel form
+int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream);

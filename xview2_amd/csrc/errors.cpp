@@ -6,6 +6,27 @@
 #include <string>
 #include <vector>
 #include "../../include/xv2.h"
+#include "amax_ctx.h"
+
+namespace xv2 {
+AmaxCtx& amax_ctx() {
+    static thread_local AmaxCtx c;
+    return c;
+}
+int& amax_depth() {
+    static thread_local int d = 0;
+    return d;
+}
+}  // namespace xv2
+
+extern "C" int xv2_amax_ctx(const void* amax_a0, const void* amax_a1, const void* amax_dy, void* amax_out) {
+    xv2::AmaxCtx& c = xv2::amax_ctx();
+    c.a0 = static_cast<const unsigned*>(amax_a0);
+    c.a1 = static_cast<const unsigned*>(amax_a1);
+    c.dy = static_cast<const unsigned*>(amax_dy);
+    c.out = static_cast<unsigned*>(amax_out);
+    return 0;
+}
 namespace xv2 {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {

@@ -20,6 +20,7 @@
 // Epilogue: optional bias, scattered NHWC store through a per-row pixel-offset table, and
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
 #include "igemm_params.h"
+#include "amax_ctx.h"
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -1763,12 +1764,6 @@ static std::mutex g_presplit_mu;
 static std::unordered_map<const void*, PresplitEntry> g_presplit;
 static std::unordered_map<const void*, PresplitEntry> g_presplit2;      // packed fp32 operand -> two scaled fp16 planes (F16X2)
 
-// F16X2 operand maxima of the NEXT convolution call of this thread (xv2_amax_ctx): consumed by fill_common()
-struct AmaxCtx {
-    const unsigned* a0 = nullptr;
-    const unsigned* a1 = nullptr;
-};
-static thread_local AmaxCtx t_amax;
 static bool f16x2_enabled() {      // XV2_F16X2=0: every launch on the three-plane bf16 form
     static const int v = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -1828,33 +1823,58 @@ __device__ __forceinline__ void presplit_block(const float* __restrict__ src, __
     }
 }
 // the same image with TWO fp16 planes of w * s (F16X2; 2048 elements per (unit, tap, slice)), s from the operand's recorded maximum
-__global__ void __launch_bounds__(256) presplit2h_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
-                                                         int T, int ctot, const unsigned* __restrict__ amax) {
-    const float s = amax_scale(amax_exponent(amax));
+// one block = one (64-row unit, 16-channel slice), all taps - as presplit_block; amax_only: record max |w| of the block instead
+template <bool AMAX_ONLY>
+__device__ __forceinline__ void presplit2h_block(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int ctot,
+                                                 int64_t blk, unsigned* __restrict__ amax) {
+    __shared__ float red[4];
     const int nsl = ctot / 16;
-    const int64_t nb = (int64_t)(nrows / 64) * nsl;
     const int r = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 4;
     const int half = (k0 >> 3) ^ ((r >> 2) & 1);
-    for (int64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) {
-        const int cs = (int)(blk % nsl), unit = (int)(blk / nsl);
-        const float* sp = src + (size_t)(unit * 64 + r) * T * ctot + cs * 16 + k0;
-        __bf16* dp = dst + ((size_t)unit * T * nsl + cs) * 2048 + r * 16 + half * 8 + (k0 & 7);
-        for (int t0 = 0; t0 < T; t0 += 3) {
-            float4 v[3];
+    const int cs = (int)(blk % nsl), unit = (int)(blk / nsl);
+    const float* sp = src + (size_t)(unit * 64 + r) * T * ctot + cs * 16 + k0;
+    float s = 1.f, m = 0.f;
+    if constexpr (!AMAX_ONLY) s = amax_scale(amax_exponent(amax));
+    __bf16* dp = dst + ((size_t)unit * T * nsl + cs) * 2048 + r * 16 + half * 8 + (k0 & 7);
+    for (int t0 = 0; t0 < T; t0 += 3) {
+        float4 v[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (t0 + u < T) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)(t0 + u) * ctot);
+        for (int u = 0; u < 3; ++u)
+            if (t0 + u < T) v[u] = *reinterpret_cast<const float4*>(sp + (size_t)(t0 + u) * ctot);
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (t0 + u < T) {
+        for (int u = 0; u < 3; ++u)
+            if (t0 + u < T) {
+                if constexpr (AMAX_ONLY) {
+                    m = amax_acc(m, v[u]);
+                } else {
                     uint2 pk[2];
                     split2hx4(v[u], s, pk[0], pk[1]);
                     __bf16* d = dp + (size_t)(t0 + u) * nsl * 2048;
                     *reinterpret_cast<uint2*>(d) = pk[0];
                     *reinterpret_cast<uint2*>(d + 1024) = pk[1];
                 }
-        }
+            }
     }
+    if constexpr (AMAX_ONLY) amax_record(amax, m, red, (unsigned)blk);
+}
+__global__ void __launch_bounds__(256) presplit2h_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
+                                                         int T, int ctot, unsigned* __restrict__ amax) {
+    const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
+    for (int64_t blk = blockIdx.x; blk < nb; blk += gridDim.x) presplit2h_block<false>(src, dst, T, ctot, blk, amax);
+}
+// table[n][7]: {src, dst, nrows, T, ctot, first block, amax slots}
+template <bool AMAX_ONLY>
+__global__ void __launch_bounds__(256) presplit2h_table_kernel(const int64_t* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 7 + 5] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t* e = table + lo * 7;
+    presplit2h_block<AMAX_ONLY>(reinterpret_cast<const float*>(e[0]), reinterpret_cast<__bf16*>(e[1]), (int)e[3], (int)e[4], blk - e[5],
+                                reinterpret_cast<unsigned*>(e[6]));
 }
 __global__ void __launch_bounds__(256) presplit_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int nrows,
                                                        int T, int ctot) {
@@ -2168,8 +2188,8 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.Bx3 = nullptr;
     p.bytesBx3 = 0;
     p.npl = 3;
-    p.amaxA0 = t_amax.a0;      // (sticky until the caller clears it: plan queries run through here too)
-    p.amaxA1 = t_amax.a1;
+    p.amaxA0 = amax_ctx().a0;      // forward: the activation sources (backward-data replaces them by the gradient's)
+    p.amaxA1 = amax_ctx().a1;
     p.amaxB = nullptr;
     p.ksplit = 1;
     p.cin_real = 3;
@@ -2263,6 +2283,7 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
                              long long* plan = nullptr, const StatsFold* fold = nullptr, const PreAct* pre = nullptr,
                              int* plan_halo = nullptr, const CoopArgs* coop = nullptr, int accumulate = 0) {
+    AmaxGuard amax_guard;
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
@@ -2469,9 +2490,12 @@ extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, 
 static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
                       float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream,
                       int accumulate = 0, const BnbArgs* bnb = nullptr, long long* plan = nullptr) {
+    AmaxGuard amax_guard;
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
+    p.amaxA0 = amax_ctx().dy;      // the A operand of a backward-data launch is the output gradient
+    p.amaxA1 = nullptr;
     p.plan_tiles = plan;
     p.accum = accumulate & (dx1 ? 3 : 1);
     set_bnb(p, bnb);
@@ -2649,14 +2673,18 @@ extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int c
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
-extern "C" int xv2_amax_ctx(const void* amax_a0, const void* amax_a1) {
-    t_amax.a0 = static_cast<const unsigned*>(amax_a0);
-    t_amax.a1 = static_cast<const unsigned*>(amax_a1);
+// max |x| ON TOP of what the slots hold (no zeroing): producers whose kernel has no recording form
+int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream) {
+    XV2_CHECK_ARG(x && slots && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "tensor_amax: n %% 4 == 0, 16-byte aligned");
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::min<long long>(cdiv(n4, 1024), 1024)), dim3(256), 0, (hipStream_t)stream, x,
+                       (size_t)n4, static_cast<unsigned*>(slots));
+    XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
 extern "C" int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* stream) {
     XV2_CHECK_ARG(x && slots && n > 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0, "tensor_amax: n %% 4 == 0, 16-byte aligned");
-    XV2_CHECK_HIP(hipMemsetAsync(slots, 0, AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream));
+    XV2_CHECK_HIP(hipMemsetAsync(slots, 0, AMAX_SLOTS * AMAX_STRIDE * sizeof(unsigned), (hipStream_t)stream));
     const long long n4 = n / 4;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::min<long long>(cdiv(n4, 1024), 1024)), dim3(256), 0, (hipStream_t)stream, x,
                        (size_t)n4, static_cast<unsigned*>(slots));
@@ -2677,7 +2705,18 @@ extern "C" int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, i
     }
     const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
     hipLaunchKernelGGL(presplit2h_kernel, dim3((unsigned)std::min<int64_t>(nb, 16384)), dim3(256), 0, (hipStream_t)stream, b_fp32,
-                       reinterpret_cast<__bf16*>(x2), nrows, T, ctot, static_cast<const unsigned*>(amax_slots));
+                       reinterpret_cast<__bf16*>(x2), nrows, T, ctot, static_cast<unsigned*>(amax_slots));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+// every registered F16X2 pair of a device table in one go (after the optimizer step): zero the slots, maxima, planes
+extern "C" int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* amax_base, int64_t amax_bytes,
+                                      void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && amax_base && amax_bytes > 0,
+                  "presplit_f16_table: bad table");
+    XV2_CHECK_HIP(hipMemsetAsync(amax_base, 0, (size_t)amax_bytes, (hipStream_t)stream));
+    hipLaunchKernelGGL(presplit2h_table_kernel<true>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    hipLaunchKernelGGL(presplit2h_table_kernel<false>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

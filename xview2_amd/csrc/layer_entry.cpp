@@ -7,6 +7,9 @@
 // every ABI call costs the Python layer ~9 us of marshalling on top of the launches themselves.  These functions issue
 // exactly the launches of the calls they replace, in the same order on the same stream - results are bit-identical.
 #include "../../include/xv2.h"
+#include "amax_ctx.h"
+
+int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream);      // igemm_conv.hip
 
 extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                                        const void* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
@@ -18,12 +21,15 @@ extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, i
     // convolution + statistics + coefficients: ONE launch (the last blocks to arrive fold the tile partials, bn_fold.h)
     // (+ the BatchNorm apply behind a gate in that same launch when its grid is resident at once: xv2_conv2d_forward_bn_act)
     (void)tiles;
+    xv2::AmaxGuard amax_guard;      // (the convolution reads the context's sources, the apply pass records into its `out`)
     int applied = 0;
     int rc = xv2_conv2d_forward_bn_act(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
                                        scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                                        scale, shift, residual, ldr, act, z, ldz, zmask, &applied, stream);
-    if (rc || applied) return rc;
     const int64_t npix = (int64_t)d->N * d->OH * d->OW;
+    if (!rc && applied && xv2::amax_ctx().out && dtype == XV2_F32 && ldz == d->Cout)      // (the gated apply does not record)
+        rc = xv2_tensor_amax_into(static_cast<const float*>(z), npix * d->Cout, xv2::amax_ctx().out, stream);
+    if (rc || applied) return rc;
     if (zmask)
         return xv2_bn_act_forward_mask(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, d->Cout, zmask, dtype, stream);
     return xv2_bn_act_forward(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, d->Cout, dtype, stream);
@@ -34,6 +40,7 @@ extern "C" int xv2_bn_act_backward(const void* dz, int lddz, const void* z, int 
                                    const float* scale, const float* shift, int act, double count, void* dy, int lddy,
                                    void* dres, int lddres, int64_t npix, int C, double* sums2, float* dgamma,
                                    float* dbeta, float* workspace, int dtype, void* stream) {
+    xv2::AmaxGuard amax_guard;
     int rc;
     if (zmask) {
         rc = xv2_bn_act_backward_reduce_mask(dz, lddz, zmask, y, ldy, mean, invstd, act, npix, C, sums2, dgamma, dbeta,

@@ -5,6 +5,8 @@
 // un-vendored ResNet/ResNeSt blocks; torch semantics (biased batch variance for normalisation,
 // unbiased for running_var, momentum 0.1, eps 1e-5).
 #include "bn_fold.h"
+#include "amax_ctx.h"
+#include <type_traits>
 #include <mutex>
 #include <cstring>
 #include <algorithm>
@@ -449,7 +451,9 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
                                                           const float* __restrict__ shift,
                                                           const T* __restrict__ res, int ldr, int act,
                                                           T* __restrict__ z, int ldz, int64_t npix, int C,
-                                                          uint8_t* __restrict__ zmask, int rev) {
+                                                          uint8_t* __restrict__ zmask, int rev, unsigned* __restrict__ amax) {
+    __shared__ float amax_red[4];
+    float zmax = 0.f;       // F16X2: max |z| of this block's elements (recorded for the convolutions that read z)
     if constexpr (VEC) {
         constexpr int NV = Vec16<T>::NV, W = 4 * NV;     // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
         const int CW = C / W;
@@ -476,6 +480,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
                 o[q].x = apply_act(o[q].x, act); o[q].y = apply_act(o[q].y, act);
                 o[q].z = apply_act(o[q].z, act); o[q].w = apply_act(o[q].w, act);
                 mbits |= (unsigned)((o[q].x > 0.f) | ((o[q].y > 0.f) << 1) | ((o[q].z > 0.f) << 2) | ((o[q].w > 0.f) << 3)) << (8 * q);
+                zmax = amax_acc(zmax, o[q]);
             }
             Vec16<T>::st(z + row * ldz + c, o);
             if (zmask) {      // one byte per 4 channels, dense rows: byte index = row * C/4 + c/4
@@ -490,9 +495,12 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
             const int c = (int)(i - row * C);
             float o = __fmaf_rn(ld1(y + row * ldy + c), scale[c], shift[c]);
             if (res) o += ld1(res + row * ldr + c);
-            st1(z + row * ldz + c, apply_act(o, act));
+            o = apply_act(o, act);
+            zmax = amax_acc(zmax, make_float4(o, o, o, o));
+            st1(z + row * ldz + c, o);
         }
     }
+    if (amax) amax_record(amax, zmax, amax_red);
 }
 
 template <bool VEC, typename T>
@@ -571,7 +579,10 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
                                                                const double* __restrict__ sums2, double count, int act,
                                                                int train, T* __restrict__ dy, int lddy,
                                                                T* __restrict__ dres, int lddres, int64_t npix, int cgw,
-                                                               int rows_per_block, int zbits, int c4tot, int rev) {
+                                                               int rows_per_block, int zbits, int c4tot, int rev,
+                                                               unsigned* __restrict__ amax) {
+    __shared__ float amax_red[4];
+    float dmax = 0.f;       // F16X2: max |dy| of this block (recorded for the backward-data / weight-gradient launches)
     constexpr int NV = Vec16<T>::NV, W = 4 * NV;      // 16-byte accesses: 4 (fp32) / 8 (bf16) channels per lane
     const int CW = cgw / W, rpp = 256 / CW;
     const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
@@ -613,6 +624,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
                 o[k] = gi[k] * g[k];
             }
         }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) dmax = amax_acc(dmax, ov[q]);
         Vec16<T>::st(dy + r * lddy + c, ov);
         if (dres) Vec16<T>::st(dres + r * lddres + c, gv);
     };
@@ -635,6 +648,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
         fetch(r, d0, z0, y0, m0);
         row(r, d0, z0, y0, m0);
     }
+    if (amax) amax_record(amax, dmax, amax_red);
 }
 
 // BatchNorm over a HANDFUL of rows (split attention's bn1 on the [N, inter] vector of pooled features, N = the batch:
@@ -839,6 +853,8 @@ template <typename T>
 static int bn_act_forward_impl(const T* y, int ldy, const float* scale, const float* shift, const T* residual,
                                int ldr, int act, T* z, int ldz, int64_t npix, int C, uint8_t* zmask, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_forward: empty");
+    AmaxGuard amax_guard;
+    unsigned* amax = std::is_same<T, float>::value ? amax_ctx().out : nullptr;      // F16X2: record max |z| (fp32 tensors)
     constexpr int W = 4 * Vec16<T>::NV;
     const bool vec = vec_ok(C, sizeof(T), {ldy, ldz, residual ? ldr : 0}, {y, z, residual}, W) &&
                      vec_ok(C, 4, {}, {scale, shift});
@@ -846,10 +862,10 @@ static int bn_act_forward_impl(const T* y, int ldy, const float* scale, const fl
     const int grid = ew_grid(npix * (vec ? C / W : C));
     if (vec)
         hipLaunchKernelGGL((bn_act_fwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C, zmask, bn_reverse(1));
+                           shift, residual, ldr, act, z, ldz, npix, C, zmask, bn_reverse(1), amax);
     else
         hipLaunchKernelGGL((bn_act_fwd_kernel<false, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, ldy, scale,
-                           shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr, 0);
+                           shift, residual, ldr, act, z, ldz, npix, C, (uint8_t*)nullptr, 0, amax);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }
@@ -916,6 +932,8 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
                              const float* shift, const double* sums2, double count, int act, int train, T* dy,
                              int lddy, T* dres, int lddres, int64_t npix, int C, void* stream) {
     XV2_CHECK_ARG(npix > 0 && C > 0, "bn_act_backward_apply: empty");
+    AmaxGuard amax_guard;
+    unsigned* amax = std::is_same<T, float>::value ? amax_ctx().out : nullptr;      // F16X2: record max |dy| (fp32 tensors)
     XV2_CHECK_ARG(z || (scale && shift), "bn backward: either z or (scale, shift) is required for the activation mask");
     constexpr int W = 4 * Vec16<T>::NV;
     const bool vecw = vec_ok(C, sizeof(T), {lddz, (z && !zbits) ? ldz : 0, ldy, lddy, dres ? lddres : 0},
@@ -930,10 +948,18 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
-                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4, bn_reverse(0));
+                           count, act, train, dy, lddy, dres, lddres, npix, cg.cgw, (int)rpb, zbits, C / 4, bn_reverse(0), amax);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
+    // (the generic forms do not record: take the maximum of what they wrote in a pass of its own - rare shapes)
+    struct AmaxAfter {
+        unsigned* slots; const void* dy; int lddy, C; int64_t npix; void* stream;
+        ~AmaxAfter() {
+            if (slots && lddy == C) xv2_tensor_amax_into(static_cast<const float*>(dy), npix * C, slots, stream);
+        }
+    } amax_after{amax, dy, lddy, C, npix, stream};
+    XV2_CHECK_ARG(!amax || (lddy == C && (npix * C) % 4 == 0), "bn_act_backward_apply: F16X2 maximum of a strided / odd-sized dy");
     const int grid = ew_grid(npix * (vec ? C / 4 : C));
     if (vec)
         hipLaunchKernelGGL((bn_act_bwd_kernel<true, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz,

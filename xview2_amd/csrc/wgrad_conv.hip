@@ -11,6 +11,7 @@
 // Replaces the weight-gradient half of autograd for every nn.Conv2d / nn.ConvTranspose2d of
 // model/layers.py and of the encoder blocks.
 #include "xv2_common.h"
+#include "amax_ctx.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -38,8 +39,13 @@ struct WgradParams {
     const float* pre_scale;
     const float* pre_shift;
     int pre_act;
+    // F16X2 (xv2_common.h): the maxima of the X sources and of dY, all three known -> the NPL = 2 kernels (two scaled fp16 planes)
+    const unsigned* amaxX0;
+    const unsigned* amaxX1;
+    const unsigned* amaxDY;
     WTap taps[52];
 };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -438,7 +444,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
 // XV2_MATH_F32X3 variant of wgrad_tr_kernel: fp32 dY / X tiles split into three bf16 planes on their way into LDS
 // (single-buffered, 60 KB for 128 x 128), six bf16 MFMAs per product.  Two raw register sets as in the implicit-GEMM
 // kernel: tile kt+1 is split on the VALU in the shadow of tile kt's MFMAs while tile kt+2 is in flight.
-template <int BM, int BN>
+template <int BM, int BN, int NPL = 3>
 __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     constexpr int MR = BM / 64, NR = BN / 64;
     constexpr int SA = BM + 32, SB = BN + 32;              // LDS row strides in bf16 elements
@@ -462,6 +468,11 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     const int dh = p.taps[tap].dh, dw = p.taps[tap].dw;
     const int ohw = p.OH * p.OW;
     const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    float sX = 1.f, sD = 1.f;      // F16X2 operand scales
+    if constexpr (NPL == 2) {
+        sX = amax_scale(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        sD = amax_scale(amax_exponent(p.amaxDY));
+    }
 
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? p.X0 : p.X1), 0,
                                                                    first ? p.bytesX0 : p.bytesX1, 0x00020000);
@@ -495,22 +506,22 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
             rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((ubase + b_const[j]) << 2) : (int)0x80000000, 0, 0);
         }
     };
-    uint2 pk[APASS + BPASS][3];
+    uint2 pk[APASS + BPASS][NPL];
     auto split_regs = [&](const i32x4 (&xa)[APASS], const i32x4 (&xb)[BPASS]) {
 #pragma unroll
         for (int j = 0; j < APASS + BPASS; ++j) {
             const i32x4 v = j < APASS ? xa[j < APASS ? j : 0] : xb[j >= APASS ? j - APASS : 0];
-            split3x4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])),
-                     pk[j][0], pk[j][1], pk[j][2]);
+            const float4 f = make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3]));
+            if constexpr (NPL == 2) split2hx4(f, j < APASS ? sD : sX, pk[j][0], pk[j][1]);
+            else split3x4(f, pk[j][0], pk[j][1], pk[j][NPL - 1]);
         }
     };
     auto store_planes = [&]() {
 #pragma unroll
         for (int j = 0; j < APASS + BPASS; ++j) {
             bf16_t* d = j < APASS ? As + (a_r + j * ARPP) * SA + a_c4 * 4 : Bs + (b_r + (j - APASS) * BRPP) * SB + b_c4 * 4;
-            *reinterpret_cast<uint2*>(d) = pk[j][0];
-            *reinterpret_cast<uint2*>(d + PL) = pk[j][1];
-            *reinterpret_cast<uint2*>(d + 2 * PL) = pk[j][2];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2*>(d + q * PL) = pk[j][q];
         }
     };
 
@@ -541,14 +552,25 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
             for (int i = 0; i < MR; ++i) {
                 ah[i] = frag(a + (16 * ks) * SA + i * 32, SA);
                 am[i] = frag(a + PL + (16 * ks) * SA + i * 32, SA);
-                al[i] = frag(a + 2 * PL + (16 * ks) * SA + i * 32, SA);
+                if constexpr (NPL == 3) al[i] = frag(a + 2 * PL + (16 * ks) * SA + i * 32, SA);
             }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 bh[j] = frag(bb + (16 * ks) * SB + j * 32, SB);
                 bm_[j] = frag(bb + PL + (16 * ks) * SB + j * 32, SB);
-                bl[j] = frag(bb + 2 * PL + (16 * ks) * SB + j * 32, SB);
+                if constexpr (NPL == 3) bl[j] = frag(bb + 2 * PL + (16 * ks) * SB + j * 32, SB);
             }
+            if constexpr (NPL == 2) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, t == 0 ? am[i] : ah[i]),
+                                                                               __builtin_bit_cast(f16x8, t == 1 ? bm_[j] : bh[j]),
+                                                                               acc[i][j], 0, 0, 0);
+            } else
 #pragma unroll
             for (int t = XV2_T0; t < 6; ++t)
 #pragma unroll
@@ -563,8 +585,8 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < APASS + BPASS; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
-        constexpr int NMFMA = 2 * (6 - XV2_T0) * MR * NR;
+            for (int q = 0; q < NPL; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
+        constexpr int NMFMA = 2 * (NPL == 2 ? 3 : 6 - XV2_T0) * MR * NR;
 #pragma unroll
         for (int g = 0; g < NMFMA; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -597,6 +619,11 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     // slab: part[split][co][T][Ctot]
     const size_t rowlen = (size_t)p.T * p.Ctot;
     float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float iX = 1.f, iD = 1.f;
+    if constexpr (NPL == 2) {
+        iX = amax_inv(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        iD = amax_inv(amax_exponent(p.amaxDY));
+    }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const size_t coloff = (size_t)tap * p.Ctot + cn0 + wn * (BN / 2) + j * 32 + l31;
@@ -605,7 +632,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = co0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                slab[(size_t)row * rowlen + coloff] = acc[i][j][r];
+                slab[(size_t)row * rowlen + coloff] = NPL == 2 ? acc[i][j][r] * iX * iD : acc[i][j][r];
             }
     }
 }
@@ -895,9 +922,10 @@ __global__ void __launch_bounds__(256, 4) wgrad_alltaps_tr_kernel(const WgradPar
 // 24-30 MFMAs per wave per row step instead of 4-5: the kernel is MFMA-bound where the bf16 one is latency-bound.
 // Wave wk takes the 16-pixel k-group (wk & 1) and the taps of one parity; which parity gets the 5-tap share alternates
 // pseudo-randomly between blocks so that the SIMDs of a CU are loaded evenly.
+template <int NPL>
 __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradParams p) {
     constexpr int PL = 2 * 32 * 32 + 4 * 34 * 32;                 // bf16 elements per plane (dY double buffer + X ring)
-    __shared__ __attribute__((aligned(16))) bf16_t planes[3 * PL];   // 38.4 KB; the epilogue fold reuses the first 16 KB
+    __shared__ __attribute__((aligned(16))) bf16_t planes[NPL * PL];   // 38.4 KB (two planes: 25.6); the epilogue fold reuses the first 16 KB
     float* smem = reinterpret_cast<float*>(planes);
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 
@@ -947,18 +975,27 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
             if (x2_ok) rx2 = pre(*reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx));
         }
     };
-    auto put = [&](int off, const float4 v) {       // off: element offset inside a plane
+    float sX = 1.f, sD = 1.f;      // F16X2 operand scales
+    if constexpr (NPL == 2) {
+        sX = amax_scale(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        sD = amax_scale(amax_exponent(p.amaxDY));
+    }
+    auto put = [&](int off, const float4 v, float s) {       // off: element offset inside a plane
         uint2 h, m, l;
-        split3x4(v, h, m, l);
+        if constexpr (NPL == 2) {
+            split2hx4(v, s, h, m);
+        } else {
+            split3x4(v, h, m, l);
+            *reinterpret_cast<uint2*>(planes + (NPL - 1) * PL + off) = l;
+        }
         *reinterpret_cast<uint2*>(planes + off) = h;
         *reinterpret_cast<uint2*>(planes + PL + off) = m;
-        *reinterpret_cast<uint2*>(planes + 2 * PL + off) = l;
     };
-    auto store_dy = [&](int buf) { put((buf * 32 + px) * 32 + c4 * 4, rd); };
+    auto store_dy = [&](int buf) { put((buf * 32 + px) * 32 + c4 * 4, rd, sD); };
     auto store_x = [&](int ih) {
         const int ring = 2 * 32 * 32 + ((ih + 4) & 3) * 34 * 32;
-        put(ring + px * 32 + c4 * 4, rx);
-        if (x2) put(ring + (32 + px) * 32 + c4 * 4, rx2);
+        put(ring + px * 32 + c4 * 4, rx, sX);
+        if (x2) put(ring + (32 + px) * 32 + c4 * 4, rx2, sX);
     };
 
     f32x16 acc[5];
@@ -996,7 +1033,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
             load_x(r + 2);
         }
         const bf16_t* ab = planes + (buf * 32 + frow) * 32 + fcol;
-        const bf16x8 ah = frag(ab), am = frag(ab + PL), al = frag(ab + 2 * PL);
+        const bf16x8 ah = frag(ab), am = frag(ab + PL), al = NPL == 3 ? frag(ab + (NPL - 1) * PL) : ah;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const bf16_t* row = planes + 2 * 32 * 32 + (((r - 1 + kh + 4) & 3) * 34 + frow) * 32 + fcol;   // input row r-1+kh
@@ -1004,8 +1041,15 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
             for (int kw = 0; kw < 3; ++kw) {
                 const int t = kh * 3 + kw;
                 if ((t & 1) != odd) continue;          // wave-uniform
-                const bf16x8 bh = frag(row + kw * 32), bm = frag(row + kw * 32 + PL), bl = frag(row + kw * 32 + 2 * PL);
+                const bf16x8 bh = frag(row + kw * 32), bm = frag(row + kw * 32 + PL);
                 f32x16 c = acc[t >> 1];
+                if constexpr (NPL == 2) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, am), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bm), c, 0, 0, 0);
+                    acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+                    continue;
+                }
+                const bf16x8 bl = frag(row + kw * 32 + (NPL - 1) * PL);
 #if XV2_T0 == 0
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
@@ -1026,11 +1070,17 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
     // fold the two k-groups of every tap through LDS and write the block's slab part[y][co][T][Ctot]
     const size_t rowlen = (size_t)9 * p.Ctot;
     float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float iX = 1.f, iD = 1.f;
+    if constexpr (NPL == 2) {
+        iX = amax_inv(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        iD = amax_inv(amax_exponent(p.amaxDY));
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const bool mine = odd == (t & 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) smem[wk * 1024 + r * 64 + lane] = mine ? acc[t >> 1][r] : 0.f;
+        for (int r = 0; r < 16; ++r)
+            smem[wk * 1024 + r * 64 + lane] = mine ? (NPL == 2 ? acc[t >> 1][r] * iX * iD : acc[t >> 1][r]) : 0.f;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1124,8 +1174,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t_kernel(const float* __rest
 // 128 B with the 32-byte chunks of pixel column p stored at chunk ^ (p & 3) (conflict-free transpose reads and stores).
 constexpr int W64_PL = 2 * 32 * 64 + 4 * 34 * 64;                 // bf16 elements per plane: dY double buffer + X ring
 __device__ __forceinline__ int w64_off(int px, int c) { return px * 64 + ((((c >> 4) ^ (px & 3)) << 4) | (c & 15)); }
+template <int NPL>
 __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradParams p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t planes64[];      // [3][W64_PL]: 76.8 KB
+    extern __shared__ __attribute__((aligned(16))) bf16_t planes64[];      // [NPL][W64_PL]: 76.8 KB (51.2)
     bf16_t* planes = planes64;
     constexpr int PL = W64_PL;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
@@ -1178,22 +1229,31 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
             if (xok2) rx2 = pre(*reinterpret_cast<const float4*>(xr + (size_t)32 * ldx));
         }
     };
-    auto put = [&](int off, const float4 v) {
+    float sX = 1.f, sD = 1.f;      // F16X2 operand scales
+    if constexpr (NPL == 2) {
+        sX = amax_scale(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        sD = amax_scale(amax_exponent(p.amaxDY));
+    }
+    auto put = [&](int off, const float4 v, float s) {
         uint2 h, m, l;
-        split3x4(v, h, m, l);
+        if constexpr (NPL == 2) {
+            split2hx4(v, s, h, m);
+        } else {
+            split3x4(v, h, m, l);
+            *reinterpret_cast<uint2*>(planes + (NPL - 1) * PL + off) = l;
+        }
         *reinterpret_cast<uint2*>(planes + off) = h;
         *reinterpret_cast<uint2*>(planes + PL + off) = m;
-        *reinterpret_cast<uint2*>(planes + 2 * PL + off) = l;
     };
     auto store_dy = [&](int buf) {
-        put(buf * 32 * 64 + w64_off(pxa, c4 * 4), rd0);
-        put(buf * 32 * 64 + w64_off(pxa + 16, c4 * 4), rd1);
+        put(buf * 32 * 64 + w64_off(pxa, c4 * 4), rd0, sD);
+        put(buf * 32 * 64 + w64_off(pxa + 16, c4 * 4), rd1, sD);
     };
     auto store_x = [&](int ih) {
         const int ring = 2 * 32 * 64 + ((ih + 4) & 3) * 34 * 64;
-        put(ring + w64_off(pxa, c4 * 4), rx0);
-        put(ring + w64_off(pxa + 16, c4 * 4), rx1);
-        if (x2) put(ring + w64_off(pxa + 32, c4 * 4), rx2);
+        put(ring + w64_off(pxa, c4 * 4), rx0, sX);
+        put(ring + w64_off(pxa + 16, c4 * 4), rx1, sX);
+        if (x2) put(ring + w64_off(pxa + 32, c4 * 4), rx2, sX);
     };
     f32x16 acc[9];
 #pragma unroll
@@ -1228,15 +1288,23 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pa = 16 * ks + frow, ca = wa * 32 + fcol;
-            const bf16x8 ah = frag(ab, pa, ca), am = frag(ab + PL, pa, ca), al = frag(ab + 2 * PL, pa, ca);
+            const bf16x8 ah = frag(ab, pa, ca), am = frag(ab + PL, pa, ca), al = NPL == 3 ? frag(ab + (NPL - 1) * PL, pa, ca) : ah;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const bf16_t* row = planes + 2 * 32 * 64 + ((r - 1 + kh + 4) & 3) * 34 * 64;      // input row r-1+kh
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     const int t = kh * 3 + kw, pb = pa + kw, cb = wb * 32 + fcol;
-                    const bf16x8 bh = frag(row, pb, cb), bm = frag(row + PL, pb, cb), bl = frag(row + 2 * PL, pb, cb);
+                    const bf16x8 bh = frag(row, pb, cb), bm = frag(row + PL, pb, cb);
                     f32x16 c = acc[t];
+                    if constexpr (NPL == 2) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, am), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bm), c, 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                    const bf16x8 bl = frag(row + (NPL - 1) * PL, pb, cb);
 #if XV2_T0 == 0
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
@@ -1259,12 +1327,17 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
     const size_t rowlen = (size_t)9 * p.Ctot;
     float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
     const int l31 = lane & 31, hh = lane >> 5;
+    float iX = 1.f, iD = 1.f;
+    if constexpr (NPL == 2) {
+        iX = amax_inv(amax_exponent(first ? p.amaxX0 : p.amaxX1));
+        iD = amax_inv(amax_exponent(p.amaxDY));
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = co0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + wb * 32 + l31] = acc[t][r];
+            slab[(size_t)row * rowlen + (size_t)t * p.Ctot + cn0 + wb * 32 + l31] = NPL == 2 ? acc[t][r] * iX * iD : acc[t][r];
         }
 }
 
@@ -1557,6 +1630,7 @@ struct WgradPre {
 static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, const float* x1, int ldx1,
                       const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                       hipStream_t stream, const WgradPre* pre = nullptr, int* plan_pre = nullptr) {
+    AmaxGuard amax_guard;
     xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3: the all-taps kernel has a split-bf16 variant; the other
     const bool x3 = dcopy.math == XV2_MATH_F32X3;      // weight-gradient kernels run the exact fp32 MFMA
     if (x3) dcopy.math = XV2_MATH_F32;
@@ -1576,6 +1650,10 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     WgradParams p;
     p.X0 = x0; p.X1 = x1; p.DY = dy; p.part = workspace;
     p.pre_scale = pre ? pre->scale : nullptr; p.pre_shift = pre ? pre->shift : nullptr; p.pre_act = pre ? pre->act : 0;
+    p.amaxX0 = amax_ctx().a0; p.amaxX1 = amax_ctx().a1; p.amaxDY = amax_ctx().dy;
+    static const int f16x2_on = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 1; }();
+    // F16X2: all operand maxima known (xv2_amax_ctx) - two scaled fp16 planes, three MFMAs per product
+    const bool h2 = x3 && f16x2_on && !pre && p.amaxX0 && p.amaxDY && (!x1 || p.amaxX1);
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1; p.ldX0 = ldx0; p.ldX1 = ldx1; p.ldDY = lddy;
     p.Cout = d->Cout;
     p.IH = d->IH; p.IW = d->IW; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride;
@@ -1607,15 +1685,23 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
         static const int kid16 = prof_register("wgrad_alltaps_kernel<bf16>");
         static const int kid16s = prof_register("wgrad_alltaps_kernel<bf16hbm>");
         static const int kidx3 = prof_register("wgrad_alltaps_kernel<f32x3>");
-        prof_begin(x3 ? kidx3 : hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+        static const int kidx2 = prof_register("wgrad_alltaps_kernel<f16x2>");
+        prof_begin(h2 ? kidx2 : x3 ? kidx3 : hs ? kid16s : (d->math ? kid16 : kid), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    (hs ? 2.0 : 4.0) * ((double)p.M * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
-        if (x3 && pl.bm == 64) {
-            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_alltaps64_x3_kernel),
+        if (h2 && pl.bm == 64) {
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_alltaps64_x3_kernel<2>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W64_PL * 2);
+            XV2_CHECK_HIP(attr_rc);
+            hipLaunchKernelGGL(wgrad_alltaps64_x3_kernel<2>, dim3(pl.tiles, pl.splitk), dim3(256), 2 * W64_PL * 2, stream, p);
+        } else if (h2) {
+            hipLaunchKernelGGL(wgrad_alltaps_x3_kernel<2>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+        } else if (x3 && pl.bm == 64) {
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_alltaps64_x3_kernel<3>),
                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * W64_PL * 2);
             XV2_CHECK_HIP(attr_rc);
-            hipLaunchKernelGGL(wgrad_alltaps64_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 3 * W64_PL * 2, stream, p);
+            hipLaunchKernelGGL(wgrad_alltaps64_x3_kernel<3>, dim3(pl.tiles, pl.splitk), dim3(256), 3 * W64_PL * 2, stream, p);
         } else if (x3)
-            hipLaunchKernelGGL(wgrad_alltaps_x3_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(wgrad_alltaps_x3_kernel<3>, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs && use_tr_wgrad() && pl.bm == 64)
             hipLaunchKernelGGL(wgrad_alltaps64_tr_kernel, dim3(pl.tiles, pl.splitk), dim3(256), 0, stream, p);
         else if (hs && use_tr_wgrad())
@@ -1638,9 +1724,18 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     } else if (x3 && p.fast && pl.wk == 1 && (pl.bm == 128 || (pl.bm == 64 && pl.bn == 64))) {
         static const int kid128 = prof_register("wgrad_tr_kernel<128,128,f32x3>");
         static const int kid64 = prof_register("wgrad_tr_kernel<64,64,f32x3>");
-        prof_begin(pl.bm == 128 ? kid128 : kid64, 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
+        static const int kid128h = prof_register("wgrad_tr_kernel<128,128,f16x2>");
+        static const int kid64h = prof_register("wgrad_tr_kernel<64,64,f16x2>");
+        prof_begin(pl.bm == 128 ? (h2 ? kid128h : kid128) : (h2 ? kid64h : kid64), 2.0 * (double)p.M * p.Cout * p.T * p.Ctot,
                    4.0 * ((double)p.M / (p.OH * p.OW) * p.IH * p.IW * p.Ctot + (double)p.M * p.Cout) + 4.0 * (double)total, stream);
-        if (pl.bm == 128) {
+        if (h2 && pl.bm == 128) {
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tr_x3_kernel<128, 128, 2>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 320 * 2);
+            XV2_CHECK_HIP(attr_rc);
+            hipLaunchKernelGGL((wgrad_tr_x3_kernel<128, 128, 2>), dim3(pl.tiles, pl.splitk), dim3(256), 2 * 32 * 320 * 2, stream, p);
+        } else if (h2) {
+            hipLaunchKernelGGL((wgrad_tr_x3_kernel<64, 64, 2>), dim3(pl.tiles, pl.splitk), dim3(256), 2 * 32 * 192 * 2, stream, p);
+        } else if (pl.bm == 128) {
             static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tr_x3_kernel<128, 128>),
                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 320 * 2);
             XV2_CHECK_HIP(attr_rc);

@@ -161,6 +161,11 @@ __device__ __forceinline__ void split2hx4(const float4 v, float s, uint2& h, uin
     split2hx2(v.z * s, v.w * s, h.y, m.y);
 }
 constexpr int AMAX_SLOTS = 64;
+constexpr int AMAX_STRIDE = 32;      // uint32 between two slots: one 128-byte line each (4096 blocks' atomics on TWO lines cost the
+                                     // BatchNorm apply pass +9 us of 20), 8 KB per tensor
+__device__ __forceinline__ float amax_acc(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 __device__ __forceinline__ unsigned wave_max_u(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
@@ -168,8 +173,8 @@ __device__ __forceinline__ unsigned wave_max_u(unsigned v) {
 }
 // biased exponent of the recorded maximum, clamped so that both the scale and its inverse are normal numbers
 __device__ __forceinline__ int amax_exponent(const unsigned* slots, const unsigned* slots1 = nullptr) {
-    unsigned v = slots[threadIdx.x & 63];
-    if (slots1) v = max(v, slots1[threadIdx.x & 63]);
+    unsigned v = slots[(threadIdx.x & 63) * AMAX_STRIDE];
+    if (slots1) v = max(v, slots1[(threadIdx.x & 63) * AMAX_STRIDE]);
     v = wave_max_u(v);
     const int e = (int)((v >> 23) & 0xffu);
     return __builtin_amdgcn_readfirstlane(min(max(e, 16), 240));
@@ -177,16 +182,17 @@ __device__ __forceinline__ int amax_exponent(const unsigned* slots, const unsign
 __device__ __forceinline__ float amax_scale(int e) { return __uint_as_float((unsigned)(268 - e) << 23); }      // |x| * s < 2^15
 __device__ __forceinline__ float amax_inv(int e) { return __uint_as_float((unsigned)(e - 14) << 23); }
 // block-level record of max |x| (bits of |x| order like the values; NaN / Inf order above every finite number)
-__device__ __forceinline__ void amax_record(unsigned* slots, float local_abs_max, float* smem4) {
+__device__ __forceinline__ void amax_record(unsigned* slots, float local_abs_max, float* smem4, unsigned slot_hint = 0xffffffffu) {
     unsigned v = wave_max_u(__float_as_uint(local_abs_max) & 0x7fffffffu);
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned*>(smem4)[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < nw; ++w) v = max(v, reinterpret_cast<unsigned*>(smem4)[w]);
-        unsigned* d = slots + (blockIdx.x & (AMAX_SLOTS - 1));
-        if (v > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_max(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* d = slots + ((slot_hint == 0xffffffffu ? blockIdx.x : slot_hint) & (AMAX_SLOTS - 1)) * AMAX_STRIDE;
+        // fire and forget (no returned value, no preceding load: a block must not wait ~2 us for a device-scope round trip -
+        // with one the BatchNorm apply pass ran 20 -> 42 us); zero maxima (all-zero blocks) are not sent
+        if (v) __hip_atomic_fetch_max(d, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -11,7 +11,7 @@ from types import SimpleNamespace
 import torch
 import torch.distributed as dist
 
-from ._capi import ConvDesc, Ptr, call, query
+from ._capi import ConvDesc, Ptr, call, query, set_amax
 
 
 def ctypes_addr(obj):
@@ -155,10 +155,77 @@ PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is
 
 
 class _PackEntry:
-    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype", "x3")
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype", "x3", "x2")
 
 
 PRESPLIT = os.environ.get("XV2_PRESPLIT", "1") != "0"
+# F16X2 (include/xv2.h): fp32 tensors, operands as two scaled fp16 planes - three matrix instructions per product instead of six
+# - for every launch whose operand maxima are known.  A tensor's maximum is recorded by the kernel that writes it (BatchNorm apply,
+# forward and backward) into 64 slots that travel with the tensor as the attribute _xv2_amax; weights get theirs when their planes
+# are refreshed.  Launches without the three maxima stay on the three-plane bf16 form.  XV2_F16X2=0 switches the mode off.
+F16X2 = os.environ.get("XV2_F16X2", "1") != "0"
+F16X2_WEIGHTS = 4096           # weight operands with slots (an arena zeroed once per refresh)
+AMAX_BYTES = 8192              # one tensor's maximum: 64 slots, one 128-byte line each (include/xv2.h)
+
+
+class _AmaxPool:
+    """slots for the maxima of activation / gradient tensors: handed out in order from two halves; entering a half zeroes it
+    and invalidates the tokens of its previous round (a tensor that old - more than 2048 layers ago - is simply 'unknown')"""
+    P = 4096
+
+    def __init__(self, device):
+        self.buf = torch.zeros((self.P, AMAX_BYTES // 4), dtype=torch.int32, device=device)
+        self.base = self.buf.data_ptr()
+        self.next = 0
+        self.gen = [1, 0]
+
+    def take(self):
+        i = self.next
+        if i == self.P:
+            i = 0
+        if i == 0 and self.gen[1]:
+            self.buf[:self.P // 2].zero_()
+            self.gen[0] += 1
+        elif i == self.P // 2:
+            if self.gen[1]:
+                self.buf[self.P // 2:].zero_()
+            self.gen[1] += 1
+        self.next = i + 1
+        h = 0 if i < self.P // 2 else 1
+        return (self.base + i * AMAX_BYTES, h, self.gen[h], self)
+
+
+_amax_pools = {}
+_wamax = {}
+
+
+def _amax_active(t):
+    return F16X2 and MATH_MODE == MATH_F32X3 and t.dtype == torch.float32 and t.is_cuda
+
+
+def _amax_new(t):
+    """a fresh (zeroed) slot token for a tensor on t's device"""
+    p = _amax_pools.get(t.device.index)
+    if p is None:
+        p = _amax_pools[t.device.index] = _AmaxPool(t.device)
+    return p.take()
+
+
+def _amax_ptr(t):
+    """device address of the slots holding max |t|, or None (unknown: the consumer stays on the three-plane form)"""
+    tok = getattr(t, "_xv2_amax", None) if t is not None else None
+    if tok is None or tok[3].gen[tok[1]] != tok[2]:
+        return None
+    return tok[0]
+
+
+def _tok_ptr(tok):
+    return tok[0] if (tok is not None and tok[3].gen[tok[1]] == tok[2]) else None
+
+
+def amax_reset():
+    """forget every pool (tests; a process that switches devices)"""
+    _amax_pools.clear()
 
 
 def _presplit_geoms(e):
@@ -188,6 +255,29 @@ def _presplit_entry(e):
         if key not in e.x3:
             e.x3[key] = torch.empty((query("xv2_presplit_bytes", rows, T, ch) // 2,), dtype=torch.bfloat16, device=src.device)
         call("xv2_presplit_weights", src, rows, T, ch, e.x3[key])
+        if F16X2:
+            if e.x2 is None:
+                e.x2 = {}
+            if key not in e.x2:
+                slots = _wamax_take(src.device)
+                if slots is None:
+                    continue
+                e.x2[key] = (torch.empty((query("xv2_presplit_f16_bytes", rows, T, ch) // 2,), dtype=torch.float16,
+                                         device=src.device), slots)
+            call("xv2_presplit_weights_f16", src, rows, T, ch, e.x2[key][0], e.x2[key][1])
+
+
+def _wamax_take(device):
+    """slots for one weight operand's maximum out of the per-device arena (None when it is full)"""
+    a = _wamax.get(device.index)
+    if a is None:
+        a = _wamax[device.index] = [torch.zeros((F16X2_WEIGHTS, AMAX_BYTES // 4), dtype=torch.int32, device=device), 0, []]
+    if a[2]:
+        return a[2].pop()
+    if a[1] >= F16X2_WEIGHTS:
+        return None
+    a[1] += 1
+    return a[0].data_ptr() + (a[1] - 1) * AMAX_BYTES
 
 
 def _forget_entry(e):
@@ -195,6 +285,12 @@ def _forget_entry(e):
         for key in e.x3:
             query("xv2_presplit_forget", key)
         e.x3 = None
+    if e.x2:
+        for planes, slots in e.x2.values():
+            for a in _wamax.values():
+                if a[0].data_ptr() <= slots < a[0].data_ptr() + F16X2_WEIGHTS * AMAX_BYTES:
+                    a[2].append(slots)
+        e.x2 = None
 
 
 def _del_pack(k):
@@ -236,7 +332,7 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
             for k in [k for k, v in _packs.items() if v.tick < cut]:
                 _del_pack(k)
         e = _PackEntry()
-        e.ohwi = e.ihwo = e.x3 = None
+        e.ohwi = e.ihwo = e.x3 = e.x2 = None
         e.geom = (Cout, Cin, KH * KW, cin_pad)
         _packs[key] = e
         _pack_table = None
@@ -304,11 +400,22 @@ def repack_all():
                     xrows.append([src.data_ptr(), e.x3[src.data_ptr()].data_ptr(), nr, T, ch, xstart])
                     xstart += query("xv2_presplit_blocks", nr, T, ch)
         xt = (torch.tensor(xrows, dtype=torch.int64).to(dev), len(xrows), xstart) if xrows else None
-        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start, xt)
-    table, n, total, xt = _pack_table
+        hrows, hstart = [], 0
+        for e in _packs.values():      # the scaled fp16 planes (F16X2): maxima + planes by a third table
+            for src, nr, T, ch in (_presplit_geoms(e) if e.x2 else []):
+                if src.data_ptr() in e.x2:
+                    planes, slots = e.x2[src.data_ptr()]
+                    hrows.append([src.data_ptr(), planes.data_ptr(), nr, T, ch, hstart, slots])
+                    hstart += query("xv2_presplit_blocks", nr, T, ch)
+        ht = (torch.tensor(hrows, dtype=torch.int64).to(dev), len(hrows), hstart) if hrows else None
+        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start, xt, ht)
+    table, n, total, xt, ht = _pack_table
     call("xv2_pack_weights_table", table, n, total)
     if xt is not None:
         call("xv2_presplit_table", xt[0], xt[1], xt[2])
+    if ht is not None:
+        arena = _wamax[ht[0].device.index]
+        call("xv2_presplit_f16_table", ht[0], ht[1], ht[2], arena[0], arena[1] * AMAX_BYTES)
     for e in _packs.values():
         e.version, e.epoch = e.w._version, WEIGHT_EPOCH
 
@@ -528,7 +635,7 @@ def _persist(tag, nfloats, device):
     return t
 
 
-def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask):
+def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask, amax=None):
     """Training-mode conv + BatchNorm + (residual) + activation of one ungrouped layer as ONE ABI call
     (xv2_conv_bn_act_forward = the three launches of _conv_forward + _bn_forward, same order, same stream).
     Returns y, z, zmask, (mean, invstd, count, scale, shift), or None when the shape has to go op by op."""
@@ -562,6 +669,10 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         zmask = torch.empty((npix * (Cout // 4),), dtype=torch.uint8, device=dev)
     residual = _same(residual, y)
     bn_stats_changed()
+    if amax is not None:      # F16X2: (slots of x0, of x1, token for z) - the apply pass of this call records max |z|
+        set_amax(amax[0], amax[1], None, amax[2][0] if amax[2] is not None else None)
+        if amax[2] is not None:
+            z._xv2_amax = amax[2]
     call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles,
          _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
          sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
@@ -890,7 +1001,7 @@ def _bn_rows_ok(y, rows, bn, training):
 BN_ROWS = os.environ.get("XV2_BN_ROWS", "1") != "0"
 
 
-def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False, split=1):
+def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=False, split=1, amax_tok=None):
     """y raw [.., C]; returns z and the context needed by _bn_backward.  `coeffs`: (mean, invstd, scale, shift)
     when the statistics reduction already derived them (xv2_bn_reduce_finalize).  want_mask: also return the
     1-bit-per-element sign mask of z (a byte per 4 channels) as a third value, or None if the shape has no mask form.
@@ -931,6 +1042,9 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
         o, oc = h * rows * C, h * C
         yh, zh = Ptr(y, o), Ptr(z, o)
         rh = None if residual is None else Ptr(residual, o)
+        if amax_tok is not None:        # F16X2: every part records into the slots of the one tensor z
+            set_amax(None, None, None, amax_tok[0])
+            z._xv2_amax = amax_tok
         if zmask is not None:
             call("xv2_bn_act_forward_mask", yh, C, Ptr(scale, oc), Ptr(shift, oc), rh, C, act, zh, C, rows, C,
                  Ptr(zmask, h * rows * (C // 4)), _dt(y))
@@ -941,7 +1055,7 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
     return z, (mean, invstd, count, scale, shift)
 
 
-def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, split=1):
+def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, split=1, amax_tok=None):
     """z may be None (layers without a residual input): the activation mask is then recomputed from y; a uint8 `z` is
     the byte mask written by xv2_bn_act_forward_mask.  split: see _bn_forward (the per-part coefficients are [S, C])."""
     mean, invstd, count, scale, shift = stats
@@ -972,6 +1086,9 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
         # column sums + apply as one ABI call (xv2_bn_act_backward: the same two launches)
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_res else None
+        if amax_tok is not None:        # F16X2: the apply pass records max |dy|
+            set_amax(None, None, None, amax_tok[0])
+            dy._xv2_amax = amax_tok
         call("xv2_bn_act_backward", dz, C, None if (z is None or masked) else z, C, z if masked else None, y, C, mean,
              invstd, gamma, scale, shift, act, float(count), dy, C, dres, C, rows, C, sums2, dgamma, dbeta, ws, dt)
         return dy, dres, dgamma, dbeta
@@ -1002,6 +1119,9 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
     for h in range(S):
         o, oc = h * rows * C, h * C
         drh = None if dres is None else Ptr(dres, o)
+        if amax_tok is not None:
+            set_amax(None, None, None, amax_tok[0])
+            dy._xv2_amax = amax_tok
         if masked:
             call("xv2_bn_act_backward_apply_mask", Ptr(dz, o), C, Ptr(z, h * rows * (C // 4)), Ptr(y, o), C,
                  Ptr(mean, oc), Ptr(invstd, oc), gamma, Ptr(sums2, oc * 2), float(count), act,
@@ -1074,8 +1194,15 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.pre = None
         if pre is not None and (not training or x1 is not None):
             x0, pre = _apply_pre(x0, pre), None
+        # F16X2: the maxima of the sources (recorded by their producers) and a slot for this layer's output
+        am_in = am_out = None
+        if _amax_active(x0) and g.groups == 1 and pre is None and not lazy and not COOP_APPLY:
+            am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
+            am_out = _amax_new(x0)
+        ctx.am_in = am_in
         if pre is None and not lazy and LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
-            fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res)
+            fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
+                                      (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None)
         if fast is not None:
             y, z, zmask, stats = fast
         elif pre is not None:
@@ -1085,6 +1212,8 @@ class ConvBnActFn(torch.autograd.Function):
         else:
             if training and COOP_APPLY and not lazy and not _sync_group(bn):
                 ap = {"residual": residual, "act": act, "want_mask": ctx.has_res}
+            if am_in is not None:
+                set_amax(_tok_ptr(am_in[0]), _tok_ptr(am_in[1]))
             y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn, apply=ap)
         if ap is not None and "z" in ap and coeffs is not None:
             # the convolution launch(es) applied the BatchNorm they derived (grouped / split-batch layers: xv2_conv2d_forward_bn_act)
@@ -1099,9 +1228,10 @@ class ConvBnActFn(torch.autograd.Function):
         elif fast is not None:
             pass
         elif ctx.has_res:
-            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split)
+            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split,
+                                          amax_tok=am_out)
         else:
-            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split)
+            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split, amax_tok=am_out)
             zmask = None
         # the activation mask of the backward pass is recomputed from y unless a residual entered before it; then it
         # comes from the byte mask written next to z (or from z itself for shapes without a mask form)
@@ -1137,9 +1267,11 @@ class ConvBnActFn(torch.autograd.Function):
         if dz is None:
             dz = torch.zeros_like(y)
         dpass, dpass1 = _same(dpass, y), _same(dpass1, y)
+        am_in = ctx.am_in
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
                                                ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec,
-                                               ctx.split)
+                                               ctx.split, _amax_new(y) if am_in is not None else None)
+        am_dy = _amax_ptr(dy)
         ctx.rec = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -1149,6 +1281,8 @@ class ConvBnActFn(torch.autograd.Function):
             if (dpass1 is not None and g.groups == 1 and dpass1.is_contiguous() and x1 is not None
                     and tuple(dpass1.shape) == tuple(x1.shape)):
                 acc1, dpass1 = dpass1, None
+            if am_dy is not None:
+                set_amax(None, None, am_dy)
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
                                            ctx.src_rec if (dpass is None and acc1 is None) else None, acc1)
@@ -1168,6 +1302,8 @@ class ConvBnActFn(torch.autograd.Function):
         elif ctx.has_pre:
             dw = _conv_backward_weight_pre(x0, (psc, psf, ctx.pre_act), dy, weight, g, ctx.wparam)
         else:
+            if am_dy is not None and am_in is not None:
+                set_amax(_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_dy)
             dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam)
         ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
