@@ -131,19 +131,24 @@ int xv2_presplit_forget(const void* b_fp32);
  *     weight gradient) and the slots `out` into which the call's BatchNorm apply pass records the maximum of the tensor it writes
  *     (xv2_bn_act_forward* / xv2_conv_bn_act_forward: z; xv2_bn_act_backward_apply* / xv2_bn_act_backward: dy).  `out` must be
  *     zero (or hold a lower bound) beforehand; NULL = unknown / not wanted;
- *   - xv2_presplit_weights_f16 takes the maximum of a packed fp32 weight operand into `amax_slots` and writes the two scaled fp16
- *     planes ([nrows/64][T][ctot/16][2][64][16], xv2_presplit_f16_bytes) and remembers the pair like xv2_presplit_weights.
- * A convolution whose plan is the halo form and whose three maxima are known runs as F16X2, every other one as F32X3; a value
- * above the recorded maximum (a slot that is stale) overflows to Inf / NaN - loud, never a silently wrong finite result.
- * XV2_F16X2=0 in the environment keeps every launch on the three-plane form. */
+ *   - a weight operand's maximum: xv2_tensor_amax over one of its packed fp32 layouts, then xv2_weight_amax_register(layout, slots)
+ *     for every layout of that weight (the per-tap kernels split the weights themselves and only need the maximum);
+ *     xv2_presplit_weights_f16 writes the two scaled fp16 planes of a 3x3 layout ([nrows/64][T][ctot/16][2][64][16],
+ *     xv2_presplit_f16_bytes) FROM the maximum already in `amax_slots` and remembers the pair like xv2_presplit_weights.  After
+ *     an optimizer step: xv2_weight_amax_table (table [n][4] int64 = {layout, float4 count, slots, first block}, an entry owns
+ *     ceil(count / 1024) blocks; zeroes amax_base .. + amax_bytes first) and then xv2_presplit_f16_table (table [n][7] =
+ *     {b_fp32, x2, nrows, T, ctot, first block, slots}, xv2_presplit_blocks() blocks per entry), both on the stream of the step;
+ *     xv2_presplit_forget drops all three kinds of registration.
+ * A convolution whose operand maxima are all known runs as F16X2 (halo form with planes, per-tap form, the split weight-gradient
+ * kernels), every other one as F32X3; a value above the recorded maximum (a slot that is stale) overflows to Inf / NaN - loud,
+ * never a silently wrong finite result.  XV2_F16X2=0 in the environment keeps every launch on the three-plane form. */
 int xv2_amax_ctx(const void* amax_a0, const void* amax_a1, const void* amax_dy, void* amax_out);
 int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* stream);
 size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot);
 int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream);
-/* all pairs of a device table [n][7] int64 = {b_fp32, x2, nrows, T, ctot, first block, amax_slots} (an entry owns
- * xv2_presplit_blocks() blocks) refreshed on one stream: the slots (one contiguous range amax_base .. + amax_bytes) are zeroed,
- * the maxima taken, the planes written - three launches per optimizer step */
-int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* amax_base, int64_t amax_bytes, void* stream);
+int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* stream);
+int xv2_weight_amax_register(const void* b_fp32, const void* amax_slots);
+int xv2_weight_amax_table(const int64_t* table, int n, int64_t total_blocks, void* amax_base, int64_t amax_bytes, void* stream);
 
 /* y = conv2d(cat(x0,x1), w) [+ bias]; replaces F.conv2d.  If `stats` != NULL the kernel also
  * writes per-channel partial sums of y and y*y per row tile: stats[tile][Cout][2]

@@ -21,6 +21,7 @@ def run(f16):
     if f16:
         x2 = torch.empty((query("xv2_presplit_f16_bytes", Co, 9, C0 + C1) // 2,), dtype=torch.float16, device="cuda")
         sw = torch.zeros(2048, dtype=torch.int32, device="cuda")
+        call("xv2_tensor_amax", ohwi, ohwi.numel(), sw)
         call("xv2_presplit_weights_f16", ohwi, Co, 9, C0 + C1, x2, sw)
         s0 = torch.zeros(2048, dtype=torch.int32, device="cuda")
         call("xv2_tensor_amax", x0, x0.numel(), s0)

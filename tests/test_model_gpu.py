@@ -786,7 +786,8 @@ def test_deferred_batchnorm_apply_is_bitwise_identical():
         pytest.skip("the deferred form exists for XV2_MATH_F32X3")
     dev = torch.device("cuda:0")
     res = {}
-    old = ops.LAZY_BN
+    old, old_h2 = ops.LAZY_BN, ops.F16X2
+    ops.F16X2 = False      # (the deferred form has no two-plane twin: both legs on the three-plane arithmetic)
     try:
         for lazy in (False, True):
             ops.LAZY_BN = lazy
@@ -812,7 +813,7 @@ def test_deferred_batchnorm_apply_is_bitwise_identical():
             del m, opt
             ops.clear_pack_cache()
     finally:
-        ops.LAZY_BN = old
+        ops.LAZY_BN, ops.F16X2 = old, old_h2
     for (l0, p0, g0), (l1, p1, g1) in zip(res[False][0], res[True][0]):
         assert l0 == l1 and torch.equal(p0, p1) and torch.equal(g0, g1)
     assert torch.equal(res[False][1], res[True][1])

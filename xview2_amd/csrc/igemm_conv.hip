@@ -112,7 +112,7 @@ template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool
           bool HALO = false, bool BX3 = false, int NPL = 3>
 __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!BX3 || HALO, "pre-split weights: halo form only");
-    static_assert(NPL == 3 || (NPL == 2 && BX3), "two fp16 planes (F16X2): halo form with pre-split weights");
+    static_assert(NPL == 3 || (NPL == 2 && X3 && (BX3 || !HALO)), "two fp16 planes (F16X2): halo form with pre-split weights, or the per-tap form");
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");
     static_assert(!HALO || ((X3 || (HS && !SMALLC)) && BM == 128), "halo form: F32X3 or bf16 storage, 128-pixel patches");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -795,13 +795,18 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         // (b) the raw registers of stage s+2 are split on the VALU in the shadow of the MFMAs and stored into the LDS buffer
         // stage s occupied, (c) stage s+3 is fetched from memory.  One barrier per stage, no LDS latency on the MFMA path.
         constexpr int LDK = 24;
-        constexpr int PL = (BM + BN) * LDK, STG = 3 * PL;
+        constexpr int PL = (BM + BN) * LDK, STG = NPL * PL;
         static_assert((size_t)2 * STG * 2 <= (size_t)MAIN_FLOATS * 4, "stage buffers fit the fp32 operand buffers");
         __bf16* sb = reinterpret_cast<__bf16*>(smem);
         const int s_begin = 2 * kt_begin, s_end = 2 * kt_end;       // stage s = K-tile s / 2, channel half s & 1
-        uint2 pk[AROWS + BROWS][3];
+        uint2 pk[AROWS + BROWS][NPL];
         float4 ra1[AROWS], rb1[BROWS];
-        bf16x8 fa0[MR][3], fb0[NR][3], fa1[MR][3], fb1[NR][3];
+        bf16x8 fa0[MR][NPL], fb0[NR][NPL], fa1[MR][NPL], fb1[NR][NPL];
+        float sA = 1.f, sB = 1.f;      // F16X2 operand scales
+        if constexpr (NPL == 2) {
+            sA = amax_scale(amax_exponent(p.amaxA0, p.amaxA1));
+            sB = amax_scale(amax_exponent(p.amaxB));
+        }
         auto gstage = [&](int st, float4 (&xa)[AROWS], float4 (&xb)[BROWS]) { gload_into(st >> 1, xa, xb, (st & 1) * 16); };
         auto split_regs = [&](const float4 (&xa)[AROWS], const float4 (&xb)[BROWS]) {
 #pragma unroll
@@ -810,9 +815,10 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #if XV2_ABL & 16
                 pk[j][0] = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
                 pk[j][1] = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
-                pk[j][2] = pk[j][0];
+                pk[j][NPL - 1] = pk[j][0];
 #else
-                split3x4(v, pk[j][0], pk[j][1], pk[j][2]);
+                if constexpr (NPL == 2) split2hx4(v, j < AROWS ? sA : sB, pk[j][0], pk[j][1]);
+                else split3x4(v, pk[j][0], pk[j][1], pk[j][NPL - 1]);
 #endif
             }
         };
@@ -825,24 +831,36 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 const int rr = r0 + RPP * (j < AROWS ? j : j - AROWS);
                 if (j < AROWS ? (BM % RPP == 0 || rr < BM) : (BN % RPP == 0 || rr < BN)) {
                     __bf16* d = sb + buf * STG + ((j < AROWS ? 0 : BM) + rr) * LDK + c4 * 4;
-                    *reinterpret_cast<uint2*>(d) = pk[j][0];
-                    *reinterpret_cast<uint2*>(d + PL) = pk[j][1];
-                    *reinterpret_cast<uint2*>(d + 2 * PL) = pk[j][2];
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint2*>(d + q * PL) = pk[j][q];
                 }
             }
         };
-        auto read_frags = [&](int buf, bf16x8 (&fa)[MR][3], bf16x8 (&fb)[NR][3]) {
+        auto read_frags = [&](int buf, bf16x8 (&fa)[MR][NPL], bf16x8 (&fb)[NR][NPL]) {
             const __bf16* a = sb + buf * STG + (wm * WTM + l31) * LDK + 8 * h;
             const __bf16* b = sb + buf * STG + (BM + wn * WTN + l31) * LDK + 8 * h;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                 for (int i = 0; i < MR; ++i) fa[i][q] = *reinterpret_cast<const bf16x8*>(a + q * PL + i * 32 * LDK);
 #pragma unroll
                 for (int j = 0; j < NR; ++j) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * PL + j * 32 * LDK);
             }
         };
-        auto mfma_stage = [&](const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3]) {
+        auto mfma_stage = [&](const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL]) {
+            if constexpr (NPL == 2) {        // fp16 planes: m*h, h*m, h*h
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i)
+#pragma unroll
+                        for (int j = 0; j < NR; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][t == 0 ? 1 : 0]),
+                                                                               __builtin_bit_cast(f16x8, fb[j][t == 1 ? 1 : 0]),
+                                                                               acc[i][j], 0, 0, 0);
+                return;
+            }
             // smallest terms first (l*h, h*l, m*m, m*h, h*m, h*h); the accumulator tiles interleave, so dependent MFMAs
             // are MR*NR issues apart
 #pragma unroll
@@ -851,15 +869,15 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
-                        const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
-                        const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+                        const int qa = t == 0 ? NPL - 1 : (t == 2 || t == 3) ? 1 : 0;
+                        const int qb = t == 1 ? NPL - 1 : (t == 2 || t == 4) ? 1 : 0;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][qa], fb[j][qb], acc[i][j], 0, 0, 0);
                     }
         };
         // iteration st: fragments of st in (fa, fb); (na, nb) receive st+1; (xa, xb) hold the raw stage st+2 (split here);
         // (za, zb) are free and receive stage st+XV2_PF (XV2_PF == 4: stage st+3 is in flight in a third register set)
-        auto iter = [&](int st, const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[NR][3], bf16x8 (&na)[MR][3],
-                        bf16x8 (&nb)[NR][3], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&za)[AROWS],
+        auto iter = [&](int st, const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL], bf16x8 (&na)[MR][NPL],
+                        bf16x8 (&nb)[NR][NPL], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&za)[AROWS],
                         float4 (&zb)[BROWS]) {
             if (st + 1 < s_end) read_frags((st + 1) & 1, na, nb);
             if (st + XV2_PF < s_end) gstage(st + XV2_PF, za, zb);
@@ -870,9 +888,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
 #pragma unroll
             for (int j = 0; j < AROWS + BROWS; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
+                for (int q = 0; q < NPL; ++q) asm volatile("" : "+v"(pk[j][q].x), "+v"(pk[j][q].y));
             // per MFMA slot (32 cycles): one fragment read of the next stage while there are any, ~4 split VALU
-            constexpr int NMFMA = (6 - XV2_T0) * MR * NR, NRD = 3 * (MR + NR);
+            constexpr int NMFMA = (NPL == 2 ? 3 : 6 - XV2_T0) * MR * NR, NRD = NPL * (MR + NR);
 #pragma unroll
             for (int g = 0; g < NMFMA; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1574,7 +1592,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     static const int kid = [] {
         char nm[96];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d,%d,%d,%d,%s>", BM, BN, WGM, WGN,
-                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? (HALO ? "c32,bf16hbm,halo" : "c32,bf16hbm") : (X3 ? (HALO ? (BX3 ? (NPL == 2 ? "c32,f16x2,halo,wx2" : "c32,f32x3,halo,wx3") : "c32,f32x3,halo") : "c32,f32x3") : (BF16 ? "c32,bf16" : "c32"))));
+                 SMALLC ? (HS ? "rgb,bf16out" : "rgb") : (HS ? (HALO ? "c32,bf16hbm,halo" : "c32,bf16hbm") : (X3 ? (HALO ? (BX3 ? (NPL == 2 ? "c32,f16x2,halo,wx2" : "c32,f32x3,halo,wx3") : "c32,f32x3,halo") : (NPL == 2 ? "c32,f16x2" : "c32,f32x3")) : (BF16 ? "c32,bf16" : "c32"))));
         return prof_register(nm);
     }();
     IgemmParams q = p;
@@ -1763,10 +1781,12 @@ struct PresplitEntry {
 static std::mutex g_presplit_mu;
 static std::unordered_map<const void*, PresplitEntry> g_presplit;
 static std::unordered_map<const void*, PresplitEntry> g_presplit2;      // packed fp32 operand -> two scaled fp16 planes (F16X2)
+static std::unordered_map<const void*, const unsigned*> g_wamax;        // packed fp32 operand -> the slots of its maximum (F16X2)
 
-static bool f16x2_enabled() {      // XV2_F16X2=0: every launch on the three-plane bf16 form
-    static const int v = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 1; }();
-    return v != 0;
+static bool f16x2_enabled(int bit = 1) {      // XV2_F16X2=0: every launch on the three-plane bf16 form
+    // (bit mask for A/B runs: 1 = halo form, 2 = per-tap form; 4 = the weight-gradient kernels, wgrad_conv.hip; default all)
+    static const int v = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 7; }();
+    return (v & bit) != 0;
 }
 
 // max |x| of a tensor into 64 slots (zeroed by the caller): the weight operands' maxima, and the test harness
@@ -1909,6 +1929,16 @@ static bool f16x2_ready(IgemmParams& p) {
     p.Bx3 = reinterpret_cast<const float*>(it->second.x3);
     p.bytesBx3 = (unsigned)((size_t)p.Nout * p.T * p.Ctot * 4);
     p.amaxB = it->second.amax;
+    p.npl = 2;
+    return true;
+}
+// ... of the per-tap form (both operands split in the kernel): the maxima of the sources and of the packed weights
+static bool f16x2_ready_pertap(IgemmParams& p) {
+    if (!f16x2_enabled(2) || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1) || p.pre_scale) return false;
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    auto it = g_wamax.find(p.B);
+    if (it == g_wamax.end()) return false;
+    p.amaxB = it->second;
     p.npl = 2;
     return true;
 }
@@ -2071,6 +2101,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             XV2_CHECK_ARG(p.sk_tickets, "igemm: ticket pool allocation failed");
             if (int rc = complete_fold(p, cdiv(maxM, 128), p.Nout / 128)) return rc;
             return p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
+                   : f16x2_ready_pertap(p)       ? launch_one<128, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream)
                    : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                    : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
                                                  : launch_one<128, 128, 2, 2, false>(p, stream);
@@ -2099,6 +2130,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
                  : (halo && p.npl == 2)        ? launch_one<128, 128, 2, 2, false, true, false, true, true, true, 2>(p, stream)
                  : (halo && p.Bx3)             ? launch_one<128, 128, 2, 2, false, true, false, true, true, true>(p, stream)
                  : halo                        ? launch_one<128, 128, 2, 2, false, true, false, true, true>(p, stream)
+                 : f16x2_ready_pertap(p)       ? launch_one<128, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream)
                  : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                  : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
                                                : launch_one<128, 128, 2, 2, false>(p, stream);
@@ -2139,6 +2171,17 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             return launch_one<64, 64, 2, 2, false, true, true>(p, stream);
         }
         return launch_one<128, 32, 4, 1, false, true, true>(p, stream);
+    }
+    if (p.math == XV2_MATH_F32X3 && f16x2_ready_pertap(p)) {
+        if (bn == 128) {
+            if (bm == 128) return launch_one<128, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream);
+            return launch_one<64, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream);
+        }
+        if (bn == 64) {
+            if (bm == 128) return launch_one<128, 64, 2, 2, false, true, false, true, false, false, 2>(p, stream);
+            return launch_one<64, 64, 2, 2, false, true, false, true, false, false, 2>(p, stream);
+        }
+        return launch_one<128, 32, 4, 1, false, true, false, true, false, false, 2>(p, stream);
     }
     if (p.math == XV2_MATH_F32X3) {
         if (bn == 128) {
@@ -2632,8 +2675,19 @@ extern "C" int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, con
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,
                                             const void* w_ihwo, void* y, int ldy, void* stream) {
     XV2_CHECK_ARG(d->C1 == 0, "conv_transpose2d: single output tensor expected");
-    if (const int rc = thin_convT_forward(d, x, ldx, w_ihwo, y, ldy, (hipStream_t)stream); rc >= 0) return rc;      // thin_conv.hip
-    return dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
+    AmaxGuard amax_guard;
+    // F16X2: the maximum of y (the next convolution's source) is taken by a pass of its own - 0.1 ms per cfg2 step against the
+    // 1.5 ms its consumers save; the epilogues of these launches do not record
+    struct AmaxAfter {
+        unsigned* slots; const void* y; int64_t n; void* stream; int rc = 0;
+        void run() { if (slots) rc = xv2_tensor_amax_into(static_cast<const float*>(y), n, slots, stream); }
+    } after{(d->math == XV2_MATH_F32X3 && ldy == d->C0) ? amax_ctx().out : nullptr, y, (int64_t)d->N * d->IH * d->IW * d->C0, stream};
+    XV2_CHECK_ARG(!amax_ctx().out || after.slots, "conv_transpose2d: F16X2 maximum of a strided / non-fp32 output");
+    int rc = thin_convT_forward(d, x, ldx, w_ihwo, y, ldy, (hipStream_t)stream);      // thin_conv.hip
+    if (rc < 0) rc = dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    after.run();
+    return after.rc;
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
@@ -2692,11 +2746,46 @@ extern "C" int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* str
     return XV2_OK;
 }
 extern "C" size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot) { return (size_t)nrows * T * ctot * 4; }
+extern "C" int xv2_weight_amax_register(const void* b_fp32, const void* amax_slots) {
+    XV2_CHECK_ARG(b_fp32 && amax_slots, "weight_amax_register: null");
+    std::lock_guard<std::mutex> lk(g_presplit_mu);
+    g_wamax[b_fp32] = static_cast<const unsigned*>(amax_slots);
+    return XV2_OK;
+}
+// table[n][4] = {x (fp32, 16-byte aligned), n4 = float4 count, slots, first block}; an entry owns ceil(n4 / 1024) blocks
+__global__ void __launch_bounds__(256) amax_table_kernel(const int64_t* __restrict__ table, int n) {
+    __shared__ float red[4];
+    int lo = 0, hi = n - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 4 + 3] <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t* e = table + lo * 4;
+    const float4* x = reinterpret_cast<const float4*>(e[0]);
+    const int64_t n4 = e[1], b = blk - e[3];
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = b * 1024 + u * 256 + threadIdx.x;
+        if (i < n4) m = amax_acc(m, x[i]);
+    }
+    amax_record(reinterpret_cast<unsigned*>(e[2]), m, red, (unsigned)b);
+}
+extern "C" int xv2_weight_amax_table(const int64_t* table, int n, int64_t total_blocks, void* amax_base, int64_t amax_bytes,
+                                     void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && amax_base && amax_bytes > 0,
+                  "weight_amax_table: bad table");
+    XV2_CHECK_HIP(hipMemsetAsync(amax_base, 0, (size_t)amax_bytes, (hipStream_t)stream));
+    hipLaunchKernelGGL(amax_table_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
 extern "C" int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream) {
     XV2_CHECK_ARG(b_fp32 && x2 && amax_slots && xv2_presplit_supported(nrows, T, ctot), "presplit_f16: unsupported operand %d x %d x %d",
                   nrows, T, ctot);
     XV2_CHECK_ARG(((uintptr_t)x2 & 15) == 0 && xv2_presplit_f16_bytes(nrows, T, ctot) < (1ull << 31), "presplit_f16: alignment / size");
-    if (int rc = xv2_tensor_amax(b_fp32, (long long)nrows * T * ctot, amax_slots, stream)) return rc;
     {
         std::lock_guard<std::mutex> lk(g_presplit_mu);
         PresplitEntry e{x2, nrows, T, ctot};
@@ -2710,12 +2799,8 @@ extern "C" int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, i
     return XV2_OK;
 }
 // every registered F16X2 pair of a device table in one go (after the optimizer step): zero the slots, maxima, planes
-extern "C" int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* amax_base, int64_t amax_bytes,
-                                      void* stream) {
-    XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && amax_base && amax_bytes > 0,
-                  "presplit_f16_table: bad table");
-    XV2_CHECK_HIP(hipMemsetAsync(amax_base, 0, (size_t)amax_bytes, (hipStream_t)stream));
-    hipLaunchKernelGGL(presplit2h_table_kernel<true>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+extern "C" int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* stream) {
+    XV2_CHECK_ARG(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "presplit_f16_table: bad table");
     hipLaunchKernelGGL(presplit2h_table_kernel<false>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
@@ -2733,9 +2818,11 @@ extern "C" int xv2_presplit_forget(const void* b_fp32) {
     if (b_fp32) {
         g_presplit.erase(b_fp32);
         g_presplit2.erase(b_fp32);
+        g_wamax.erase(b_fp32);
     } else {
         g_presplit.clear();
         g_presplit2.clear();
+        g_wamax.clear();
     }
     return XV2_OK;
 }

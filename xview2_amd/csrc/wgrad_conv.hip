@@ -1651,7 +1651,7 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     p.X0 = x0; p.X1 = x1; p.DY = dy; p.part = workspace;
     p.pre_scale = pre ? pre->scale : nullptr; p.pre_shift = pre ? pre->shift : nullptr; p.pre_act = pre ? pre->act : 0;
     p.amaxX0 = amax_ctx().a0; p.amaxX1 = amax_ctx().a1; p.amaxDY = amax_ctx().dy;
-    static const int f16x2_on = [] { const char* e = getenv("XV2_F16X2"); return e ? atoi(e) : 1; }();
+    static const int f16x2_on = [] { const char* e = getenv("XV2_F16X2"); return (e ? atoi(e) : 7) & 4; }();
     // F16X2: all operand maxima known (xv2_amax_ctx) - two scaled fp16 planes, three MFMAs per product
     const bool h2 = x3 && f16x2_on && !pre && p.amaxX0 && p.amaxDY && (!x1 || p.amaxX1);
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1; p.ldX0 = ldx0; p.ldX1 = ldx1; p.ldDY = lddy;

@@ -57,7 +57,10 @@ class ConvTranspose(nn.Module):  # layers.py:80-86
         self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2, bias=False)
 
     def forward(self, x, passthrough=False):
-        return ops.ConvTranspose2x2Fn.apply(x, self.conv.weight, passthrough)
+        out = ops.ConvTranspose2x2Fn.apply(x, self.conv.weight, passthrough)
+        if passthrough:
+            ops.carry_amax(x, out[1])
+        return out
 
 
 class UpsampleBlock(nn.Module):  # layers.py:131-168

@@ -66,8 +66,9 @@ class _Pool(nn.Module):
     def forward(self, x):
         if self.alias_request and xnn.want_aliases(x):
             y, self.alias_out = self.fn(x, True)
-            return y
-        return self.fn(x, False)
+            ops.carry_amax(x, self.alias_out)
+            return ops.carry_amax(x, y)          # (max |pool(x)| <= max |x|: the source's maximum bounds the pooled tensor)
+        return ops.carry_amax(x, self.fn(x, False))
 
 
 def _maxpool():
@@ -149,7 +150,7 @@ class StBottleneck(nn.Module):
             out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
         out = self.conv2(out)
         if self.avd:
-            out = ops.AvgPoolFn.apply(out, 3, self.avd_stride, 1, False, True)
+            out = ops.carry_amax(out, ops.AvgPoolFn.apply(out, 3, self.avd_stride, 1, False, True))
         idt = x
         if self.downsample is not None:
             k = self.downsample.pool_k
@@ -158,8 +159,10 @@ class StBottleneck(nn.Module):
                 pooled = x
             elif want:
                 pooled, self.alias_out = ops.AvgPoolFn.apply(x, k, k, 0, True, False, True)
+                ops.carry_amax(x, self.alias_out)
+                ops.carry_amax(x, pooled)
             else:
-                pooled = ops.AvgPoolFn.apply(x, k, k, 0, True, False)
+                pooled = ops.carry_amax(x, ops.AvgPoolFn.apply(x, k, k, 0, True, False))
             if want and k == 1:
                 idt, self.alias_out = xnn.conv_bn_act(self.downsample[1], self.downsample[2], pooled, passthrough=True)
             else:

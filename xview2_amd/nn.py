@@ -76,8 +76,14 @@ def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthro
         return _with_aliases(z, x0, x1, passthrough)
     bump_bn_counter(bn)
     # lazy_out: the result feeds exactly ONE further conv_bn_act call and nothing else (see ops.ConvBnActFn.forward)
-    return ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
-                                 ops.BnState(bn, SYNC_BN), act, bn.training, passthrough, lazy_out)
+    out = ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
+                                ops.BnState(bn, SYNC_BN), act, bn.training, passthrough, lazy_out)
+    if passthrough == 3:
+        ops.carry_amax(x0, out[1])
+        ops.carry_amax(x1, out[2])
+    elif passthrough:
+        ops.carry_amax(x0 if passthrough == 1 else x1, out[1])
+    return out
 
 
 def _with_aliases(z, x0, x1, passthrough):

@@ -155,7 +155,7 @@ PACK_CACHE_MAX = 8192     # entries; beyond that the least recently used half is
 
 
 class _PackEntry:
-    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype", "x3", "x2")
+    __slots__ = ("w", "version", "epoch", "ohwi", "ihwo", "geom", "tick", "owner", "dtype", "x3", "x2", "amax", "amax_reg")
 
 
 PRESPLIT = os.environ.get("XV2_PRESPLIT", "1") != "0"
@@ -223,6 +223,15 @@ def _tok_ptr(tok):
     return tok[0] if (tok is not None and tok[3].gen[tok[1]] == tok[2]) else None
 
 
+def carry_amax(src, alias):
+    """a pass-through alias (a Function output that IS one of its inputs) is a new tensor object: hand the source's recorded
+    maximum on to it"""
+    tok = getattr(src, "_xv2_amax", None) if src is not None else None
+    if tok is not None and alias is not None:
+        alias._xv2_amax = tok
+    return alias
+
+
 def amax_reset():
     """forget every pool (tests; a process that switches devices)"""
     _amax_pools.clear()
@@ -242,11 +251,30 @@ def _presplit_geoms(e):
     return out
 
 
+def _weight_amax(e):
+    """F16X2: the maximum of the entry's weights (taken from one packed fp32 layout) registered for all of its layouts"""
+    src = e.ohwi if e.ohwi is not None else e.ihwo
+    if not F16X2 or e.dtype != XV2_F32 or MATH_MODE != MATH_F32X3 or e.geom[3] == 4 or src is None:
+        return False
+    if e.amax is None:
+        e.amax = _wamax_take(src.device)
+        e.amax_reg = set()
+        if e.amax is None:
+            return False
+    call("xv2_tensor_amax", src, src.numel(), e.amax)
+    for t in (e.ohwi, e.ihwo):
+        if t is not None and t.data_ptr() not in e.amax_reg:
+            query("xv2_weight_amax_register", t, e.amax)
+            e.amax_reg.add(t.data_ptr())
+    return True
+
+
 def _presplit_entry(e):
     """bf16-plane copies of the entry's packed layouts (the weight operand of the halo kernels goes global -> LDS by DMA)"""
+    have_amax = _weight_amax(e)
     geoms = _presplit_geoms(e)
     if not geoms:
-        _forget_entry(e)       # (a mode switch: planes that are no longer refreshed must not stay registered)
+        _forget_entry(e, keep_amax=have_amax)       # (a mode switch: planes that are no longer refreshed must not stay registered)
         return
     for src, rows, T, ch in geoms:
         key = src.data_ptr()
@@ -255,16 +283,13 @@ def _presplit_entry(e):
         if key not in e.x3:
             e.x3[key] = torch.empty((query("xv2_presplit_bytes", rows, T, ch) // 2,), dtype=torch.bfloat16, device=src.device)
         call("xv2_presplit_weights", src, rows, T, ch, e.x3[key])
-        if F16X2:
+        if have_amax:
             if e.x2 is None:
                 e.x2 = {}
             if key not in e.x2:
-                slots = _wamax_take(src.device)
-                if slots is None:
-                    continue
                 e.x2[key] = (torch.empty((query("xv2_presplit_f16_bytes", rows, T, ch) // 2,), dtype=torch.float16,
-                                         device=src.device), slots)
-            call("xv2_presplit_weights_f16", src, rows, T, ch, e.x2[key][0], e.x2[key][1])
+                                         device=src.device), e.amax)
+            call("xv2_presplit_weights_f16", src, rows, T, ch, e.x2[key][0], e.amax)
 
 
 def _wamax_take(device):
@@ -280,17 +305,27 @@ def _wamax_take(device):
     return a[0].data_ptr() + (a[1] - 1) * AMAX_BYTES
 
 
-def _forget_entry(e):
+def _forget_entry(e, keep_amax=False):
     if e.x3:
         for key in e.x3:
             query("xv2_presplit_forget", key)
         e.x3 = None
-    if e.x2:
-        for planes, slots in e.x2.values():
-            for a in _wamax.values():
-                if a[0].data_ptr() <= slots < a[0].data_ptr() + F16X2_WEIGHTS * AMAX_BYTES:
-                    a[2].append(slots)
-        e.x2 = None
+    e.x2 = None
+    if keep_amax:
+        if e.amax is not None:      # (xv2_presplit_forget dropped the registration of those layouts as well)
+            e.amax_reg = set()
+            for t in (e.ohwi, e.ihwo):
+                if t is not None:
+                    query("xv2_weight_amax_register", t, e.amax)
+                    e.amax_reg.add(t.data_ptr())
+        return
+    if e.amax is not None:
+        for key in e.amax_reg:
+            query("xv2_presplit_forget", key)
+        for a in _wamax.values():
+            if a[0].data_ptr() <= e.amax < a[0].data_ptr() + F16X2_WEIGHTS * AMAX_BYTES:
+                a[2].append(e.amax)
+        e.amax, e.amax_reg = None, None
 
 
 def _del_pack(k):
@@ -332,7 +367,7 @@ def _pack(w_oihw, cin_pad, want_ohwi, want_ihwo, half=False):
             for k in [k for k, v in _packs.items() if v.tick < cut]:
                 _del_pack(k)
         e = _PackEntry()
-        e.ohwi = e.ihwo = e.x3 = e.x2 = None
+        e.ohwi = e.ihwo = e.x3 = e.x2 = e.amax = e.amax_reg = None
         e.geom = (Cout, Cin, KH * KW, cin_pad)
         _packs[key] = e
         _pack_table = None
@@ -393,29 +428,36 @@ def repack_all():
         xrows, xstart = [], 0
         for e in _packs.values():      # the bf16-plane copies, refreshed by a second table-driven launch
             geoms = _presplit_geoms(e)
-            if not geoms:
-                _forget_entry(e)
+            if not geoms and (e.x3 or e.x2):
+                _forget_entry(e, keep_amax=e.amax is not None)      # (planes only: the weights' maximum stays registered)
             for src, nr, T, ch in geoms:
                 if e.x3 and src.data_ptr() in e.x3:
                     xrows.append([src.data_ptr(), e.x3[src.data_ptr()].data_ptr(), nr, T, ch, xstart])
                     xstart += query("xv2_presplit_blocks", nr, T, ch)
         xt = (torch.tensor(xrows, dtype=torch.int64).to(dev), len(xrows), xstart) if xrows else None
-        hrows, hstart = [], 0
-        for e in _packs.values():      # the scaled fp16 planes (F16X2): maxima + planes by a third table
+        arows, astart, hrows, hstart = [], 0, [], 0
+        for e in _packs.values():      # F16X2: the weights' maxima (every fp32 entry), then the scaled fp16 planes of the 3x3 layouts
+            if e.amax is None:
+                continue
+            src = e.ohwi if e.ohwi is not None else e.ihwo
+            arows.append([src.data_ptr(), src.numel() // 4, e.amax, astart])
+            astart += (src.numel() // 4 + 1023) // 1024
             for src, nr, T, ch in (_presplit_geoms(e) if e.x2 else []):
                 if src.data_ptr() in e.x2:
-                    planes, slots = e.x2[src.data_ptr()]
-                    hrows.append([src.data_ptr(), planes.data_ptr(), nr, T, ch, hstart, slots])
+                    hrows.append([src.data_ptr(), e.x2[src.data_ptr()][0].data_ptr(), nr, T, ch, hstart, e.amax])
                     hstart += query("xv2_presplit_blocks", nr, T, ch)
+        at = (torch.tensor(arows, dtype=torch.int64).to(dev), len(arows), astart) if arows else None
         ht = (torch.tensor(hrows, dtype=torch.int64).to(dev), len(hrows), hstart) if hrows else None
-        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start, xt, ht)
-    table, n, total, xt, ht = _pack_table
+        _pack_table = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), start, xt, at, ht)
+    table, n, total, xt, at, ht = _pack_table
     call("xv2_pack_weights_table", table, n, total)
     if xt is not None:
         call("xv2_presplit_table", xt[0], xt[1], xt[2])
-    if ht is not None:
-        arena = _wamax[ht[0].device.index]
-        call("xv2_presplit_f16_table", ht[0], ht[1], ht[2], arena[0], arena[1] * AMAX_BYTES)
+    if at is not None:
+        arena = _wamax[at[0].device.index]
+        call("xv2_weight_amax_table", at[0], at[1], at[2], arena[0], arena[1] * AMAX_BYTES)
+        if ht is not None:
+            call("xv2_presplit_f16_table", ht[0], ht[1], ht[2])
     for e in _packs.values():
         e.version, e.epoch = e.w._version, WEIGHT_EPOCH
 
@@ -1196,7 +1238,9 @@ class ConvBnActFn(torch.autograd.Function):
             x0, pre = _apply_pre(x0, pre), None
         # F16X2: the maxima of the sources (recorded by their producers) and a slot for this layer's output
         am_in = am_out = None
-        if _amax_active(x0) and g.groups == 1 and pre is None and not lazy and not COOP_APPLY:
+        # (training mode only: the eval forward stays on the three-plane form like the fused inference launches, whose epilogues
+        #  do not record maxima - the two inference paths remain bit-identical)
+        if training and _amax_active(x0) and g.groups == 1 and pre is None and not lazy and not COOP_APPLY:
             am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
             am_out = _amax_new(x0)
         ctx.am_in = am_in
@@ -1367,6 +1411,10 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         d = _desc(N, 2 * H, 2 * W, Cout, 0, Cin, g, H, W, half)  # the equivalent 2x2/s2 convolution
         _, ihwo = _pack(weight.contiguous(), Cout, False, True, half)
         y = _act((N, 2 * H, 2 * W, Cout), x)
+        if _amax_active(x) and x.requires_grad:      # F16X2 (training): y's maximum for the block's first convolution
+            tok = _amax_new(x)
+            set_amax(None, None, _amax_ptr(x_in), tok[0])
+            y._xv2_amax = tok
         call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
         ctx.save_for_backward(x, weight)
         ctx.d = d
