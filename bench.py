@@ -34,7 +34,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 (--precision 16 runs only)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 / fp16 (v_mfma_f32_32x32x16_bf16 / _f16)
+
+
+def fp32_split_peak(training=True):
+    """the instruction stream's own bound of fp32 tensors on the 16-bit MFMA: F16X2 (two scaled fp16 planes, 3 MFMAs per product;
+    training-mode launches whose operand maxima are known - all but a handful) or F32X3 (three bf16 planes, 6 MFMAs per product)"""
+    from xview2_amd import ops
+    return round(PEAK_BF16_MFMA_TFLOPS / (3 if (ops.F16X2 and training) else 6), 1)
+
+
+def kernel_peak(name, precision):
+    if "f16x2" in name:
+        return round(PEAK_BF16_MFMA_TFLOPS / 3, 1)
+    if "f32x3" in name:
+        return round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
+    return PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS
+
+
+F32_SPLIT_TEXT = ("fp32 tensors, fp32 accumulation; products on the 16-bit MFMA from exact operand splits: F16X2 = two fp16 planes of "
+                  "x * 2^k (k from the tensor's recorded max |x|), 3 MFMAs per product, for every launch whose operand maxima are known; "
+                  "F32X3 = three bf16 planes, 6 MFMAs per product, for the rest (XV2_F16X2=0: everywhere; XV2_F32X3=0: exact-fp32 MFMA)")
 F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
 F_ENC_GFLOP_PER_IMG = {"resnet50": 170.8, "resnest50": 224.3}   # SURVEY.md 8(a): encoder forward only
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
@@ -292,8 +312,8 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
         ops.set_storage_dtype(None) if hasattr(ops, "set_storage_dtype") else None
     gf = F_ENC_GFLOP_PER_IMG.get(encoder, 0.0) * batch * (size / 1024.0) ** 2
     x3 = precision == 32 and ops.fp32_math() == ops.MATH_F32X3
-    peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else
-            PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
+    peak = (fp32_split_peak(True) if x3 else PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
+    peak_eval = fp32_split_peak(False) if x3 else peak
     mfma_ms = sum(r["ms"] for r in rows) / iters
     counted = sum(r["gflop"] for r in rows) / iters
     return {"encoder": encoder, "precision": precision, "batch": batch, "size": size,
@@ -301,12 +321,13 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
             "forward_ms": round(wall_ms, 3), "mfma_kernels_ms": round(mfma_ms, 3),
             "mfma_util_whole_forward": round(gf / wall_ms / peak, 4),
             "mfma_util_in_mfma_kernels": round(gf / mfma_ms / peak, 4) if mfma_ms else None,
-            "math": "f32x3 (3-way bf16 split, 6 bf16 MFMAs per product; peak = bf16 dense peak / 6)" if x3 else
+            "math": (F32_SPLIT_TEXT + "; peak = 16-bit dense peak / 3 (F16X2, training mode) resp. / 6 (F32X3, eval mode)") if x3 else
                     "fp32 MFMA" if precision == 32 else "bf16 MFMA, bf16 tensors",
+            "vs_f32x3_bound_416.7": round(gf / wall_ms / (PEAK_BF16_MFMA_TFLOPS / 6), 4) if x3 else None,
             "vs_fp32_mfma_peak_157.3": round(gf / wall_ms / PEAK_F32_MFMA_TFLOPS, 4) if precision == 32 else None,
-            "eval_mode": {"forward_ms": round(wall_eval, 3),
+            "eval_mode": {"forward_ms": round(wall_eval, 3), "peak_tflops": peak_eval,
                           "mfma_kernels_ms": round(sum(r["ms"] for r in rows_eval) / iters, 3),
-                          "mfma_util_whole_forward": round(gf / wall_eval / peak, 4),
+                          "mfma_util_whole_forward": round(gf / wall_eval / peak_eval, 4),
                           "note": "model.eval(): BatchNorm folded into the convolution epilogue, one launch per conv"},
             "note": "training-mode forward (batch statistics: conv+stats, BN apply, split attention, pooling kernels "
                     "all inside forward_ms); utilisation = SURVEY 8(a) conv FLOPs / time / dense MFMA peak",
@@ -421,7 +442,7 @@ def config_leg(name, a, precision, size, batch, dev, steps=10, warmup=3, parity=
     gflop = sum(r["gflop"] for r in rows) / 2
     gbytes = sum(r["mbytes"] for r in rows) / 2e3
     x3 = precision == 32 and ops.fp32_math() == ops.MATH_F32X3
-    peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
+    peak = (fp32_split_peak(True) if x3 else PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS)
     out = {"config": name, "value": round(batch * steps / dt, 3), "unit": unit, "ms_per_step": round(ms, 3),
            "steps": steps, "warmup": max(1, warmup), "dtype": "f32" if precision == 32 else "bf16", "loss": final_loss,
            "launch": "eager, no per-launch event brackets in the timed steps",
@@ -693,8 +714,7 @@ def main():
     value = world * opt.batch * opt.steps / dt
 
     x3 = opt.precision == 32 and _xops.fp32_math() == _xops.MATH_F32X3
-    step_peak = (round(PEAK_BF16_MFMA_TFLOPS / 6, 1) if x3 else
-                 PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS)
+    step_peak = (fp32_split_peak(True) if x3 else PEAK_F32_MFMA_TFLOPS if opt.precision == 32 else PEAK_BF16_MFMA_TFLOPS)
     roof = None
     if prof and rows:
         # dominant kernel: its launches inside the TIMED region; the per-kernel table: the extra bracketed pass
@@ -706,15 +726,16 @@ def main():
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
             traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
         iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
-        peak = step_peak
+        peak = kernel_peak(top["kernel"], opt.precision)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic,
-                "math": "f32x3: fp32 tensors and accumulation, each product = 6 bf16 MFMA products of exact 3-way bf16 "
-                        "operand splits; peak = bf16 dense MFMA peak / 6 (the instruction stream's own bound); "
-                        "achieved counts ALGORITHMIC fp32 flops (2*M*N*K); peak is quoted at the 2.4 GHz maximum clock - "
-                        "under these kernels the chip is power-limited to ~1.6 - 1.9 GHz effective (GRBM_GUI_ACTIVE, "
-                        "profiles/r03_pmc_halo.md), where the same bound is ~280 - 330 TFLOP/s" if x3 else
+                "math": (F32_SPLIT_TEXT + ".  This kernel: " + ("F16X2, peak = 16-bit dense MFMA peak / 3" if "f16x2" in top["kernel"]
+                                                                else "F32X3, peak = bf16 dense MFMA peak / 6") +
+                         " (the instruction stream's own bound); achieved counts ALGORITHMIC fp32 flops (2*M*N*K); peaks are quoted "
+                         "at the 2.4 GHz maximum clock - under these kernels the chip is power-limited to ~1.6 - 1.9 GHz effective "
+                         "(GRBM_GUI_ACTIVE, profiles/r03_pmc_halo.md)") if x3 else
                         "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA",
+                "frac_of_f32x3_bound_416.7": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6), 4) if x3 else None,
                 "frac_of_fp32_mfma_peak_157.3": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if opt.precision == 32 else None,
                 "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                   "command on an earlier run of THIS round's kernels (scripts/profile_bench.sh; PMC "
@@ -724,7 +745,8 @@ def main():
                 "avg_launch_us": round(top["ms"] / top["launches"] * 1e3, 2),
                 "gflop_per_launch": round(top["gflop"] / top["launches"], 3),
                 "launches_timed": top["launches"],
-                "note": "'halo,wx3' = the round-3 form of the 3x3 / stride-1 forward and backward-data launches: 4 x 32 pixel patches, "
+                "note": "'halo,wx2' / 'halo,wx3' = the halo form of the 3x3 / stride-1 forward and backward-data launches (two scaled fp16 planes / "
+                        "three bf16 planes): 4 x 32 pixel patches, "
                         "the halo of a 16-channel slice split and stored once for nine taps, weights pre-split once per step and "
                         "streamed global -> LDS by DMA (DESIGN.md section 4); unsplit launches fold their BatchNorm statistics "
                         "(bn_fold.h), split-K slabs are summed by splitk_reduce_kernel; "
@@ -739,6 +761,7 @@ def main():
                 "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
                                      "gflop_per_step": round(tot_gf / psteps, 1)},
                 "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
+                                "frac_of_its_bound": round(r["gflop"] / r["ms"] / kernel_peak(r["kernel"], opt.precision), 3),
                                 "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
                                for r in rows]}
     model_tf = value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3
@@ -753,8 +776,7 @@ def main():
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
-                                   "fp32 tensors, products as exact 3-way bf16 splits on the bf16 MFMA (6 MFMAs per product, "
-                                   "fp32 accumulate; XV2_F32X3=0 selects the exact-fp32 MFMA)" if x3 else "fp32" if opt.precision == 32 else
+                                   F32_SPLIT_TEXT if x3 else "fp32" if opt.precision == 32 else
                                    "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
                    "global_batch": world * opt.batch,
                    "parallelism": "dp%d" % world + (" (ranks SHARE one GPU over gloo: code-path test, not a scaling "

@@ -1,0 +1,222 @@
+"""F16X2 (include/xv2.h): fp32 tensors, operands as two scaled fp16 planes, three MFMAs per product, for every launch whose
+operand maxima are known.  The tests pin (a) WHICH kernels ran, (b) that the results are as close to an fp64 convolution as
+the three-plane bf16 form's (both are fp32-class), (c) that the recorded maxima are exact, (d) that a maximum that is too
+small is loud (Inf / NaN, never a silently wrong finite number), (e) that the operand-maximum context serves one call."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+SLOT_INTS = 2048          # one tensor's maximum: 64 slots, one 128-byte line each
+
+
+def _slots():
+    return torch.zeros(SLOT_INTS, dtype=torch.int32, device=DEV)
+
+
+def _amax_of(t):
+    from xview2_amd._capi import call
+    s = _slots()
+    call("xv2_tensor_amax", t, t.numel(), s)
+    return s
+
+
+def _recorded(slots):
+    """the maximum the 64 slots hold, as a float"""
+    v = slots.view(-1, 32)[:, 0].max().item()
+    return ctypes.c_float.from_buffer(ctypes.c_uint32(v & 0xffffffff)).value
+
+
+class _prof:
+    def __enter__(self):
+        from xview2_amd import _capi
+        _capi.query("xv2_prof_enable", 1)
+        return self
+
+    def names(self):
+        from xview2_amd import _capi
+        torch.cuda.synchronize()
+        out = []
+        for i in range(_capi.query("xv2_prof_num_records")):
+            kid, ms, fl, by = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            _capi._func("xv2_prof_record")(i, ctypes.addressof(kid), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(by))
+            out.append(_capi.query("xv2_prof_kernel_name", kid.value).decode())
+        return out
+
+    def __exit__(self, *exc):
+        from xview2_amd import _capi
+        _capi.query("xv2_prof_enable", 0)
+
+
+def _rel(a, ref):
+    e = a.double() - ref
+    return (e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def _need_f32x3():
+    from xview2_amd import ops
+    if ops.MATH_MODE != ops.MATH_F32X3 or not ops.F16X2:
+        pytest.skip("F16X2 is the two-plane form of XV2_MATH_F32X3")
+
+
+CASES = [  # N, H, W, C0, C1, Cout, k
+    (2, 64, 64, 128, 0, 128, 3),       # halo form, 128-column tile
+    (2, 64, 64, 64, 64, 64, 3),        # halo form, two sources (decoder block), 64-column tile
+    (2, 32, 32, 256, 0, 512, 1),       # per-tap form
+    (1, 96, 64, 96, 32, 64, 3),        # halo form, ragged channel counts (32-channel chunks), two sources
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_forward_backward_data_backward_weight_run_two_plane_kernels_at_fp32_accuracy(case):
+    """conv forward / backward-data / backward-weight with known operand maxima: the f16x2 kernels run, and their distance
+    from the fp64 result is that of the three-plane form (within 1.5x, and below 2e-6 of the result's rms)"""
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    N, H, W, C0, C1, Co, k = case
+    torch.manual_seed(7)
+    g = ops.conv_cfg(k, k, 1, k // 2)
+    spread = torch.exp(torch.randn(1, 1, 1, C0 + C1, device=DEV))
+    xx = torch.relu(torch.randn(N, H, W, C0 + C1, device=DEV)) * spread
+    x0 = xx[..., :C0].contiguous()
+    x1 = xx[..., C0:].contiguous() if C1 else None
+    w = torch.randn(Co, C0 + C1, k, k, device=DEV) * 0.03
+    dy = torch.randn(N, H, W, Co, device=DEV) * 1e-6 * torch.exp(2 * torch.randn(N, H, W, 1, device=DEV))     # gradient-sized values
+    xr, wr, dr = xx.permute(0, 3, 1, 2).double().requires_grad_(), w.double().requires_grad_(), dy.permute(0, 3, 1, 2).double()
+    yr = torch.nn.functional.conv2d(xr, wr, padding=k // 2)
+    yr.backward(dr)
+    ref = {"y": yr.detach().permute(0, 2, 3, 1), "dx": xr.grad.permute(0, 2, 3, 1), "dw": wr.grad}
+    ops._pack(w, C0 + C1, True, True)           # (both layouts: planes + registered maximum, as a training step has them)
+    a0, a1, ad = _amax_of(x0), (_amax_of(x1) if C1 else None), _amax_of(dy)
+    res = {}
+    for h2 in (False, True):
+        with _prof() as pr:
+            if h2:
+                set_amax(a0, a1)
+            y = ops._conv_forward(x0, x1, w, g, None, True)[0]
+            if h2:
+                set_amax(None, None, ad)
+            dx0, dx1 = ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
+            if h2:
+                set_amax(a0, a1, ad)
+            dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g)
+            names = pr.names()
+        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_"))]
+        assert len(convs) == 3, names
+        assert all(("f16x2" in n) == h2 for n in convs), convs
+        dx = torch.cat([dx0, dx1], dim=-1) if C1 else dx0
+        res[h2] = {"y": _rel(y, ref["y"]), "dx": _rel(dx, ref["dx"]), "dw": _rel(dw, ref["dw"])}
+    for kx in ("y", "dx", "dw"):
+        assert res[True][kx] <= max(1.5 * res[False][kx], 2e-7), (kx, res)
+        assert res[True][kx] < 2e-6, (kx, res)
+
+
+def test_batchnorm_apply_passes_record_the_exact_maximum_of_what_they_write():
+    """training-mode conv + BatchNorm + ReLU (layer-level call) records max |z|; the BatchNorm backward records max |dy|"""
+    _need_f32x3()
+    from xview2_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 32, 32, 64, device=DEV).requires_grad_()
+    conv = torch.nn.Conv2d(64, 128, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(128).to(DEV)
+    from xview2_amd import nn as xnn
+    z = xnn.conv_bn_act(conv, bn, x, act=ops.ACT_RELU)
+    tok = z._xv2_amax
+    torch.cuda.synchronize()
+    pool = tok[3]
+    idx = (tok[0] - pool.base) // ops.AMAX_BYTES
+    assert _recorded(pool.buf[idx]) == z.detach().abs().max().item()
+    # backward: the gradient of the convolution output is internal to the node - take it from the op-level pieces instead
+    y = torch.randn(2, 32, 32, 128, device=DEV)
+    st = ops._bn_forward(y, None, ops.ACT_RELU, ops.BnState(bn, False), None, True)
+    dz = torch.randn_like(y) * 1e-5
+    tok2 = ops._amax_new(y)
+    dyv = ops._bn_backward(dz, None, y, st[1], bn.weight, ops.ACT_RELU, ops.BnState(bn, False), True, False, None, 1, tok2)[0]
+    torch.cuda.synchronize()
+    idx2 = (tok2[0] - tok2[3].base) // ops.AMAX_BYTES
+    assert _recorded(tok2[3].buf[idx2]) == dyv.abs().max().item()
+    assert ops._amax_ptr(dyv) == tok2[0]
+
+
+def test_a_maximum_that_is_too_small_is_loud():
+    """a stale slot (recorded maximum far below the tensor's) must not yield finite garbage: the scaled values overflow fp16"""
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    torch.manual_seed(1)
+    g = ops.conv_cfg(3, 3, 1, 1)
+    x = torch.randn(1, 32, 32, 64, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV) * 0.05
+    ops._pack(w, 64, True, False)
+    small = _amax_of(x * 1e-4)                    # claims max |x| is 10^4 times smaller than it is
+    set_amax(small, None)
+    y = ops._conv_forward(x, None, w, g, None, True)[0]
+    assert not torch.isfinite(y).all()
+    good = _amax_of(x)
+    set_amax(good, None)
+    y = ops._conv_forward(x, None, w, g, None, True)[0]
+    assert torch.isfinite(y).all()
+
+
+def test_the_operand_maximum_context_serves_exactly_one_call():
+    """xv2_amax_ctx is cleared when the convolution it was set for returns: the next call runs the three-plane form"""
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    torch.manual_seed(2)
+    g = ops.conv_cfg(3, 3, 1, 1)
+    x = torch.relu(torch.randn(2, 32, 32, 64, device=DEV))
+    w = torch.randn(64, 64, 3, 3, device=DEV) * 0.05
+    ops._pack(w, 64, True, False)
+    base = ops._conv_forward(x, None, w, g, None, True)[0]           # no context: three planes
+    ax = _amax_of(x)
+    set_amax(ax, None)
+    with _prof() as pr:
+        y2 = ops._conv_forward(x, None, w, g, None, True)[0]
+        y3 = ops._conv_forward(x, None, w, g, None, True)[0]
+        names = [n for n in pr.names() if n.startswith("igemm_kernel")]
+    assert "f16x2" in names[0] and "f16x2" not in names[1], names
+    assert torch.equal(y3, base) and not torch.equal(y2, base)
+    assert (y2 - base).abs().max() <= 1e-5 * base.abs().max()
+
+
+def test_training_step_with_and_without_two_plane_kernels_agree_like_two_fp32_runs():
+    """a resnet50 U-Net step at 128^2 with F16X2 on and off: same loss to 1e-6; the gradients of this randomly initialised network
+    are ill-conditioned (an fp32 run is 2 % away from an fp64 one: profiles/r02_full_size_grad_parity.json), so the two runs are
+    held to that distance - cosine > 0.999"""
+    _need_f32x3()
+    import bench
+    from xview2_amd import criterion, networks, ops
+    from xview2_amd.optim import FlatAdamW
+    from xview2_amd.weights import deterministic_init_
+    a = bench.make_args("resnet50", "pre", "dice")
+    out = {}
+    old = ops.F16X2
+    try:
+        for h2 in (False, True):
+            ops.F16X2 = h2
+            torch.manual_seed(0)
+            m = networks.UNetLoc(a)
+            deterministic_init_(m, 1)
+            m.to(DEV).train()
+            opt = FlatAdamW(m.parameters(), lr=1e-3)
+            x, y = bench.synthetic_batch(a, 2, 128, 1, DEV)
+            opt.zero_grad()
+            with _prof() as pr:
+                loss = criterion.Loss(a)(m(x), y)
+                loss.backward()
+                ops.join_wgrad_stream()
+                names = pr.names()
+            n2 = sum("f16x2" in n for n in names)
+            assert (n2 > 60) if h2 else (n2 == 0), (h2, n2, len(names))
+            out[h2] = (float(loss), opt.flat_g.clone())
+            del m, opt
+            ops.clear_pack_cache()
+    finally:
+        ops.F16X2 = old
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    g0, g1 = out[False][1].double(), out[True][1].double()
+    assert torch.dot(g0, g1) / (g0.norm() * g1.norm()) > 0.999

@@ -124,7 +124,11 @@ def set_amax(a0=None, a1=None, dy=None, out=None):
     or None.  Handed to the library right before that call; the library clears the context when a convolution /
     BatchNorm-apply entry point returns, so it serves exactly one layer."""
     global _amax_pending
-    _amax_pending = (a0, a1, dy, out) if (a0 or a1 or dy or out) else None
+    if a0 is None and a1 is None and dy is None and out is None:
+        _amax_pending = None
+        return
+    # (tensors: the caller keeps them alive until the launch has run)
+    _amax_pending = tuple(a.data_ptr() if isinstance(a, torch.Tensor) else a for a in (a0, a1, dy, out))
 
 
 def call(name, *args):

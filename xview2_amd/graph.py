@@ -31,11 +31,14 @@ class GraphedStep:
             if bn.training and bn.num_batches_tracked is not None:
                 self._bumped.append(bn)
         xnn.bump_bn_counter = recording_bump
+        from . import ops
         try:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
+                ops.amax_begin_capture()      # F16X2: the replays zero the operand-maximum slots they re-use
                 self.loss = step_fn(*static_inputs)
         finally:
+            ops.amax_end_capture()
             xnn.bump_bn_counter = orig
         # capture records the launches WITHOUT executing them: undo the host-side bookkeeping of that pass
         optimizer.step_count -= 1

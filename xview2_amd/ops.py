@@ -178,9 +178,12 @@ class _AmaxPool:
         self.base = self.buf.data_ptr()
         self.next = 0
         self.gen = [1, 0]
+        self.capturing = False
 
     def take(self):
         i = self.next
+        if self.capturing and i >= self.P // 2:
+            return None          # (amax_begin_capture: only the first half is zeroed by the graph)
         if i == self.P:
             i = 0
         if i == 0 and self.gen[1]:
@@ -230,6 +233,23 @@ def carry_amax(src, alias):
     if tok is not None and alias is not None:
         alias._xv2_amax = tok
     return alias
+
+
+def amax_begin_capture():
+    """hipGraph capture of a training step: the slots the captured launches name are re-used by every replay, so the graph itself
+    must zero them first - all pools restart at slot 0 and the zeroing of their first half is recorded as the graph's first node
+    (a step that needs more than half a pool falls back to 'unknown' for the rest: the second half is not re-zeroed by replays)"""
+    for p in _amax_pools.values():
+        p.buf[:p.P // 2].zero_()
+        p.gen[0] += 1
+        p.gen[1] += 1          # (tokens of the second half would go stale between replays: invalidate them as they are made)
+        p.next = 0
+        p.capturing = True
+
+
+def amax_end_capture():
+    for p in _amax_pools.values():
+        p.capturing = False
 
 
 def amax_reset():
@@ -1413,8 +1433,9 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         y = _act((N, 2 * H, 2 * W, Cout), x)
         if _amax_active(x) and x.requires_grad:      # F16X2 (training): y's maximum for the block's first convolution
             tok = _amax_new(x)
-            set_amax(None, None, _amax_ptr(x_in), tok[0])
-            y._xv2_amax = tok
+            if tok is not None:
+                set_amax(None, None, _amax_ptr(x_in), tok[0])
+                y._xv2_amax = tok
         call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
         ctx.save_for_backward(x, weight)
         ctx.d = d
