@@ -23,11 +23,11 @@ def per_kernel(db, counter):
 
 def pretty(mangled):
     """mangled kernel symbol -> the name bench.py's in-library profiler registers (roofline.kernel)"""
-    if "wgrad_alltaps_x3_kernel" in mangled:
-        return "wgrad_alltaps_kernel<f32x3>"
-    m = re.match(r"_ZN3xv2\d+wgrad_tr_x3_kernelILi(\d+)ELi(\d+)E", mangled)
+    if "wgrad_alltaps_x3_kernel" in mangled or "wgrad_alltaps64_x3_kernel" in mangled:      # (one registered name for both tilings)
+        return "wgrad_alltaps_kernel<f16x2>" if "ILi2E" in mangled else "wgrad_alltaps_kernel<f32x3>"
+    m = re.match(r"_ZN3xv2\d+wgrad_tr_x3_kernelILi(\d+)ELi(\d+)ELi(\d)E", mangled)
     if m:
-        return "wgrad_tr_kernel<%s,%s,f32x3>" % (m.group(1), m.group(2))
+        return "wgrad_tr_kernel<%s,%s,%s>" % (m.group(1), m.group(2), "f16x2" if m.group(3) == "2" else "f32x3")
     if "wgrad_alltaps_tr_kernel" in mangled:
         return "wgrad_alltaps_kernel<bf16hbm>"
     if "wgrad_alltaps_kernel" in mangled:
@@ -46,10 +46,11 @@ def pretty(mangled):
     if not m:
         return None
     args = re.findall(r"L([ib])(\d+)E", m.group(2))
-    vals = [int(v) for _, v in args] + [0, 0, 0, 0, 0, 0]
+    vals = [int(v) for _, v in args] + [0, 0, 0, 0, 0, 0, 0]
     if m.group(1) == "igemm":
-        smallc, bf16, hs, x3, halo, bx3 = vals[4], vals[5], vals[6], vals[7], vals[8], vals[9]
-        x3tag = "c32,f32x3" + (",halo" if halo else "") + (",wx3" if bx3 else "")
+        smallc, bf16, hs, x3, halo, bx3, npl = vals[4], vals[5], vals[6], vals[7], vals[8], vals[9], vals[10]
+        x3tag = (("c32,f16x2" + (",halo" if halo else "") + (",wx2" if bx3 else "")) if npl == 2 else
+                 ("c32,f32x3" + (",halo" if halo else "") + (",wx3" if bx3 else "")))
         tag = ("rgb,bf16out" if hs else "rgb") if smallc else (
             "c32,bf16hbm" if hs else (x3tag if x3 else ("c32,bf16" if bf16 else "c32")))
         return "igemm_kernel<%d,%d,%d,%d,%s>" % (vals[0], vals[1], vals[2], vals[3], tag)

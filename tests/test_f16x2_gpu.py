@@ -100,9 +100,7 @@ def test_forward_backward_data_backward_weight_run_two_plane_kernels_at_fp32_acc
             if h2:
                 set_amax(None, None, ad)
             dx0, dx1 = ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
-            if h2:
-                set_amax(a0, a1, ad)
-            dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g)
+            dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g, None, None, (a0, a1, ad) if h2 else None)
             names = pr.names()
         convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_"))]
         assert len(convs) == 3, names

@@ -536,7 +536,8 @@ def _applied():
     return _applied_flag
 
 
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None, apply=None):
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None, apply=None,
+                  amax_in=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.
     `pre` = (scale, shift, act): x0 is the RAW output of the producing convolution and that layer's BatchNorm + activation
     is applied in this convolution's operand load (xv2_conv2d_forward_bn_pre) when the plan allows it - two more values are
@@ -609,6 +610,8 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             ihwo_out.append(ihwo)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_forward_workspace", d)
+        if amax_in is not None:      # F16X2: the sources' maxima (for a group: the whole tensor's - an upper bound)
+            set_amax(amax_in[0], amax_in[1])
         if fused is not None:
             fsc, fsh, fres, fact = fused
             call("xv2_conv2d_forward_fused", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(fsc, gi * Coutg),
@@ -743,7 +746,7 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None, amax_dy=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
     the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
     that produced source 0 - its BatchNorm-backward statistics are taken in the same epilogue when the plan allows."""
@@ -769,6 +772,8 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
         acc = (1 if add_to0 is not None else 0) | (2 if add_to1 is not None else 0)
+        if amax_dy is not None:
+            set_amax(None, None, amax_dy)
         if (bnrec is not None and G == 1 and C1t == 0 and add_to1 is None and bnrec.y.dtype == dy.dtype and
                 dy.numel() // Cout_t * C0t <= FUSE_BN_BWD_MAX):
             tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
@@ -863,7 +868,8 @@ def _conv_backward_weight_pre(y0, pre, dy, weight, g, wparam=None):
     return dw
 
 
-def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
+def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None, amax=None):
+    """amax: F16X2 maxima (slots of x0, x1, dy) or None"""
     global _join_queued
     # Asynchronous only for the first gradient a parameter receives in a step AND when it goes straight into the
     # flat buffer: autograd then merely adopts the tensor.  Any other case (plain autograd accumulation, shared
@@ -876,14 +882,14 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
         # the compute stream - order them behind the side stream before the new contribution is produced.
         if ASYNC_WGRAD and _wgrad_stream is not None and x0.is_cuda:
             torch.cuda.current_stream().wait_stream(_wgrad_stream)
-        return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam)
+        return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, None, amax)
     if not _join_queued:
         # the compute stream re-joins the side stream when this backward pass ends, whoever consumes the gradients
         try:
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             _join_queued = True
         except RuntimeError:      # not inside a backward pass (direct call): stay synchronous
-            return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
+            return _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out, amax)
     side = _side_stream()
     if LAYER_CALLS and g.groups == 1:
         # one ABI call: event record on the compute stream, wait + launch on the side stream (the Python event /
@@ -894,13 +900,15 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None):
         _, OH, OW, Cout_t = dy.shape
         d = _desc(N, IH, IW, C0t, C1t, Cout_t, g, OH, OW, dy.dtype == torch.bfloat16)
         ws = _side_workspace(query("xv2_conv2d_backward_weight_workspace", d), side, dy.device)
+        if amax is not None:
+            set_amax(*amax)
         call("xv2_conv2d_backward_weight_async", d, x0, C0t, x1, C1t, dy, Cout_t, out, weight.shape[1], ws,
              side.cuda_stream)
         dw = out
     else:
         side.wait_stream(torch.cuda.current_stream())          # dy (and x) are ready on the compute stream
         with torch.cuda.stream(side):
-            dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out)
+            dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out, amax)
     for t in (x0, x1, dy):                                 # keep the caching allocator from recycling them early
         if t is not None:
             t.record_stream(side)
@@ -922,7 +930,7 @@ def _side_workspace(nbytes, side, device):
     return t
 
 
-def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
+def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None, amax=None):
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     _, OH, OW, Cout_t = dy.shape
@@ -933,6 +941,8 @@ def _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam=None, out=None):
     for gi in range(G):
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, dy.dtype == torch.bfloat16)
         ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+        if amax is not None:
+            set_amax(*amax)
         call("xv2_conv2d_backward_weight", d, Ptr(x0, gi * C0g), C0t, x1, C1t, Ptr(dy, gi * Coutg), Cout_t,
              Ptr(dw, gi * Coutg * cin_real * g.kh * g.kw), cin_real, ws)
     return dw
@@ -1260,7 +1270,7 @@ class ConvBnActFn(torch.autograd.Function):
         am_in = am_out = None
         # (training mode only: the eval forward stays on the three-plane form like the fused inference launches, whose epilogues
         #  do not record maxima - the two inference paths remain bit-identical)
-        if training and _amax_active(x0) and g.groups == 1 and pre is None and not lazy and not COOP_APPLY:
+        if training and _amax_active(x0) and pre is None and not lazy and not COOP_APPLY:
             am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
             am_out = _amax_new(x0)
         ctx.am_in = am_in
@@ -1276,9 +1286,8 @@ class ConvBnActFn(torch.autograd.Function):
         else:
             if training and COOP_APPLY and not lazy and not _sync_group(bn):
                 ap = {"residual": residual, "act": act, "want_mask": ctx.has_res}
-            if am_in is not None:
-                set_amax(_tok_ptr(am_in[0]), _tok_ptr(am_in[1]))
-            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn, apply=ap)
+            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn, apply=ap,
+                                            amax_in=(_tok_ptr(am_in[0]), _tok_ptr(am_in[1])) if am_in is not None else None)
         if ap is not None and "z" in ap and coeffs is not None:
             # the convolution launch(es) applied the BatchNorm they derived (grouped / split-batch layers: xv2_conv2d_forward_bn_act)
             z, zmask = ap["z"], ap["zmask"]
@@ -1345,11 +1354,9 @@ class ConvBnActFn(torch.autograd.Function):
             if (dpass1 is not None and g.groups == 1 and dpass1.is_contiguous() and x1 is not None
                     and tuple(dpass1.shape) == tuple(x1.shape)):
                 acc1, dpass1 = dpass1, None
-            if am_dy is not None:
-                set_amax(None, None, am_dy)
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
-                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1)
+                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1, am_dy)
             ctx.src_rec = None
             if dpass is not None:
                 dx0 = dx0 + dpass
@@ -1366,9 +1373,8 @@ class ConvBnActFn(torch.autograd.Function):
         elif ctx.has_pre:
             dw = _conv_backward_weight_pre(x0, (psc, psf, ctx.pre_act), dy, weight, g, ctx.wparam)
         else:
-            if am_dy is not None and am_in is not None:
-                set_amax(_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_dy)
-            dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam)
+            wam = (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_dy) if (am_dy is not None and am_in is not None) else None
+            dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam, wam)
         ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
                 dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None, None)
