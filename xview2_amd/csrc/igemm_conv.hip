@@ -57,8 +57,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LDS_LD = BK + 4;
 constexpr int LDS_LD_H_ = BK + 8;
 // floats of LDS shared by the main-loop operand buffers and the epilogue staging tile
-template <int BM, int BN, bool HIN, int NH, bool HALO = false>
+template <int BM, int BN, bool HIN, int NH, bool HALO = false, int NPL = 3>
 constexpr int igemm_main_floats() {
+    if (NPL == 2 && !HALO && !HIN) {      // F16X2, per-tap form: two stage buffers of two fp16 planes [BM + BN][24], or the epilogue tile
+        const int loop = 2 * 2 * (BM + BN) * 24 / 2, epi = BM * (BN + 4);      // (64 x 128: 37 KB instead of 55 - three blocks per CU)
+        return loop > epi ? loop : epi;
+    }
     if (HALO && HIN) {      // bf16 storage: two halo buffers [208][32] bf16 + three weight stages [BN][32] bf16, or half the tile
         const int loop = (2 * 208 * 32 + 3 * BN * 32) / 2, epi = (BM / NH) * (BN + 4);
         return loop > epi ? loop : epi;
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
     // bf16 operands: the LDS image is half as large, and with the epilogue staged in two row halves a block needs
     // ~45 KB instead of 74 KB - three blocks per CU instead of two hide more of the global-load latency
     constexpr int NH = (HIN && WGM >= 2) ? 2 : 1;       // epilogue staging passes
-    constexpr int MAIN_FLOATS = igemm_main_floats<BM, BN, HIN, NH, HALO>();
+    constexpr int MAIN_FLOATS = igemm_main_floats<BM, BN, HIN, NH, HALO, X3 ? NPL : 3>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][LDS_LD]
     float* Bs = smem + 2 * BM * LDS_LD;     // [2][BN][LDS_LD]
@@ -1544,9 +1548,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool HIN, int WGM, bool HALO = false>
+template <int BM, int BN, bool HIN, int WGM, bool HALO = false, int NPL = 3>
 constexpr size_t igemm_smem_bytes() {
-    return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1, HALO>() * 4 + BM * 4 + 4 * BN * 2 * 4;
+    return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1, HALO, NPL>() * 4 + BM * 4 + 4 * BN * 2 * 4;
 }
 
 // ---- launches whose blocks wait for each other (StatsFold::gate) --------------------------------------------------------
@@ -1582,7 +1586,7 @@ int coop_capacity(const void* kern, int threads, size_t smem) {
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
           bool HALO = false, bool BX3 = false, int NPL = 3>
 static int launch_one(const IgemmParams& p, hipStream_t stream) {
-    constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM, HALO>();
+    constexpr size_t smem = igemm_smem_bytes<BM, BN, HS && !SMALLC, WGM, HALO, X3 ? NPL : 3>();
     auto kern = igemm_kernel<BM, BN, WGM, WGN, SMALLC, BF16, HS, X3, HALO, BX3, NPL>;
     // one-time setup per instantiation; C++11 guarantees the initialiser of a function-local static runs exactly once
     // even with concurrent callers (the library may be driven from several host threads, one stream each)
