@@ -123,11 +123,13 @@ int xv2_presplit_forget(const void* b_fp32);
  * the epilogue multiplies by 1 / (s_a * s_b) - exact.  Measured against an fp64 convolution it is as close as an fp32 one
  * (scripts/chk_f16x2.py); F.conv2d on the reference's GPU path defaults to TF32, 2^-11.  The mode needs the operands' maxima:
  *   - a tensor's maximum lives in 64 uint32 "slots" (bit patterns of |x|; the maximum of the 64 is the tensor's), written with
- *     atomicMax by the kernel that PRODUCES the tensor (xv2_bn_act_forward_amax, ...) or by xv2_tensor_amax (zeroes the slots
- *     first, then one pass over x); a producer that cannot know the maximum leaves the consumer on the three-plane bf16 form;
- *   - xv2_amax_ctx(a0, a1, dy, out) names, for the NEXT launching call of THIS host thread only (the context is cleared when
- *     that call returns; size / plan queries do not consume it... but convolution plan queries do: set it right before the
- *     call), the slots of the activation sources x0 / x1 (forward, weight gradient), of the output gradient dy (backward-data,
+ *     atomicMax by the kernel that PRODUCES the tensor (the BatchNorm apply passes, below) or by xv2_tensor_amax (zeroes the
+ *     slots first, then one pass over x); one slot per 128-byte line, i.e. 64 x 32 uint32 = 8 KB per tensor (the atomics of
+ *     a few thousand blocks on one or two lines cost the producer more than the mode returns); a producer that cannot know the
+ *     maximum leaves the consumer on the three-plane bf16 form;
+ *   - xv2_amax_ctx(a0, a1, dy, out) names, for the NEXT convolution / BatchNorm-apply / layer call of THIS host thread only
+ *     (every such entry point clears the context when it returns - also the convolutions' plan queries, so set it right
+ *     before the call), the slots of the activation sources x0 / x1 (forward, weight gradient), of the output gradient dy (backward-data,
  *     weight gradient) and the slots `out` into which the call's BatchNorm apply pass records the maximum of the tensor it writes
  *     (xv2_bn_act_forward* / xv2_conv_bn_act_forward: z; xv2_bn_act_backward_apply* / xv2_bn_act_backward: dy).  `out` must be
  *     zero (or hold a lower bound) beforehand; NULL = unknown / not wanted;

@@ -53,7 +53,8 @@ def main():
     loads = [subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, XV2_STRESS_LOAD="%d" % (20 + 12 * reps)))
              for _ in range(nload)]
     time.sleep(15)
-    a = bench.make_args(enc)
+    # XV2_STRESS_POST=1: the siamese damage model on 6-channel pairs (BASELINE configs[3] in shape) instead of the localisation net
+    a = bench.make_args(enc, "post", "focal+dice", "siamese") if os.environ.get("XV2_STRESS_POST") else bench.make_args(enc)
     x, y = bench.synthetic_batch(a, 2, 1024, 1, "cuda")
     ref = None
     bad = 0

@@ -32,13 +32,15 @@ class GraphedStep:
                 self._bumped.append(bn)
         xnn.bump_bn_counter = recording_bump
         from . import ops
+        # F16X2: the replays zero the operand-maximum slots they re-use (a pool owned by this graph)
+        self._amax = ops.amax_begin_capture(optimizer.flat_p.device)
         try:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                ops.amax_begin_capture()      # F16X2: the replays zero the operand-maximum slots they re-use
+                ops.amax_capture_started(self._amax)
                 self.loss = step_fn(*static_inputs)
         finally:
-            ops.amax_end_capture()
+            ops.amax_end_capture(self._amax)
             xnn.bump_bn_counter = orig
         # capture records the launches WITHOUT executing them: undo the host-side bookkeeping of that pass
         optimizer.step_count -= 1

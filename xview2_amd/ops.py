@@ -235,21 +235,32 @@ def carry_amax(src, alias):
     return alias
 
 
-def amax_begin_capture():
+def amax_begin_capture(device):
     """hipGraph capture of a training step: the slots the captured launches name are re-used by every replay, so the graph itself
-    must zero them first - all pools restart at slot 0 and the zeroing of their first half is recorded as the graph's first node
-    (a step that needs more than half a pool falls back to 'unknown' for the rest: the second half is not re-zeroed by replays)"""
-    for p in _amax_pools.values():
-        p.buf[:p.P // 2].zero_()
-        p.gen[0] += 1
-        p.gen[1] += 1          # (tokens of the second half would go stale between replays: invalidate them as they are made)
-        p.next = 0
-        p.capturing = True
+    must zero them first.  The capture gets a pool of its OWN (returned: the graph's owner keeps it alive) whose first half is
+    zeroed by the graph's first node; eager code goes back to its pool afterwards, so replays and eager steps never share slots.
+    A step that needs more than half a pool falls back to 'unknown' for the rest (the second half is not re-zeroed by replays)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    p = _AmaxPool(torch.device("cuda", idx))     # (call BEFORE the capture begins: an allocation)
+    return (idx, _amax_pools.get(idx), p)
 
 
-def amax_end_capture():
-    for p in _amax_pools.values():
-        p.capturing = False
+def amax_capture_started(state):
+    """first thing inside the capture: switch to the graph's pool and record the zeroing of its first half"""
+    idx, eager, p = state
+    p.capturing = True
+    _amax_pools[idx] = p
+    p.buf[:p.P // 2].zero_()
+
+
+def amax_end_capture(state):
+    idx, eager, p = state
+    p.capturing = False
+    if eager is not None:
+        _amax_pools[idx] = eager
+    else:
+        _amax_pools.pop(idx, None)
 
 
 def amax_reset():
