@@ -1064,6 +1064,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         __syncthreads();
         sk_reducer = *flag != 0;
     }
+    float omax = 0.f;                                     // F16X2: max |value stored to Out0| (IgemmParams::amax_out)
     float4 ss1 = make_float4(0, 0, 0, 0), ss2 = ss1;      // reducer: statistics of the summed tile (this thread's 4 channels)
     const bool do_stats = p.stats && p.ksplit == 1 && !p.bnb_y;
     if (do_stats) {
@@ -1215,6 +1216,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
             st4(o, v);
+            if (p.amax_out && col < p.N0) omax = amax_acc(omax, v);
             if (bnb) {      // y in the storage type; g = the value as STORED (what the BatchNorm backward will read)
                 const float4 yv = ld4(reinterpret_cast<const OT*>(p.bnb_y) + (size_t)off * p.bnb_ldy + col);
                 v = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));
@@ -1250,6 +1252,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
     }
     if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
   }
+    // (blocks that stored FINAL values: unsplit launches and the in-launch reducers; slab writers leave it to the slab sum)
+    if (!HS && p.amax_out && (p.ksplit == 1 || (skf && sk_reducer))) amax_record(p.amax_out, omax, red, blockIdx.x + 13 * blockIdx.y);
     if (skf && !sk_reducer) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its slab stores are at the coherence point
         __syncthreads();
@@ -1361,8 +1365,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              const float* __restrict__ ep_scale,
                                                              const float* __restrict__ ep_shift,
                                                              const OT* __restrict__ ep_res, int ep_ldres, int ep_act,
-                                                             const StatsFold fold, const CoopApply ca) {
+                                                             const StatsFold fold, const CoopApply ca, unsigned* __restrict__ amax_out) {
     __shared__ float sh[256 * 8];
+    float omax = 0.f;      // F16X2: max |value stored to out0| (IgemmParams::amax_out)
     __shared__ int fold_flag;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
@@ -1402,6 +1407,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                     a.x += old.x; a.y += old.y; a.z += old.z; a.w += old.w;
                 }
                 st4(o, a);
+                if (amax_out && c < N0) omax = amax_acc(omax, a);
             };
             // ksplit <= 8: ALL eight rows of this thread (5 - 8 slabs: four at a time) and all their slabs in flight at once (up to 32 loads of 16 bytes,
             // slab count as a compile-time constant: no branch between the loads), then the sums in the fixed slab order -
@@ -1545,7 +1551,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                 }
             }
         }
-    }
+    }    if (amax_out) amax_record(amax_out, omax, sh, blockIdx.x + 13 * blockIdx.y);
 }
 
 template <int BM, int BN, bool HIN, int WGM, bool HALO = false, int NPL = 3>
@@ -1625,6 +1631,7 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
     double abytes = ein * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
                                (SMALLC ? q.cin_real : q.Ctot) + (double)q.Nout * q.T * (SMALLC ? q.cin_real : q.Ctot));
     for (int c = 0; c < q.ncls; ++c) abytes += eout * (double)q.cls[c].M * q.Nout;
+    if (!HS && q.amax_out && q.amax_recorded) *q.amax_recorded = 1;      // (this kernel or, behind a slab launch, the slab sum records)
     prof_begin(kid, flops, abytes, stream);
     hipLaunchKernelGGL(kern, dim3(grid, q.ncls, q.ksplit), dim3(256), smem, stream, q);
     prof_end(stream);
@@ -2145,11 +2152,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (p.math == XV2_MATH_BF16_STORE)
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum | rolled,
-                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold, ca);
+                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold, ca, (unsigned*)nullptr);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum | rolled, p.ep_scale, p.ep_shift,
-                               p.ep_res, p.ep_ldres, p.ep_act, fold, ca);
+                               p.ep_res, p.ep_ldres, p.ep_act, fold, ca, p.amax_out);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -2238,6 +2245,8 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.amaxA0 = amax_ctx().a0;      // forward: the activation sources (backward-data replaces them by the gradient's)
     p.amaxA1 = amax_ctx().a1;
     p.amaxB = nullptr;
+    p.amax_out = nullptr;
+    p.amax_recorded = nullptr;
     p.ksplit = 1;
     p.cin_real = 3;
     p.math = d->math;
@@ -2543,6 +2552,11 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     if (rc) return rc;
     p.amaxA0 = amax_ctx().dy;      // the A operand of a backward-data launch is the output gradient
     p.amaxA1 = nullptr;
+    int amax_recorded = 0;
+    if (!plan && d->math == XV2_MATH_F32X3) {      // F16X2: the maximum of dx0 for ITS consumers (a transposed convolution's backward)
+        p.amax_out = amax_ctx().out;
+        p.amax_recorded = &amax_recorded;
+    }
     p.plan_tiles = plan;
     p.accum = accumulate & (dx1 ? 3 : 1);
     set_bnb(p, bnb);
@@ -2609,7 +2623,12 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     }
     if (ncls == 0) return XV2_OK;
     p.ncls = ncls;
-    return igemm_launch(p, false, (s == 1) ? workspace : nullptr, stream);
+    if (int rc2 = igemm_launch(p, false, (s == 1) ? workspace : nullptr, stream)) return rc2;
+    if (p.amax_out && !amax_recorded) {      // (direct / streaming kernels: a pass of its own over dx0)
+        XV2_CHECK_ARG(lddx0 == d->C0, "backward_data: F16X2 maximum of a strided dx0");
+        return xv2_tensor_amax_into(dx0, (int64_t)d->N * d->IH * d->IW * d->C0, p.amax_out, stream);
+    }
+    return XV2_OK;
 }
 
 extern "C" int xv2_conv2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
@@ -2680,28 +2699,26 @@ extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* 
                                             const void* w_ihwo, void* y, int ldy, void* stream) {
     XV2_CHECK_ARG(d->C1 == 0, "conv_transpose2d: single output tensor expected");
     AmaxGuard amax_guard;
-    // F16X2: the maximum of y (the next convolution's source) is taken by a pass of its own - 0.1 ms per cfg2 step against the
-    // 1.5 ms its consumers save; the epilogues of these launches do not record
-    struct AmaxAfter {
-        unsigned* slots; const void* y; int64_t n; void* stream; int rc = 0;
-        void run() { if (slots) rc = xv2_tensor_amax_into(static_cast<const float*>(y), n, slots, stream); }
-    } after{(d->math == XV2_MATH_F32X3 && ldy == d->C0) ? amax_ctx().out : nullptr, y, (int64_t)d->N * d->IH * d->IW * d->C0, stream};
-    XV2_CHECK_ARG(!amax_ctx().out || after.slots, "conv_transpose2d: F16X2 maximum of a strided / non-fp32 output");
+    // F16X2: the maximum of y (the next convolution's source): the tiled kernels record it in their epilogue (dgrad_impl);
+    // behind the streaming kernel it is taken by a pass of its own
+    unsigned* slots = (d->math == XV2_MATH_F32X3 && ldy == d->C0) ? amax_ctx().out : nullptr;
+    XV2_CHECK_ARG(!amax_ctx().out || slots, "conv_transpose2d: F16X2 maximum of a strided / non-fp32 output");
     int rc = thin_convT_forward(d, x, ldx, w_ihwo, y, ldy, (hipStream_t)stream);      // thin_conv.hip
-    if (rc < 0) rc = dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
-    if (rc) return rc;
-    after.run();
-    return after.rc;
+    if (rc < 0) return dgrad_impl(d, (const float*)x, ldx, (const float*)w_ihwo, (float*)y, ldy, nullptr, 0, nullptr, (hipStream_t)stream);
+    if (rc == 0 && slots) rc = xv2_tensor_amax_into(static_cast<const float*>(y), (int64_t)d->N * d->IH * d->IW * d->C0, slots, stream);
+    return rc;
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
                                                   const void* w_ohwi, void* dx, int lddx, void* stream) {
+    AmaxGuard amax_guard;      // (the streaming kernel does not read the context: it must still end with this call)
     if (const int rc = thin_convT_backward_data(d, dy, lddy, w_ohwi, dx, lddx, 0, (hipStream_t)stream); rc >= 0) return rc;
     return xv2_conv2d_forward(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream);
 }
 
 extern "C" int xv2_conv_transpose2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi,
                                                       void* dx, int lddx, int accumulate, float* workspace, void* stream) {
+    AmaxGuard amax_guard;
     if (const int rc = thin_convT_backward_data(d, dy, lddy, w_ohwi, dx, lddx, accumulate, (hipStream_t)stream); rc >= 0) return rc;
     return conv_forward_impl(d, (const float*)dy, lddy, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)dx, lddx, nullptr,
                              workspace, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, accumulate);

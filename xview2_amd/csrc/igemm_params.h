@@ -39,6 +39,8 @@ struct IgemmParams {
     const unsigned* amaxA0;
     const unsigned* amaxA1;
     const unsigned* amaxB;
+    unsigned* amax_out;              // != NULL: the epilogue records max |value stored to Out0| (columns < N0) into these 64 slots
+    int* amax_recorded;              // host: set to 1 by the launcher when the kernel it picked records (else the caller takes a pass)
     int C0, C1, Ctot;  // channels per tap from source 0 / 1, Ctot = C0 + C1
     int ldA0, ldA1;
     int IH, IW;        // spatial size of A

@@ -757,7 +757,8 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None, amax_dy=None):
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None, amax_dy=None,
+                        amax_out=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
     the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
     that produced source 0 - its BatchNorm-backward statistics are taken in the same epilogue when the plan allows."""
@@ -783,8 +784,8 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_backward_data_workspace", d)
         acc = (1 if add_to0 is not None else 0) | (2 if add_to1 is not None else 0)
-        if amax_dy is not None:
-            set_amax(None, None, amax_dy)
+        if amax_dy is not None:      # F16X2: dy's maximum; amax_out: a token - the launch records max |dx0| into it
+            set_amax(None, None, amax_dy, amax_out[0] if (amax_out is not None and G == 1) else None)
         if (bnrec is not None and G == 1 and C1t == 0 and add_to1 is None and bnrec.y.dtype == dy.dtype and
                 dy.numel() // Cout_t * C0t <= FUSE_BN_BWD_MAX):
             tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
@@ -796,6 +797,8 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
                 continue
         call("xv2_conv2d_backward_data_acc", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
              acc, _ws(wsb, dy) if wsb else None)
+    if amax_out is not None and amax_dy is not None and G == 1:
+        dx0._xv2_amax = amax_out
     return dx0, dx1
 
 
@@ -1285,6 +1288,8 @@ class ConvBnActFn(torch.autograd.Function):
             am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
             am_out = _amax_new(x0)
         ctx.am_in = am_in
+        # (a source that is a transposed convolution's output: its backward wants the maximum of the gradient sent back)
+        ctx.want_dx_amax = am_in is not None and bool(getattr(x0_in, "_xv2_convT_out", False))
         if pre is None and not lazy and LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
                                       (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None)
@@ -1367,7 +1372,8 @@ class ConvBnActFn(torch.autograd.Function):
                 acc1, dpass1 = dpass1, None
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
                                            x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
-                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1, am_dy)
+                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1, am_dy,
+                                           _amax_new(y) if (ctx.want_dx_amax and am_dy is not None and dpass is None) else None)
             ctx.src_rec = None
             if dpass is not None:
                 dx0 = dx0 + dpass
@@ -1453,8 +1459,10 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
             if tok is not None:
                 set_amax(None, None, _amax_ptr(x_in), tok[0])
                 y._xv2_amax = tok
+            y._xv2_convT_out = True          # its consumer records the maximum of the gradient it sends back (backward below)
         call("xv2_conv_transpose2d_forward", d, x, Cin, ihwo, y, Cout)
         ctx.save_for_backward(x, weight)
+        ctx.x_tok = getattr(x_in, "_xv2_amax", None)
         ctx.d = d
         ctx.wparam = weight
         return (y, x_in) if passthrough else y
@@ -1464,6 +1472,8 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         if dy is None:
             return dpass, None, None
+        am_dy = _amax_ptr(dy) if _amax_active(x) else None      # F16X2: recorded by the backward-data launch that produced dy
+        am_x = _tok_ptr(ctx.x_tok) if am_dy is not None else None
         dy = _same(dy, x).contiguous()
         d = ctx.d
         Cin, Cout = weight.shape[0], weight.shape[1]
@@ -1475,10 +1485,13 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
             if acc is not None:      # summed onto the other consumer's gradient in the epilogue
                 dx = acc
                 wsb = query("xv2_conv2d_forward_workspace", d)
+                set_amax(am_dy)          # (the equivalent forward convolution reads dy as its source)
                 call("xv2_conv_transpose2d_backward_data_acc", d, dy, Cout, ohwi, dx, Cin, 1, _ws(wsb, dy) if wsb else None)
                 if ctx.needs_input_grad[1]:
                     dw = _grad_like(ctx.wparam)
                     ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+                    if am_x is not None:
+                        set_amax(am_dy, None, am_x)      # (weight gradient of the equivalent convolution: X = dy, dY = x)
                     call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
                 return dx, dw, None
             dx = torch.empty_like(x)
@@ -1489,10 +1502,13 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
                      rec.invstd, rec.scale, rec.shift, rec.act, part)
                 rec.part, rec.tiles, rec.token = part, tiles, (dx.data_ptr(), dx._version)
             else:
+                set_amax(am_dy)
                 call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
         if ctx.needs_input_grad[1]:
             dw = _grad_like(ctx.wparam)
             ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
+            if am_x is not None:
+                set_amax(am_dy, None, am_x)
             call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
         if dpass is not None and dx is not None:
             dx = dx + _same(dpass, dx)
