@@ -66,6 +66,7 @@ CASES = [  # N, H, W, C0, C1, Cout, k
     (2, 64, 64, 64, 64, 64, 3),        # halo form, two sources (decoder block), 64-column tile
     (2, 32, 32, 256, 0, 512, 1),       # per-tap form
     (1, 96, 64, 96, 32, 64, 3),        # halo form, ragged channel counts (32-channel chunks), two sources
+    (1, 64, 64, 32, 0, 32, 3),         # the 32-channel direct kernel (halo + weights resident in LDS)
 ]
 
 
@@ -102,7 +103,7 @@ def test_forward_backward_data_backward_weight_run_two_plane_kernels_at_fp32_acc
             dx0, dx1 = ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
             dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g, None, None, (a0, a1, ad) if h2 else None)
             names = pr.names()
-        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_"))]
+        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_", "direct3x3"))]
         assert len(convs) == 3, names
         assert all(("f16x2" in n) == h2 for n in convs), convs
         dx = torch.cat([dx0, dx1], dim=-1) if C1 else dx0

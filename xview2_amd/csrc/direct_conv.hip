@@ -34,6 +34,7 @@ constexpr size_t D_SMEM_H = (size_t)(D_HALO + 9 * 32) * D_LDH * 2 + 4 * 32 * 2 *
 constexpr int D_TH_X3 = 8, D_HALO_X3 = (D_TH_X3 + 2) * D_HW;      // 340 pixels
 constexpr int D_PLH = D_HALO_X3 * D_LDH, D_PLW = 9 * 32 * D_LDH;      // plane sizes in elements
 constexpr size_t D_SMEM_X3 = (size_t)3 * (D_PLH + D_PLW) * 2 + D_TH_X3 * 32 * 2 * 4;
+constexpr size_t D_SMEM_X2 = (size_t)2 * (D_PLH + D_PLW) * 2 + D_TH_X3 * 32 * 2 * 4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int hperm(int px) { return (px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3); }
@@ -46,9 +47,11 @@ __device__ __forceinline__ int hperm(int px) { return (px & ~15) | ((px & 3) << 
 // and the BatchNorm statistics are taken on the rounded values.
 // X3 = true (XV2_MATH_F32X3): fp32 tensors; halo and weights are split into three bf16 terms (split3x4) on their way
 // into LDS, every tap step is the six significant bf16 cross products: 108 MFMAs per wave and patch.
-template <bool BF16, bool HS = false, bool X3 = false>
+// NPL = 2 (F16X2, xv2_common.h): two scaled fp16 planes, three MFMAs per tap step (54 per wave and patch), 98 KB of LDS.
+template <bool BF16, bool HS = false, bool X3 = false, int NPL = 3>
 __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const IgemmParams p, int npatches) {
     static_assert(!X3 || (BF16 && !HS), "split-bf16 mode: fp32 tensors, bf16 MFMA");
+    static_assert(NPL == 3 || (NPL == 2 && X3), "two planes: the F32X3 kernel's fp16 form");
     constexpr int TH = X3 ? D_TH_X3 : D_TH, NT = TH * 64, NW = TH;      // patch rows = waves
     constexpr int HALO = (TH + 2) * D_HW, HPERM = HALO / 16 * 16, PLH = HALO * D_LDH;
     constexpr int ESH = HS ? 1 : 2;
@@ -56,10 +59,15 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;                         // [204][36]
     float* wts = smem + D_HALO * D_LD;          // [9][32][36]
-    float* red = X3 ? smem + 3 * (PLH + D_PLW) / 2
+    float* red = X3 ? smem + NPL * (PLH + D_PLW) / 2
                     : HS ? smem + (D_HALO + 9 * 32) * D_LDH / 2 : wts + 9 * 32 * D_LD;   // [4][32][2]
     __bf16* halo_h = reinterpret_cast<__bf16*>(smem);         // HS: [204][40] bf16;  X3: [3 planes][204][40]
-    __bf16* wts_h = halo_h + (X3 ? 3 : 1) * PLH;             // HS: [9][32][40] bf16; X3: [3 planes][9][32][40]
+    __bf16* wts_h = halo_h + (X3 ? NPL : 1) * PLH;           // HS: [9][32][40] bf16; X3: [NPL planes][9][32][40]
+    float sA = 1.f, sB = 1.f;                                 // F16X2 operand scales
+    if constexpr (NPL == 2) {
+        sA = amax_scale(amax_exponent(p.amaxA0));
+        sB = amax_scale(amax_exponent(p.amaxB));
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -96,11 +104,16 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
             const int off = ((nn * p.T + p.taps[t].slot) * 32 + c4 * 4) << 2;
             const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0);
             uint2 sh, sm, sl;
-            split3x4(make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])), sh, sm, sl);
+            const float4 f = make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3]));
             __bf16* d = wts_h + (t * 32 + nn) * D_LDH + c4 * 4;
+            if constexpr (NPL == 2) {
+                split2hx4(f, sB, sh, sm);
+            } else {
+                split3x4(f, sh, sm, sl);
+                *reinterpret_cast<uint2*>(d + (NPL - 1) * D_PLW) = sl;
+            }
             *reinterpret_cast<uint2*>(d) = sh;
             *reinterpret_cast<uint2*>(d + D_PLW) = sm;
-            *reinterpret_cast<uint2*>(d + 2 * D_PLW) = sl;
         }
     } else if constexpr (HS) {
         for (int e = tid; e < 9 * 32 * 4; e += 256) {
@@ -155,12 +168,17 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
                 if constexpr (X3) {
                     const int px = (e >> 3) < HPERM ? hperm(e >> 3) : (e >> 3);
                     uint2 sh, sm, sl;
-                    split3x4(make_float4(__int_as_float(hr[j][0]), __int_as_float(hr[j][1]), __int_as_float(hr[j][2]),
-                                         __int_as_float(hr[j][3])), sh, sm, sl);
+                    const float4 f = make_float4(__int_as_float(hr[j][0]), __int_as_float(hr[j][1]), __int_as_float(hr[j][2]),
+                                                 __int_as_float(hr[j][3]));
                     __bf16* d = halo_h + px * D_LDH + (e & 7) * 4;
+                    if constexpr (NPL == 2) {
+                        split2hx4(f, sA, sh, sm);
+                    } else {
+                        split3x4(f, sh, sm, sl);
+                        *reinterpret_cast<uint2*>(d + (NPL - 1) * PLH) = sl;
+                    }
                     *reinterpret_cast<uint2*>(d) = sh;
                     *reinterpret_cast<uint2*>(d + PLH) = sm;
-                    *reinterpret_cast<uint2*>(d + 2 * PLH) = sl;
                 } else if constexpr (HS)
                     *reinterpret_cast<i32x4*>(halo_h + (e >> 2) * D_LDH + (e & 3) * 8) = hr[j];
                 else
@@ -200,10 +218,18 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
                 for (int kk = 0; kk < 2; ++kk) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + kk * 16);
                     const bf16x8 am = *reinterpret_cast<const bf16x8*>(a + PLH + kk * 16);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 2 * PLH + kk * 16);
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(b + kk * 16);
                     const bf16x8 bm = *reinterpret_cast<const bf16x8*>(b + D_PLW + kk * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + 2 * D_PLW + kk * 16);
+                    if constexpr (NPL == 2) {
+                        typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, am), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bm), acc2, 0, 0, 0);
+                        if (kk == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+                        else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc2, 0, 0, 0);
+                        continue;
+                    }
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + (NPL - 1) * PLH + kk * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(b + (NPL - 1) * D_PLW + kk * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -253,6 +279,11 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
         if constexpr (BF16) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        }
+        if constexpr (NPL == 2) {      // undo the operand scales (powers of two: exact)
+            const float ia = amax_inv(amax_exponent(p.amaxA0)), ib = amax_inv(amax_exponent(p.amaxB));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] * ia * ib;
         }
         // epilogue straight from registers: a pixel's 32 channels are one 128-byte line (lanes 0..31)
         const int tw = patch % tiles_w;
@@ -349,6 +380,9 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_X3);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(direct3x3_n32_kernel<true, false, true, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM_X2);
         return e;
     }();
     XV2_CHECK_HIP(attr_rc);
@@ -356,6 +390,7 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     static const int kid16 = prof_register("direct3x3_n32_kernel<bf16>");
     static const int kid16s = prof_register("direct3x3_n32_kernel<bf16hbm>");
     static const int kidx3 = prof_register("direct3x3_n32_kernel<f32x3>");
+    static const int kidx2 = prof_register("direct3x3_n32_kernel<f16x2>");
     const bool x3 = p.math == XV2_MATH_F32X3;
     const ClassInfo& c = p.cls[0];
     const int npatches = c.M / ((x3 ? D_TH_X3 : D_TH) * D_TW);
@@ -363,6 +398,7 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     // (the three-plane image of F32X3, 118 KB: 1 per CU)
     int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
     IgemmParams q = p;
+    const bool h2 = x3 && f16x2_ready_pertap(q);      // F16X2: maxima of the source and of the weights known
     if (p.fold.on) {
         const int S = p.fold.S;
         XV2_CHECK_ARG(p.stats && S >= 1 && npatches % S == 0, "direct3x3: %d patches do not split into %d BatchNorm parts",
@@ -377,8 +413,10 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);
-    prof_begin(x3 ? kidx3 : p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
-    if (x3)
+    prof_begin(h2 ? kidx2 : x3 ? kidx3 : p.math == XV2_MATH_BF16_STORE ? kid16s : (p.math ? kid16 : kid), flops, abytes, stream);
+    if (h2)
+        hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true, 2>), dim3(grid), dim3(512), D_SMEM_X2, stream, q, npatches);
+    else if (x3)
         hipLaunchKernelGGL((direct3x3_n32_kernel<true, false, true>), dim3(grid), dim3(512), D_SMEM_X3, stream, q, npatches);
     else if (p.math == XV2_MATH_BF16_STORE)
         hipLaunchKernelGGL((direct3x3_n32_kernel<true, true>), dim3(grid), dim3(256), D_SMEM_H, stream, q, npatches);

@@ -1944,7 +1944,7 @@ static bool f16x2_ready(IgemmParams& p) {
     return true;
 }
 // ... of the per-tap form (both operands split in the kernel): the maxima of the sources and of the packed weights
-static bool f16x2_ready_pertap(IgemmParams& p) {
+bool f16x2_ready_pertap(IgemmParams& p) {
     if (!f16x2_enabled(2) || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1) || p.pre_scale) return false;
     std::lock_guard<std::mutex> lk(g_presplit_mu);
     auto it = g_wamax.find(p.B);

@@ -95,6 +95,10 @@ struct IgemmParams {
 
 constexpr int BK = 32;
 
+// igemm_conv.hip: F16X2 for a launch that splits both operands itself - the maxima of the source(s) and of the packed weights
+// are known (fills p.amaxB, p.npl = 2)
+bool f16x2_ready_pertap(IgemmParams& p);
+
 // direct_conv.hip: 3x3 / stride 1 convolutions 32 -> 32 channels keep the weights and the input halo in LDS
 bool direct3x3_eligible(const IgemmParams& p, bool smallc);
 int direct3x3_launch(const IgemmParams& p, hipStream_t stream);
