@@ -25,8 +25,26 @@ def main():
         w = torch.randn(Co, C0 + C1, k, k, device=dev) * 0.05
         OH, OW = ops._out_hw(H, W, g)
         dy = torch.randn(N, OH, OW, Co, device=dev).to(adt)
-        for what, fn in (("fwd", lambda: ops._conv_forward(x0, x1, w, g, None, True)),
-                         ("dgrad", lambda: ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1))):
+        h2 = os.environ.get("XV2_SWEEP_H2") == "1" and adt == torch.float32      # F16X2: hand the operand maxima to every call
+        if h2:
+            from xview2_amd._capi import call, set_amax
+            ops._pack(w, C0 + C1, True, True)
+            sl = [torch.zeros(2048, dtype=torch.int32, device=dev) for _ in range(3)]
+            call("xv2_tensor_amax", x0, x0.numel(), sl[0])
+            if x1 is not None:
+                call("xv2_tensor_amax", x1, x1.numel(), sl[1])
+            call("xv2_tensor_amax", dy, dy.numel(), sl[2])
+
+        def fwd():
+            if h2:
+                set_amax(sl[0], sl[1] if x1 is not None else None)
+            return ops._conv_forward(x0, x1, w, g, None, True)
+
+        def dgrad():
+            if h2:
+                set_amax(None, None, sl[2])
+            return ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
+        for what, fn in (("fwd", fwd), ("dgrad", dgrad)):
             os.environ.pop("XV2_FORCE_TILE", None)
             _capi.query_cache_clear()
             base = prof_time(fn, 10)

@@ -1708,7 +1708,8 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     // (6-12 MFMAs per stage and barrier; measured 143 vs 190 TFLOP/s on the 116-GFLOP decoder layers)
     // (64-channel outputs, round 3: 128 x 64 measured 5 % FASTER than 64 x 64 at equal rounds - dec4.c1 132 vs 126, l1.conv2 104
     //  vs 98 TFLOP/s - so there the 64-row tile only wins when it needs fewer rounds)
-    const double eff64 = math == XV2_MATH_F32X3 ? (bn == 64 ? 0.48 : 0.65) : 0.92;
+    static const double eff64_x3 = [] { const char* e = getenv("XV2_EFF64"); return e ? atof(e) : 0.65; }();      // (A/B runs)
+    const double eff64 = math == XV2_MATH_F32X3 ? (bn == 64 ? 0.48 : eff64_x3) : 0.92;
     const double c64 = rounds(cdiv(M, 64) * ntn, cap64) * 64.0 * k / eff64;
     if (c64 < best * 0.97) {
         best = c64;
