@@ -39,9 +39,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 / fp16 (v_mfma_f32_32x32x16_b
 
 def fp32_split_peak(training=True):
     """the instruction stream's own bound of fp32 tensors on the 16-bit MFMA: F16X2 (two scaled fp16 planes, 3 MFMAs per product;
-    training-mode launches whose operand maxima are known - all but a handful) or F32X3 (three bf16 planes, 6 MFMAs per product)"""
+    launches whose operand maxima are known - all but a handful) or F32X3 (three bf16 planes, 6 MFMAs per product)"""
     from xview2_amd import ops
-    return round(PEAK_BF16_MFMA_TFLOPS / (3 if (ops.F16X2 and training) else 6), 1)
+    return round(PEAK_BF16_MFMA_TFLOPS / (3 if ops.F16X2 else 6), 1)      # (training and inference launches alike)
 
 
 def kernel_peak(name, precision):
@@ -321,7 +321,7 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
             "forward_ms": round(wall_ms, 3), "mfma_kernels_ms": round(mfma_ms, 3),
             "mfma_util_whole_forward": round(gf / wall_ms / peak, 4),
             "mfma_util_in_mfma_kernels": round(gf / mfma_ms / peak, 4) if mfma_ms else None,
-            "math": (F32_SPLIT_TEXT + "; peak = 16-bit dense peak / 3 (F16X2, training mode) resp. / 6 (F32X3, eval mode)") if x3 else
+            "math": (F32_SPLIT_TEXT + "; peak = 16-bit dense peak / 3 (F16X2) resp. / 6 (XV2_F16X2=0)") if x3 else
                     "fp32 MFMA" if precision == 32 else "bf16 MFMA, bf16 tensors",
             "vs_f32x3_bound_416.7": round(gf / wall_ms / (PEAK_BF16_MFMA_TFLOPS / 6), 4) if x3 else None,
             "vs_fp32_mfma_peak_157.3": round(gf / wall_ms / PEAK_F32_MFMA_TFLOPS, 4) if precision == 32 else None,

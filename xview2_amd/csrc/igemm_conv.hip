@@ -2335,6 +2335,7 @@ struct CoopArgs {         // IgemmParams::cz ..: BatchNorm apply in the same lau
     int* applied;
 };
 
+static int amax_rows_into(const float* x, int64_t rows, int C, int64_t ld, unsigned* slots, hipStream_t stream);      // below
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
                              float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
@@ -2409,7 +2410,17 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
                       "conv2d_forward: operands of 2 GiB or more (or more than 32 taps) are not supported");
         p.bytesA0 = (unsigned)b0; p.bytesA1 = (unsigned)b1; p.bytesB = (unsigned)bw;
     }
-    return igemm_launch(p, smallc, workspace, (hipStream_t)stream);
+    // F16X2, inference (fused epilogue): record max |z| for the next layer - in the epilogue of the tiled kernels, by a pass
+    // of its own behind the direct / streaming / stem kernels
+    int amax_recorded = 0;
+    if (ep && !dry && !plan && p.math != XV2_MATH_BF16_STORE && p.math != XV2_MATH_BF16) {
+        p.amax_out = amax_ctx().out;
+        p.amax_recorded = &amax_recorded;
+    }
+    if (int rc2 = igemm_launch(p, smallc, workspace, (hipStream_t)stream)) return rc2;
+    if (p.amax_out && !amax_recorded)
+        return amax_rows_into(y, (int64_t)d->N * d->OH * d->OW, d->Cout, ldy, p.amax_out, (hipStream_t)stream);
+    return XV2_OK;
 }
 
 extern "C" int xv2_conv2d_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
@@ -2746,6 +2757,26 @@ extern "C" int xv2_presplit_weights(const float* b_fp32, int nrows, int T, int c
     const int64_t nb = (int64_t)(nrows / 64) * (ctot / 16);
     hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)std::min<int64_t>(nb, 16384)), dim3(256), 0, (hipStream_t)stream,
                        b_fp32, reinterpret_cast<__bf16*>(x3), nrows, T, ctot);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+// ... of a row-strided tensor [rows][C] with row pitch ld (a channel slice of a wider tensor)
+__global__ void __launch_bounds__(256) amax_rows_kernel(const float* __restrict__ x, int64_t rows, int C4, int64_t ld,
+                                                         unsigned* __restrict__ slots) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const int64_t total = rows * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C4;
+        m = amax_acc(m, *reinterpret_cast<const float4*>(x + r * ld + (i - r * C4) * 4));
+    }
+    amax_record(slots, m, red);
+}
+static int amax_rows_into(const float* x, int64_t rows, int C, int64_t ld, unsigned* slots, hipStream_t stream) {
+    XV2_CHECK_ARG(x && slots && rows > 0 && C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "amax_rows: 4-element rows");
+    const int64_t n4 = rows * (C / 4);
+    hipLaunchKernelGGL(amax_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 1024), 1024)), dim3(256), 0, stream, x, rows, C / 4,
+                       ld, slots);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
 }

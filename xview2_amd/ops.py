@@ -548,7 +548,7 @@ def _applied():
 
 
 def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None, apply=None,
-                  amax_in=None):
+                  amax_in=None, amax_out=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.
     `pre` = (scale, shift, act): x0 is the RAW output of the producing convolution and that layer's BatchNorm + activation
     is applied in this convolution's operand load (xv2_conv2d_forward_bn_pre) when the plan allows it - two more values are
@@ -621,8 +621,9 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             ihwo_out.append(ihwo)
         d = _desc(N, IH, IW, C0g, C1t, Coutg, g, OH, OW, half)
         wsb = query("xv2_conv2d_forward_workspace", d)
-        if amax_in is not None:      # F16X2: the sources' maxima (for a group: the whole tensor's - an upper bound)
-            set_amax(amax_in[0], amax_in[1])
+        if amax_in is not None:      # F16X2: the sources' maxima (for a group: the whole tensor's - an upper bound);
+            # amax_out (fused inference form): the epilogue records max |z| - every group into the one tensor's slots
+            set_amax(amax_in[0], amax_in[1], None, amax_out[0] if amax_out is not None else None)
         if fused is not None:
             fsc, fsh, fres, fact = fused
             call("xv2_conv2d_forward_fused", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(fsc, gi * Coutg),
@@ -1240,7 +1241,16 @@ def conv_bn_act_infer(x0, x1, weight, residual, g, bn, act):
         half = (STORAGE == torch.bfloat16) if (x0.shape[-1] == 4 and x1 is None) else x0.dtype == torch.bfloat16
         residual = residual.to(torch.bfloat16 if half else torch.float32).contiguous()
     scale, shift = _bn_eval_scale_shift(bn, x0)
-    z, _ = _conv_forward(x0, x1, weight, g, None, want_stats=False, fused=(scale, shift, residual, act))
+    am_in = am_out = None
+    if _amax_active(x0) and not (x0.shape[-1] == 4 and x1 is None):      # F16X2 (the RGB stem's image has no recorded maximum)
+        am_in = (_amax_ptr(x0), _amax_ptr(x1))
+        am_out = _amax_new(x0)
+    elif _amax_active(x0):
+        am_in, am_out = (None, None), _amax_new(x0)
+    z, _ = _conv_forward(x0, x1, weight, g, None, want_stats=False, fused=(scale, shift, residual, act), amax_in=am_in,
+                         amax_out=am_out)
+    if am_out is not None:
+        z._xv2_amax = am_out
     return z
 
 
@@ -1282,9 +1292,9 @@ class ConvBnActFn(torch.autograd.Function):
             x0, pre = _apply_pre(x0, pre), None
         # F16X2: the maxima of the sources (recorded by their producers) and a slot for this layer's output
         am_in = am_out = None
-        # (training mode only: the eval forward stays on the three-plane form like the fused inference launches, whose epilogues
-        #  do not record maxima - the two inference paths remain bit-identical)
-        if training and _amax_active(x0) and pre is None and not lazy and not COOP_APPLY:
+        # (eval mode too: the fused inference launches record the same maxima in their epilogues - conv_bn_act_infer - so the
+        #  two inference paths stay bit-identical)
+        if _amax_active(x0) and pre is None and not lazy and not COOP_APPLY:
             am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
             am_out = _amax_new(x0)
         ctx.am_in = am_in
@@ -1454,7 +1464,7 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         d = _desc(N, 2 * H, 2 * W, Cout, 0, Cin, g, H, W, half)  # the equivalent 2x2/s2 convolution
         _, ihwo = _pack(weight.contiguous(), Cout, False, True, half)
         y = _act((N, 2 * H, 2 * W, Cout), x)
-        if _amax_active(x) and x.requires_grad:      # F16X2 (training): y's maximum for the block's first convolution
+        if _amax_active(x):      # F16X2: y's maximum for the block's first convolution
             tok = _amax_new(x)
             if tok is not None:
                 set_amax(None, None, _amax_ptr(x_in), tok[0])
