@@ -160,6 +160,34 @@ def cpu_baseline(a, size, batch, seed, timed_steps=3):
 STRICT_BF16_GATE = {"logits_rms_rel_max": 0.30, "grad_cosine_min": 0.25, "argmax_agreement_min": 0.92}
 
 
+def split_form_error(dev):
+    """fp32-class evidence for the two split forms, measured in this run: one 3x3 layer (2 x 128^2, 128 -> 128, inputs with a
+    per-channel spread of e^N(0,1)) through the HIP path with the operand maxima known (F16X2: two fp16 planes, 3 MFMAs per
+    product) and unknown (F32X3: three bf16 planes, 6 MFMAs), and torch's own fp32 convolution, each against an fp64 convolution:
+    rms error / rms of the result.  All three are the fp32 accumulation's error."""
+    from xview2_amd import ops
+    from xview2_amd._capi import call, set_amax
+    if ops.MATH_MODE != ops.MATH_F32X3:
+        return None
+    g0 = torch.Generator(device="cpu").manual_seed(11)
+    N, H, C, Co = 2, 128, 128, 128
+    x = (torch.relu(torch.randn(N, H, H, C, generator=g0)) * torch.exp(torch.randn(1, 1, 1, C, generator=g0))).to(dev)
+    w = (torch.randn(Co, C, 3, 3, generator=g0) * 0.03).to(dev)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    rel = lambda t: float(((t.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+    g = ops.conv_cfg(3, 3, 1, 1)
+    ops._pack(w, C, True, False)
+    out = {"f32x3": rel(ops._conv_forward(x, None, w, g, None, True)[0])}
+    if ops.F16X2:
+        slots = torch.zeros(ops.AMAX_BYTES // 4, dtype=torch.int32, device=dev)
+        call("xv2_tensor_amax", x, x.numel(), slots)
+        set_amax(slots, None)
+        out["f16x2"] = rel(ops._conv_forward(x, None, w, g, None, True)[0])
+    out["torch_fp32_conv2d"] = rel(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1))
+    out["what"] = "rms(result - fp64 result) / rms(fp64 result) of one 3x3 layer, 2 x 128^2 x 128 -> 128 (bench.py split_form_error)"
+    return out
+
+
 def parity_block(ref, hip, precision, size=1024, strict16=False):
     """full-size first-step comparison of the HIP path with the CPU oracle (same batch, same key-seeded weights)"""
     lo, lh = ref["loss"], hip["loss"]
@@ -821,6 +849,11 @@ def main():
                 % (opt.size, opt.size, opt.batch),
                 make_args("resnest200", "post", "focal+dice", "fused", attention=True, ppm=True, deep_supervision=True), 16,
                 opt.size, opt.batch, dev, steps=8, warmup=4, parity=False, unit="pairs/sec", cross=True))
+    if rank == 0 and world == 1 and opt.precision == 32:
+        try:
+            out["split_form_error_vs_fp64"] = split_form_error(dev)
+        except Exception as e:      # (evidence, not the measurement: never fail the line for it)
+            out["split_form_error_vs_fp64"] = {"error": repr(e)}
     if rank == 0 and not opt.no_cpu_baseline and world == 1:
         cb, ref = cpu_baseline(a, opt.cpu_size or opt.size, opt.batch, 1)
         out["cpu_baseline"] = cb
