@@ -67,6 +67,8 @@ CASES = [  # N, H, W, C0, C1, Cout, k
     (2, 32, 32, 256, 0, 512, 1),       # per-tap form
     (1, 96, 64, 96, 32, 64, 3),        # halo form, ragged channel counts (32-channel chunks), two sources
     (1, 64, 64, 32, 0, 32, 3),         # the 32-channel direct kernel (halo + weights resident in LDS)
+    (2, 256, 160, 64, 0, 256, 1),      # the streaming 1x1 kernel (weights resident in LDS, >= 65536 pixels), forward ...
+    (2, 256, 160, 256, 0, 64, 1),      # ... and as the other layer's backward-data shape
 ]
 
 
@@ -103,7 +105,7 @@ def test_forward_backward_data_backward_weight_run_two_plane_kernels_at_fp32_acc
             dx0, dx1 = ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
             dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g, None, None, (a0, a1, ad) if h2 else None)
             names = pr.names()
-        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_", "direct3x3"))]
+        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_", "direct3x3", "thin1x1"))]
         assert len(convs) == 3, names
         assert all(("f16x2" in n) == h2 for n in convs), convs
         dx = torch.cat([dx0, dx1], dim=-1) if C1 else dx0

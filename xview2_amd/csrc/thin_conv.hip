@@ -31,6 +31,8 @@ struct ThinParams {
     int M, ldA, ldo, accum, tiles;
     unsigned bytesA;
     int W;                // MODE 1 / 2: width of the SMALL grid of the 2x2 / stride-2 transposed convolution (W % 32 == 0)
+    const unsigned* amaxA;    // F16X2 (PF = 2): the recorded maxima of the activations and of the weights (xv2_common.h)
+    const unsigned* amaxB;
 };
 
 // MODE 1 / 2: nn.ConvTranspose2d(k = 2, s = 2) (model/layers.py:80-86) of the 1024^2 decoder level, forward and backward-data.
@@ -47,10 +49,13 @@ __device__ __forceinline__ int ct_pixel(int m, int W, int t) {
 // whose 32-column blocks are the four output pixels of an input pixel (each store is still a full 128-byte line); the packed
 // weight rows (channel-major, tap-minor) are re-ordered tap-major while they are staged.  MODE 2: its backward-data = the
 // 2x2 / stride-2 convolution 32 -> 64: K = 4 taps x 32 channels GATHERED from the four big-grid pixels of a small-grid pixel.
-template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0>
-__global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const ThinParams p) {
+// PF = 2 (fp32 tensors, F16X2): two scaled fp16 planes instead of three bf16 ones - 3 MFMAs per product, 4 (K + 8) N bytes of LDS:
+// two blocks per CU where the three-plane image leaves room for one (no accumulating form)
+template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0, int PF = 3>
+__global__ void __launch_bounds__(WAVES * 64, (HS || PF == 2) ? 2 : 1) thin1x1_kernel(const ThinParams p) {
     static_assert(MODE == 0 || (MODE == 1 && K == 64 && N == 128) || (MODE == 2 && K == 128 && N == 64), "transposed-convolution shapes");
-    constexpr int P = HS ? 1 : 3;              // bf16 planes of the weights
+    static_assert(PF == 3 || (PF == 2 && !HS && MODE == 0), "two planes: fp32 tensors, plain 1x1 form");
+    constexpr int P = HS ? 1 : PF;             // 16-bit planes of the weights
     constexpr int KP = K + 8;                  // LDS row pitch in bf16: (K + 8) / 2 dwords = 4 mod 32 -> conflict-free b128 reads
     constexpr int NB = N / 32, KC = K / 64, KCU = KC > 2 ? 1 : KC;
     constexpr int PLANE = N * KP;
@@ -99,6 +104,12 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
     };
     i32x4 rawn[NRAW];
     if (tile < p.tiles) issue(tile, sub0, 0, rawn);         // in flight under the weight staging
+    float sA = 1.f, sB = 1.f, iAB0 = 1.f, iAB1 = 1.f;       // F16X2 operand scales and their inverses
+    if constexpr (PF == 2) {
+        const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
+        sA = amax_scale(ea); sB = amax_scale(eb);
+        iAB0 = amax_inv(ea); iAB1 = amax_inv(eb);
+    }
 
     // ---- weights -> LDS (fp32: exact 3-way bf16 split, once per block)
     // (all loads of a thread in flight before the first is used: one memory round trip, not one per 16 bytes)
@@ -130,11 +141,15 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
                 const int i = tid + (u0 + u) * NT, ng = i / (K / 4), c4 = i - ng * (K / 4);
                 const int n = MODE == 1 ? (ng & 3) * 32 + (ng >> 2) : ng;
                 uint2 q0, q1, q2;
-                split3x4(v[u], q0, q1, q2);
                 __bf16* d = sw + n * KP + c4 * 4;
+                if constexpr (PF == 2) {
+                    split2hx4(v[u], sB, q0, q1);
+                } else {
+                    split3x4(v[u], q0, q1, q2);
+                    *reinterpret_cast<uint2*>(d + (P - 1) * PLANE) = q2;
+                }
                 *reinterpret_cast<uint2*>(d) = q0;
                 *reinterpret_cast<uint2*>(d + PLANE) = q1;
-                *reinterpret_cast<uint2*>(d + 2 * PLANE) = q2;
             }
         }
     }
@@ -192,11 +207,16 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
                         xa[ks][0] = __builtin_bit_cast(bf16x8, rawn[ks]);
                     } else {
                         uint2 a0, a1, a2, b0, b1, b2;
-                        split3x4(__builtin_bit_cast(float4, rawn[2 * ks]), a0, a1, a2);
-                        split3x4(__builtin_bit_cast(float4, rawn[2 * ks + 1]), b0, b1, b2);
+                        if constexpr (PF == 2) {
+                            split2hx4(__builtin_bit_cast(float4, rawn[2 * ks]), sA, a0, a1);
+                            split2hx4(__builtin_bit_cast(float4, rawn[2 * ks + 1]), sA, b0, b1);
+                        } else {
+                            split3x4(__builtin_bit_cast(float4, rawn[2 * ks]), a0, a1, a2);
+                            split3x4(__builtin_bit_cast(float4, rawn[2 * ks + 1]), b0, b1, b2);
+                            xa[ks][P - 1] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+                        }
                         xa[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
                         xa[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
-                        xa[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
                     }
                 }
                 {   // the next slice (of this block of pixels, of the next block, or of the wave's next tile) goes in flight
@@ -224,11 +244,20 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
 #pragma unroll
                             for (int jj = 0; jj < 2; ++jj)
                                 acc[jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[ks][0], wb[jj][0], acc[jp + jj], 0, 0, 0);
+                        } else if constexpr (PF == 2) {
+                            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                            for (int t = 0; t < 3; ++t)        // m*h, h*m, h*h
+#pragma unroll
+                                for (int jj = 0; jj < 2; ++jj)
+                                    acc[jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xa[ks][t == 0 ? 1 : 0]),
+                                                                                          __builtin_bit_cast(f16x8, wb[jj][t == 1 ? 1 : 0]),
+                                                                                          acc[jp + jj], 0, 0, 0);
                         } else {
 #pragma unroll
                             for (int t = 0; t < 6; ++t) {      // smallest terms first, as in igemm_conv.hip
-                                const int qa = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;
-                                const int qb = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+                                const int qa = t == 0 ? P - 1 : (t == 2 || t == 3) ? 1 : 0;
+                                const int qb = t == 1 ? P - 1 : (t == 2 || t == 4) ? 1 : 0;
 #pragma unroll
                                 for (int jj = 0; jj < 2; ++jj)
                                     acc[jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[ks][qa], wb[jj][qb], acc[jp + jj], 0, 0, 0);
@@ -236,6 +265,12 @@ __global__ void __launch_bounds__(WAVES * 64, HS ? 2 : 1) thin1x1_kernel(const T
                         }
                     }
                     if (kc == KC - 1) {
+                        if constexpr (PF == 2) {      // undo the operand scales (powers of two: exact)
+#pragma unroll
+                            for (int j = jp; j < jp + 2; ++j)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * iAB0 * iAB1;
+                        }
                         // ---- these two column blocks are complete: their statistics and stores go out under the MFMAs
                         // of the next pair
 #pragma unroll
@@ -312,11 +347,11 @@ static bool thin_enabled() {      // XV2_THIN=0: these layers stay on the tiled 
     return on;
 }
 
-template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0>
+template <int K, int N, bool HS, int WAVES, int SUBS, int MODE = 0, int PF = 3>
 static int thin_launch_one(const ThinParams& q, const char* name, double flops, double abytes, hipStream_t stream) {
     constexpr int WPT = 4 / SUBS;
-    constexpr size_t smem = (size_t)(HS ? 1 : 3) * N * (K + 8) * 2 + (WPT > 1 ? (size_t)WPT * N * 8 : 0);
-    auto kern = thin1x1_kernel<K, N, HS, WAVES, SUBS, MODE>;
+    constexpr size_t smem = (size_t)(HS ? 1 : PF) * N * (K + 8) * 2 + (WPT > 1 ? (size_t)WPT * N * 8 : 0);
+    auto kern = thin1x1_kernel<K, N, HS, WAVES, SUBS, MODE, PF>;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     XV2_CHECK_HIP(attr_rc);
@@ -351,10 +386,18 @@ bool thin1x1_eligible(const IgemmParams& p, bool smallc) {
 
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
     ThinParams q;
+    q.amaxA = q.amaxB = nullptr;
     q.A = p.A0; q.B = p.B; q.Out = p.Out0; q.stats = p.stats;
     q.M = p.cls[0].M; q.ldA = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1; q.W = 0;
     q.tiles = (int)cdiv(q.M, 128);
     q.bytesA = p.bytesA0;
+    q.amaxA = q.amaxB = nullptr;
+    IgemmParams pc = p;
+    const bool h2 = !q.accum && f16x2_ready_pertap(pc);      // F16X2: the maxima of the source and of the weights are known
+    if (h2) {
+        q.amaxA = pc.amaxA0;
+        q.amaxB = pc.amaxB;
+    }
     const int K = p.Ctot, N = p.Nout;
     const bool hs = p.math == XV2_MATH_BF16_STORE;
     const double es = hs ? 2.0 : 4.0;
@@ -365,7 +408,8 @@ int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
     if (K == KK && N == NN)                                                                                          \
         return hs ? (wide ? thin_launch_one<KK, NN, true, 2, 2>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream)  \
                           : thin_launch_one<KK, NN, true, 2, 4>(q, "thin1x1_kernel<" #KK "," #NN ",bf16hbm>", flops, abytes, stream)) \
-                  : thin_launch_one<KK, NN, false, 4, 4>(q, "thin1x1_kernel<" #KK "," #NN ",f32x3>", flops, abytes, stream);
+                  : h2 ? thin_launch_one<KK, NN, false, 4, 4, 0, 2>(q, "thin1x1_kernel<" #KK "," #NN ",f16x2>", flops, abytes, stream) \
+                       : thin_launch_one<KK, NN, false, 4, 4>(q, "thin1x1_kernel<" #KK "," #NN ",f32x3>", flops, abytes, stream);
     XV2_THIN_CASE(64, 64)
     XV2_THIN_CASE(64, 128)
     XV2_THIN_CASE(64, 256)
@@ -393,6 +437,7 @@ static bool thin_ct_shape(const xv2_conv_desc* d, int ld_small, int ld_big, cons
 int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, hipStream_t stream) {
     if (!thin_ct_shape(d, ldx, ldy, x, w_ihwo, y)) return -1;
     ThinParams q;
+    q.amaxA = q.amaxB = nullptr;
     q.A = x; q.B = w_ihwo; q.Out = y; q.stats = nullptr;
     q.M = d->N * d->OH * d->OW; q.ldA = ldx; q.ldo = ldy; q.accum = 0; q.W = d->OW;
     q.tiles = (int)cdiv(q.M, 128);
@@ -412,6 +457,7 @@ int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, c
     static const bool force = [] { const char* e = getenv("XV2_THIN_CT"); return e && atoi(e) == 2; }();
     if (d->math != XV2_MATH_BF16_STORE && !force) return -1;
     ThinParams q;
+    q.amaxA = q.amaxB = nullptr;
     q.A = dy; q.B = w_ohwi; q.Out = dx; q.stats = nullptr;
     q.M = d->N * d->OH * d->OW; q.ldA = lddy; q.ldo = lddx; q.accum = accumulate & 1; q.W = d->OW;
     q.tiles = (int)cdiv(q.M, 128);
