@@ -45,9 +45,11 @@
 #define XV2_HB3 0      // halo form, 64-column tiles: force 3 blocks per CU (168 VGPRs)
 #endif
 #ifndef XV2_PF
-#define XV2_PF 3      // F32X3 main loop: stages between a global load and its split (3: two raw register sets, 4: three -
-                      // measured identical on every cfg2 layer and on the step, 256 instead of 240 VGPRs: the loads are not
-                      // latency-exposed; under this kernel the chip is power-limited)
+#define XV2_PF 3      // three-plane per-tap main loop: stages between a global load and its split (3: two raw register sets,
+                      // 4: three - measured identical on every cfg2 layer and on the step, and the 128 x 128 tile spills: the
+                      // chip is power-limited there).  The two-plane F16X2 form always runs 4 deep: a stage
+                      // holds half the MFMA work and the load latency shows - -0.2 ms per cfg2 step (22.88 -> 22.67 ms, two
+                      // same-box pairs; isolated layers unchanged), 219 VGPRs for the 128 x 128 tile
 #endif
 
 namespace xv2 {
@@ -799,6 +801,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         // (b) the raw registers of stage s+2 are split on the VALU in the shadow of the MFMAs and stored into the LDS buffer
         // stage s occupied, (c) stage s+3 is fetched from memory.  One barrier per stage, no LDS latency on the MFMA path.
         constexpr int LDK = 24;
+        constexpr int PF = NPL == 2 ? 4 : XV2_PF;      // prefetch depth in stages (XV2_PF above)
         constexpr int PL = (BM + BN) * LDK, STG = NPL * PL;
         static_assert((size_t)2 * STG * 2 <= (size_t)MAIN_FLOATS * 4, "stage buffers fit the fp32 operand buffers");
         __bf16* sb = reinterpret_cast<__bf16*>(smem);
@@ -884,7 +887,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
                         bf16x8 (&nb)[NR][NPL], float4 (&xa)[AROWS], float4 (&xb)[BROWS], float4 (&za)[AROWS],
                         float4 (&zb)[BROWS]) {
             if (st + 1 < s_end) read_frags((st + 1) & 1, na, nb);
-            if (st + XV2_PF < s_end) gstage(st + XV2_PF, za, zb);
+            if (st + PF < s_end) gstage(st + PF, za, zb);
             split_regs(xa, xb);
             mfma_stage(fa, fb);
             // pin the split results here: the instruction selector otherwise sinks the whole split below its consumer
@@ -911,34 +914,36 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         if (s_begin + 2 < s_end) gstage(s_begin + 2, ra, rb);
         split_regs(ra1, rb1);
         store_planes(1);
-#if XV2_PF == 4
-        float4 ra2[AROWS], rb2[BROWS];
-        if (s_begin + 3 < s_end) gstage(s_begin + 3, ra1, rb1);
-#endif
+        float4 ra2[PF == 4 ? AROWS : 1], rb2[PF == 4 ? BROWS : 1];
+        if constexpr (PF == 4) {
+            if (s_begin + 3 < s_end) gstage(s_begin + 3, ra1, rb1);
+        }
         __syncthreads();
         read_frags(0, fa0, fb0);
         // the first fragments land before the loop is entered: otherwise the loop header, reached from here and from the
         // back edge, waits for lgkmcnt(0) in EVERY iteration - on the next stage's reads it has just issued
         __builtin_amdgcn_s_waitcnt(0xc07f);
-#if XV2_PF == 4
+        if constexpr (PF == 4) {
         // raw sets rotate with period 3, fragment sets with period 2: six iterations per trip (the stage count is even;
         // iterations past s_end are skipped as a whole)
+        auto& r2a = reinterpret_cast<float4(&)[AROWS]>(ra2);
+        auto& r2b = reinterpret_cast<float4(&)[BROWS]>(rb2);
         for (int st = s_begin; st < s_end; st += 6) {
-            iter(st, fa0, fb0, fa1, fb1, ra, rb, ra2, rb2);
+            iter(st, fa0, fb0, fa1, fb1, ra, rb, r2a, r2b);
             iter(st + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra, rb);
             if (st + 2 >= s_end) break;
-            iter(st + 2, fa0, fb0, fa1, fb1, ra2, rb2, ra1, rb1);
-            iter(st + 3, fa1, fb1, fa0, fb0, ra, rb, ra2, rb2);
+            iter(st + 2, fa0, fb0, fa1, fb1, r2a, r2b, ra1, rb1);
+            iter(st + 3, fa1, fb1, fa0, fb0, ra, rb, r2a, r2b);
             if (st + 4 >= s_end) break;
             iter(st + 4, fa0, fb0, fa1, fb1, ra1, rb1, ra, rb);
-            iter(st + 5, fa1, fb1, fa0, fb0, ra2, rb2, ra1, rb1);
+            iter(st + 5, fa1, fb1, fa0, fb0, r2a, r2b, ra1, rb1);
         }
-#else
+        } else {
         for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even
             iter(st, fa0, fb0, fa1, fb1, ra, rb, ra1, rb1);
             iter(st + 1, fa1, fb1, fa0, fb0, ra1, rb1, ra, rb);
         }
-#endif
+        }
     } else {
     // 3-stage pipeline: registers <- global (tile kt+2), LDS[buf^1] <- registers (tile kt+1), MFMA on LDS[buf]
     // (tile kt).  The LDS store of the next tile sits at the START of an iteration, so nothing but the MFMA
