@@ -4,6 +4,7 @@ never drift from the C ABI.  `call("xv2_...", *args)` accepts torch tensors (-> 
 import ctypes
 import os
 import re
+import threading
 
 import torch
 
@@ -116,27 +117,32 @@ def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
 
-_amax_pending = None
+class _Pending(threading.local):
+    """per host thread, like the library's context itself: another thread's launches (a loader thread's augmentation calls, the
+    autograd engine's worker) must neither flush nor clear what this thread set for ITS next call"""
+    ctx = None
+
+
+_amax_pending = _Pending()
 
 
 def set_amax(a0=None, a1=None, dy=None, out=None):
-    """F16X2 operand maxima (include/xv2.h xv2_amax_ctx) of the NEXT launching call: device addresses of 64-slot arrays
-    or None.  Handed to the library right before that call; the library clears the context when a convolution /
+    """F16X2 operand maxima (include/xv2.h xv2_amax_ctx) of the NEXT launching call of this thread: device addresses of 64-slot
+    arrays or None.  Handed to the library right before that call; the library clears the context when a convolution /
     BatchNorm-apply entry point returns, so it serves exactly one layer."""
-    global _amax_pending
     if a0 is None and a1 is None and dy is None and out is None:
-        _amax_pending = None
+        _amax_pending.ctx = None
         return
     # (tensors: the caller keeps them alive until the launch has run)
-    _amax_pending = tuple(a.data_ptr() if isinstance(a, torch.Tensor) else a for a in (a0, a1, dy, out))
+    _amax_pending.ctx = tuple(a.data_ptr() if isinstance(a, torch.Tensor) else a for a in (a0, a1, dy, out))
 
 
 def call(name, *args):
     """Status-returning entry point on the current torch stream (stream argument appended)."""
-    global _amax_pending
-    if _amax_pending is not None:
-        (_funcs.get("xv2_amax_ctx") or _func("xv2_amax_ctx"))(*_amax_pending)
-        _amax_pending = None
+    pend = _amax_pending.ctx
+    if pend is not None:
+        (_funcs.get("xv2_amax_ctx") or _func("xv2_amax_ctx"))(*pend)
+        _amax_pending.ctx = None
     f = _funcs.get(name) or _func(name)
     get = _TO_C.get
     conv = []
