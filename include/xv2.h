@@ -208,6 +208,10 @@ int64_t xv2_coop_count(void);
  * never written to memory.  Results identical bit for bit to xv2_bn_act_forward + xv2_conv2d_forward_bn.  Only for the halo
  * plan of XV2_MATH_F32X3 (3x3, stride 1, pad 1, one source, fp32 tensors): ask xv2_conv2d_forward_pre_supported(d) first;
  * the statistics fold (XV2_BN_FOLD) must be on.  Other arguments as for xv2_conv2d_forward_bn. */
+/* In-launch statistics fold of the convolution kernels (bn_fold.h: the last blocks to arrive reduce the tile partials and derive
+ * the BatchNorm coefficients - no separate reduction launch): 1 = on, 0 = off, -1 = back to the environment (XV2_BN_FOLD, default
+ * off since round 4; the gated launches imply it).  Both forms give the same statistics up to summation order. */
+int xv2_set_bn_fold(int on);
 int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d);
 int xv2_conv2d_forward_bn_pre(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
                               const float* pre_shift, int pre_act, const void* w_ohwi, void* y, int ldy,

@@ -31,6 +31,7 @@ class gated:
         ops.COOP_APPLY = self.on
         cap = (1 << 30) if (gated.full or not os.environ.get("PYTEST_XDIST_WORKER")) else int(os.environ.get("XV2_COOP_BLOCKS", "40"))
         _lib().xv2_set_coop_blocks(cap if self.on else 0)
+        _lib().xv2_set_bn_fold(1)       # both forms on the in-launch statistics fold (the gated one needs it): same summation order
         self.n0 = _lib().xv2_coop_count()
         return self
 
@@ -42,6 +43,7 @@ class gated:
         torch.cuda.synchronize()
         ops.COOP_APPLY = self.old
         _lib().xv2_set_coop_blocks(-1)
+        _lib().xv2_set_bn_fold(-1)
 
 
 # N, H, W, C0, C1, Cout, k, stride, pad, groups, residual, act

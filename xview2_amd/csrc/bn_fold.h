@@ -98,7 +98,8 @@ static inline int stats_fold_tickets(const StatsFold& f) { return f.S * f.ngroup
 unsigned* take_tickets(int n);      // norm_act.hip: zero-initialised device pool, handed out round-robin
 int coop_capacity(const void* kern, int threads, size_t smem);   // igemm_conv.hip: blocks of `kern` the chip holds at once
 int coop_block_cap();               // igemm_conv.hip: XV2_COOP_BLOCKS / xv2_set_coop_blocks cap on gated grids
-bool bn_fold_enabled();             // norm_act.hip: XV2_BN_FOLD=0 restores the separate reduction launches (A/B runs)
+bool bn_fold_enabled();             // norm_act.hip: XV2_BN_FOLD=1 (or gated launches requested) folds the statistics in-launch
+bool coop_requested();              // igemm_conv.hip: XV2_COOP=1 or xv2_set_coop_blocks(n > 0)
 
 // ---- gate: a launch-wide "the reduction is final" hand-off between blocks that are all resident -------------------------
 // coop_open: called by ONE thread of the finishing block after that block's result stores were issued write-through and

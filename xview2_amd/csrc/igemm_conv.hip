@@ -1582,6 +1582,7 @@ static bool coop_enabled() {
     static const int v = [] { const char* e = getenv("XV2_COOP"); return e ? atoi(e) : 0; }();
     return v != 0 || g_coop_blocks > 0;
 }
+bool coop_requested() { return coop_enabled(); }
 int coop_block_cap() {
     static const int envcap = [] { const char* e = getenv("XV2_COOP_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
     return g_coop_blocks >= 0 ? g_coop_blocks : envcap;

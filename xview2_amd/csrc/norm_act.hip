@@ -137,16 +137,26 @@ struct ColOp {
 
 // XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply, bit 2 = the backward column sums walk
 // their tensors last-to-first
-// XV2_BN_FOLD (A/B runs): bit 0 = the convolution kernels fold their statistics tiles in-launch (default ON: measured
-// -0.2 ms per cfg2 fp32 step, -1.7 ms per resnest50 bf16 step against the separate reduction launch); bit 1 = the column
+// XV2_BN_FOLD: bit 0 = the convolution kernels fold their statistics tiles in-launch.  Round 3 measured it -0.2 ms per cfg2
+// fp32 step and -1.7 ms per resnest50 bf16 step against the separate reduction launch and made it the default.  Round 4 turned
+// it OFF by default: (a) with this round's planner and kernels the separate launch measures 0.4 - 0.6 % FASTER on cfg2 fp32,
+// cfg2 bf16 and cfg3 and 0.4 % slower on cfg4 (same-box pairs); (b) with six test processes crowding one
+// GPU, siamese / reproducibility comparisons of the model tests failed intermittently (about one run in five) with the fold on -
+// also with F16X2 off - and not once in six repetitions with it off: an inter-block hand-off that is not proven race-free under
+// that load has no place on the default path.  It stays available (XV2_BN_FOLD=1) and is implied by the gated launches
+// (XV2_COOP / xv2_set_coop_blocks), which need it.  bit 1 = the column
 // sums of the BatchNorm backward do the same (default OFF: under that HBM-streaming kernel every device-scope load of
 // the fold is a ~2.5 us round trip and the two-level tail costs +16.7 us per launch where the separate, idle-chip
 // reduction kernel takes 12.5 us - profiles/r03_fold_ab.md)
 static int bn_fold_bits() {
-    static const int v = [] { const char* e = getenv("XV2_BN_FOLD"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("XV2_BN_FOLD"); return e ? atoi(e) : 0; }();
     return v;
 }
-bool bn_fold_enabled() { return (bn_fold_bits() & 1) != 0; }
+static int g_bn_fold_override = -1;      // xv2_set_bn_fold(): 0 / 1 overrides the environment (tests, A/B runs in one process); -1: env
+bool bn_fold_enabled() {
+    if (g_bn_fold_override >= 0) return g_bn_fold_override != 0 || coop_requested();
+    return (bn_fold_bits() & 1) != 0 || coop_requested();
+}
 static bool bn_fold_backward() { return (bn_fold_bits() & 2) != 0; }
 
 static int bn_reverse(int bit) {
@@ -741,6 +751,11 @@ static inline int ew_grid(int64_t total) {
 }  // namespace xv2
 
 using namespace xv2;
+
+extern "C" int xv2_set_bn_fold(int on) {
+    g_bn_fold_override = on < 0 ? -1 : (on != 0);
+    return XV2_OK;
+}
 
 extern "C" int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
                                    void* stream) {
