@@ -940,7 +940,12 @@ def test_presplit_weight_planes_are_the_exact_three_way_split():
     w = (torch.randn(Cout, Cin, 3, 3) * 0.05).to(dev())
     w[0, 0, 0, 0] = 1e-30            # a denormal-range residual and a large value survive the split as well
     w[1, 2, 1, 1] = 3.0e4
-    ohwi, ihwo = ops._pack(w, Cin, True, True, False)
+    old_h2 = ops.F16X2
+    ops.F16X2 = False            # (with F16X2 on the entry gets the two scaled fp16 planes instead - next test)
+    try:
+        ohwi, ihwo = ops._pack(w, Cin, True, True, False)
+    finally:
+        ops.F16X2 = old_h2
     key = (w.data_ptr(), Cout, Cin, 3, 3, Cin, ops.XV2_F32)
     e = ops._packs[key]
     assert e.x3 and len(e.x3) == 2
@@ -952,6 +957,39 @@ def test_presplit_weight_planes_are_the_exact_three_way_split():
         total = planes[:, :, :, 0] + planes[:, :, :, 1] + planes[:, :, :, 2]                   # [unit][tap][slice][64][2][8]
         back = total.reshape(rows // 64, 9, ch // 16, 64, 16).permute(0, 3, 1, 2, 4).reshape(rows, 9, ch)
         assert torch.equal(back, packed.reshape(rows, 9, ch)), "hi + mid + lo != packed fp32 operand"
+    ops.clear_pack_cache()
+
+
+def test_f16x2_weight_planes_hold_the_scaled_weights_to_22_bits():
+    """xv2_presplit_weights_f16: two fp16 planes of w * s in the same LDS-image layout ([rows/64][tap][channels/16][2][64][16]), s the
+    power of two that brings the recorded max |w| below 2^15: (h + m) / s equals w to 2^-21 of max |w| (elementwise: 22 bits for
+    every weight within 2^18 of the maximum), and the three-plane copies are not made for such an entry"""
+    import ctypes
+    from xview2_amd import ops
+    if ops.MATH_MODE != ops.MATH_F32X3 or not ops.PRESPLIT or not ops.F16X2:
+        pytest.skip("the two-plane copies are made under XV2_MATH_F32X3 with F16X2 on")
+    torch.manual_seed(6)
+    Cout, Cin = 128, 192
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).to(dev())
+    w[1, 2, 1, 1] = 0.7              # the maximum
+    ohwi, ihwo = ops._pack(w, Cin, True, True, False)
+    e = ops._packs[(w.data_ptr(), Cout, Cin, 3, 3, Cin, ops.XV2_F32)]
+    assert e.x2 and len(e.x2) == 2 and not e.x3 and e.amax is not None
+    torch.cuda.synchronize()
+    arena = ops._wamax[w.device.index][0]
+    slot = arena[(e.amax - arena.data_ptr()) // ops.AMAX_BYTES].view(-1, 32)[:, 0].max().item()
+    amax = ctypes.c_float.from_buffer(ctypes.c_uint32(slot & 0xffffffff)).value
+    assert amax == float(w.abs().max())
+    s = 2.0 ** (14 - int(torch.floor(torch.log2(torch.tensor(amax))).item()))          # amax * s in [2^14, 2^15)
+    for packed, rows, ch in ((ohwi, Cout, Cin), (ihwo, Cin, Cout)):
+        planes = e.x2[packed.data_ptr()][0].view(rows // 64, 9, ch // 16, 2, 64, 2, 8).float()
+        r = torch.arange(64, device=planes.device)
+        swap = ((r >> 2) & 1).bool()
+        planes = torch.where(swap.view(1, 1, 1, 1, 64, 1, 1), planes.flip(5), planes)
+        total = (planes[:, :, :, 0].double() + planes[:, :, :, 1].double()) / s
+        back = total.reshape(rows // 64, 9, ch // 16, 64, 16).permute(0, 3, 1, 2, 4).reshape(rows, 9, ch)
+        err = (back - packed.reshape(rows, 9, ch).double()).abs().max().item()
+        assert err <= amax * 2.0 ** -21, err
     ops.clear_pack_cache()
 
 

@@ -309,11 +309,15 @@ def _presplit_entry(e):
         return
     for src, rows, T, ch in geoms:
         key = src.data_ptr()
-        if e.x3 is None:
-            e.x3 = {}
-        if key not in e.x3:
-            e.x3[key] = torch.empty((query("xv2_presplit_bytes", rows, T, ch) // 2,), dtype=torch.bfloat16, device=src.device)
-        call("xv2_presplit_weights", src, rows, T, ch, e.x3[key])
+        if not have_amax or e.x3:
+            # three bf16 planes (F32X3 halo form).  With F16X2 on they are not made: every training / inference launch of a 3x3
+            # layer whose operand maxima are known reads the two fp16 planes below, and the rare launch without maxima splits the
+            # weights in the kernel (bit-identical, ~5 % slower) - one table launch per step and 6 bytes per weight less
+            if e.x3 is None:
+                e.x3 = {}
+            if key not in e.x3:
+                e.x3[key] = torch.empty((query("xv2_presplit_bytes", rows, T, ch) // 2,), dtype=torch.bfloat16, device=src.device)
+            call("xv2_presplit_weights", src, rows, T, ch, e.x3[key])
         if have_amax:
             if e.x2 is None:
                 e.x2 = {}
