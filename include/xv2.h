@@ -146,6 +146,7 @@ int xv2_presplit_forget(const void* b_fp32);
  * never a silently wrong finite result.  XV2_F16X2=0 in the environment keeps every launch on the three-plane form. */
 int xv2_amax_ctx(const void* amax_a0, const void* amax_a1, const void* amax_dy, void* amax_out);
 int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* stream);
+int xv2_presplit_f16_supported(int nrows, int T, int ctot);   /* 3x3 layouts as xv2_presplit_supported; 1x1 layouts with nrows % 64 == 0, ctot % 16 == 0 */
 size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot);
 int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream);
 int xv2_presplit_f16_table(const int64_t* table, int n, int64_t total_blocks, void* stream);

@@ -216,3 +216,51 @@ def test_autoaugment_policy_keeps_geometry_of_image_and_mask_together(tree):
     ds = pl.TrainPostDataset(os.path.join(root, "train"), "post", True, csv)
     s = ds[0]
     assert s["image"].shape == (6, 512, 512) and s["mask"].shape == (512, 512) and s["mask"].dtype == np.uint8
+
+
+def test_device_loader_indexes_one_off_tiles_after_the_whole_batch_is_cached(tree, monkeypatch):
+    """a zoomed sample FOLLOWED by a not yet cached one in the same batch - the one-off 512 x 512 window
+    must keep its index although the later sample grows the tile cache; and the loader's random stream follows
+    (seed, rank, epoch) instead of the never-seeded module default."""
+    from xview2_amd.data_loading import data_module as dm
+    root, csv = tree
+    monkeypatch.setattr(pl, "DEFAULT_INDEX", csv)
+    ds = pl.fetch_pytorch_loader(os.path.join(root, "train"), "pre", True, {"batch_size": 1}, False, True).dataset
+    seen = []
+
+    def fake_aug(cache):
+        def run(plist, rows, extra=()):
+            for p, r in zip(plist, rows):
+                src = cache.imgs[r] if r < len(cache) else extra[r - len(cache)][0]
+                assert tuple(src.shape)[:2] == (p["H"], p["W"]), (r, len(cache), tuple(src.shape), p["H"], p["W"])
+                seen.append(r >= len(cache))
+            n = len(plist)
+            return torch.zeros(n, 512, 512, 3, dtype=torch.uint8), torch.zeros(n, 512, 512, dtype=torch.uint8)
+        return run
+
+    class _Img:                                   # ops.DeviceImage needs the HIP library: not under test here
+        def __init__(self, u8):
+            self.u8 = u8
+    import xview2_amd.ops as ops
+    monkeypatch.setattr(ops, "DeviceImage", _Img)
+    calls = {"n": 0}
+
+    def scale_first_of_each_batch(rng, p=0.2, scale_limit=(0.0, 0.3)):
+        calls["n"] += 1
+        rng.random()
+        return 1.0 + rng.uniform(*scale_limit) if calls["n"] % 2 == 1 else None
+    monkeypatch.setattr(pl, "draw_scale", scale_first_of_each_batch)
+    loader = dm.DeviceAugLoader(ds, 2, "cpu", seed=3, threads=1)
+    loader.aug = fake_aug(loader.cache)
+    batches = list(loader)                        # first epoch: every tile uncached when its batch starts
+    assert len(batches) == len(loader) and seen[0::2] == [True] * len(batches) and not any(seen[1::2])
+    # stream: a function of (seed, rank, epoch)
+    def first_draw(seed, rank, epoch):
+        ld = dm.DeviceAugLoader(ds, 1, "cpu", rank=rank, world_size=2 if rank else 1, seed=seed, threads=1)
+        ld.aug = fake_aug(ld.cache)
+        ld.set_epoch(epoch)
+        calls["n"] = 0
+        next(iter(ld))
+        return ld.rng.bit_generator.state["state"]["state"]
+    a = first_draw(3, 0, 0)
+    assert a == first_draw(3, 0, 0) and a != first_draw(4, 0, 0) and a != first_draw(3, 0, 1) and a != first_draw(3, 1, 0)

@@ -1,0 +1,112 @@
+"""sg_conv.hip - the small-grid convolution kernel (intra-block split-K over wave groups, activations straight to registers,
+pre-split fp16 weight planes by DMA; F16X2 arithmetic) on the layer shapes it was built for: the 1x1 / 3x3 layers of the
+/8 ... /32 encoder levels of the ResNet / ResNeSt bottlenecks (oracle/backbones.py:27-58, model/unet.py:45-52) at their TRUE
+size, forward (+ BatchNorm statistics partials) and backward-data (+ accumulation), against an fp64 convolution.  The
+profiler names pin WHICH kernel ran; the error gate is the one of tests/test_f16x2_gpu.py (fp32-class: < 2e-6 of the
+result's rms, within 1.5x of the three-plane form)."""
+import pytest
+import torch
+
+from tests.test_f16x2_gpu import _amax_of, _need_f32x3, _prof, _rel
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+CASES = [  # N, H, W, Cin, Cout, k, stride, dil
+    (2, 64, 64, 1024, 256, 1, 1, 1),      # l3 conv1 (M = 8192)
+    (2, 64, 64, 256, 1024, 1, 1, 1),      # l3 conv3
+    (2, 32, 32, 2048, 512, 1, 1, 1),      # l4 conv1 (M = 2048)
+    (2, 32, 32, 512, 2048, 1, 1, 1),      # l4 conv3
+    (2, 128, 128, 512, 128, 1, 1, 1),     # l2 conv1 (M = 32768)
+    (2, 128, 128, 128, 512, 1, 1, 1),     # l2 conv3
+    (2, 64, 64, 256, 256, 3, 1, 1),       # l3 conv2
+    (2, 32, 32, 512, 512, 3, 1, 1),       # l4 conv2
+    (2, 128, 128, 256, 512, 1, 2, 1),     # l3 downsample: 1x1 / stride 2
+    (2, 128, 128, 128, 128, 3, 2, 1),     # l3 first block conv2: 3x3 / stride 2
+    (2, 64, 64, 256, 256, 3, 1, 2),       # dilated encoder (--dilation 2)
+    (1, 40, 24, 64, 192, 1, 1, 1),        # ragged: M = 960 (not a multiple of 64), N = 192 (64-column tiles), K = 64
+    (3, 20, 12, 128, 64, 3, 1, 1),        # ragged 3x3: M = 720, N = 64
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_small_grid_kernel_forward_statistics_and_backward_data(case):
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    N, H, W, Ci, Co, k, st, dil = case
+    pad = dil * (k // 2)
+    torch.manual_seed(11)
+    g = ops.conv_cfg(k, k, st, pad, dil)
+    x = torch.relu(torch.randn(N, H, W, Ci, device=DEV)) * torch.exp(torch.randn(1, 1, 1, Ci, device=DEV))
+    w = torch.randn(Co, Ci, k, k, device=DEV) * 0.03
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
+    dy = torch.randn(N, OH, OW, Co, device=DEV) * 1e-6 * torch.exp(2 * torch.randn(N, OH, OW, 1, device=DEV))
+    xr, wr = x.permute(0, 3, 1, 2).double().requires_grad_(), w.double()
+    yr = torch.nn.functional.conv2d(xr, wr, stride=st, padding=pad, dilation=dil)
+    yr.backward(dy.permute(0, 3, 1, 2).double())
+    ref_y, ref_dx = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+    ops._pack(w, Ci, True, True)
+    ax, ad = _amax_of(x), _amax_of(dy)
+    res = {}
+    for sg in (False, True):
+        with _prof() as pr:
+            if sg:
+                set_amax(ax, None)
+            y, sums = ops._conv_forward(x, None, w, g, None, True)[:2]
+            if sg:
+                set_amax(None, None, ad)
+            dx = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]
+            names = pr.names()
+        convs = [n for n in names if n.startswith(("igemm_kernel", "sg_conv", "thin1x1"))]
+        if sg:
+            # (a strided 3x3 backward-data is four output-parity classes: the tiled kernel's; the ragged cases' forward plans
+            #  128-row statistics tiles on 64-column tiles, a geometry this kernel has no instantiation for)
+            want = 1 if ((st != 1 and k != 1) or Co % 128 != 0) else 2
+            assert sum(n.startswith("sg_conv_kernel") for n in convs) == want, names
+        else:
+            assert not any(n.startswith("sg_conv") for n in convs), names
+        res[sg] = {"y": _rel(y, ref_y), "dx": _rel(dx, ref_dx)}
+        # BatchNorm statistics partials: the folded sums are those of the y this launch wrote
+        yy = y.double().reshape(-1, Co)
+        got = sums.reshape(-1, Co, 2) if sums.dim() == 3 else sums.reshape(1, Co, 2)
+        tot = got.sum(0)
+        s1, s2 = yy.sum(0), (yy * yy).sum(0)
+        assert torch.allclose(tot[:, 0], s1, rtol=1e-5, atol=1e-5 * s2.sqrt().max().item()), (sg, (tot[:, 0] - s1).abs().max())
+        assert torch.allclose(tot[:, 1], s2, rtol=1e-5), (sg, ((tot[:, 1] - s2) / s2).abs().max())
+    for kx in ("y", "dx"):
+        assert res[True][kx] <= max(1.5 * res[False][kx], 2e-7), (kx, res)
+        assert res[True][kx] < 2e-6, (kx, res)
+    if st == 1:
+        # accumulating form (the bottleneck input's gradient arrives on top of the shortcut's) and bit-reproducibility
+        base = torch.randn(N, H, W, Ci, device=DEV) * 1e-6
+        outs = []
+        for _ in range(2):
+            tgt = base.clone()
+            set_amax(None, None, ad)
+            with _prof() as pr:
+                ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0, add_to0=tgt)
+                assert any(n.startswith("sg_conv_kernel") for n in pr.names()), pr.names()
+            outs.append(tgt)
+        assert torch.equal(outs[0], outs[1])
+        assert _rel(outs[0], ref_dx + base.double()) < 2e-6
+
+
+def test_small_grid_kernel_records_the_maximum_of_what_it_stores():
+    """backward-data with an `out` slot array (the gradient a transposed convolution's backward reads): exact max |dx|"""
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    from tests.test_f16x2_gpu import _recorded, _slots
+    torch.manual_seed(3)
+    N, H, W, Ci, Co = 2, 32, 32, 256, 128
+    g = ops.conv_cfg(1, 1, 1, 0)
+    w = torch.randn(Co, Ci, 1, 1, device=DEV) * 0.05
+    dy = torch.randn(N, H, W, Co, device=DEV)
+    ops._pack(w, Ci, True, True)
+    out = _slots()
+    with _prof() as pr:
+        set_amax(None, None, _amax_of(dy), out)
+        dx = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]
+        assert any(n.startswith("sg_conv_kernel") for n in pr.names()), pr.names()
+    assert _recorded(out) == dx.abs().max().item()

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("XV2_LIB", os.path.join(_HERE, "libxv2.so"))
-SOURCES = ["errors.cpp", "igemm_conv.hip", "direct_conv.hip", "thin_conv.hip", "stem_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
+SOURCES = ["errors.cpp", "igemm_conv.hip", "direct_conv.hip", "thin_conv.hip", "sg_conv.hip", "stem_conv.hip", "wgrad_conv.hip", "norm_act.hip", "pool.hip", "pointwise.hip",
            "loss_optim.hip", "xchg.hip", "augment.hip", "layer_entry.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("XV2_EXTRA_FLAGS", "").split()

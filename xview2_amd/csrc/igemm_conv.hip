@@ -2028,6 +2028,13 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     if (getenv("XV2_DEBUG_TILE"))
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
                 splitk_ws != nullptr, bm, bn, ks);
+    if (!p.plan_halo && !smallc && p.ncls == 1 && p.math == XV2_MATH_F32X3) {
+        // small grids (the /8 ... /32 encoder levels): sg_conv.hip instead of a 64-row / split-K plan of the tiled kernel.  It
+        // writes the statistics partials in the geometry of THAT plan (what the caller's buffers were sized for).
+        const int R = (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
+        IgemmParams q = p;
+        if (f16x2_ready(q) && sg_conv_eligible(q, smallc, R)) return sg_conv_launch(q, R, stream);
+    }
     p.ksplit = ks;
     p.part = splitk_ws;
     p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);
@@ -2805,6 +2812,11 @@ extern "C" int xv2_tensor_amax(const float* x, int64_t n, void* slots, void* str
     return XV2_OK;
 }
 extern "C" size_t xv2_presplit_f16_bytes(int nrows, int T, int ctot) { return (size_t)nrows * T * ctot * 4; }
+// layouts that get the two fp16 planes: the 3x3 layers (halo form, sg_conv.hip) and, since round 5, the 1x1 layers (sg_conv.hip)
+extern "C" int xv2_presplit_f16_supported(int nrows, int T, int ctot) {
+    if (T == 9) return xv2_presplit_supported(nrows, T, ctot);
+    return (T == 1 && nrows % 64 == 0 && ctot % 16 == 0) ? 1 : 0;
+}
 extern "C" int xv2_weight_amax_register(const void* b_fp32, const void* amax_slots) {
     XV2_CHECK_ARG(b_fp32 && amax_slots, "weight_amax_register: null");
     std::lock_guard<std::mutex> lk(g_presplit_mu);
@@ -2842,7 +2854,7 @@ extern "C" int xv2_weight_amax_table(const int64_t* table, int n, int64_t total_
     return XV2_OK;
 }
 extern "C" int xv2_presplit_weights_f16(const float* b_fp32, int nrows, int T, int ctot, void* x2, void* amax_slots, void* stream) {
-    XV2_CHECK_ARG(b_fp32 && x2 && amax_slots && xv2_presplit_supported(nrows, T, ctot), "presplit_f16: unsupported operand %d x %d x %d",
+    XV2_CHECK_ARG(b_fp32 && x2 && amax_slots && xv2_presplit_f16_supported(nrows, T, ctot), "presplit_f16: unsupported operand %d x %d x %d",
                   nrows, T, ctot);
     XV2_CHECK_ARG(((uintptr_t)x2 & 15) == 0 && xv2_presplit_f16_bytes(nrows, T, ctot) < (1ull << 31), "presplit_f16: alignment / size");
     {

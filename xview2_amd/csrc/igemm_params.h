@@ -113,6 +113,12 @@ int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const voi
 int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi, void* dx, int lddx,
                              int accumulate, hipStream_t stream);
 
+// sg_conv.hip: single-class, single-source convolutions (1x1 / 3x3, any stride / dilation) over small grids (M <= ~32768
+// pixels) in the F16X2 form: intra-block split-K over wave groups, activations straight to registers, pre-split weight planes by
+// DMA.  `R` = rows per BatchNorm statistics tile of the plan the caller's buffers were sized for (it writes that geometry).
+bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R);
+int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream);
+
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them
 bool stem7x7_eligible(const IgemmParams& p, bool smallc);

@@ -50,7 +50,15 @@ class DeviceAugLoader:
         self.aug = DeviceAugmenter(self.cache)
         self.rows, self.host_masks = {}, {}
         self.threads = max(1, int(threads))
-        self.rng = None
+        self._rng, self._rng_pinned, self._rng_epoch = None, False, None
+
+    @property
+    def rng(self):
+        return self._rng
+
+    @rng.setter
+    def rng(self, g):                              # an assigned stream is kept as it is (replay tests)
+        self._rng, self._rng_pinned = g, g is not None
 
     def __len__(self):
         return (len(self.ds) // self.world) // self.bs
@@ -79,8 +87,13 @@ class DeviceAugLoader:
         from . import pytorch_loader as pl
         from .device_aug import draw_params
         from ..ops import DeviceImage
-        if self.rng is None:
-            self.rng = pl._rng()                   # the stream the worker path would consume (seed_worker / the module default)
+        if self.rng is None or self._rng_epoch != self.epoch:
+            # a private stream per (seed, rank, epoch): follows --seed, differs between the ranks of a data-parallel job
+            # and does not restart from the same state after a resume (the worker path seeds per worker and rank from
+            # torch.initial_seed(), pytorch_loader.seed_worker); tests that replay the worker path assign self.rng.
+            if not self._rng_pinned:
+                self._rng = np.random.default_rng([int(self.seed), int(self.rank), int(self.epoch)])
+            self._rng_epoch = self.epoch
         order = self._order()
         ahead = 4 * self.bs
         with ThreadPoolExecutor(self.threads) as pool:
@@ -93,8 +106,11 @@ class DeviceAugLoader:
             for b in range(len(order) // self.bs):
                 prefetch(b * self.bs)
                 plist, rows, extra = [], [], []
-                for i in order[b * self.bs:(b + 1) * self.bs]:
-                    row, mask = self._row(i, pending)
+                # every cache row of the batch is resolved BEFORE a one-off tile gets its index: cache.add() of a later,
+                # not yet cached sample would otherwise shift len(cache) under an earlier zoomed sample's index
+                resolved = [self._row(i, pending) for i in order[b * self.bs:(b + 1) * self.bs]]
+                base = len(self.cache)
+                for row, mask in resolved:
                     s = pl.draw_scale(self.rng)
                     if s is None:
                         plist.append(draw_params(self.rng, mask, self.cache.imgs[row].shape[2] // 3))
@@ -109,7 +125,7 @@ class DeviceAugLoader:
                     p.update(H=p["h"], W=p["w"], y0=0, x0=0)
                     extra.append((torch.from_numpy(win).to(self.device), torch.from_numpy(wm).to(self.device)))
                     plist.append(p)
-                    rows.append(len(self.cache) + len(extra) - 1)
+                    rows.append(base + len(extra) - 1)
                 img, mask = self.aug(plist, rows, extra)
                 yield {"image": DeviceImage(img), "mask": mask}
 

@@ -268,16 +268,19 @@ def amax_reset():
     _amax_pools.clear()
 
 
-def _presplit_geoms(e):
-    """(packed fp32 layout, rows, taps, channels) of the entry's layouts that the halo form of the split-bf16 kernel can
-    read pre-split (xv2_presplit_weights: 3x3 taps, 64-row units, 32-channel chunks; fp32 tensors only)"""
+def _presplit_geoms(e, planes=3):
+    """(packed fp32 layout, rows, taps, channels) of the entry's layouts that exist pre-split for the kernels that stream
+    their weight operand global -> LDS by DMA (fp32 tensors only): planes = 3 - three bf16 planes, the halo form of the
+    split-bf16 kernel (xv2_presplit_weights: 3x3 taps, 64-row units, 32-channel chunks); planes = 2 - two scaled fp16 planes
+    (F16X2: the halo form and the small-grid kernel sg_conv.hip, which also takes the 1x1 layers: xv2_presplit_f16_supported)"""
     Cout, Cin, T, cin_pad = e.geom
     out = []
     if not PRESPLIT or e.dtype != XV2_F32 or cin_pad == 4 or MATH_MODE != MATH_F32X3:
         return out      # (planes made under F32X3 stay registered if the mode is switched later: harmless, just unused)
-    if e.ohwi is not None and query("xv2_presplit_supported", Cout, T, cin_pad) == 1:
+    fn = "xv2_presplit_supported" if planes == 3 else "xv2_presplit_f16_supported"
+    if e.ohwi is not None and query(fn, Cout, T, cin_pad) == 1:
         out.append((e.ohwi, Cout, T, cin_pad))
-    if e.ihwo is not None and query("xv2_presplit_supported", cin_pad, T, Cout) == 1:
+    if e.ihwo is not None and query(fn, cin_pad, T, Cout) == 1:
         out.append((e.ihwo, cin_pad, T, Cout))
     return out
 
@@ -292,6 +295,7 @@ def _weight_amax(e):
         e.amax_reg = set()
         if e.amax is None:
             return False
+        _invalidate_pack_table()      # (the refresh tables list the slots: a stale table would zero them and not refill them)
     call("xv2_tensor_amax", src, src.numel(), e.amax)
     for t in (e.ohwi, e.ihwo):
         if t is not None and t.data_ptr() not in e.amax_reg:
@@ -300,13 +304,31 @@ def _weight_amax(e):
     return True
 
 
+def _invalidate_pack_table():
+    global _pack_table
+    _pack_table = None
+
+
 def _presplit_entry(e):
     """bf16-plane copies of the entry's packed layouts (the weight operand of the halo kernels goes global -> LDS by DMA)"""
     have_amax = _weight_amax(e)
-    geoms = _presplit_geoms(e)
-    if not geoms:
+    geoms = _presplit_geoms(e, 3)
+    geoms2 = _presplit_geoms(e, 2) if have_amax else []
+    if not geoms and not geoms2:
         _forget_entry(e, keep_amax=have_amax)       # (a mode switch: planes that are no longer refreshed must not stay registered)
         return
+    keys3 = {src.data_ptr() for src, _, _, _ in geoms}
+    for src, rows, T, ch in geoms2:
+        if src.data_ptr() in keys3:
+            continue                                 # (3x3 layouts: below, next to their three-plane copies)
+        key = src.data_ptr()
+        if e.x2 is None:
+            e.x2 = {}
+        if key not in e.x2:
+            e.x2[key] = (torch.empty((query("xv2_presplit_f16_bytes", rows, T, ch) // 2,), dtype=torch.float16,
+                                     device=src.device), e.amax)
+            _invalidate_pack_table()
+        call("xv2_presplit_weights_f16", src, rows, T, ch, e.x2[key][0], e.amax)
     for src, rows, T, ch in geoms:
         key = src.data_ptr()
         if not have_amax or e.x3:
@@ -324,6 +346,7 @@ def _presplit_entry(e):
             if key not in e.x2:
                 e.x2[key] = (torch.empty((query("xv2_presplit_f16_bytes", rows, T, ch) // 2,), dtype=torch.float16,
                                          device=src.device), e.amax)
+                _invalidate_pack_table()
             call("xv2_presplit_weights_f16", src, rows, T, ch, e.x2[key][0], e.amax)
 
 
@@ -462,8 +485,8 @@ def repack_all():
         dev = next(iter(_packs.values())).w.device
         xrows, xstart = [], 0
         for e in _packs.values():      # the bf16-plane copies, refreshed by a second table-driven launch
-            geoms = _presplit_geoms(e)
-            if not geoms and (e.x3 or e.x2):
+            geoms = _presplit_geoms(e, 3)
+            if not geoms and not _presplit_geoms(e, 2) and (e.x3 or e.x2):
                 _forget_entry(e, keep_amax=e.amax is not None)      # (planes only: the weights' maximum stays registered)
             for src, nr, T, ch in geoms:
                 if e.x3 and src.data_ptr() in e.x3:
@@ -477,7 +500,7 @@ def repack_all():
             src = e.ohwi if e.ohwi is not None else e.ihwo
             arows.append([src.data_ptr(), src.numel() // 4, e.amax, astart])
             astart += (src.numel() // 4 + 1023) // 1024
-            for src, nr, T, ch in (_presplit_geoms(e) if e.x2 else []):
+            for src, nr, T, ch in (_presplit_geoms(e, 2) if e.x2 else []):
                 if src.data_ptr() in e.x2:
                     hrows.append([src.data_ptr(), e.x2[src.data_ptr()][0].data_ptr(), nr, T, ch, hstart, e.amax])
                     hstart += query("xv2_presplit_blocks", nr, T, ch)
