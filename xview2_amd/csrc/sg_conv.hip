@@ -34,7 +34,7 @@ struct SgParams {
     const unsigned* amaxA;    // recorded maxima (64 slots each, xv2_common.h)
     const unsigned* amaxB;
     unsigned* amax_out;       // != nullptr: record max |value stored|
-    unsigned bytesA, bytesB;
+    unsigned bytesA, bytesB, bytesO;
     int M, N, C, T, lda, ldo, accum, R;
     int IH, IW, OHl, OWl, s_in, osN, osH, osW, os0;
     int mtiles, ntiles, nsl;  // nsl = C / 16
@@ -72,11 +72,15 @@ __device__ __forceinline__ void sg_lds_read2_wait(unsigned a0, unsigned a1, floa
 }
 
 // WM = 32-row blocks of the tile (one wave each), G = K groups, NB = 32-column blocks: block tile (32 WM) x (32 NB), WM * G waves.
+// PLAIN = 1x1 / stride 1 / dense output rows (pixel index = GEMM row on both sides): no pixel decode, no tap bookkeeping.
 // BOTH operands reach LDS by DMA (the first version loaded the activations into registers two K steps ahead: the compiler's
 // vmcnt bookkeeping then waited for loads issued a moment earlier, and inline-asm loads with hand-written waits were copied
 // - v_mov ahead of the s_waitcnt - by the register allocator: wrong results from the second, L2-warm launch on).  With DMA only,
 // every wave issues the same number of loads per iteration and ONE wait count serves the whole kernel.
-template <int WM, int G, int NB>
+// What bounds a launch of this size is INSTRUCTION ISSUE outside the K loop (measured: 10.5 us at K = 64 for a version with
+// ~2300 instructions of prologue + epilogue per wave, two waves per SIMD): the epilogue exchanges the partial tiles as 16-byte
+// vectors and stores through a buffer resource (32-bit offsets), the DMA addresses are a per-lane constant + a scalar.
+template <int WM, int G, int NB, bool PLAIN>
 __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams p) {
     constexpr int BM = 32 * WM, BN = 32 * NB;
     constexpr int BSL = NB * 2048;             // bytes of one group's weight stage: NB * 32 rows x 16 channels x 2 planes x 2 B
@@ -86,7 +90,8 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     constexpr int ND = NB * 2 / WM;            // 1 KB weight pieces per wave and stage (+ 2 activation pieces: its own 32 rows)
     constexpr int NPW = ND + 2;
     constexpr int S = NB * 16 / G;             // accumulator registers a wave OWNS after the group reduction
-    static_assert(NB % 2 == 0 && (NB * 2) % WM == 0 && S >= 8 && (NB * 16) % G == 0, "tile shape");
+    constexpr int NV = NB * 4;                 // 16-byte vectors of a lane's accumulators
+    static_assert(NB % 2 == 0 && (NB * 2) % WM == 0 && S >= 8 && S % 4 == 0 && (NB * 16) % G == 0 && ND <= 4, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // ring of 3 stages; then the group reduction
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,8 +104,9 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (L >= total) return;
     const int mt = L / p.ntiles, nt = L - mt * p.ntiles;
+    const int row0 = mt * BM + m * 32;
 
-    // ---- pixels: the row this lane feeds to the MFMA / stores (l31), and the two rows whose 16-byte chunks it fetches by DMA ----
+    // ---- the two rows whose 16-byte chunks this lane fetches by DMA ----
     // an activation stage of a wave = its 32 rows x 64 bytes; LDS position q (16-byte units) = row * 4 + (chunk ^ ((row >> 2) & 3)):
     // fragment reads of one chunk over 16 consecutive rows then hit 16 different 16-byte bank groups
     auto decode = [&](int row, int& ih0, int& iw0, int& pixbase, int& opx) {
@@ -111,78 +117,96 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         pixbase = (n * p.IH + ih0) * p.IW + iw0;
         opx = n * p.osN + a * p.osH + b * p.osW + p.os0;
     };
-    const int row0 = mt * BM + m * 32;
-    int opix;
-    {
-        int t0, t1, t2;
-        decode(row0 + l31, t0, t1, t2, opix);
-    }
     int dih[2], diw[2], dpix[2], dchk[2];
     bool dok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int r = u * 16 + (lane >> 2), cs = lane & 3;
-        int ox;
-        decode(row0 + r, dih[u], diw[u], dpix[u], ox);
         dok[u] = row0 + r < p.M;
         dchk[u] = (cs ^ ((r >> 2) & 3)) * 4;             // first channel (of the 16-channel step) this lane's chunk holds
+        if constexpr (PLAIN) {
+            dpix[u] = row0 + r;
+            dih[u] = diw[u] = 0;
+        } else {
+            int ox;
+            decode(row0 + r, dih[u], diw[u], dpix[u], ox);
+        }
     }
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.bytesA, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bx2), 0, p.bytesB, 0x00020000);
 
     const int nsteps = p.T * p.nsl / G;        // 16-channel K steps of this group
     const int ks0 = g * nsteps;
-    int td = ks0 / p.nsl, sd = ks0 - td * p.nsl, id = 0;      // DMA stream position: tap, 16-channel slice, step
-    // (the tap of the DMA stream lives in registers and is re-read from the kernel arguments only when the stream moves on to
-    //  the next tap: a scalar load inside the loop makes the compiler wait for lgkmcnt(0) - i.e. for the LDS fragment reads
-    //  issued a moment earlier - in every iteration)
-    Tap tp = p.taps[td];
+    int td = ks0 / p.nsl, sd = ks0 - td * p.nsl, left = nsteps;      // DMA stream: tap, 16-channel slice, stages still to issue
+    // per-lane DMA offsets: a constant per tap (recomputed when the stream moves to the next tap) + a scalar per stage
+    const int bvo = lane * 16;
+    int avo[2], bso[NB / 2];
+    auto set_tap = [&]() {
+        const Tap tp = p.taps[td < p.T ? td : 0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bool ok = dok[u];
+            if constexpr (!PLAIN) {
+                const int ih = dih[u] + tp.dh, iw = diw[u] + tp.dw;
+                ok = ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            }
+            avo[u] = ok ? ((dpix[u] + (PLAIN ? 0 : tp.dh * p.IW + tp.dw)) * p.lda + dchk[u]) * 4 : (int)0x80000000;
+        }
+#pragma unroll
+        for (int un = 0; un < NB / 2; ++un) bso[un] = (((nt * (NB / 2) + un) * p.T + tp.slot) * p.nsl) * 4096;
+    };
+    set_tap();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     auto dma = [&](int slot) {
         // stage (td, sd) -> ring slot.  Past the group's last stage every offset lies beyond the buffer: the hardware writes
         // zeros into a slot nobody reads any more, and every iteration issues the same NPW loads
-        const bool live = id < nsteps;
+        const bool live = left > 0;
+        const int vb = live ? bvo : (int)0x80000000;
         char* sb = smem + slot * STAGE + g * GSL;
 #pragma unroll
         for (int u = 0; u < ND; ++u) {          // weights: piece = (64-row unit, 1 KB quarter) of the pre-split image
-            const int piece = m * ND + u, unit = piece >> 2, cq = piece & 3;
-            const int goff = live ? (((nt * (NB / 2) + unit) * p.T + tp.slot) * p.nsl + sd) * 4096 + cq * 1024 + lane * 16 : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(sb + unit * 4096 + cq * 1024), 16, goff, 0, 0, 0);
+            const int piece = m * ND + u, unit = piece >> 2;
+            // (the 1 KB quarter is an instruction immediate: a switch on the wave-uniform piece)
+            const int so = bso[NB == 2 ? 0 : (unit & 1)] + sd * 4096;
+            __attribute__((address_space(3))) char* dst = (__attribute__((address_space(3))) char*)(sb + unit * 4096);
+            // (the instruction's immediate offset applies to BOTH addresses - global and LDS: the LDS pointer is the unit's base)
+            switch (piece & 3) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst), 16, vb, so, 0, 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst), 16, vb, so, 1024, 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst), 16, vb, so, 2048, 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst), 16, vb, so, 3072, 0); break;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {           // activations: rows 16 u .. 16 u + 15 of this wave's block, tap (dh, dw); padding -> zeros
-            const int ih = dih[u] + tp.dh, iw = diw[u] + tp.dw;
-            const bool ok = live && dok[u] && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
-            const int goff = ok ? ((dpix[u] + tp.dh * p.IW + tp.dw) * p.lda + sd * 16 + dchk[u]) * 4 : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sb + BSL + m * 2048 + u * 1024), 16, goff, 0, 0, 0);
-        }
-        ++id;
+        for (int u = 0; u < 2; ++u)             // activations: rows 16 u .. 16 u + 15 of this wave's block; padding / rows past M -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sb + BSL + m * 2048 + u * 1024), 16,
+                                                     live ? avo[u] : (int)0x80000000, sd * 64, 0, 0);
+        --left;
         if (++sd == p.nsl) {
             sd = 0;
             ++td;
-            tp = p.taps[td < p.T ? td : 0];
+            set_tap();
         }
     };
     f16x8 bfrag[2][NB][2];
+    const unsigned boff = (unsigned)(l31 * 32 + ((h ^ ((l31 >> 2) & 1)) * 16));        // row l31 (+ 32: same swizzle bit) of a 64-row unit
     auto read_b = [&](int slot, f16x8 (&fb)[NB][2]) {
-        const char* base = smem + slot * STAGE + g * GSL;
+        const char* base = smem + slot * STAGE + g * GSL + boff;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int r = (j & 1) * 32 + l31;
-            const char* b = base + (j >> 1) * 4096 + r * 32 + ((h ^ ((r >> 2) & 1)) * 16);
+            const char* b = base + (j >> 1) * 4096 + (j & 1) * 1024;
             fb[j][0] = *reinterpret_cast<const f16x8*>(b);
             fb[j][1] = *reinterpret_cast<const f16x8*>(b + 2048);
         }
     };
     // activation fragment of a stage: chunks 2 h, 2 h + 1 of row l31 -> the two scaled fp16 planes (ah, am)
-    const unsigned aoff0 = (unsigned)(BSL + m * 2048 + l31 * 64 + (((2 * h) ^ ((l31 >> 2) & 3)) * 16));
-    const unsigned aoff1 = (unsigned)(BSL + m * 2048 + l31 * 64 + (((2 * h + 1) ^ ((l31 >> 2) & 3)) * 16));
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned aoff0 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((2 * h) ^ ((l31 >> 2) & 3)) * 16));
+    const unsigned aoff1 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((2 * h + 1) ^ ((l31 >> 2) & 3)) * 16));
     float sA = 1.f;
     auto read_split_a = [&](int slot, f16x8& ah, f16x8& am) {
-        const unsigned base = lds0 + slot * STAGE + g * GSL;
         float4 ra[2];
-        sg_lds_read2_wait(base + aoff0, base + aoff1, ra);
+        sg_lds_read2_wait(aoff0 + slot * STAGE, aoff1 + slot * STAGE, ra);
         uint2 a0, a1, b0, b1;
         split2hx4(ra[0], sA, a0, a1);
         split2hx4(ra[1], sA, b0, b1);
@@ -190,12 +214,12 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         am = __builtin_bit_cast(f16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
     };
 
-    // ---- prologue: the operand scales (their loads first: waiting for them must not drain the streams), three stages in flight ----
-    const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
-    asm volatile("" ::: "memory");
+    // ---- prologue: three stages in flight, then the operand scales (their loads are the youngest: the wait for them covers the
+    // stages, which the first iteration needs anyway) ----
     dma(0);
     dma(1);
     dma(2);
+    const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
     sA = amax_scale(ea);
     const float inv = amax_inv(ea) * amax_inv(eb);
 
@@ -244,70 +268,65 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         }
     }
 
-    // ---- epilogue: the G partial tiles meet in LDS; wave (m, g) owns accumulator registers [g S, (g + 1) S) of row block m ----
+    // ---- epilogue: the G partial tiles meet in LDS as 16-byte vectors (vector v = accumulator registers 4 v .. 4 v + 3 of a lane:
+    // column block v / 4, rows 8 (v % 4) + 4 h .. + 3); wave (m, g) then owns vectors [g S / 4, (g + 1) S / 4) of row block m ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last three DMA stages lay past the end: zeros)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);            // [WM][G owners][G - 1 sources][S][64]
+    constexpr int SV = S / 4;
+    float4* red = reinterpret_cast<float4*>(smem);          // [WM][G sources][NV][64]
     if constexpr (G > 1) {
 #pragma unroll
-        for (int s = 0; s < NB * 16; ++s) {
-            const int o = s / S;
-            if (o != g) red[((((m * G + o) * (G - 1)) + (g - (g > o ? 1 : 0))) * S + (s - o * S)) * 64 + lane] = acc[s / 16][s % 16];
+        for (int v = 0; v < NV; ++v)
+            red[((m * G + g) * NV + v) * 64 + lane] = make_float4(acc[v / 4][4 * (v % 4)], acc[v / 4][4 * (v % 4) + 1], acc[v / 4][4 * (v % 4) + 2],
+                                                                  acc[v / 4][4 * (v % 4) + 3]);
+    }
+    // rows / columns this lane stores: vector q of the wave <-> column block jq, rows 8 kq + 4 h + (0 .. 3)
+    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.Out, 0, p.bytesO, 0x00020000);
+    const int col0 = nt * BN + l31;
+    int ooff[S];          // byte offset of each owned element, or past the buffer for rows >= M
+    int opix = 0;         // (general geometry: lane l31 decodes the output pixel of row l31 once, the others fetch it by shuffle)
+    if constexpr (!PLAIN) {
+        int t0, t1, t2;
+        decode(row0 + l31, t0, t1, t2, opix);
+    }
+#pragma unroll
+    for (int q = 0; q < SV; ++q) {
+        const int v = g * SV + q, jq = v / 4, kq = v % 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rw = 8 * kq + 4 * h + e;
+            const int px = PLAIN ? row0 + rw : __shfl(opix, rw, 64);
+            ooff[4 * q + e] = row0 + rw < p.M ? (px * p.ldo + col0 + jq * 32) * 4 : (int)0x80000000;
         }
     }
-    // rows this lane stores: register r <-> row (r & 3) + 8 (r >> 2) + 4 h of the 32-row block
     float oldv[S];
-    int orow[S];
-    bool oval[S];
-#pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int s = g * S + q, r = s % 16, rw = (r & 3) + 8 * (r >> 2) + 4 * h;
-        orow[q] = __shfl(opix, rw, 64);
-        oval[q] = mt * BM + m * 32 + rw < p.M;
-    }
-    const int col0 = nt * BN + l31;
     if (p.accum) {
 #pragma unroll
-        for (int q = 0; q < S; ++q) {
-            const int s = g * S + q;
-            oldv[q] = oval[q] ? p.Out[(size_t)orow[q] * p.ldo + col0 + (s / 16) * 32] : 0.f;
-        }
+        for (int q = 0; q < S; ++q) oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, ooff[q], 0, 0));
     }
     __syncthreads();
     float fin[S];
 #pragma unroll
-    for (int q = 0; q < S; ++q) {
-        const int s = g * S + q;
-        float v = 0.f;
-        bool first = true;
+    for (int q = 0; q < SV; ++q) {
+        float4 v4;
+        if constexpr (G > 1) {
+            v4 = red[((m * G + 0) * NV + g * SV + q) * 64 + lane];
 #pragma unroll
-        for (int src = 0; src < G; ++src) {      // group order: a fixed sum
-            float t;
-            if (src == g) {
-                // (g is wave-uniform but not a compile-time constant: select the register by a small switch)
-                t = 0.f;
-#pragma unroll
-                for (int gg = 0; gg < G; ++gg)
-                    if (gg == g) t = acc[(gg * S + q) / 16][(gg * S + q) % 16];
-            } else {
-                t = red[((((m * G + g) * (G - 1)) + (src - (src > g ? 1 : 0))) * S + q) * 64 + lane];
+            for (int src = 1; src < G; ++src) {      // group order: a fixed sum
+                const float4 t = red[((m * G + src) * NV + g * SV + q) * 64 + lane];
+                v4.x += t.x; v4.y += t.y; v4.z += t.z; v4.w += t.w;
             }
-            v = first ? t : v + t;
-            first = false;
+        } else {
+            v4 = make_float4(acc[q / 4][4 * (q % 4)], acc[q / 4][4 * (q % 4) + 1], acc[q / 4][4 * (q % 4) + 2], acc[q / 4][4 * (q % 4) + 3]);
         }
-        (void)s;
-        fin[q] = v * inv;
+        fin[4 * q] = v4.x * inv; fin[4 * q + 1] = v4.y * inv; fin[4 * q + 2] = v4.z * inv; fin[4 * q + 3] = v4.w * inv;
     }
     float amx = 0.f;
 #pragma unroll
     for (int q = 0; q < S; ++q) {
-        const int s = g * S + q;
-        if (oval[q]) {
-            const float y = fin[q];
-            const float v = p.accum ? y + oldv[q] : y;
-            p.Out[(size_t)orow[q] * p.ldo + col0 + (s / 16) * 32] = v;
-            amx = fmaxf(amx, fabsf(v));
-        }
+        const float v = p.accum ? fin[q] + oldv[q] : fin[q];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsO, ooff[q], 0, 0);      // (rows past M: dropped by the hardware)
+        if (ooff[q] >= 0) amx = fmaxf(amx, fabsf(v));
     }
     if (p.amax_out) {
         const unsigned v = wave_max_u(__float_as_uint(amx) & 0x7fffffffu);
@@ -326,7 +345,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int q = k * (S / NOB); q < (k + 1) * (S / NOB); ++q)
-                if (oval[q]) {
+                if (ooff[q] >= 0) {
                     a += fin[q];              // BatchNorm statistics: of the convolution's own result
                     b += fin[q] * fin[q];
                 }
@@ -348,9 +367,9 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
                     a += v.x;
                     b += v.y;
                 }
-            const int64_t row0 = (int64_t)mt * BM + (int64_t)tl * p.R;
-            if (row0 < p.M)
-                *reinterpret_cast<float2*>(p.stats + ((size_t)(row0 / p.R) * p.N + nt * BN + c) * 2) = make_float2(a, b);
+            const int64_t r0 = (int64_t)mt * BM + (int64_t)tl * p.R;
+            if (r0 < p.M)
+                *reinterpret_cast<float2*>(p.stats + ((size_t)(r0 / p.R) * p.N + nt * BN + c) * 2) = make_float2(a, b);
         }
     }
 }
@@ -360,18 +379,19 @@ static int sg_mode() {      // XV2_SG=0: these layers stay on the tiled implicit
     return v;
 }
 
-template <int WM, int G, int NB>
+template <int WM, int G, int NB, bool PLAIN>
 static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStream_t stream) {
     constexpr size_t ring = (size_t)3 * G * (NB + WM) * 2048;
-    constexpr size_t redb = (size_t)WM * G * (G - 1) * (NB * 16 / G) * 256;
+    constexpr size_t redb = G > 1 ? (size_t)WM * G * NB * 4 * 1024 : 0;
     constexpr size_t smem = (ring > redb ? ring : redb) + 1024;
-    auto kern = sg_conv_kernel<WM, G, NB>;
+    static_assert(smem <= 160 * 1024, "LDS");
+    auto kern = sg_conv_kernel<WM, G, NB, PLAIN>;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     XV2_CHECK_HIP(attr_rc);
     static const int kid = [] {
         char nm[64];
-        snprintf(nm, sizeof(nm), "sg_conv_kernel<%d,%d,g%d,f16x2>", 32 * WM, 32 * NB, G);
+        snprintf(nm, sizeof(nm), "sg_conv_kernel<%d,%d,g%d,%sf16x2>", 32 * WM, 32 * NB, G, PLAIN ? "1x1," : "");
         return prof_register(nm);
     }();
     const int total = q.mtiles * q.ntiles, grid = 8 * ((total + 7) / 8);
@@ -414,6 +434,14 @@ static int sg_config(int64_t M, int N, int ksteps, int R) {
     return best;
 }
 
+// extent of the output tensor in bytes (the epilogue stores through a buffer resource with 32-bit offsets)
+static long long sg_out_bytes(const IgemmParams& p) {
+    const ClassInfo& c = p.cls[0];
+    const long long n = c.M / std::max(1, c.OHl * c.OWl);
+    const long long last = (n - 1) * p.osN + (long long)(c.OHl - 1) * p.osH + (long long)(c.OWl - 1) * p.osW + c.os0;
+    return (last * p.ldo0 + p.Nout) * 4;
+}
+
 bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     if (sg_mode() == 0 || smallc || p.math != XV2_MATH_F32X3 || p.npl != 2 || !p.Bx3 || !p.amaxA0 || !p.amaxB) return false;
     if (p.ncls != 1 || p.A1 || p.C1 != 0 || p.Out1 || p.N0 != p.Nout || p.T > 9) return false;
@@ -421,7 +449,7 @@ bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     const ClassInfo& c = p.cls[0];
     if (c.tap0 != 0 || c.ntaps != p.T || p.Ctot % 16 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A0) & 15) || (p.ldA0 % 4) != 0) return false;
-    if ((long long)p.bytesA0 >= (1ll << 31)) return false;
+    if ((long long)p.bytesA0 >= (1ll << 31) || sg_out_bytes(p) >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.Out0) & 3)) return false;
     if (sg_mode() != 2 && c.M > 40000) return false;        // larger grids fill the chip with the tiled kernels
     return sg_config(c.M, p.Nout, p.T * (p.Ctot / 16), p.stats ? R : 0) != 0;
 }
@@ -432,6 +460,7 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     q.A = p.A0; q.Bx2 = p.Bx3; q.Out = p.Out0; q.stats = p.stats;
     q.amaxA = p.amaxA0; q.amaxB = p.amaxB; q.amax_out = p.amax_out;
     q.bytesA = p.bytesA0; q.bytesB = p.bytesBx3;
+    q.bytesO = (unsigned)sg_out_bytes(p);
     q.M = c.M; q.N = p.Nout; q.C = p.Ctot; q.T = p.T; q.lda = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1;
     q.R = p.stats ? R : 32;
     q.IH = p.IH; q.IW = p.IW; q.OHl = c.OHl; q.OWl = c.OWl; q.s_in = p.s_in;
@@ -447,12 +476,20 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     const double abytes = 4.0 * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
                                  (double)c.M * p.Nout);
     if (p.amax_out && p.amax_recorded) *p.amax_recorded = 1;
+    // PLAIN: 1x1 / stride 1, pixel index = GEMM row on both sides
+    const bool plain = p.T == 1 && p.s_in == 1 && p.taps[0].dh == 0 && p.taps[0].dw == 0 && c.os0 == 0 && p.osW == 1 && p.osH == c.OWl &&
+                       p.osN == c.OHl * c.OWl && c.OHl == p.IH && c.OWl == p.IW;
+#define XV2_SG_CASE(CFG, WM_, G_, NB_)                                                         \
+    case CFG:                                                                                    \
+        return plain ? sg_launch_one<WM_, G_, NB_, true>(q, flops, abytes, stream)               \
+                     : sg_launch_one<WM_, G_, NB_, false>(q, flops, abytes, stream);
     switch (cfg) {
-        case 224: return sg_launch_one<2, 2, 4>(q, flops, abytes, stream);
-        case 244: return sg_launch_one<2, 4, 4>(q, flops, abytes, stream);
-        case 242: return sg_launch_one<2, 4, 2>(q, flops, abytes, stream);
-        case 424: return sg_launch_one<4, 2, 4>(q, flops, abytes, stream);
+        XV2_SG_CASE(224, 2, 2, 4)
+        XV2_SG_CASE(244, 2, 4, 4)
+        XV2_SG_CASE(242, 2, 4, 2)
+        XV2_SG_CASE(424, 4, 2, 4)
     }
+#undef XV2_SG_CASE
     set_error("sg_conv: no instantiation for configuration %d", cfg);
     return XV2_EINVAL;
 }
