@@ -105,7 +105,7 @@ def test_forward_backward_data_backward_weight_run_two_plane_kernels_at_fp32_acc
             dx0, dx1 = ops._conv_backward_data(dy, w, g, (N, H, W), C0, C1)
             dw = ops._conv_backward_weight_impl(x0, x1, dy, w, g, None, None, (a0, a1, ad) if h2 else None)
             names = pr.names()
-        convs = [n for n in names if n.startswith(("igemm_kernel", "wgrad_", "direct3x3", "thin1x1"))]
+        convs = [n for n in names if n.startswith(("igemm_kernel", "sg_conv_kernel", "wgrad_", "direct3x3", "thin1x1"))]
         assert len(convs) == 3, names
         assert all(("f16x2" in n) == h2 for n in convs), convs
         dx = torch.cat([dx0, dx1], dim=-1) if C1 else dx0
@@ -178,7 +178,7 @@ def test_the_operand_maximum_context_serves_exactly_one_call():
     with _prof() as pr:
         y2 = ops._conv_forward(x, None, w, g, None, True)[0]
         y3 = ops._conv_forward(x, None, w, g, None, True)[0]
-        names = [n for n in pr.names() if n.startswith("igemm_kernel")]
+        names = [n for n in pr.names() if n.startswith(("igemm_kernel", "sg_conv_kernel"))]
     assert "f16x2" in names[0] and "f16x2" not in names[1], names
     assert torch.equal(y3, base) and not torch.equal(y2, base)
     assert (y2 - base).abs().max() <= 1e-5 * base.abs().max()

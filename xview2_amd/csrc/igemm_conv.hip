@@ -2029,11 +2029,19 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
                 splitk_ws != nullptr, bm, bn, ks);
     if (!p.plan_halo && !smallc && p.ncls == 1 && p.math == XV2_MATH_F32X3) {
-        // small grids (the /8 ... /32 encoder levels): sg_conv.hip instead of a 64-row / split-K plan of the tiled kernel.  It
-        // writes the statistics partials in the geometry of THAT plan (what the caller's buffers were sized for).
-        const int R = (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
+        // small grids (the /8 ... /32 encoder levels): sg_conv.hip instead of a 64-row / split-K plan of the tiled kernel.
+        // Forward launches with statistics: the descriptor queries (xv2_conv2d_forward_stats_tiles / _tile_rows / _workspace)
+        // already answered with sg_planned_rows() for this shape, so the partials have that geometry whichever kernel runs -
+        // if the operands are not ready for it (no recorded maxima, no fp16 planes) the tiled kernel takes 64-row tiles, unsplit.
+        const int planned = (p.stats && !p.A1 && p.C1 == 0 && !p.bnb_y) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
+        const int R = planned ? planned : (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
         IgemmParams q = p;
         if (f16x2_ready(q) && sg_conv_eligible(q, smallc, R)) return sg_conv_launch(q, R, stream);
+        if (planned) {
+            XV2_CHECK_ARG(planned == 64, "igemm: the small-grid plan expects 64-row statistics tiles");
+            bm = 64;
+            ks = 1;
+        }
     }
     p.ksplit = ks;
     p.part = splitk_ws;
@@ -2297,13 +2305,22 @@ static inline int fwd_nkt(const xv2_conv_desc* d) {
 
 using namespace xv2;
 
+// rows per statistics tile when the forward pass of this descriptor is planned for sg_conv.hip (single source), else 0
+static int fwd_sg_rows(const xv2_conv_desc* d) {
+    if (is_rgb(d) || d->C1 != 0) return 0;
+    return sg_planned_rows((int64_t)d->N * d->OH * d->OW, d->Cout, d->C0, d->KH * d->KW, d->math);
+}
 extern "C" int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d) {
+    if (const int r = fwd_sg_rows(d)) return cdiv((int64_t)d->N * d->OH * d->OW, r);
     return igemm_stats_tiles((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" int64_t xv2_conv2d_forward_stats_tile_rows(const xv2_conv_desc* d) {
+    if (const int r = fwd_sg_rows(d)) return r;
     return igemm_stats_tile_rows((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d) {
+    // (a shape planned for sg_conv.hip keeps the tiled plan's workspace: launches WITHOUT statistics whose operands are not
+    //  ready for it still run that plan, split K included)
     return igemm_splitk_bytes((int64_t)d->N * d->OH * d->OW, d->Cout, is_rgb(d), fwd_nkt(d), d->math);
 }
 extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {

@@ -117,6 +117,7 @@ int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, c
 // pixels) in the F16X2 form: intra-block split-K over wave groups, activations straight to registers, pre-split weight planes by
 // DMA.  `R` = rows per BatchNorm statistics tile of the plan the caller's buffers were sized for (it writes that geometry).
 bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R);
+int sg_planned_rows(int64_t M, int N, int C, int T, int math);      // rows per statistics tile when the shape is planned for it, else 0
 int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream);
 
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input

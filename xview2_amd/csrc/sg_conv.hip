@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#ifndef XV2_SGABL
+#define XV2_SGABL 0      // timing ablations (results are garbage): 1 no MFMA, 2 no DMA inside the K loop, 4 no operand split, 8 no barrier
+#endif
+
 namespace xv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,10 +38,17 @@ struct SgParams {
     const unsigned* amaxA;    // recorded maxima (64 slots each, xv2_common.h)
     const unsigned* amaxB;
     unsigned* amax_out;       // != nullptr: record max |value stored|
+    // inference epilogue (IgemmParams::ep_*): out = act(conv * scale[c] + shift[c] [+ res]) - the arithmetic of bn_act_fwd_kernel
+    const float* ep_scale;
+    const float* ep_shift;
+    const float* ep_res;      // residual with the output's geometry (same pixel stride), or nullptr
+    const float* bias;
+    int ep_act;
     unsigned bytesA, bytesB, bytesO;
     int M, N, C, T, lda, ldo, accum, R;
     int IH, IW, OHl, OWl, s_in, osN, osH, osW, os0;
     int mtiles, ntiles, nsl;  // nsl = C / 16
+    float rcp_ntiles;
     Tap taps[9];
 };
 
@@ -103,7 +114,12 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     const int total = p.mtiles * p.ntiles, per = (total + 7) >> 3;
     const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (L >= total) return;
-    const int mt = L / p.ntiles, nt = L - mt * p.ntiles;
+    // (L / ntiles by a float reciprocal + fix-up: the generic 32-bit division is ~40 instructions, and what bounds a launch of this
+    //  size is instruction issue outside the K loop)
+    int mt = (int)(__uint2float_rz((unsigned)L) * p.rcp_ntiles);
+    if (mt * p.ntiles > L) --mt;
+    if ((mt + 1) * p.ntiles <= L) ++mt;
+    const int nt = L - mt * p.ntiles;
     const int row0 = mt * BM + m * 32;
 
     // ---- the two rows whose 16-byte chunks this lane fetches by DMA ----
@@ -137,7 +153,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
 
     const int nsteps = p.T * p.nsl / G;        // 16-channel K steps of this group
     const int ks0 = g * nsteps;
-    int td = ks0 / p.nsl, sd = ks0 - td * p.nsl, left = nsteps;      // DMA stream: tap, 16-channel slice, stages still to issue
+    int td = PLAIN ? 0 : ks0 / p.nsl, sd = ks0 - td * p.nsl, left = nsteps;      // DMA stream: tap, 16-channel slice, stages still to issue
     // per-lane DMA offsets: a constant per tap (recomputed when the stream moves to the next tap) + a scalar per stage
     const int bvo = lane * 16;
     int avo[2], bso[NB / 2];
@@ -207,6 +223,11 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     auto read_split_a = [&](int slot, f16x8& ah, f16x8& am) {
         float4 ra[2];
         sg_lds_read2_wait(aoff0 + slot * STAGE, aoff1 + slot * STAGE, ra);
+#if XV2_SGABL & 4
+        ah = __builtin_bit_cast(f16x8, ra[0]);
+        am = __builtin_bit_cast(f16x8, ra[1]);
+        return;
+#endif
         uint2 a0, a1, b0, b1;
         split2hx4(ra[0], sA, a0, a1);
         split2hx4(ra[1], sA, b0, b1);
@@ -242,19 +263,36 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     // Issue order: stages 0 1 2 | 3 | 4 | ...; needed at (a) of iteration i: stage i + 1; behind it: stage i + 2 = NPW loads.
     auto step = [&](auto PH, int i, int slot) {
         constexpr int ph = decltype(PH)::value;
+#if !(XV2_SGABL & 2)
         sg_wait_vm<NPW>();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(XV2_SGABL & 8)
         __builtin_amdgcn_s_barrier();
+#endif
         const int nslot = slot == 2 ? 0 : slot + 1;
         if (i + 1 < nsteps) read_b(nslot, bfrag[ph ^ 1]);
+#if !(XV2_SGABL & 2)
         dma(slot);
+#endif
+#if XV2_SGABL & 1
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afm[ph], bfrag[ph][j][0], acc[j], 0, 0, 0);
-        if (i + 1 < nsteps) read_split_a(nslot, afh[ph ^ 1], afm[ph ^ 1]);
+        // (unconditional - behind the last stage it reads a slot of zeros: the split then sits in ONE scheduling region with the
+        //  MFMAs below and can be interleaved with them; two waves of a SIMD run this code in lockstep behind the barrier, so a
+        //  VALU-only phase is a phase with an idle matrix pipe)
+        read_split_a(nslot, afh[ph ^ 1], afm[ph ^ 1]);
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ph], bfrag[ph][j][1], acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afh[ph], bfrag[ph][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2 * NB; ++j) {          // 1 MFMA, then 4 of the split's ~32 VALU instructions
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 32 / (2 * NB), 0);
+        }
     };
     {
         int slot = 0;
@@ -283,12 +321,15 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     // rows / columns this lane stores: vector q of the wave <-> column block jq, rows 8 kq + 4 h + (0 .. 3)
     __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.Out, 0, p.bytesO, 0x00020000);
     const int col0 = nt * BN + l31;
-    int ooff[S];          // byte offset of each owned element, or past the buffer for rows >= M
+    // byte offset of each owned element, or past the buffer for rows >= M (their values are zeros - zero activation rows - and are
+    // dropped by the store; in the sums and the maximum they change nothing)
+    int ooff[S];
     int opix = 0;         // (general geometry: lane l31 decodes the output pixel of row l31 once, the others fetch it by shuffle)
     if constexpr (!PLAIN) {
         int t0, t1, t2;
         decode(row0 + l31, t0, t1, t2, opix);
     }
+    const int rows_left = p.M - row0 - 4 * h;       // rows of this half-wave's first row group that exist
 #pragma unroll
     for (int q = 0; q < SV; ++q) {
         const int v = g * SV + q, jq = v / 4, kq = v % 4;
@@ -296,7 +337,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         for (int e = 0; e < 4; ++e) {
             const int rw = 8 * kq + 4 * h + e;
             const int px = PLAIN ? row0 + rw : __shfl(opix, rw, 64);
-            ooff[4 * q + e] = row0 + rw < p.M ? (px * p.ldo + col0 + jq * 32) * 4 : (int)0x80000000;
+            ooff[4 * q + e] = 8 * kq + e < rows_left ? (px * p.ldo + col0 + jq * 32) * 4 : (int)0x80000000;
         }
     }
     float oldv[S];
@@ -321,14 +362,38 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         }
         fin[4 * q] = v4.x * inv; fin[4 * q + 1] = v4.y * inv; fin[4 * q + 2] = v4.z * inv; fin[4 * q + 3] = v4.w * inv;
     }
-    float amx = 0.f;
+    float outv[S];
+    if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < SV; ++q) {
+            const float bv = p.bias[col0 + ((g * SV + q) / 4) * 32];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fin[4 * q + e] += bv;
+        }
+    }
+    if (p.ep_scale) {      // (eval-mode BatchNorm folded to scale / shift, residual, activation: xv2_conv2d_forward_fused)
+        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ep_res ? p.ep_res : p.Out), 0, p.bytesO, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < SV; ++q) {
+            const int c = col0 + ((g * SV + q) / 4) * 32;
+            const float sc = p.ep_scale[c], sf = p.ep_shift[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = __fmaf_rn(fin[4 * q + e], sc, sf);
+                if (p.ep_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, ooff[4 * q + e], 0, 0));
+                fin[4 * q + e] = apply_act(v, p.ep_act);
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < S; ++q) {
-        const float v = p.accum ? fin[q] + oldv[q] : fin[q];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsO, ooff[q], 0, 0);      // (rows past M: dropped by the hardware)
-        if (ooff[q] >= 0) amx = fmaxf(amx, fabsf(v));
+        outv[q] = p.accum ? fin[q] + oldv[q] : fin[q];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv[q]), rsO, ooff[q], 0, 0);      // (rows past M: dropped by the hardware)
     }
     if (p.amax_out) {
+        float amx = 0.f;
+#pragma unroll
+        for (int q = 0; q < S; ++q) amx = fmaxf(amx, fabsf(outv[q]));
         const unsigned v = wave_max_u(__float_as_uint(amx) & 0x7fffffffu);
         if (lane == 0 && v)
             __hip_atomic_fetch_max(p.amax_out + ((blockIdx.x * (WM * G) + wave) & (AMAX_SLOTS - 1)) * AMAX_STRIDE, v, __ATOMIC_RELAXED,
@@ -344,11 +409,10 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         for (int k = 0; k < NOB; ++k) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int q = k * (S / NOB); q < (k + 1) * (S / NOB); ++q)
-                if (ooff[q] >= 0) {
-                    a += fin[q];              // BatchNorm statistics: of the convolution's own result
-                    b += fin[q] * fin[q];
-                }
+            for (int q = k * (S / NOB); q < (k + 1) * (S / NOB); ++q) {
+                a += fin[q];                  // BatchNorm statistics: of the convolution's own result (rows past M: zeros)
+                b += fin[q] * fin[q];
+            }
             a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 32, 64);
             const int id = S >= 16 ? g * NOB + k : g;
@@ -402,36 +466,39 @@ static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStre
     return XV2_OK;
 }
 
-// configuration for a problem: 0 = not this kernel's; else WM * 100 + G * 10 + NB
-static int sg_config(int64_t M, int N, int ksteps, int R) {
+// Configuration for a problem (WM * 100 + G * 10 + NB; 0 = not this kernel's), from the per-layer table of scripts/bench_sg.py
+// (profiles/r05_sg_layers.txt): what decides is how many 64 x 128 tiles there are for the 256 CUs -
+//   <= 160 tiles: 64 x 64 tiles, eight waves (the /32 level at batch 2: M = 2048, N = 512);
+//   <= 384 tiles: 64 x 128 tiles, eight waves (G = 4), one block per CU (the /16 level: M = 8192, N = 256);
+//   more:         64 x 128 tiles, four waves (G = 2), two blocks per CU - the prologue / epilogue of one block under the K loop
+//                 of the other (the /8 level, and wide outputs at /16 and /32).
+// The 128 x 128 form (424) never won and is kept for statistics plans with 128-row tiles.  `R` = rows per statistics tile the
+// caller's buffers expect (0: no statistics): the configuration must write that geometry (R <= its tile rows).
+static bool sg_fits(int cfg, int N, int ksteps, int R) {
+    const int wm = cfg / 100, g = (cfg / 10) % 10, nb = cfg % 10;
+    return N % (32 * nb) == 0 && ksteps % g == 0 && ksteps / g >= 1 && (R == 0 || (R <= 32 * wm && (32 * wm) % R == 0 && R % 32 == 0));
+}
+int sg_pick(int64_t M, int N, int ksteps, int R) {
     if (N % 64 != 0 || ksteps < 2) return 0;
     static const int force = [] { const char* e = getenv("XV2_SG_CFG"); return e ? atoi(e) : 0; }();     // tuning runs: "244" etc.
-    auto fits = [&](int cfg) {
-        const int wm = cfg / 100, g = (cfg / 10) % 10, nb = cfg % 10;
-        return N % (32 * nb) == 0 && ksteps % g == 0 && ksteps / g >= 1 && (R == 0 || (R <= 32 * wm && (32 * wm) % R == 0 && R % 32 == 0));
-    };
-    if (force) return fits(force) ? force : 0;
-    const int cands[] = {224, 244, 242, 424};      // 64 x 128 (4 waves / 8 waves), 64 x 64 (8 waves), 128 x 128 (8 waves)
-    int best = 0;
-    double bestc = 1e30;
-    for (int cfg : cands) {
-        if (!fits(cfg)) continue;
-        const int wm = cfg / 100, g = (cfg / 10) % 10, nb = cfg % 10;
-        const int64_t blocks = cdiv(M, 32 * wm) * (N / (32 * nb));
-        const int percu = (wm * g == 4) ? 2 : 1;                       // co-resident blocks per CU
-        const double rounds = (double)cdiv(blocks, 256 * percu);
-        // time ~ rounds x (MFMA work of a block / its waves' share of the CU) with a floor per K step for the weight stream
-        const double waves = wm * g * percu;                            // waves per CU while the round runs
-        const double mf = (double)wm * nb * ksteps * 3.0 * 32.0 / 4.0 * percu;      // MFMA cycles per SIMD and round
-        const double eff = waves >= 8 ? 1.0 : 0.7;
-        const double bytes = (double)(32 * wm + 32 * nb) * ksteps * 64.0 * percu;   // operand bytes per CU and round
-        const double t = rounds * std::max(mf / eff, bytes / 48.0);                 // ~48 B / clk / CU from L2
-        if (t < bestc) {
-            bestc = t;
-            best = cfg;
-        }
-    }
-    return best;
+    if (force) return sg_fits(force, N, ksteps, R) ? force : 0;
+    const int64_t t = N % 128 == 0 ? cdiv(M, 64) * (N / 128) : 0;
+    int order[4];
+    if (t == 0 || t <= 160) { order[0] = 242; order[1] = 244; order[2] = 224; order[3] = 424; }
+    else if (t <= 384)      { order[0] = 244; order[1] = 224; order[2] = 242; order[3] = 424; }
+    else                    { order[0] = 224; order[1] = 244; order[2] = 424; order[3] = 242; }
+    for (int c : order)
+        if (sg_fits(c, N, ksteps, R)) return c;
+    return 0;
+}
+
+// A launch that is PLANNED for this kernel from its shape alone (the statistics-geometry queries of the convolution descriptor
+// and the launcher must agree before the operand maxima are known): rows per statistics tile of that plan, 0 = not planned.
+// The launcher falls back to a 64-row tiling of the tiled kernel - the same geometry - when the operands turn out not to be ready.
+int sg_planned_rows(int64_t M, int N, int C, int T, int math) {
+    if (sg_mode() == 0 || math != XV2_MATH_F32X3 || C % 16 != 0 || T > 9 || N % 64 != 0 || M > 40000) return 0;
+    const int cfg = sg_pick(M, N, T * (C / 16), 0);
+    return cfg ? 32 * (cfg / 100) : 0;
 }
 
 // extent of the output tensor in bytes (the epilogue stores through a buffer resource with 32-bit offsets)
@@ -445,13 +512,15 @@ static long long sg_out_bytes(const IgemmParams& p) {
 bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     if (sg_mode() == 0 || smallc || p.math != XV2_MATH_F32X3 || p.npl != 2 || !p.Bx3 || !p.amaxA0 || !p.amaxB) return false;
     if (p.ncls != 1 || p.A1 || p.C1 != 0 || p.Out1 || p.N0 != p.Nout || p.T > 9) return false;
-    if (p.bias || p.ep_scale || p.bnb_y || p.pre_scale || p.cz || p.fold.on || p.plan_halo || p.plan_tiles) return false;
+    if (p.bnb_y || p.pre_scale || p.cz || p.fold.on || p.plan_halo || p.plan_tiles) return false;
+    if (p.ep_scale && ((p.ep_res && p.ep_ldres != p.ldo0) || p.stats || (p.accum & 1))) return false;
+    if (p.bias && p.stats) return false;
     const ClassInfo& c = p.cls[0];
     if (c.tap0 != 0 || c.ntaps != p.T || p.Ctot % 16 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A0) & 15) || (p.ldA0 % 4) != 0) return false;
     if ((long long)p.bytesA0 >= (1ll << 31) || sg_out_bytes(p) >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.Out0) & 3)) return false;
     if (sg_mode() != 2 && c.M > 40000) return false;        // larger grids fill the chip with the tiled kernels
-    return sg_config(c.M, p.Nout, p.T * (p.Ctot / 16), p.stats ? R : 0) != 0;
+    return sg_pick(c.M, p.Nout, p.T * (p.Ctot / 16), p.stats ? R : 0) != 0;
 }
 
 int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
@@ -459,6 +528,7 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     SgParams q;
     q.A = p.A0; q.Bx2 = p.Bx3; q.Out = p.Out0; q.stats = p.stats;
     q.amaxA = p.amaxA0; q.amaxB = p.amaxB; q.amax_out = p.amax_out;
+    q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_res = p.ep_res; q.ep_act = p.ep_act; q.bias = p.bias;
     q.bytesA = p.bytesA0; q.bytesB = p.bytesBx3;
     q.bytesO = (unsigned)sg_out_bytes(p);
     q.M = c.M; q.N = p.Nout; q.C = p.Ctot; q.T = p.T; q.lda = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1;
@@ -468,10 +538,11 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     q.nsl = p.Ctot / 16;
     for (int t = 0; t < p.T; ++t) q.taps[t] = p.taps[t];
     for (int t = p.T; t < 9; ++t) q.taps[t] = p.taps[0];
-    const int cfg = sg_config(c.M, p.Nout, p.T * q.nsl, p.stats ? R : 0);
+    const int cfg = sg_pick(c.M, p.Nout, p.T * q.nsl, p.stats ? R : 0);
     const int wm = cfg / 100, nb = cfg % 10;
     q.mtiles = (int)cdiv(c.M, 32 * wm);
     q.ntiles = p.Nout / (32 * nb);
+    q.rcp_ntiles = 1.0f / (float)q.ntiles;
     const double flops = 2.0 * (double)c.M * p.Nout * (double)p.T * p.Ctot;
     const double abytes = 4.0 * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
                                  (double)c.M * p.Nout);
