@@ -52,9 +52,12 @@ def kernel_peak(name, precision):
     return PEAK_F32_MFMA_TFLOPS if precision == 32 else PEAK_BF16_MFMA_TFLOPS
 
 
-F32_SPLIT_TEXT = ("fp32 tensors, fp32 accumulation; products on the 16-bit MFMA from exact operand splits: F16X2 = two fp16 planes of "
-                  "x * 2^k (k from the tensor's recorded max |x|), 3 MFMAs per product, for every launch whose operand maxima are known; "
-                  "F32X3 = three bf16 planes, 6 MFMAs per product, for the rest (XV2_F16X2=0: everywhere; XV2_F32X3=0: exact-fp32 MFMA)")
+F32_SPLIT_TEXT = ("fp32 tensors, fp32 accumulation; products on the 16-bit MFMA from operand splits: F16X2 = two fp16 planes of "
+                  "x * 2^k (k from the tensor's recorded max |x|; 22 significant bits for elements within 2^18 of the maximum, an "
+                  "absolute error of 2^-39 of the maximum below that - fp32-CLASS, not exact: measured as close to an fp64 convolution "
+                  "as an fp32 one, split_form_error_vs_fp64), 3 MFMAs per product, for every launch whose operand maxima are known; "
+                  "F32X3 = three bf16 planes (an exact 24-bit split, the three smallest of nine cross terms dropped), 6 MFMAs per "
+                  "product, for the rest (XV2_F16X2=0: everywhere; XV2_F32X3=0: exact-fp32 MFMA)")
 F_FWD_GFLOP_PER_IMG = {"resnet50": 525.3, "resnest50": 578.8}   # SURVEY.md 8(d), conv FLOPs, 1024x1024
 F_ENC_GFLOP_PER_IMG = {"resnet50": 170.8, "resnest50": 224.3}   # encoder forward only
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
@@ -226,6 +229,9 @@ def parity_block(ref, hip, precision, size=1024, strict16=False):
     out = {"hip_first_loss": lh, "oracle_loss": lo, "rel": abs(lh - lo) / max(abs(lo), 1e-12),
            "logits_rel": logits_rel, "argmax_mismatch_px": int(diff.sum()),
            "argmax_mismatch_px_outside_ties": int((diff & (gap > 1e-3)).sum()), "pixels": int(diff.numel()),
+           "argmax_label_maps": "exact outside ties: %d of %d pixels differ, %d of them outside the tie margin (top-2 gap <= 1e-3 "
+                                "of the logit range; the CPU fp32 oracle differs from its own fp64 run on such pixels too)" % (
+                                    int(diff.sum()), int(diff.numel()), int((diff & (gap > 1e-3)).sum())),
            "grad_rel_global": (num / max(den, 1e-300)) ** 0.5,
            "grad_rel_median": rels[len(rels) // 2][0] if rels else None,
            "grad_rel_max": rels[-1][0] if rels else None, "grad_rel_max_key": rels[-1][1] if rels else None,
@@ -278,6 +284,62 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def per_kernel_row(r, steps, precision):
+    """one kernel of the step against BOTH roofs: the MFMA bound of its instruction stream (kernel_peak) and
+    its algorithmic bytes (inputs + weights + outputs once) at the achievable HBM rate; the binding roof is the larger floor"""
+    peak = kernel_peak(r["kernel"], precision)
+    t_mfma = r["gflop"] / peak                      # ms
+    t_hbm = r["mbytes"] / HBM_ACHIEVABLE_GBS        # MB / (GB/s) = ms
+    return {"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
+            "frac_of_its_bound": round(t_mfma / r["ms"], 3),
+            "hbm_gbs_algorithmic": round(r["mbytes"] / r["ms"], 1),
+            "frac_of_hbm_6290": round(t_hbm / r["ms"], 3),
+            "binding_roof": "hbm" if t_hbm > t_mfma else "mfma",
+            "frac_of_binding_roof": round(max(t_mfma, t_hbm) / r["ms"], 3),
+            "ms_per_step": round(r["ms"] / steps, 3), "launches_per_step": r["launches"] / steps}
+
+
+def collectives_probe(optim, reducer, step, barrier, world, step_ms):
+    """First-run evidence for the multi-GPU path (every rank runs it, outside the timed region):
+    (1) the gradient all-reduce alone - the reducer's own buckets, back to back, nothing else on the device - as time and BUS
+    bandwidth (2 (N - 1) / N x bytes / time: the per-link figure a ring over point-to-point xGMI is bound by);
+    (2) the step with the collectives SERIALISED behind backward (reducer.overlap = False) against the timed, overlapped step:
+    overlap fraction = (serialised - overlapped) / all-reduce time.  MAX over ranks, like the headline."""
+    import torch.distributed as dist
+    flat = optim.flat_g
+    nbytes = flat.numel() * 4
+
+    def timed(fn, reps):
+        barrier()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        barrier()
+        t = torch.tensor([(time.time() - t0) / reps * 1e3], dtype=torch.float64, device=flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_buckets():
+        for s0, e0, _ in reducer.buckets:
+            dist.all_reduce(flat[s0:e0])
+    saved = flat.clone()
+    all_buckets()                      # warm the communicators / channels of these sizes
+    ar_ms = timed(all_buckets, 5)
+    flat.copy_(saved)
+    reducer.overlap = False
+    try:
+        step()
+        serial_ms = timed(step, 5)
+    finally:
+        reducer.overlap = True
+    return {"allreduce_bytes": nbytes, "buckets": len(reducer.buckets), "allreduce_ms": round(ar_ms, 3),
+            "bus_gbs": round(2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1),
+            "step_ms_overlapped": round(step_ms, 3), "step_ms_collectives_serialised": round(serial_ms, 3),
+            "overlap_fraction": round(max(0.0, min(1.0, (serial_ms - step_ms) / ar_ms)), 3) if ar_ms > 0 else None,
+            "what": "gradient all-reduce of the flat buffer in the reducer's buckets alone (bus bandwidth = 2 (N - 1) / N x bytes / "
+                    "time) and the step with the collectives serialised behind backward; overlap = hidden share of the all-reduce"}
 
 
 def collect_prof(_capi):
@@ -549,6 +611,9 @@ def main():
     ap.add_argument("--no-big-configs", action="store_true",
                     help="skip the per-GPU-step legs of cfg4 (siamese resnest101) and cfg5 (fused resnest200) of the default line")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event bracketing of MFMA launches")
+    ap.add_argument("--no-split-check", action="store_true",
+                    help="skip split_form_error_vs_fp64 (its torch / MIOpen fp64 comparator launches foreign kernels: keep it out of "
+                         "rocprofv3 runs of this command)")
     ap.add_argument("--cpu-size", type=int, default=None, help="tile size of the CPU baseline sample")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step from a captured hipGraph (measured equal to eager launches on 1 GPU: "
@@ -666,6 +731,35 @@ def main():
         return {"loss": float(loss.detach()), "logits": p0.float().clone(), "labels": _xops.argmax_labels(p0.float()),
                 "grads": grads}
 
+    if world > 1 and os.environ.get("XV2_SYNCBN") is None and not opt.share_gpu:
+        # SyncBatchNorm transport of the bench: the one-shot peer exchange (xGMI stores, csrc/xchg.hip) if it survives a TRIAL on
+        # this node - construction + verified handshake (dist.PeerExchange), then two whole training steps, then a collective
+        # agreement that no rank saw a timeout or a non-finite loss; otherwise EVERY rank drops the exchange and rebuilds model,
+        # optimizer and reducer on RCCL collectives.  The trial steps are untimed and ahead of the warm-up.
+        os.environ["XV2_SYNCBN"] = "auto"
+        ok = True
+        try:
+            for _ in range(2):
+                lt = step()
+            torch.cuda.synchronize()
+            ok = xdist.peer_exchange_healthy() and bool(torch.isfinite(lt.detach()).item())
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("rank %d: SyncBatchNorm trial failed (%s: %s)\n" % (rank, type(e).__name__, e))
+            ok = False
+        if not xdist._all_ok(ok):
+            if rank == 0:
+                sys.stderr.write("SyncBatchNorm: the one-shot peer exchange did not survive its trial - RCCL collectives from here on\n")
+            xdist.reset_peer_exchange()
+            os.environ["XV2_SYNCBN"] = "rccl"
+        # (either way the timed run starts from the initial weights again)
+        del model, optim, reducer
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        model = networks.UNetLoc(a) if a.type == "pre" else networks.get_dmg_unet(a)
+        deterministic_init_(model, 1)
+        model.to(dev).train()
+        optim = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.0)
+        reducer = xdist.GradReducer(optim)
     for i in range(opt.warmup):
         l0 = run()
         if i == 0 and graphed is None and world == 1:
@@ -697,6 +791,9 @@ def main():
     barrier()
     dt = time.time() - t0
     xdist.check_peer_exchange()      # one-shot SyncBatchNorm exchange (XV2_SYNCBN=auto / oneshot): a timed-out exchange is an error
+    coll = None
+    if world > 1 and reducer.enabled and graphed is None:
+        coll = collectives_probe(optim, reducer, step, barrier, world, dt / opt.steps * 1e3)
     if hip_first is None and world == 1 and graphed is None and opt.warmup == 0:
         sys.stderr.write("no warm-up step: the parity block needs the first step outside the timed region\n")
     rows, iso = [], []
@@ -776,8 +873,11 @@ def main():
                 "note": "'halo,wx2' / 'halo,wx3' = the halo form of the 3x3 / stride-1 forward and backward-data launches (two scaled fp16 planes / "
                         "three bf16 planes): 4 x 32 pixel patches, "
                         "the halo of a 16-channel slice split and stored once for nine taps, weights pre-split once per step and "
-                        "streamed global -> LDS by DMA (DESIGN.md section 4); unsplit launches fold their BatchNorm statistics "
-                        "(bn_fold.h), split-K slabs are summed by splitk_reduce_kernel; "
+                        "streamed global -> LDS by DMA (DESIGN.md section 4); 'sg_conv_kernel' = the small-grid kernel of the /8 ... /32 "
+                        "encoder levels (csrc/sg_conv.hip: K split over wave groups inside a block, both operands by LDS-DMA); BatchNorm "
+                        "statistics partials are reduced by a launch of their own (the in-launch fold is off), split-K slabs of the tiled "
+                        "kernels are summed by splitk_reduce_kernel; per_kernel[] prices every kernel against BOTH roofs - the MFMA bound of "
+                        "its instruction stream and its algorithmic bytes at the achievable HBM rate (6.29 TB/s) - and names the binding one; "
                         "achieved/avg_launch_us: HIP events around every 7th launch of this kernel inside the timed region "
                         "(weight-gradient kernels co-scheduled on a side stream); 'isolated' = same kernel with every "
                         "launch alone on the chip; per_kernel/all_mfma_kernels: an extra untimed pass with every "
@@ -788,10 +888,7 @@ def main():
                     "avg_launch_us": round(iso_top["ms"] / iso_top["launches"] * 1e3, 2)},
                 "all_mfma_kernels": {"achieved": round(tot_gf / tot_ms, 2), "ms_per_step": round(tot_ms / psteps, 3),
                                      "gflop_per_step": round(tot_gf / psteps, 1)},
-                "per_kernel": [{"kernel": r["kernel"], "tflops": round(r["gflop"] / r["ms"], 2),
-                                "frac_of_its_bound": round(r["gflop"] / r["ms"] / kernel_peak(r["kernel"], opt.precision), 3),
-                                "ms_per_step": round(r["ms"] / psteps, 3), "launches_per_step": r["launches"] / psteps}
-                               for r in rows]}
+                "per_kernel": [per_kernel_row(r, psteps, opt.precision) for r in rows]}
     model_tf = value * 3 * F_FWD_GFLOP_PER_IMG.get(opt.encoder, 0.0) * (opt.size / 1024.0) ** 2 / 1e3
     out = {
         "metric": "training images/sec (1024x1024, bs=2/GPU)", "value": round(value, 3), "unit": "images/sec",
@@ -820,6 +917,8 @@ def main():
             model_tf / world / step_peak, 4),
         "roofline": roof,
     }
+    if coll is not None:
+        out["collectives"] = coll
     if rank == 0 and world == 1 and not opt.no_encoder_probe:
         # north_star target figure (configs[2] model): MFMA utilisation of the resnest50 encoder forward, both math modes
         del model, optim, reducer
@@ -849,7 +948,7 @@ def main():
                 % (opt.size, opt.size, opt.batch),
                 make_args("resnest200", "post", "focal+dice", "fused", attention=True, ppm=True, deep_supervision=True), 16,
                 opt.size, opt.batch, dev, steps=8, warmup=4, parity=False, unit="pairs/sec", cross=True))
-    if rank == 0 and world == 1 and opt.precision == 32:
+    if rank == 0 and world == 1 and opt.precision == 32 and not opt.no_split_check:
         try:
             out["split_form_error_vs_fp64"] = split_form_error(dev)
         except Exception as e:      # (evidence, not the measurement: never fail the line for it)

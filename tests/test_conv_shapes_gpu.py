@@ -79,9 +79,28 @@ def close(a, b, tol, what):
     return err
 
 
+def _give_amax(t):
+    """F16X2: record max |t| and attach the slots to the tensor, as the producing BatchNorm apply pass would have"""
+    from xview2_amd import ops
+    from xview2_amd._capi import call
+    tok = ops._amax_new(t)
+    call("xv2_tensor_amax", t, t.numel(), tok[0])
+    t._xv2_amax = tok
+
+
+_MFMA_PREFIXES = ("igemm_kernel", "sg_conv_kernel", "wgrad_", "direct3x3", "thin1x1", "thin_convT")
+
+
 @pytest.mark.parametrize("case", CONVS, ids=[c[0] for c in CONVS])
 def test_cfg2_conv_layer_at_true_size(case):
+    """Each layer runs TWICE on the HIP path: without operand maxima (the three-plane bf16 kernels, XV2_MATH_F32X3) and with them
+    (F16X2: the two-plane fp16 kernels the bench step runs - halo / small-grid / per-tap forward and backward-data, all-taps /
+    transposing weight gradients - with the split-K / slab plans of the true size).  Both must hold the
+    op-level tolerances against the host reference, the profiler names pin which kernels ran, and the two-plane form may not
+    be further from the reference than 1.5x the three-plane form (+ 1e-6 of the tensor maximum: the host reference is itself
+    an fp32 evaluation).  The incoming gradient is gradient-like: per-pixel magnitudes spread log-normally."""
     from xview2_amd import ops
+    from tests.test_f16x2_gpu import _prof
     name, C0, C1, Cout, k, s, H, with_res = case
     torch.manual_seed(C0 + 3 * C1 + 7 * Cout + k + s + H)
     pad = k // 2
@@ -90,22 +109,45 @@ def test_cfg2_conv_layer_at_true_size(case):
     w = torch.randn(Cout, C0 + C1, k, k) * (2.0 / (k * k * (C0 + C1))) ** 0.5
     gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1
     act_t, act_h = (F.relu, ops.ACT_RELU) if with_res else (lambda v: F.leaky_relu(v, 0.01), ops.ACT_LEAKY)
-    # HIP path
-    bnm = torch.nn.BatchNorm2d(Cout).to(DEV)
-    with torch.no_grad():
-        bnm.weight.copy_(gamma)
-        bnm.bias.copy_(beta)
-    wg = w.to(DEV).requires_grad_(True)
-    a0 = nhwc(x0).requires_grad_(True)
-    a1 = nhwc(x1).requires_grad_(True) if C1 else None
-    res = torch.randn(B, Cout, (H + 2 * pad - k) // s + 1, (H + 2 * pad - k) // s + 1) if with_res else None
-    r2 = nhwc(res).requires_grad_(True) if with_res else None
-    z = ops.ConvBnActFn.apply(a0, a1, wg, bnm.weight, bnm.bias, r2, ops.conv_cfg(k, k, s, pad), ops.BnState(bnm),
-                              act_h, True)
-    dz = torch.randn(z.shape[0], z.shape[3], z.shape[1], z.shape[2])
-    z.backward(nhwc(dz))
-    torch.cuda.synchronize()
-    zh = nchw(z)
+    OH = (H + 2 * pad - k) // s + 1
+    res = torch.randn(B, Cout, OH, OH) if with_res else None
+    dz = torch.randn(B, Cout, OH, OH) * torch.exp(torch.randn(B, 1, OH, OH))
+    two_plane = bool(ops.F16X2 and ops.MATH_MODE == ops.MATH_F32X3)
+
+    def run_hip(with_maxima):
+        bnm = torch.nn.BatchNorm2d(Cout).to(DEV)
+        with torch.no_grad():
+            bnm.weight.copy_(gamma)
+            bnm.bias.copy_(beta)
+        wg = w.to(DEV).requires_grad_(True)
+        a0 = nhwc(x0).requires_grad_(True)
+        a1 = nhwc(x1).requires_grad_(True) if C1 else None
+        r2 = nhwc(res).requires_grad_(True) if with_res else None
+        if with_maxima:
+            _give_amax(a0)
+            if a1 is not None:
+                _give_amax(a1)
+        with _prof() as pr:
+            z = ops.ConvBnActFn.apply(a0, a1, wg, bnm.weight, bnm.bias, r2, ops.conv_cfg(k, k, s, pad), ops.BnState(bnm),
+                                      act_h, True)
+            z.backward(nhwc(dz))
+            ops.join_wgrad_stream()
+            names = [n for n in pr.names() if n.startswith(_MFMA_PREFIXES)]
+        torch.cuda.synchronize()
+        dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
+        return {"z": nchw(z), "dx": dx, "dw": wg.grad.detach().cpu(), "dgamma": bnm.weight.grad.cpu(), "dbeta": bnm.bias.grad.cpu(),
+                "dres": nchw(r2.grad) if with_res else None, "rv": bnm.running_var.cpu(), "names": names}
+
+    ops.F16X2 = False            # (the BatchNorm backward would otherwise record max |dy| and the backward-data run on two planes)
+    try:
+        runs = {False: run_hip(False)}
+    finally:
+        ops.F16X2 = two_plane
+    if two_plane:
+        runs[True] = run_hip(True)
+        conv_names = [n for n in runs[True]["names"] if not n.startswith("wgrad_reduce")]
+        assert len(conv_names) >= 3 and all("f16x2" in n for n in conv_names), runs[True]["names"]
+        assert not any("f16x2" in n for n in runs[False]["names"]), runs[False]["names"]
     # host reference
     xr = (torch.cat([x0, x1], 1) if C1 else x0).clone().requires_grad_(True)
     wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
@@ -113,23 +155,33 @@ def test_cfg2_conv_layer_at_true_size(case):
     yr = F.batch_norm(F.conv2d(xr, wr, None, s, pad), rm, rv, gr, br, True, 0.1, 1e-5)
     rr = res.clone().requires_grad_(True) if with_res else None
     pre = yr + rr if with_res else yr
-    close(zh, act_t(pre), 2e-4, name + " z")
-    # activation-derivative flips at near-zero pre-activations (see the module docstring)
-    flips = (zh > 0) != (pre.detach() > 0)
-    nflip = int(flips.sum())
-    assert nflip <= 2e-5 * flips.numel() + 2, "%s: %d sign flips" % (name, nflip)
-    if nflip:
-        assert float(pre.detach()[flips].abs().max()) <= 1e-4 * float(pre.detach().abs().max()), name + ": a flip away from zero"
-    slope = torch.where(zh > 0, 1.0, 0.0 if with_res else 0.01)      # the HIP path's own activation mask
-    (pre * slope).backward(dz)
-    close(bnm.running_var, rv, 2e-4, name + " running_var")
-    dx = nchw(a0.grad) if not C1 else torch.cat([nchw(a0.grad), nchw(a1.grad)], 1)
-    close(dx, xr.grad, 5e-4, name + " dx")
-    close(wg.grad, wr.grad, 5e-4, name + " dw")
-    close(bnm.weight.grad, gr.grad, 5e-4, name + " dgamma")
-    close(bnm.bias.grad, br.grad, 5e-4, name + " dbeta")
-    if with_res:
-        close(nchw(r2.grad), rr.grad, 1e-6, name + " dres")
+    errs = {}
+    for mode, out in runs.items():
+        tag = name + (" [f16x2]" if mode else " [f32x3]")
+        zh = out["z"]
+        e = {"z": close(zh, act_t(pre), 2e-4, tag + " z")}
+        # activation-derivative flips at near-zero pre-activations (see the module docstring)
+        flips = (zh > 0) != (pre.detach() > 0)
+        nflip = int(flips.sum())
+        assert nflip <= 2e-5 * flips.numel() + 2, "%s: %d sign flips" % (tag, nflip)
+        if nflip:
+            assert float(pre.detach()[flips].abs().max()) <= 1e-4 * float(pre.detach().abs().max()), tag + ": a flip away from zero"
+        slope = torch.where(zh > 0, 1.0, 0.0 if with_res else 0.01)      # the HIP path's own activation mask
+        for t in (xr, wr, gr, br, rr):
+            if t is not None:
+                t.grad = None
+        (pre * slope).backward(dz, retain_graph=True)
+        close(out["rv"], rv, 2e-4, tag + " running_var")
+        e["dx"] = close(out["dx"], xr.grad, 5e-4, tag + " dx")
+        e["dw"] = close(out["dw"], wr.grad, 5e-4, tag + " dw")
+        close(out["dgamma"], gr.grad, 5e-4, tag + " dgamma")
+        close(out["dbeta"], br.grad, 5e-4, tag + " dbeta")
+        if with_res:
+            close(out["dres"], rr.grad, 1e-6, tag + " dres")
+        errs[mode] = e
+    if two_plane:
+        for kx in ("z", "dx", "dw"):
+            assert errs[True][kx] <= 1.5 * errs[False][kx] + 1e-6, (name, kx, errs)
 
 
 @pytest.mark.parametrize("shape", CONVT, ids=["convT %d->%d @%d" % c for c in CONVT])
@@ -143,13 +195,18 @@ def test_cfg2_conv_transpose_at_true_size(shape):
     yr = F.conv_transpose2d(xr, wr, None, 2)
     dy = torch.randn_like(yr)
     yr.backward(dy)
-    a, wg = nhwc(x).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    y = ops.ConvTranspose2x2Fn.apply(a, wg)
-    y.backward(nhwc(dy))
-    torch.cuda.synchronize()
-    close(nchw(y), yr, 2e-4, "convT y")
-    close(nchw(a.grad), xr.grad, 5e-4, "convT dx")
-    close(wg.grad, wr.grad, 5e-4, "convT dw")
+    for with_maxima in (False, True):        # three-plane kernels, then (input maximum known) the two-plane forward where one exists
+        a, wg = nhwc(x).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        if with_maxima:
+            _give_amax(a)
+        y = ops.ConvTranspose2x2Fn.apply(a, wg)
+        y.backward(nhwc(dy))
+        ops.join_wgrad_stream()
+        torch.cuda.synchronize()
+        tag = "convT [maxima]" if with_maxima else "convT"
+        close(nchw(y), yr, 2e-4, tag + " y")
+        close(nchw(a.grad), xr.grad, 5e-4, tag + " dx")
+        close(wg.grad, wr.grad, 5e-4, tag + " dw")
 
 
 def test_conv_transpose_1024_level_bf16_and_pass_through_alias():

@@ -65,7 +65,7 @@ def test_single_rank_nccl_step_equals_plain_step():
         ops.FORCE_COLLECTIVES = False
         ops.BN_ROWS = old_rows
         xnn.SYNC_BN = False
-        xdist.reset_peer_exchange()      # (XV2_SYNCBN defaults to auto: a one-rank exchange was built over this group)
+        xdist.reset_peer_exchange()      # (XV2_SYNCBN=auto / oneshot would have built a one-rank exchange over this group)
         dist.destroy_process_group()
 
 
@@ -138,7 +138,7 @@ def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=F
     training step of the HIP path on this rank's share of a global batch of `total`"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", XV2_COOP="0")
-    os.environ.setdefault("XV2_SYNCBN", "rccl")      # (the transport tests set it; the default is auto)
+    os.environ.setdefault("XV2_SYNCBN", "rccl")      # (the transport tests set it; rccl is also the library default)
     if exact_fp32:
         os.environ["XV2_F32X3"] = "0"        # read when xview2_amd.ops is imported (spawned process: not yet)
     import torch.distributed as dist

@@ -221,3 +221,37 @@ def test_training_step_with_and_without_two_plane_kernels_agree_like_two_fp32_ru
     assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
     g0, g1 = out[False][1].double(), out[True][1].double()
     assert torch.dot(g0, g1) / (g0.norm() * g1.norm()) > 0.999
+
+
+def test_an_outlier_in_the_gradient_documents_the_range_of_the_two_plane_form():
+    """F16X2 scales a tensor by its maximum: elements within 2^18 of it keep 22 bits, smaller ones an ABSOLUTE error of 2^-39 of
+    the maximum, and below ~2^-39 of the maximum they flush to zero (xv2_common.h split2hx2).  One pixel of dy 2^30 x larger than
+    the rest leaves the rest with ~9 significant bits; 2^44 x larger flushes the rest to exactly zero - finite, never NaN / Inf,
+    while the three-plane form (no range information) keeps fp32 accuracy in both cases.  This is the documented price of the
+    mode; BatchNorm-normalised gradients of the U-Net span far less (the bench's first step holds its gradient gate with it)."""
+    _need_f32x3()
+    from xview2_amd import ops
+    from xview2_amd._capi import set_amax
+    torch.manual_seed(5)
+    N, H, W, Ci, Co = 2, 32, 32, 128, 128
+    g = ops.conv_cfg(1, 1, 1, 0)
+    w = torch.randn(Co, Ci, 1, 1, device=DEV) * 0.05
+    ops._pack(w, Ci, True, True)
+    for shift, lo, hi in ((30, 2.0 ** -12, 2.0 ** -7), (44, 1.0, 1.0)):
+        dy = torch.randn(N, H, W, Co, device=DEV)
+        dy[0, 0, 0] *= 2.0 ** shift
+        ref = torch.einsum("nhwk,kc->nhwc", dy.double(), w.double()[:, :, 0, 0])
+        dx3 = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]                 # no maxima: three planes
+        set_amax(None, None, _amax_of(dy))
+        with _prof() as pr:
+            dx2 = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]
+            assert any("f16x2" in n for n in pr.names()), pr.names()
+        assert torch.isfinite(dx2).all()
+        rest = torch.ones(N, H, W, dtype=torch.bool, device=DEV)
+        rest[0, 0, 0] = False
+        assert _rel(dx3[rest], ref[rest]) < 2e-6 and _rel(dx3[~rest], ref[~rest]) < 2e-6
+        assert _rel(dx2[~rest], ref[~rest]) < 2e-6                                   # the outlier's own pixel: full accuracy
+        e = _rel(dx2[rest], ref[rest])
+        assert lo <= e <= hi, (shift, e)
+        if shift == 44:
+            assert float(dx2[rest].abs().max()) == 0.0                               # flushed, not garbage

@@ -188,7 +188,7 @@ class PeerExchange:
     PeerExchangeUnavailable - `stats_all_reduce_` then stays with torch.distributed (XV2_SYNCBN=auto).  Coarse-grained
     exchange memory (the runtime refused fine-grained) is accepted only when all ranks share ONE device.
     Developed with ranks sharing one GPU (tests/test_dist_gpu.py, world 2 .. 8); it has never met an xGMI link, hence
-    the default transport stays RCCL and `auto` verifies before it trusts."""
+    the library default stays RCCL (syncbn_transport) and `auto` verifies before it trusts."""
     ROW = 2 * 2 * 4096          # doubles per row: S <= 2 parts x [C <= 4096][2]
 
     def __init__(self, group=None, verify=8):
@@ -316,14 +316,18 @@ _peer_exchange_off = False        # auto mode: construction failed once - stay w
 
 
 def syncbn_transport():
-    """XV2_SYNCBN = auto (default: the one-shot peer exchange if its collective construction and its verified handshake succeed
-    on EVERY rank, else torch.distributed.all_reduce = RCCL, with one warning) | rccl (the collective library, no attempt) |
-    oneshot (the peer exchange or an error).  Why auto is the default although the exchange has never met an xGMI link: the
-    alternative is 2 x 126 (cfg2) ... 2 x 606 (cfg5) latency-bound collectives per step on the compute stream; construction is
-    all-or-nothing across the ranks (any failure anywhere -> every rank stays with RCCL), the handshake compares 8 exchanges of
-    1 .. 16384 doubles with the rank-ordered host sum under a short spin limit, and a later timeout poisons its result with
-    NaN instead of hanging or drifting."""
-    return os.environ.get("XV2_SYNCBN", "auto")
+    """XV2_SYNCBN = rccl (default: torch.distributed.all_reduce per BatchNorm layer and direction) | auto (the one-shot peer
+    exchange if its collective construction and its verified handshake succeed on EVERY rank, else RCCL with one warning) |
+    oneshot (the peer exchange or an error).  The library default is RCCL since round 5: the exchange has never met
+    an xGMI link, its wait is a bounded spin, and a training loop has rank skew that a collective simply waits out (rank 0 writing
+    a checkpoint) where a timed-out exchange poisons every later result with NaN.  bench.py opts into `auto` behind a trial of
+    its own (a few steps, a collective agreement, a rebuild on RCCL if any rank disagrees): its steps run between barriers."""
+    return os.environ.get("XV2_SYNCBN", "rccl")
+
+
+def peer_exchange_healthy():
+    """host-side (synchronises): no exchange of this rank has timed out so far (True also when no exchange object exists)"""
+    return _peer_exchange is None or int(_peer_exchange.timeout.item()) == 0
 
 
 def stats_all_reduce_(t):

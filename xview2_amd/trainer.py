@@ -102,6 +102,11 @@ class Trainer:
                 if score is not None and (self.best_score is None or score >= self.best_score):
                     self.best_score = score
                     self.save_checkpoint(model, os.path.join(ckdir, "best.ckpt"), epoch, optimizer)
+            if self.world > 1:
+                # rank 0 alone wrote the checkpoints: the others wait here instead of inside the next epoch's first SyncBatchNorm
+                # exchange (a collective would wait anyway; the one-shot peer exchange has a bounded wait - ADVICE r04)
+                import torch.distributed as tdist
+                tdist.barrier()
         if self.world > 1:
             xdist.reset_peer_exchange()          # unmap the peers' exchange buffers, free this rank's own
         return model
