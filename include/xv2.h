@@ -400,6 +400,17 @@ int xv2_bn_rows_backward(const float* dz, const float* z, const float* y, const 
  *   + xv2_bn_reduce_finalize + xv2_bn_act_forward[_mask] (zmask != NULL selects the mask form).  Single-process
  *   training-mode BatchNorm only (SyncBatchNorm keeps the op-level calls around its all-reduce).
  * xv2_bn_act_backward = xv2_bn_act_backward_reduce[_mask] + xv2_bn_act_backward_apply[_mask] (training mode). */
+/* Statistics reduction + coefficients + running statistics + apply pass of a training-mode BatchNorm in ONE launch (round 5):
+ * = xv2_bn_reduce_finalize followed by xv2_bn_act_forward(_mask) - the same sums in the same order, bit-identical results - for
+ * layers whose partial count is small (xv2_bn_reduce_finalize_act_forward_supported: C % 32 == 0, tiles <= 128, statistics fold
+ * off); every block owns 32 channels and a range of rows and repeats the reduction for its own channels.  Reference:
+ * model/layers.py:93-100 (nn.BatchNorm2d in training mode + activation).  zmask NULL: no byte mask. */
+int xv2_bn_reduce_finalize_act_forward_supported(int64_t tiles, int64_t npix, int C);
+int xv2_bn_reduce_finalize_act_forward(const float* partial, int64_t tiles, int C, double* sums, double count,
+                                       const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                       float* shift, const void* y, int ldy, const void* residual, int ldr, int act, void* z,
+                                       int ldz, int64_t npix, uint8_t* zmask, int dtype, void* stream);
 int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                             const void* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
                             float* workspace, double* sums, double* scratch, double count,

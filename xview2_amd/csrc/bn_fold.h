@@ -31,21 +31,30 @@ struct BnFinalize {
 };
 
 // contraction off: every kernel that inlines this must agree bit for bit (hipcc contracts a*b+c by default)
+// mean, 1 / std and the folded (scale, shift) of one channel from its sums: THE arithmetic of every BatchNorm forward here
+__device__ inline void bn_channel_coeffs(const BnFinalize& f, int c, double s1, double s2, double& m, double& var, double& is, float& sc,
+                                         float& sf) {
+#pragma clang fp contract(off)
+    m = s1 / f.count;
+    const double mm = m * m;
+    var = s2 / f.count - mm;
+    if (var < 0.0) var = 0.0;
+    is = 1.0 / sqrt(var + (double)f.eps);
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+    sc = g * (float)is;
+    const float msc = (float)m * sc;
+    sf = b - msc;
+}
 __device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1, double s2, int out_off = 0) {
 #pragma clang fp contract(off)
-    const double m = s1 / f.count;
-    const double mm = m * m;
-    double var = s2 / f.count - mm;
-    if (var < 0.0) var = 0.0;
-    const double is = 1.0 / sqrt(var + (double)f.eps);
+    double m, var, is;
+    float sc, sf;
+    bn_channel_coeffs(f, c, s1, s2, m, var, is, sc, sf);
     f.mean[out_off + c] = (float)m;
     f.invstd[out_off + c] = (float)is;
-    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-    const float sc = g * (float)is;
-    const float msc = (float)m * sc;
     // (write-through: with a gate - see StatsFold::gate - the other blocks of this launch read them right away)
     __hip_atomic_store(f.scale + out_off + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(f.shift + out_off + c, b - msc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f.shift + out_off + c, sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f.running_mean) {
         const double vc = var * f.count;
         const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;

@@ -20,8 +20,16 @@ extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, i
                                        int ldz, uint8_t* zmask, int dtype, void* stream) {
     // convolution + statistics + coefficients: ONE launch (the last blocks to arrive fold the tile partials, bn_fold.h)
     // (+ the BatchNorm apply behind a gate in that same launch when its grid is resident at once: xv2_conv2d_forward_bn_act)
-    (void)tiles;
     xv2::AmaxGuard amax_guard;      // (the convolution reads the context's sources, the apply pass records into its `out`)
+    const int64_t npix_f = (int64_t)d->N * d->OH * d->OW;
+    if (stats_partials && mean && tiles > 0 && xv2_bn_reduce_finalize_act_forward_supported(tiles, npix_f, d->Cout)) {
+        // small layers: convolution, then ONE launch for the statistics reduction, the coefficients and the apply pass
+        int rc0 = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
+        if (rc0) return rc0;
+        return xv2_bn_reduce_finalize_act_forward(stats_partials, tiles, d->Cout, sums, count, gamma, beta, eps, momentum,
+                                                  running_mean, running_var, mean, invstd, scale, shift, y, ldy, residual, ldr,
+                                                  act, z, ldz, npix_f, zmask, dtype, stream);
+    }
     int applied = 0;
     int rc = xv2_conv2d_forward_bn_act(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
                                        scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
