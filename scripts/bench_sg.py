@@ -34,7 +34,9 @@ def records():
         nm = _capi.query("xv2_prof_kernel_name", kid.value).decode()
         out.setdefault(nm, []).append(ms.value * 1000)
     return out
-print("%-30s %7s | %-44s %7s | %-44s %7s" % ("layer", "GFLOP", "forward kernel", "us", "backward-data kernel", "us"))
+print("%-30s %7s %6s %6s | %-40s %7s %5s | %-40s %7s %5s" % ("layer", "GFLOP", "mfma", "hbm", "forward kernel", "us", "roof", "backward-data kernel", "us", "roof"))
+print("(mfma = GFLOP / 833.3 TFLOP/s, the F16X2 instruction stream's bound; hbm = algorithmic bytes (input + weights + output once) / 6.29 TB/s; "
+      "roof = the larger of the two floors / measured time; times = HIP events around the launch, ~2.5 us above rocprofv3's kernel duration)")
 tot = [0.0, 0.0]
 for name, N, H, W, Ci, Co, k, st in SHAPES:
     if filt not in name:
@@ -69,5 +71,9 @@ for name, N, H, W, Ci, Co, k, st in SHAPES:
         res.append((nm[:44], us))
         tot[which] += us
     gf = 2.0 * N * OH * OW * Co * Ci * k * k / 1e9
-    print("%-30s %7.2f | %-44s %7.1f | %-44s %7.1f" % (name, gf, res[0][0], res[0][1], res[1][0], res[1][1]))
+    mb = 4.0 * (N * H * W * Ci + Co * Ci * k * k + N * OH * OW * Co) / 1e6
+    t_m, t_h = gf / 833.3 * 1e3, mb / 6290.0 * 1e3          # us
+    fl = max(t_m, t_h)
+    print("%-30s %7.2f %6.1f %6.1f | %-40s %7.1f %5.2f | %-40s %7.1f %5.2f" % (
+        name, gf, t_m, t_h, res[0][0][:40], res[0][1], fl / res[0][1], res[1][0][:40], res[1][1], fl / res[1][1]))
 print("total forward %.1f us, backward-data %.1f us (split-K slab sums and statistics reductions are separate launches, not in these numbers)" % (tot[0], tot[1]))

@@ -37,6 +37,14 @@ def main(db, which=6):
         print("  queue %s: %4d kernels, busy %.3f ms, span %.3f ms, gaps<20us: %d totalling %.3f ms (median %.2f us)" % (
             q, len(L), busy / 1e6, (L[-1][1] - L[0][0]) / 1e6, len(small), sum(small) / 1e6,
             sorted(small)[len(small) // 2] / 1e3 if small else 0))
+    # the largest holes of the busiest queue (the compute stream): what ran before and after them
+    q0 = max(byq.items(), key=lambda kv: len(kv[1]))[1]
+    holes = sorted(((q0[i + 1][0] - q0[i][1], i) for i in range(len(q0) - 1)), reverse=True)[:14]
+    print("  largest gaps on the compute queue (us, after -> before):")
+    for g, i in holes:
+        print("     %8.1f  %-44s -> %s" % (g / 1e3, short(q0[i][2])[:44], short(q0[i + 1][2])[:44]))
+    big = sum(g for g, _ in holes if g >= 20000)
+    print("  gaps >= 20 us among them: %.3f ms" % (big / 1e6))
     # union busy / overlap
     ev = []
     for n, s, e, q in step:
