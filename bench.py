@@ -160,7 +160,10 @@ def cpu_baseline(a, size, batch, seed, timed_steps=3):
 # BLOCK given the fp32 path's input is within 2e-2 rms (tests/test_fullsize_gpu.py, the fine-grained check).  The gates below
 # are what a wrong kernel on the path still fails: a broken forward layer gives an rms error ~1.4 and label agreement ~0.5, a
 # broken backward layer a gradient cosine of 0 +- 0.05.
-STRICT_BF16_GATE = {"logits_rms_rel_max": 0.30, "grad_cosine_min": 0.25, "argmax_agreement_min": 0.92}
+# (round 5: the cosine gate moved from 0.25 to 0.40 - measured 0.52 on every box so far; the backward arithmetic itself is pinned
+#  block by block at this size, input and weight gradients of every block within 0.15 rms of its fp32 twin:
+#  tests/test_fullsize_gpu.py::test_bf16_block_backward_against_fp32_blocks_at_full_size)
+STRICT_BF16_GATE = {"logits_rms_rel_max": 0.30, "grad_cosine_min": 0.40, "argmax_agreement_min": 0.92}
 
 
 def split_form_error(dev):
@@ -461,11 +464,13 @@ def cross_check(a, precision, size, batch, dev, first):
     #  agreement 0.46, logits rms 0.98: 132 split-attention blocks whose BatchNorm over two values flips sign under a bf16-sized
     #  perturbation - the whole-network label map of cfg5 carries no information at batch 2 (64 x 64: 0.52);
     #  its arithmetic is pinned block by block at full size, tests/test_fullsize_gpu.py: worst block rms 8.5e-3)
-    gate = {"loss_rel": 1e-3 if precision == 32 else 1e-2, "argmax_agreement_min": 0.90 if precision == 32 else 0.0}
+    # (a --precision 16 leg has NO label-map gate: a gate of 0.0 cannot fail and is not one - the figure is reported; what pins the
+    #  bf16 arithmetic of these networks is block-wise, forward and backward, at this size: tests/test_fullsize_gpu.py)
+    gate = {"loss_rel": 1e-3, "argmax_agreement_min": 0.90} if precision == 32 else {"loss_rel": 1e-2}
     return {"against": "the same first step forward on the HIP path with %s" % (
                 "the exact-fp32 MFMA (XV2_MATH_F32)" if precision == 32 else "fp32 tensors (default fp32 math)"),
             "loss": first["loss"], "loss_other": loss, "loss_rel": rel, "logits_rms_rel": rms, "argmax_agreement": agree,
-            "gate": gate, "pass": bool(rel <= gate["loss_rel"] and agree >= gate["argmax_agreement_min"]),
+            "gate": gate, "pass": bool(rel <= gate["loss_rel"] and agree >= gate.get("argmax_agreement_min", 0.0)),
             "note": "ResNeSt at batch 2: split attention's BatchNorm over two values makes the logits chaotic (DESIGN.md section 7), "
                     "so they are reported; gated: the loss, and for fp32 legs the label maps"}
 
