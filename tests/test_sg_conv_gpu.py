@@ -109,3 +109,53 @@ def test_small_grid_kernel_records_the_maximum_of_what_it_stores():
         dx = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]
         assert any(n.startswith("sg_conv_kernel") for n in pr.names()), pr.names()
     assert _recorded(out) == dx.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 32 == 0 and c[3] >= 128], ids=lambda c: "x".join(map(str, c)))
+def test_small_grid_kernel_bf16_storage(case):
+    """--precision 16 (XV2_MATH_BF16_STORE): the same kernel on bf16 tensors - 32-channel stages, v_mfma_f32_32x32x16_bf16, no
+    operand split - forward (+ statistics on the values as stored) and backward-data (+ accumulation) against an fp64 convolution
+    of the bf16-rounded operands: within the output rounding (rms <= 4e-3 = 2^-8), XV2_SG_BF16=0 kernels as the yardstick (within
+    1.2x), profiler names pin the kernel."""
+    from xview2_amd import ops
+    N, H, W, Ci, Co, k, st, dil = case
+    pad = dil * (k // 2)
+    torch.manual_seed(13)
+    g = ops.conv_cfg(k, k, st, pad, dil)
+    x = (torch.relu(torch.randn(N, H, W, Ci, device=DEV)) * torch.exp(0.5 * torch.randn(1, 1, 1, Ci, device=DEV))).bfloat16()
+    w = torch.randn(Co, Ci, k, k, device=DEV) * 0.03
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
+    dy = torch.randn(N, OH, OW, Co, device=DEV).bfloat16()
+    xr, wr = x.float().permute(0, 3, 1, 2).double().requires_grad_(), w.bfloat16().double()
+    yr = torch.nn.functional.conv2d(xr, wr, stride=st, padding=pad, dilation=dil)
+    yr.backward(dy.float().permute(0, 3, 1, 2).double())
+    ref_y, ref_dx = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+    old_mode = ops.MATH_MODE
+    ops.MATH_MODE = ops.MATH_BF16
+    ops.set_storage_dtype(torch.bfloat16)
+    try:
+        with _prof() as pr:
+            y, sums = ops._conv_forward(x, None, w, g, None, True)[:2]
+            dx = ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0)[0]
+            names = [n for n in pr.names() if n.startswith(("igemm_kernel", "sg_conv", "thin1x1"))]
+        want = 1 if (st != 1 and k != 1) else 2
+        assert sum(n.startswith("sg_conv_kernel") and "bf16hbm" in n for n in names) == want, names
+        assert y.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16
+        assert _rel(y.float(), ref_y) <= 4e-3 and _rel(dx.float(), ref_dx) <= 4e-3, (_rel(y.float(), ref_y), _rel(dx.float(), ref_dx))
+        yy = y.double().reshape(-1, Co)
+        tot = sums.reshape(-1, Co, 2).sum(0) if sums.dim() == 3 else sums
+        s1, s2 = yy.sum(0), (yy * yy).sum(0)
+        assert torch.allclose(tot[:, 0], s1, rtol=1e-5, atol=1e-5 * s2.sqrt().max().item())
+        assert torch.allclose(tot[:, 1], s2, rtol=1e-5)
+        if st == 1:
+            base = (torch.randn(N, H, W, Ci, device=DEV)).bfloat16()
+            outs = []
+            for _ in range(2):
+                tgt = base.clone()
+                ops._conv_backward_data(dy, w, g, (N, H, W), Ci, 0, add_to0=tgt)
+                outs.append(tgt)
+            assert torch.equal(outs[0], outs[1])
+            assert _rel(outs[0].float(), ref_dx + base.double()) <= 4e-3
+    finally:
+        ops.MATH_MODE = old_mode
+        ops.set_storage_dtype(None)

@@ -2028,7 +2028,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     if (getenv("XV2_DEBUG_TILE"))
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
                 splitk_ws != nullptr, bm, bn, ks);
-    if (!p.plan_halo && !smallc && p.ncls == 1 && p.math == XV2_MATH_F32X3) {
+    if (!p.plan_halo && !smallc && p.ncls == 1 && (p.math == XV2_MATH_F32X3 || p.math == XV2_MATH_BF16_STORE)) {
         // small grids (the /8 ... /32 encoder levels): sg_conv.hip instead of a 64-row / split-K plan of the tiled kernel.
         // Forward launches with statistics: the descriptor queries (xv2_conv2d_forward_stats_tiles / _tile_rows / _workspace)
         // already answered with sg_planned_rows() for this shape, so the partials have that geometry whichever kernel runs -
@@ -2036,7 +2036,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         const int planned = (p.stats && !p.A1 && p.C1 == 0 && !p.bnb_y) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
         const int R = planned ? planned : (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
         IgemmParams q = p;
-        if (f16x2_ready(q) && sg_conv_eligible(q, smallc, R)) return sg_conv_launch(q, R, stream);
+        if ((p.math == XV2_MATH_BF16_STORE || f16x2_ready(q)) && sg_conv_eligible(q, smallc, R)) return sg_conv_launch(q, R, stream);
         if (planned) {
             XV2_CHECK_ARG(planned == 64, "igemm: the small-grid plan expects 64-row statistics tiles");
             bm = 64;

@@ -425,7 +425,8 @@ template <typename T>
 static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, double* scratch, hipStream_t st,
                         float* f0 = nullptr, float* f1 = nullptr, const BnFinalize* fin = nullptr) {
     int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));
-    if (S < 1) S = 1;
+    static const int force_s1 = [] { const char* e = getenv("XV2_STATS_S1"); return e ? atoi(e) : 0; }();      // (race hunting: no ticket hand-off)
+    if (S < 1 || force_s1) S = 1;
     const int groups = (int)cdiv(C, 32);
     XV2_CHECK_ARG(groups <= 4096, "reduce_stats: C=%d too large", C);
     unsigned* tickets = S > 1 ? take_tickets(groups) : nullptr;

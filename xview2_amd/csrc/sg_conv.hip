@@ -29,11 +29,13 @@ namespace xv2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct SgParams {
-    const float* A;           // [pixels][lda] fp32 activations (forward) / output gradient (backward-data)
-    const void* Bx2;          // two scaled fp16 planes of the packed weights: [N / 64][T][C / 16][2][64][16]
-    float* Out;               // [pixels][ldo]
+    const void* A;            // [pixels][lda] activations (forward) / output gradient (backward-data): fp32, or bf16 (HS)
+    const void* Bx2;          // fp32 tensors: two scaled fp16 planes of the packed weights [N / 64][T][C / 16][2][64][16];
+                              // bf16 storage: the packed bf16 weights themselves [N][T][C]
+    void* Out;                // [pixels][ldo], the tensors' element type
     float* stats;             // [ceil(M / R)][N][2] BatchNorm partials (sum, sum of squares) or nullptr
     const unsigned* amaxA;    // recorded maxima (64 slots each, xv2_common.h)
     const unsigned* amaxB;
@@ -47,7 +49,7 @@ struct SgParams {
     unsigned bytesA, bytesB, bytesO;
     int M, N, C, T, lda, ldo, accum, R;
     int IH, IW, OHl, OWl, s_in, osN, osH, osW, os0;
-    int mtiles, ntiles, nsl;  // nsl = C / 16
+    int mtiles, ntiles, nsl;  // nsl = K stages per tap: C / 16 (fp32 tensors), C / 32 (bf16 storage)
     float rcp_ntiles;
     Tap taps[9];
 };
@@ -91,8 +93,13 @@ __device__ __forceinline__ void sg_lds_read2_wait(unsigned a0, unsigned a1, floa
 // What bounds a launch of this size is INSTRUCTION ISSUE outside the K loop (measured: 10.5 us at K = 64 for a version with
 // ~2300 instructions of prologue + epilogue per wave, two waves per SIMD): the epilogue exchanges the partial tiles as 16-byte
 // vectors and stores through a buffer resource (32-bit offsets), the DMA addresses are a per-lane constant + a scalar.
-template <int WM, int G, int NB, bool PLAIN>
+// HS = bf16 storage (XV2_MATH_BF16_STORE, --precision 16): bf16 activations / packed weights / outputs, v_mfma_f32_32x32x16_bf16,
+// no operand split and no scales; a stage is 32 channels - the same 64-byte rows, the same 1 KB DMA pieces and the same LDS image
+// as the 16 fp32 channels of the F16X2 form - read as two 16-channel MFMA steps; statistics on the values as stored.
+template <int WM, int G, int NB, bool PLAIN, bool HS>
 __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams p) {
+    constexpr int ES = HS ? 2 : 4;             // bytes per tensor element
+    constexpr int CHK = 16 / ES;               // channels per 16-byte chunk
     constexpr int BM = 32 * WM, BN = 32 * NB;
     constexpr int BSL = NB * 2048;             // bytes of one group's weight stage: NB * 32 rows x 16 channels x 2 planes x 2 B
     constexpr int ASL = WM * 2048;             // ... of its activation stage: BM rows x 16 channels fp32
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     for (int u = 0; u < 2; ++u) {
         const int r = u * 16 + (lane >> 2), cs = lane & 3;
         dok[u] = row0 + r < p.M;
-        dchk[u] = (cs ^ ((r >> 2) & 3)) * 4;             // first channel (of the 16-channel step) this lane's chunk holds
+        dchk[u] = (cs ^ ((r >> 2) & 3)) * CHK;           // first channel (of the stage) this lane's chunk holds
         if constexpr (PLAIN) {
             dpix[u] = row0 + r;
             dih[u] = diw[u] = 0;
@@ -148,7 +155,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
             decode(row0 + r, dih[u], diw[u], dpix[u], ox);
         }
     }
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.bytesA, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bx2), 0, p.bytesB, 0x00020000);
 
     const int nsteps = p.T * p.nsl / G;        // 16-channel K steps of this group
@@ -156,7 +163,9 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     int td = PLAIN ? 0 : ks0 / p.nsl, sd = ks0 - td * p.nsl, left = nsteps;      // DMA stream: tap, 16-channel slice, stages still to issue
     // per-lane DMA offsets: a constant per tap (recomputed when the stream moves to the next tap) + a scalar per stage
     const int bvo = lane * 16;
-    int avo[2], bso[NB / 2];
+    // (HS: per-piece lane offsets into the packed weights + one scalar.  Scalars, not an array: a captured int[ND] inside the DMA
+    //  lambda made the HOST stub of one instantiation vanish without a diagnostic - undefined symbol at load time)
+    int avo[2], bso[NB / 2], bvh0 = 0, bvh1 = 0, bvh2 = 0, bvh3 = 0, bsh = 0;
     auto set_tap = [&]() {
         const Tap tp = p.taps[td < p.T ? td : 0];
 #pragma unroll
@@ -166,11 +175,26 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
                 const int ih = dih[u] + tp.dh, iw = diw[u] + tp.dw;
                 ok = ok && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
             }
-            avo[u] = ok ? ((dpix[u] + (PLAIN ? 0 : tp.dh * p.IW + tp.dw)) * p.lda + dchk[u]) * 4 : (int)0x80000000;
+            avo[u] = ok ? ((dpix[u] + (PLAIN ? 0 : tp.dh * p.IW + tp.dw)) * p.lda + dchk[u]) * ES : (int)0x80000000;
         }
+        if constexpr (HS) {
+            bsh = tp.slot * p.C * 2;
+        } else {
 #pragma unroll
-        for (int un = 0; un < NB / 2; ++un) bso[un] = (((nt * (NB / 2) + un) * p.T + tp.slot) * p.nsl) * 4096;
+            for (int un = 0; un < NB / 2; ++un) bso[un] = (((nt * (NB / 2) + un) * p.T + tp.slot) * p.nsl) * 4096;
+        }
     };
+    if constexpr (HS) {
+        // weight stage = BN rows x 64 bytes, the same swizzled image as the activations': piece = 16 rows, lane -> (row, chunk)
+        auto piece_off = [&](int u) {
+            const int r = (m * ND + u) * 16 + (lane >> 2);
+            return ((nt * BN + r) * p.T * p.C + (((lane & 3) ^ ((r >> 2) & 3)) * 8)) * 2;
+        };
+        bvh0 = piece_off(0);
+        if constexpr (ND > 1) bvh1 = piece_off(1);
+        if constexpr (ND > 2) bvh2 = piece_off(2);
+        if constexpr (ND > 3) bvh3 = piece_off(3);
+    }
     set_tap();
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -180,6 +204,14 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         const bool live = left > 0;
         const int vb = live ? bvo : (int)0x80000000;
         char* sb = smem + slot * STAGE + g * GSL;
+        if constexpr (HS) {
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {        // weights: piece = 16 rows x 64 bytes of the packed bf16 operand
+                const int vo = u == 0 ? bvh0 : u == 1 ? bvh1 : u == 2 ? bvh2 : bvh3;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(sb + (m * ND + u) * 1024), 16,
+                                                         live ? vo : (int)0x80000000, bsh + sd * 64, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < ND; ++u) {          // weights: piece = (64-row unit, 1 KB quarter) of the pre-split image
             const int piece = m * ND + u, unit = piece >> 2;
@@ -194,6 +226,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
                 default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst), 16, vb, so, 3072, 0); break;
             }
         }
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)             // activations: rows 16 u .. 16 u + 15 of this wave's block; padding / rows past M -> zeros
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sb + BSL + m * 2048 + u * 1024), 16,
@@ -205,24 +238,37 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
             set_tap();
         }
     };
-    f16x8 bfrag[2][NB][2];
-    const unsigned boff = (unsigned)(l31 * 32 + ((h ^ ((l31 >> 2) & 1)) * 16));        // row l31 (+ 32: same swizzle bit) of a 64-row unit
+    f16x8 bfrag[2][NB][2];      // [double buffer][column block][fp32 tensors: plane h / m; bf16 storage: MFMA step 0 / 1] (bit patterns)
+    const unsigned boff = HS ? (unsigned)(l31 * 64) : (unsigned)(l31 * 32 + ((h ^ ((l31 >> 2) & 1)) * 16));
     auto read_b = [&](int slot, f16x8 (&fb)[NB][2]) {
         const char* base = smem + slot * STAGE + g * GSL + boff;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const char* b = base + (j >> 1) * 4096 + (j & 1) * 1024;
-            fb[j][0] = *reinterpret_cast<const f16x8*>(b);
-            fb[j][1] = *reinterpret_cast<const f16x8*>(b + 2048);
+            if constexpr (HS) {      // row 32 j + l31 (its swizzle bits are l31's), chunks h and 2 + h
+                const char* b = base + j * 2048;
+                fb[j][0] = *reinterpret_cast<const f16x8*>(b + ((h ^ ((l31 >> 2) & 3)) * 16));
+                fb[j][1] = *reinterpret_cast<const f16x8*>(b + (((2 + h) ^ ((l31 >> 2) & 3)) * 16));
+            } else {
+                const char* b = base + (j >> 1) * 4096 + (j & 1) * 1024;
+                fb[j][0] = *reinterpret_cast<const f16x8*>(b);
+                fb[j][1] = *reinterpret_cast<const f16x8*>(b + 2048);
+            }
         }
     };
     // activation fragment of a stage: chunks 2 h, 2 h + 1 of row l31 -> the two scaled fp16 planes (ah, am)
-    const unsigned aoff0 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((2 * h) ^ ((l31 >> 2) & 3)) * 16));
-    const unsigned aoff1 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((2 * h + 1) ^ ((l31 >> 2) & 3)) * 16));
+    // (fp32 tensors: chunks 2 h, 2 h + 1 = the lane's 8 channels of the 16-channel step; bf16 storage: chunks h and 2 + h = its 8
+    //  channels of MFMA step 0 and of step 1)
+    const unsigned aoff0 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((HS ? h : 2 * h) ^ ((l31 >> 2) & 3)) * 16));
+    const unsigned aoff1 = lds0 + (unsigned)(g * GSL + BSL + m * 2048 + l31 * 64 + (((HS ? 2 + h : 2 * h + 1) ^ ((l31 >> 2) & 3)) * 16));
     float sA = 1.f;
     auto read_split_a = [&](int slot, f16x8& ah, f16x8& am) {
         float4 ra[2];
         sg_lds_read2_wait(aoff0 + slot * STAGE, aoff1 + slot * STAGE, ra);
+        if constexpr (HS) {      // (the registers ARE the operands: ah = step 0, am = step 1)
+            ah = __builtin_bit_cast(f16x8, ra[0]);
+            am = __builtin_bit_cast(f16x8, ra[1]);
+            return;
+        }
 #if XV2_SGABL & 4
         ah = __builtin_bit_cast(f16x8, ra[0]);
         am = __builtin_bit_cast(f16x8, ra[1]);
@@ -240,9 +286,12 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     dma(0);
     dma(1);
     dma(2);
-    const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
-    sA = amax_scale(ea);
-    const float inv = amax_inv(ea) * amax_inv(eb);
+    float inv = 1.f;
+    if constexpr (!HS) {
+        const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
+        sA = amax_scale(ea);
+        inv = amax_inv(ea) * amax_inv(eb);
+    }
 
     f32x16 acc[NB];
 #pragma unroll
@@ -278,6 +327,16 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
 #if XV2_SGABL & 1
         return;
 #endif
+        if constexpr (HS) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afh[ph]), __builtin_bit_cast(bf16x8, bfrag[ph][j][0]), acc[j], 0, 0, 0);
+            read_split_a(nslot, afh[ph ^ 1], afm[ph ^ 1]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afm[ph]), __builtin_bit_cast(bf16x8, bfrag[ph][j][1]), acc[j], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afm[ph], bfrag[ph][j][0], acc[j], 0, 0, 0);
         // (unconditional - behind the last stage it reads a slot of zeros: the split then sits in ONE scheduling region with the
@@ -337,13 +396,16 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         for (int e = 0; e < 4; ++e) {
             const int rw = 8 * kq + 4 * h + e;
             const int px = PLAIN ? row0 + rw : __shfl(opix, rw, 64);
-            ooff[4 * q + e] = 8 * kq + e < rows_left ? (px * p.ldo + col0 + jq * 32) * 4 : (int)0x80000000;
+            ooff[4 * q + e] = 8 * kq + e < rows_left ? (px * p.ldo + col0 + jq * 32) * ES : (int)0x80000000;
         }
     }
     float oldv[S];
     if (p.accum) {
 #pragma unroll
-        for (int q = 0; q < S; ++q) oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, ooff[q], 0, 0));
+        for (int q = 0; q < S; ++q) {
+            if constexpr (HS) oldv[q] = bf16_to_f32((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsO, ooff[q], 0, 0));
+            else oldv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsO, ooff[q], 0, 0));
+        }
     }
     __syncthreads();
     float fin[S];
@@ -372,7 +434,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         }
     }
     if (p.ep_scale) {      // (eval-mode BatchNorm folded to scale / shift, residual, activation: xv2_conv2d_forward_fused)
-        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ep_res ? p.ep_res : p.Out), 0, p.bytesO, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(p.ep_res ? (void*)const_cast<float*>(p.ep_res) : p.Out, 0, p.bytesO, 0x00020000);
 #pragma unroll
         for (int q = 0; q < SV; ++q) {
             const int c = col0 + ((g * SV + q) / 4) * 32;
@@ -388,7 +450,13 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
 #pragma unroll
     for (int q = 0; q < S; ++q) {
         outv[q] = p.accum ? fin[q] + oldv[q] : fin[q];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv[q]), rsO, ooff[q], 0, 0);      // (rows past M: dropped by the hardware)
+        if constexpr (HS) {      // rounded once, at the store; the statistics below are taken on the value as stored
+            const bf16_t sv = f32_to_bf16(outv[q]);
+            __builtin_amdgcn_raw_buffer_store_b16((short)sv, rsO, ooff[q], 0, 0);
+            fin[q] = bf16_to_f32(sv);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, outv[q]), rsO, ooff[q], 0, 0);      // (rows past M: dropped by the hardware)
+        }
     }
     if (p.amax_out) {
         float amx = 0.f;
@@ -443,19 +511,19 @@ static int sg_mode() {      // XV2_SG=0: these layers stay on the tiled implicit
     return v;
 }
 
-template <int WM, int G, int NB, bool PLAIN>
+template <int WM, int G, int NB, bool PLAIN, bool HS>
 static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStream_t stream) {
     constexpr size_t ring = (size_t)3 * G * (NB + WM) * 2048;
     constexpr size_t redb = G > 1 ? (size_t)WM * G * NB * 4 * 1024 : 0;
     constexpr size_t smem = (ring > redb ? ring : redb) + 1024;
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = sg_conv_kernel<WM, G, NB, PLAIN>;
+    auto kern = sg_conv_kernel<WM, G, NB, PLAIN, HS>;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     XV2_CHECK_HIP(attr_rc);
     static const int kid = [] {
         char nm[64];
-        snprintf(nm, sizeof(nm), "sg_conv_kernel<%d,%d,g%d,%sf16x2>", 32 * WM, 32 * NB, G, PLAIN ? "1x1," : "");
+        snprintf(nm, sizeof(nm), "sg_conv_kernel<%d,%d,g%d,%s%s>", 32 * WM, 32 * NB, G, PLAIN ? "1x1," : "", HS ? "bf16hbm" : "f16x2");
         return prof_register(nm);
     }();
     const int total = q.mtiles * q.ntiles, grid = 8 * ((total + 7) / 8);
@@ -495,9 +563,17 @@ int sg_pick(int64_t M, int N, int ksteps, int R) {
 // A launch that is PLANNED for this kernel from its shape alone (the statistics-geometry queries of the convolution descriptor
 // and the launcher must agree before the operand maxima are known): rows per statistics tile of that plan, 0 = not planned.
 // The launcher falls back to a 64-row tiling of the tiled kernel - the same geometry - when the operands turn out not to be ready.
+static bool sg_bf16_enabled() {      // XV2_SG_BF16=0: --precision 16 launches stay on the tiled kernels (A/B runs)
+    static const int v = [] { const char* e = getenv("XV2_SG_BF16"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+// channels per K stage: 16 fp32 channels (F16X2) or 32 bf16 channels (bf16 storage) - 64 bytes of a pixel either way
+static int sg_stage_channels(int math) { return math == XV2_MATH_BF16_STORE ? 32 : 16; }
 int sg_planned_rows(int64_t M, int N, int C, int T, int math) {
-    if (sg_mode() == 0 || math != XV2_MATH_F32X3 || C % 16 != 0 || T > 9 || N % 64 != 0 || M > 40000) return 0;
-    const int cfg = sg_pick(M, N, T * (C / 16), 0);
+    if (sg_mode() == 0 || (math != XV2_MATH_F32X3 && !(math == XV2_MATH_BF16_STORE && sg_bf16_enabled()))) return 0;
+    const int kc = sg_stage_channels(math);
+    if (C % kc != 0 || T > 9 || N % 64 != 0 || M > 40000) return 0;
+    const int cfg = sg_pick(M, N, T * (C / kc), 0);
     return cfg ? 32 * (cfg / 100) : 0;
 }
 
@@ -506,36 +582,41 @@ static long long sg_out_bytes(const IgemmParams& p) {
     const ClassInfo& c = p.cls[0];
     const long long n = c.M / std::max(1, c.OHl * c.OWl);
     const long long last = (n - 1) * p.osN + (long long)(c.OHl - 1) * p.osH + (long long)(c.OWl - 1) * p.osW + c.os0;
-    return (last * p.ldo0 + p.Nout) * 4;
+    return (last * p.ldo0 + p.Nout) * (p.math == XV2_MATH_BF16_STORE ? 2 : 4);
 }
 
 bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
-    if (sg_mode() == 0 || smallc || p.math != XV2_MATH_F32X3 || p.npl != 2 || !p.Bx3 || !p.amaxA0 || !p.amaxB) return false;
+    const bool hs = p.math == XV2_MATH_BF16_STORE;
+    if (sg_mode() == 0 || smallc) return false;
+    if (hs ? (!sg_bf16_enabled() || p.ep_scale || p.amax_out) : (p.math != XV2_MATH_F32X3 || p.npl != 2 || !p.Bx3 || !p.amaxA0 || !p.amaxB)) return false;
     if (p.ncls != 1 || p.A1 || p.C1 != 0 || p.Out1 || p.N0 != p.Nout || p.T > 9) return false;
     if (p.bnb_y || p.pre_scale || p.cz || p.fold.on || p.plan_halo || p.plan_tiles) return false;
     if (p.ep_scale && ((p.ep_res && p.ep_ldres != p.ldo0) || p.stats || (p.accum & 1))) return false;
     if (p.bias && p.stats) return false;
     const ClassInfo& c = p.cls[0];
-    if (c.tap0 != 0 || c.ntaps != p.T || p.Ctot % 16 != 0) return false;
-    if ((reinterpret_cast<uintptr_t>(p.A0) & 15) || (p.ldA0 % 4) != 0) return false;
-    if ((long long)p.bytesA0 >= (1ll << 31) || sg_out_bytes(p) >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.Out0) & 3)) return false;
+    const int kc = sg_stage_channels(p.math);
+    if (c.tap0 != 0 || c.ntaps != p.T || p.Ctot % kc != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A0) & 15) || (p.ldA0 % (hs ? 8 : 4)) != 0 || (hs && (reinterpret_cast<uintptr_t>(p.B) & 15))) return false;
+    if (hs && (long long)p.Nout * p.T * p.Ctot * 2 >= (1ll << 31)) return false;
+    if ((long long)p.bytesA0 >= (1ll << 31) || sg_out_bytes(p) >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.Out0) & (hs ? 1 : 3))) return false;
     if (sg_mode() != 2 && c.M > 40000) return false;        // larger grids fill the chip with the tiled kernels
-    return sg_pick(c.M, p.Nout, p.T * (p.Ctot / 16), p.stats ? R : 0) != 0;
+    return sg_pick(c.M, p.Nout, p.T * (p.Ctot / kc), p.stats ? R : 0) != 0;
 }
 
 int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     const ClassInfo& c = p.cls[0];
     SgParams q;
-    q.A = p.A0; q.Bx2 = p.Bx3; q.Out = p.Out0; q.stats = p.stats;
+    const bool hs = p.math == XV2_MATH_BF16_STORE;
+    q.A = p.A0; q.Bx2 = hs ? (const void*)p.B : (const void*)p.Bx3; q.Out = p.Out0; q.stats = p.stats;
     q.amaxA = p.amaxA0; q.amaxB = p.amaxB; q.amax_out = p.amax_out;
     q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_res = p.ep_res; q.ep_act = p.ep_act; q.bias = p.bias;
-    q.bytesA = p.bytesA0; q.bytesB = p.bytesBx3;
+    q.bytesA = p.bytesA0; q.bytesB = hs ? (unsigned)((size_t)p.Nout * p.T * p.Ctot * 2) : p.bytesBx3;
     q.bytesO = (unsigned)sg_out_bytes(p);
     q.M = c.M; q.N = p.Nout; q.C = p.Ctot; q.T = p.T; q.lda = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1;
     q.R = p.stats ? R : 32;
     q.IH = p.IH; q.IW = p.IW; q.OHl = c.OHl; q.OWl = c.OWl; q.s_in = p.s_in;
     q.osN = p.osN; q.osH = p.osH; q.osW = p.osW; q.os0 = c.os0;
-    q.nsl = p.Ctot / 16;
+    q.nsl = p.Ctot / sg_stage_channels(p.math);
     for (int t = 0; t < p.T; ++t) q.taps[t] = p.taps[t];
     for (int t = p.T; t < 9; ++t) q.taps[t] = p.taps[0];
     const int cfg = sg_pick(c.M, p.Nout, p.T * q.nsl, p.stats ? R : 0);
@@ -544,16 +625,18 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     q.ntiles = p.Nout / (32 * nb);
     q.rcp_ntiles = 1.0f / (float)q.ntiles;
     const double flops = 2.0 * (double)c.M * p.Nout * (double)p.T * p.Ctot;
-    const double abytes = 4.0 * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
-                                 (double)c.M * p.Nout);
+    const double abytes = (hs ? 2.0 : 4.0) * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
+                                              (double)c.M * p.Nout);
     if (p.amax_out && p.amax_recorded) *p.amax_recorded = 1;
     // PLAIN: 1x1 / stride 1, pixel index = GEMM row on both sides
     const bool plain = p.T == 1 && p.s_in == 1 && p.taps[0].dh == 0 && p.taps[0].dw == 0 && c.os0 == 0 && p.osW == 1 && p.osH == c.OWl &&
                        p.osN == c.OHl * c.OWl && c.OHl == p.IH && c.OWl == p.IW;
 #define XV2_SG_CASE(CFG, WM_, G_, NB_)                                                         \
     case CFG:                                                                                    \
-        return plain ? sg_launch_one<WM_, G_, NB_, true>(q, flops, abytes, stream)               \
-                     : sg_launch_one<WM_, G_, NB_, false>(q, flops, abytes, stream);
+        return hs ? (plain ? sg_launch_one<WM_, G_, NB_, true, true>(q, flops, abytes, stream)         \
+                           : sg_launch_one<WM_, G_, NB_, false, true>(q, flops, abytes, stream))       \
+                  : (plain ? sg_launch_one<WM_, G_, NB_, true, false>(q, flops, abytes, stream)        \
+                           : sg_launch_one<WM_, G_, NB_, false, false>(q, flops, abytes, stream));
     switch (cfg) {
         XV2_SG_CASE(224, 2, 2, 4)
         XV2_SG_CASE(244, 2, 4, 4)
