@@ -748,6 +748,11 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
             read_a(0, fa0);
             read_bx(0, fb0);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            // EVERY wave holds its first fragments before any wave's first iteration re-fills ring slot 0 (the DMA of stage 3):
+            // in the loop that ordering comes from the barrier that ends the previous iteration, here it needs its own.  Without
+            // it a wave delayed between the barrier above and its reads (another process's waves on the same CU) picked up
+            // stage 3's weights as stage 0's - profiles/r05_race_halo_prologue.md
+            __syncthreads();
             int tp = 0, cs = cs_begin, bc = 0;
             for (int st = s_begin; st < s_end; st += 2) {
                 iterx(st, tp, cs, bc, fa0, fb0, fa1, fb1);
@@ -779,6 +784,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         read_a(0, fa0);
         read_b(0, fb0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        __syncthreads();      // (see the pre-split form above: the first iteration stores stage 2 into the buffer of stage 0)
         int tp = 0, cs = cs_begin;
         for (int st = s_begin; st < s_end; st += 2) {        // the stage count is even (two slices per 32-channel chunk)
             iter(st, tp, cs, fa0, fb0, fa1, fb1, rbb, rbb1);
@@ -923,6 +929,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 
         // the first fragments land before the loop is entered: otherwise the loop header, reached from here and from the
         // back edge, waits for lgkmcnt(0) in EVERY iteration - on the next stage's reads it has just issued
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        // ... and in EVERY wave before the first iteration stores stage 2 into the buffer of stage 0 ("every wave read it before
+        // the last barrier" holds from the second iteration on; profiles/r05_race_halo_prologue.md)
+        __syncthreads();
         if constexpr (PF == 4) {
         // raw sets rotate with period 3, fragment sets with period 2: six iterations per trip (the stage count is even;
         // iterations past s_end are skipped as a whole)
