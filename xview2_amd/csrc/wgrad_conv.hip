@@ -43,8 +43,25 @@ struct WgradParams {
     const unsigned* amaxX0;
     const unsigned* amaxX1;
     const unsigned* amaxDY;
+    int xcd_order;      // 1: XCD-aware block order (wgrad_block)
     WTap taps[52];
 };
+// Block order of the weight-gradient grids (x = (co, ci[, tap]) tile, y = pixel range).  The hardware hands linear block L to XCD L % 8,
+// so the tiles of ONE pixel range - which all read the same dY rows and X rows - land on eight different L2s and each operand row is
+// fetched from HBM once per XCD it meets (rocprofv3 FETCH_SIZE of wgrad_alltaps<f16x2>: 360 MB per launch against 128 MB algorithmic).
+// Re-numbered so that XCD k works through a CONTIGUOUS range of (pixel range, tile) pairs: the tiles of a pixel range follow each other on
+// one XCD and its L2 serves the re-reads.  (bx, by) is a bijection of the grid: every slab is written exactly once, as before.
+__device__ __forceinline__ void wgrad_block(int on, int& bx, int& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if (!on) return;
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int l = by * gx + bx;
+    const int q = nwg >> 3, r = nwg & 7, xcd = l & 7, loc = l >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = bid % gx;
+    by = bid / gx;
+}
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,13 +87,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     float* Bs = smem + 2 * 32 * BM;   // [2][32][BN]   X tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int l31 = lane & 31, h = lane >> 5;
     const int wk = wave % WK;
     const int wmn = wave / WK;
     const int wm = wmn / WGN, wn = wmn % WGN;
 
     // block -> (row tile, tap, column tile)
-    int b = blockIdx.x;
+    int b = bx;
     const int tn = b % p.tiles_n;
     b /= p.tiles_n;
     int tap = 0;
@@ -111,7 +130,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     }
     const int ohw = p.OH * p.OW;
 
-    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt0 = by * p.kt_per_split;
     const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
 
     float4 ra[APASS], rb[BPASS];
@@ -272,7 +291,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 
     // store the slab: part[split*WK + wk][co][T][Ctot]   (SMALLC: [co][T*4])
     const size_t rowlen = (size_t)p.T * p.Ctot;
-    float* slab = p.part + (size_t)(blockIdx.y * WK + wk) * p.Cout * rowlen;
+    float* slab = p.part + (size_t)(by * WK + wk) * p.Cout * rowlen;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int col = cn0 + wn * (NR * 32) + j * 32 + l31;
@@ -318,9 +337,11 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
     bf16_t* Bs = As + 2 * 32 * SA;                         // [2][32 px][SB]   X tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    int b = blockIdx.x;
+    int b = bx;
     const int tn = b % p.tiles_n;
     b /= p.tiles_n;
     const int tap = b % p.T;
@@ -329,7 +350,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
     const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
     const int dh = p.taps[tap].dh, dw = p.taps[tap].dw;
     const int ohw = p.OH * p.OW;
-    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int kt0 = by * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
 
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? p.X0 : p.X1), 0,
                                                                    first ? p.bytesX0 : p.bytesX1, 0x00020000);
@@ -427,7 +448,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
     }
     // slab: part[split][co][T][Ctot]
     const size_t rowlen = (size_t)p.T * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const size_t coloff = (size_t)tap * p.Ctot + cn0 + wn * (BN / 2) + j * 32 + l31;
@@ -456,9 +477,11 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     bf16_t* Bs = As + 32 * SA;                             // [32 px][SB]   X tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    int b = blockIdx.x;
+    int b = bx;
     const int tn = b % p.tiles_n;
     b /= p.tiles_n;
     const int tap = b % p.T;
@@ -467,7 +490,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     const int ldx = first ? p.ldX0 : p.ldX1, xch = first ? cn0 : cn0 - p.C0;
     const int dh = p.taps[tap].dh, dw = p.taps[tap].dw;
     const int ohw = p.OH * p.OW;
-    const int kt0 = blockIdx.y * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
+    const int kt0 = by * p.kt_per_split, kt1 = min(kt0 + p.kt_per_split, p.ktiles);
     float sX = 1.f, sD = 1.f;      // F16X2 operand scales
     if constexpr (NPL == 2) {
         sX = amax_scale(amax_exponent(first ? p.amaxX0 : p.amaxX1));
@@ -618,7 +641,7 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
     }
     // slab: part[split][co][T][Ctot]
     const size_t rowlen = (size_t)p.T * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
     float iX = 1.f, iD = 1.f;
     if constexpr (NPL == 2) {
         iX = amax_inv(amax_exponent(first ? p.amaxX0 : p.amaxX1));
@@ -658,11 +681,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
     float* Xs = smem + 2 * 32 * LDP;    // [4 ring rows][34 px][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int l31 = lane & 31, h = lane >> 5;
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
     const int co0 = tm * 32, cn0 = tn * 32;
     const int chunks = p.ktiles, rows_per = p.kt_per_split;
-    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int strip = by / chunks, chunk = by % chunks;
     const int tilesW = p.OW / 32;
     const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
     const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
@@ -777,7 +802,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps_kernel(const WgradParams
 
     // sum the 4 waves' k-partials through LDS (16 KB per tap) and write the block's slab part[y][co][T][Ctot]
     const size_t rowlen = (size_t)9 * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if constexpr (BF16) {
@@ -815,10 +840,12 @@ __global__ void __launch_bounds__(256, 4) wgrad_alltaps_tr_kernel(const WgradPar
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
     const int co0 = tm * 32, cn0 = tn * 32;
     const int chunks = p.ktiles, rows_per = p.kt_per_split;
-    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int strip = by / chunks, chunk = by % chunks;
     const int tilesW = p.OW / 32;
     const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
     const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
@@ -897,7 +924,7 @@ __global__ void __launch_bounds__(256, 4) wgrad_alltaps_tr_kernel(const WgradPar
 
     // fold the two k-groups of every tap through LDS and write the block's slab part[y][co][T][Ctot]
     const size_t rowlen = (size_t)9 * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const bool mine = (wk >> 1) == (t & 1);
@@ -930,10 +957,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 
     const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
     const int co0 = tm * 32, cn0 = tn * 32;
     const int chunks = p.ktiles, rows_per = p.kt_per_split;
-    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int strip = by / chunks, chunk = by % chunks;
     const int tilesW = p.OW / 32;
     const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
     const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
@@ -1006,7 +1035,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
 
     const int i16 = lane & 15, grp = lane >> 4;
     const int q0 = 16 * (wk & 1);
-    const int flip = (blockIdx.x ^ (blockIdx.x >> 3) ^ blockIdx.y ^ (blockIdx.y >> 3)) & 1;
+    const int flip = (bx ^ (bx >> 3) ^ by ^ (by >> 3)) & 1;
     const int odd = (wk >> 1) ^ flip;
     const int frow = q0 + 8 * (grp >> 1) + (i16 >> 2), fcol = 16 * (grp & 1) + 4 * (i16 & 3);
     auto frag = [&](const bf16_t* base) {
@@ -1069,7 +1098,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
 
     // fold the two k-groups of every tap through LDS and write the block's slab part[y][co][T][Ctot]
     const size_t rowlen = (size_t)9 * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
     float iX = 1.f, iD = 1.f;
     if constexpr (NPL == 2) {
         iX = amax_inv(amax_exponent(first ? p.amaxX0 : p.amaxX1));
@@ -1181,11 +1210,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
     constexpr int PL = W64_PL;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int wa = wave >> 1, wb = wave & 1;                            // co half / ci half of this wave's quadrant
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
     const int co0 = tm * 64, cn0 = tn * 64;
     const int chunks = p.ktiles, rows_per = p.kt_per_split;
-    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int strip = by / chunks, chunk = by % chunks;
     const int tilesW = p.OW / 32;
     const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
     const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
@@ -1325,7 +1356,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
     }
     // every wave writes its quadrant of the block's slab part[y][co][T][Ctot] (C layout of the 32x32 MFMA)
     const size_t rowlen = (size_t)9 * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
     const int l31 = lane & 31, hh = lane >> 5;
     float iX = 1.f, iD = 1.f;
     if constexpr (NPL == 2) {
@@ -1348,11 +1379,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_tr_kernel(const WgradP
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    wgrad_block(p.xcd_order, bx, by);
     const int wa = wave >> 1, wb = wave & 1;
-    const int tn = blockIdx.x % p.tiles_n, tm = blockIdx.x / p.tiles_n;
+    const int tn = bx % p.tiles_n, tm = bx / p.tiles_n;
     const int co0 = tm * 64, cn0 = tn * 64;
     const int chunks = p.ktiles, rows_per = p.kt_per_split;
-    const int strip = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
+    const int strip = by / chunks, chunk = by % chunks;
     const int tilesW = p.OW / 32;
     const int n = strip / tilesW, ow0 = (strip % tilesW) * 32;
     const int r0 = chunk * rows_per, r1 = min(r0 + rows_per, p.OH);
@@ -1434,7 +1467,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_tr_kernel(const WgradP
         __syncthreads();
     }
     const size_t rowlen = (size_t)9 * p.Ctot;
-    float* slab = p.part + (size_t)blockIdx.y * p.Cout * rowlen;
+    float* slab = p.part + (size_t)by * p.Cout * rowlen;
     const int l31 = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -1660,6 +1693,8 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     p.M = d->N * d->OH * d->OW;
     p.T = d->KH * d->KW;
     p.ktiles = pl.ktiles; p.kt_per_split = pl.kt_per;
+    static const int xcd_on = [] { const char* e = getenv("XV2_WGRAD_XCD"); return e ? atoi(e) : 1; }();      // (A/B runs: 0 = dispatch order)
+    p.xcd_order = xcd_on;
     p.tiles_n = pl.smallc ? (int)cdiv(p.T * 4, pl.bn) : p.Ctot / pl.bn;
     const size_t total = (size_t)d->Cout * p.T * p.Ctot;
     {
