@@ -1547,7 +1547,8 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
         //  64 x 64: 0.2 - 0.5, 32 x 32: 0.6 - 1.5 against the isolated-kernel values 5.2 / 2.25 of round 3, cfg2 fp32 21.18 -> 20.71 ms.
         //  The model prices a launch alone on the chip; on the side stream, next to the compute stream's HBM-bound BatchNorm passes,
         //  what a plan costs is its slab traffic and the CUs it holds - fewer, fatter blocks and fewer row chunks win.  bf16 storage
-        //  keeps its constants: 64 x 64 everywhere lost 0.75 ms on resnest50.)
+        //  likewise: 64 x 64 constant 1.144 -> 0.3, cfg2 --precision 16 13.09 -> 12.72 ms, cfg3 16.45 -> 15.9 ms, three same-box pairs -
+        //  round 3's "64 x 64 everywhere loses 0.75 ms on resnest50" no longer holds with the small-grid layers on sg_conv.)
         static const double trow64 = [] { const char* e = getenv("XV2_W64_TROW"); return e ? atof(e) : 0.4; }();
         const double slab_mb = 1e-6 * (double)d->Cout * 9.0 * Ctot * 4.0;
         const double slab_us = std::min(0.02 + 0.7 * slab_mb, 1.0 + 0.15 * slab_mb);   // per slab; small slabs sum in parallel
@@ -1562,7 +1563,9 @@ static WgradPlan make_plan(const xv2_conv_desc* d, bool x3 = false) {
             const int cap = wgrad_cap_override() ? wgrad_cap_override() : t64 ? 512 : x3 ? 768 : d->math ? 1024 : 512;
             // (64 x 64 row-step times fitted to the measured ratios on the 116-GFLOP layers: 0.86 split-bf16, ~0.7 bf16)
             static const double trow32 = [] { const char* e = getenv("XV2_W32_TROW"); return e ? atof(e) : 1.0; }();
-            const double t_row = t64 ? (x3 ? trow64 : 1.144) : x3 ? trow32 : d->math ? 0.8 : 2.4;
+            static const double trow64h = [] { const char* e = getenv("XV2_W64_TROW_HS"); return e ? atof(e) : 0.3; }();
+            static const double trow32h = [] { const char* e = getenv("XV2_W32_TROW_HS"); return e ? atof(e) : 0.8; }();
+            const double t_row = t64 ? (x3 ? trow64 : trow64h) : x3 ? trow32 : d->math ? trow32h : 2.4;
             double best_cost = 0.0;
             chunks_out = 1;
             for (int c = 1; c <= maxchunks && c <= 64; ++c) {
