@@ -563,6 +563,10 @@ int sg_pick(int64_t M, int N, int ksteps, int R) {
 // A launch that is PLANNED for this kernel from its shape alone (the statistics-geometry queries of the convolution descriptor
 // and the launcher must agree before the operand maxima are known): rows per statistics tile of that plan, 0 = not planned.
 // The launcher falls back to a 64-row tiling of the tiled kernel - the same geometry - when the operands turn out not to be ready.
+static int64_t sg_mlimit() {      // (A/B runs: XV2_SG_MLIMIT)
+    static const int64_t v = [] { const char* e = getenv("XV2_SG_MLIMIT"); return e ? (int64_t)atoll(e) : (int64_t)40000; }();
+    return v;
+}
 static bool sg_bf16_enabled() {      // XV2_SG_BF16=0: --precision 16 launches stay on the tiled kernels (A/B runs)
     static const int v = [] { const char* e = getenv("XV2_SG_BF16"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -572,7 +576,7 @@ static int sg_stage_channels(int math) { return math == XV2_MATH_BF16_STORE ? 32
 int sg_planned_rows(int64_t M, int N, int C, int T, int math) {
     if (sg_mode() == 0 || (math != XV2_MATH_F32X3 && !(math == XV2_MATH_BF16_STORE && sg_bf16_enabled()))) return 0;
     const int kc = sg_stage_channels(math);
-    if (C % kc != 0 || T > 9 || N % 64 != 0 || M > 40000) return 0;
+    if (C % kc != 0 || T > 9 || N % 64 != 0 || M > sg_mlimit()) return 0;
     const int cfg = sg_pick(M, N, T * (C / kc), 0);
     return cfg ? 32 * (cfg / 100) : 0;
 }
@@ -599,7 +603,7 @@ bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     if ((reinterpret_cast<uintptr_t>(p.A0) & 15) || (p.ldA0 % (hs ? 8 : 4)) != 0 || (hs && (reinterpret_cast<uintptr_t>(p.B) & 15))) return false;
     if (hs && (long long)p.Nout * p.T * p.Ctot * 2 >= (1ll << 31)) return false;
     if ((long long)p.bytesA0 >= (1ll << 31) || sg_out_bytes(p) >= (1ll << 31) || (reinterpret_cast<uintptr_t>(p.Out0) & (hs ? 1 : 3))) return false;
-    if (sg_mode() != 2 && c.M > 40000) return false;        // larger grids fill the chip with the tiled kernels
+    if (sg_mode() != 2 && c.M > sg_mlimit()) return false;        // larger grids fill the chip with the tiled kernels
     return sg_pick(c.M, p.Nout, p.T * (p.Ctot / kc), p.stats ? R : 0) != 0;
 }
 
