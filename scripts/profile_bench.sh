@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt /tmp/pf /tmp/pw
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-encoder-probe "$@" > $OUT/bench_under_trace.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-encoder-probe --no-split-check "$@" > $OUT/bench_under_trace.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-encoder-probe --no-prof --no-split-check "$@" > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-encoder-probe --no-prof --no-split-check "$@" > /dev/null 2>&1
 cd $R
