@@ -42,6 +42,14 @@ def pretty(mangled):
     m = re.match(r"_ZN3xv2\d+wgrad_tr_kernelILi(\d+)ELi(\d+)E", mangled)
     if m:
         return "wgrad_tr_kernel<%s,%s,bf16hbm>" % (m.group(1), m.group(2))
+    m = re.match(r"_ZN3xv2\d+sg_conv_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E", mangled)
+    if m:
+        wm, g, nb, plain, hs = (int(v) for v in m.groups())
+        return "sg_conv_kernel<%d,%d,g%d,%s%s>" % (32 * wm, 32 * nb, g, "1x1," if plain else "", "bf16hbm" if hs else "f16x2")
+    for nm in ("bn_act_bwd_rows_kernel", "column_partials_kernel", "bn_act_fwd_kernel", "reduce_stats_kernel", "wgrad_reduce_t_kernel",
+               "wgrad_reduce_kernel", "splitk_reduce_kernel", "adamw_dev_kernel", "stem7x7_kernel", "stem7x7_wgrad_kernel"):
+        if nm in mangled:
+            return nm
     m = re.match(r"_ZN3xv2\d+(igemm|wgrad)_kernelI(.*?)EEv", mangled)
     if not m:
         return None
