@@ -186,6 +186,10 @@ class _AmaxPool:
             return None          # (amax_begin_capture: only the first half is zeroed by the graph)
         if i == self.P:
             i = 0
+        if (i == 0 or i == self.P // 2) and self.gen[1] and _wgrad_stream is not None and not self.capturing:
+            # weight-gradient launches still queued on the side stream read their operands' slots there: the half is zeroed on the
+            # compute stream only behind them (twice per 4096 layers - cfg5 takes ~1300 per step)
+            torch.cuda.current_stream().wait_stream(_wgrad_stream)
         if i == 0 and self.gen[1]:
             self.buf[:self.P // 2].zero_()
             self.gen[0] += 1
