@@ -56,3 +56,20 @@ if os.environ.get("XV2_PROF_EXCESS") == "1":
     for e in ex[:70]:
         print("#%3d %-46s %7.3f ms  bound %6.3f  excess %6.3f   %7.2f GF %7.1f MB  %s" % (
             e[6], e[5], e[1], e[2], e[0], e[3], e[4], "flops" if e[3] / 210.0 > e[4] / 5000.0 else "bytes"))
+# Both roofs for EVERY launch: MFMA floor = flops / the bound of the launch's instruction stream (833.3 TFLOP/s two
+# fp16 planes, 416.7 three bf16 planes, 2500 bf16 storage, 157.3 exact fp32), HBM floor = algorithmic bytes / 6.29 TB/s; roof = the
+# larger floor / measured time; launch order (forward, then backward)
+if os.environ.get("XV2_PROF_ROOFS") == "1":
+    def bound(name):
+        return 833.3 if "f16x2" in name else 416.7 if "f32x3" in name else 2500.0 if "bf16" in name else 157.3
+    rows.sort(key=lambda r: r[4])
+    clears = 0
+    print("%4s %-46s %8s %8s %8s %8s %6s %6s %6s" % ("#", "kernel", "us", "GFLOP", "MB(alg)", "TFLOP/s", "mfma", "hbm", "roof"))
+    for ms, gf, mb, name, i in rows:
+        fm, fh = gf / bound(name) / ms, mb / 6290.0 / ms
+        ok = gf / 833.3 / ms >= 0.25 or fh >= 0.6
+        clears += ok
+        print("%4d %-46s %8.1f %8.2f %8.1f %8.1f %6.2f %6.2f %6.2f %s" % (i, name, ms * 1e3, gf, mb, gf / ms, fm, fh, max(fm, fh), "*" if ok else ""))
+    print("launches at >= 0.25 of 833 TFLOP/s or >= 0.6 of their HBM floor (*): %d of %d; time in them %.2f of %.2f ms" % (
+        clears, len(rows), sum(r[0] for r in rows if (r[1] / 833.3 / r[0] >= 0.25 or r[2] / 6290.0 / r[0] >= 0.6)), tot))
+
