@@ -23,6 +23,9 @@ SHAPES = [  # name, N, H, W, Cin, Cout, k, stride
     ("l4.conv2 512->512 3x3 @32", 2, 32, 32, 512, 512, 3, 1),
     ("l4.0.ds 1024->2048 s2 @64", 2, 64, 64, 1024, 2048, 1, 2),
 ]
+if os.environ.get("XV2_BENCH_SG_BIG") == "1":      # the /4 and /2 levels (M = 131072 / 524288): only with XV2_SG_MLIMIT raised do they run sg_conv
+    SHAPES = [("l1.conv2 64->64 3x3 @256", 2, 256, 256, 64, 64, 3, 1), ("l2.0.conv1 256->128 @256", 2, 256, 256, 256, 128, 1, 1),
+              ("dec4.c2 64->64 3x3 @512", 2, 512, 512, 64, 64, 3, 1), ("dec3.c2 128->128 3x3 @256", 2, 256, 256, 128, 128, 3, 1)]
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
 ITERS = 20
 def records():

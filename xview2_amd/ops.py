@@ -872,11 +872,30 @@ def wgrad_stream():
 _join_queued = False
 
 
+# Operands of launches on the side stream must outlive them.  Tensor.record_stream() does that through the caching allocator (an
+# event per block, polled on later allocations: ~3 us of host time per tensor, ~200 tensors per step); holding a reference until the
+# compute stream has joined the side stream does the same for the price of a list append - and of memory: the gradients of a backward
+# pass then stay allocated until its end (cfg2: +2.8 GB).  XV2_SIDE_KEEP=0: record_stream.
+SIDE_KEEP = os.environ.get("XV2_SIDE_KEEP", "1") != "0"
+_side_keep = []
+
+
+def _keep_for_side(tensors, side):
+    if SIDE_KEEP and _join_queued:          # (a join is scheduled for the end of this backward pass: the references die there)
+        _side_keep.append(tensors)
+        return
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+
+
 def join_wgrad_stream():
     global _join_queued
     _join_queued = False
     if _wgrad_stream is not None:
         torch.cuda.current_stream().wait_stream(_wgrad_stream)
+    # (allocations that re-use these blocks are made on the compute stream, behind the wait above)
+    _side_keep.clear()
 
 
 def _conv_backward_weight_pre(y0, pre, dy, weight, g, wparam=None):
@@ -909,8 +928,7 @@ def _conv_backward_weight_pre(y0, pre, dy, weight, g, wparam=None):
     call("xv2_conv2d_backward_weight_pre_async", d, y0, C0t, pre[0], pre[1], pre[2], dy, Cout_t, dw, ws,
          side.cuda_stream if side is not None else None)
     if side is not None:
-        for t in (y0, dy, pre[0], pre[1]):
-            t.record_stream(side)
+        _keep_for_side((y0, dy, pre[0], pre[1]), side)
     return dw
 
 
@@ -955,9 +973,7 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None, amax=None):
         side.wait_stream(torch.cuda.current_stream())          # dy (and x) are ready on the compute stream
         with torch.cuda.stream(side):
             dw = _conv_backward_weight_impl(x0, x1, dy, weight, g, wparam, out, amax)
-    for t in (x0, x1, dy):                                 # keep the caching allocator from recycling them early
-        if t is not None:
-            t.record_stream(side)
+    _keep_for_side((x0, x1, dy), side)                     # keep the caching allocator from recycling them early
     return dw
 
 
