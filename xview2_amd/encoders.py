@@ -116,10 +116,11 @@ class SplAtConv2d(nn.Module):
 
     def forward(self, x):
         x = xnn.conv_bn_act(self.conv, self.bn0, x, act=ops.ACT_RELU)
-        xnn.bump_bn_counter(self.bn1)
-        out = ops.SplitAttentionFn.apply(x, self.fc1.weight, self.fc1.bias, self.bn1.weight, self.bn1.bias,
-                                         self.fc2.weight, self.fc2.bias, ops.BnState(self.bn1, xnn.SYNC_BN),
-                                         self.bn1.training)
+        m = self._modules
+        bn1, f1, f2 = m["bn1"], m["fc1"]._parameters, m["fc2"]._parameters      # (dict reads: Module.__getattr__ is the slow path)
+        xnn.bump_bn_counter(bn1)
+        bs = ops.BnState(bn1, xnn.SYNC_BN)
+        out = ops.SplitAttentionFn.apply(x, f1["weight"], f1["bias"], bs.weight, bs.bias, f2["weight"], f2["bias"], bs, bn1.training)
         # (the attention weights of a channel are a softmax over the radix: |sum_r att_r * x_r| <= max |x| - the input's
         #  recorded maximum bounds the output)
         return ops.carry_amax(x, out)

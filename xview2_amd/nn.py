@@ -35,7 +35,9 @@ def _flush_bn_counter(bn, *_):
 def bump_bn_counter(bn):
     """num_batches_tracked += 1 without a device launch per layer per step: counted on the host and written
     back whenever the module's state_dict is taken (checkpoint surface stays exact)."""
-    if not (bn.training and bn.num_batches_tracked is not None):
+    # (parameters and buffers are read from the module's own dicts on the hot path: Module.__getattr__ is the slow fallback of the
+    #  attribute lookup - 0.36 us a piece, 7700 of them per cfg5 step)
+    if not (bn.training and bn._buffers.get("num_batches_tracked") is not None):
         return
     if not hasattr(bn, "_xv2_pending"):
         bn._xv2_pending = 0
@@ -76,8 +78,9 @@ def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthro
         return _with_aliases(z, x0, x1, passthrough)
     bump_bn_counter(bn)
     # lazy_out: the result feeds exactly ONE further conv_bn_act call and nothing else (see ops.ConvBnActFn.forward)
-    out = ops.ConvBnActFn.apply(x0, x1, conv.weight, bn.weight, bn.bias, residual, _cfg(conv),
-                                ops.BnState(bn, SYNC_BN), act, bn.training, passthrough, lazy_out)
+    bs = ops.BnState(bn, SYNC_BN)
+    out = ops.ConvBnActFn.apply(x0, x1, conv._parameters["weight"], bs.weight, bs.bias, residual, _cfg(conv),
+                                bs, act, bn.training, passthrough, lazy_out)
     if passthrough == 3:
         ops.carry_amax(x0, out[1])
         ops.carry_amax(x1, out[2])
@@ -105,7 +108,8 @@ def conv(conv_m, x0, x1=None):
 
 def bn_act(bn, y, act=ops.ACT_NONE, residual=None):
     bump_bn_counter(bn)
-    return ops.BnActFn.apply(y, bn.weight, bn.bias, residual, ops.BnState(bn, SYNC_BN), act, bn.training)
+    bs = ops.BnState(bn, SYNC_BN)
+    return ops.BnActFn.apply(y, bs.weight, bs.bias, residual, bs, act, bn.training)
 
 
 def head_conv(conv_m, x, nchw_out=True):

@@ -1272,8 +1272,9 @@ class BnState:
     __slots__ = ("weight", "bias", "running_mean", "running_var", "eps", "momentum", "sync")
 
     def __init__(self, m, sync=False):
-        self.weight, self.bias = m.weight, m.bias
-        self.running_mean, self.running_var = m.running_mean, m.running_var
+        p, b = m._parameters, m._buffers          # (not m.weight ...: Module.__getattr__ is the slow path of the lookup)
+        self.weight, self.bias = p["weight"], p["bias"]
+        self.running_mean, self.running_var = b["running_mean"], b["running_var"]
         self.eps, self.momentum = m.eps, m.momentum
         self.sync = sync
 
