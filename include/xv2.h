@@ -567,6 +567,29 @@ int xv2_argmax_nchw(const float* logits, int N, int C, int64_t hw, int add, uint
 int xv2_f1_counts(const uint8_t* pred, const uint8_t* target, int64_t total, int n_class, int masked,
                   int64_t* counts, void* stream);
 
+/* ---- grouped layers behind one call (ResNeSt's radix-2 3x3 convolution: reference call site model/unet.py:52 via the
+ * resnest encoders, oracle/backbones.py:115-171 Conv2d(groups = 2) -> bn0 -> ReLU).  `d` describes ONE group (C0 and Cout are
+ * channels per group), the ld* arguments are the channel strides of the whole tensors, w[g] are the packed weights of group g.
+ * Each function issues exactly the per-group calls named in its comment, group after group: bit-identical to them. */
+/* groups x xv2_conv2d_forward_bn (statistics + coefficients of the group's channels), then ONE xv2_bn_act_forward[_mask] over
+ * all groups * Cout channels */
+int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int groups, const void* x0, int ldx0,
+                                    const void* const* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
+                                    float* workspace, double* sums, double* scratch, double count,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* mean, float* invstd,
+                                    float* scale, float* shift, const void* residual, int ldr, int act, void* z,
+                                    int ldz, uint8_t* zmask, int dtype, void* stream);
+/* groups x xv2_conv2d_backward_data_acc */
+int xv2_conv2d_backward_data_grouped(const xv2_conv_desc* d, int groups, const void* dy, int lddy,
+                                     const void* const* w_ihwo, void* dx0, int lddx0, int accumulate,
+                                     float* workspace, int dtype, void* stream);
+/* xv2_conv2d_backward_weight_async for the first group (the hop to side_stream), xv2_conv2d_backward_weight on side_stream for
+ * the others; dw_oihw holds the groups' gradients back to back ([groups * Cout][cin_real][KH][KW]) */
+int xv2_conv2d_backward_weight_async_grouped(const xv2_conv_desc* d, int groups, const void* x0, int ldx0,
+                                             const void* dy, int lddy, float* dw_oihw, int cin_real,
+                                             float* workspace, int dtype, void* side_stream, void* stream);
+
 /* ---- optimizer (model/plt.py:154 torch.optim.AdamW) ---------------------------------------- */
 int xv2_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,

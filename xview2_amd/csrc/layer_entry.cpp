@@ -8,6 +8,7 @@
 // exactly the launches of the calls they replace, in the same order on the same stream - results are bit-identical.
 #include "../../include/xv2.h"
 #include "amax_ctx.h"
+#include "xv2_common.h"
 
 int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream);      // igemm_conv.hip
 
@@ -111,3 +112,70 @@ extern "C" int xv2_splat_tail_backward(const void* x, const void* dout, int N, i
     if (rc) return rc;
     return xv2_splat_apply_backward(x, att, dout, dgap, N, hw, C, dx, nullptr, workspace, dtype, stream);
 }
+
+// ---- grouped layers (ResNeSt's radix-2 3x3 convolution, oracle/backbones.py:115-171: Conv2d(groups = 2) -> bn0 -> ReLU) ----
+// The op-level path walks the groups in Python: per group one xv2_conv2d_forward_bn / _backward_data_acc / _backward_weight call
+// with channel-offset pointers (and, for the weight gradient, a Python-level stream switch).  132 such layers per cfg5 step made
+// 924 of its 2820 ABI calls.  These entry points issue the same calls, group after group, in the same order on the same streams -
+// bit-identical - behind one call each.  `d` is the geometry of ONE group (C0, Cout = channels per group); ld* are the strides of
+// the whole tensors; w[g] the packed weights of group g.
+extern "C" int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int groups, const void* x0, int ldx0,
+                                               const void* const* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
+                                               float* workspace, double* sums, double* scratch, double count,
+                                               const float* gamma, const float* beta, float eps, float momentum,
+                                               float* running_mean, float* running_var, float* mean, float* invstd,
+                                               float* scale, float* shift, const void* residual, int ldr, int act, void* z,
+                                               int ldz, uint8_t* zmask, int dtype, void* stream) {
+    XV2_CHECK_ARG(d && groups >= 1 && w_ohwi && x0 && y && z && mean && invstd && scale && shift && gamma && beta && running_mean &&
+                      running_var && sums && tiles > 0, "conv_bn_act_forward_grouped: null argument / no statistics tiles");
+    xv2::AmaxGuard amax_guard;      // the context's sources serve every group, its `out` the apply pass
+    const size_t es = dtype == XV2_BF16 ? 2 : 4;
+    const int ctot = groups * d->Cout;
+    for (int g = 0; g < groups; ++g) {
+        const int og = g * d->Cout;
+        int rc = xv2_conv2d_forward_bn(d, static_cast<const char*>(x0) + (size_t)g * d->C0 * es, ldx0, nullptr, 0, w_ohwi[g],
+                                       static_cast<char*>(y) + (size_t)og * es, ldy, stats_partials, workspace, 1, ctot,
+                                       sums + (size_t)og * 2, scratch, count, gamma + og, beta + og, eps, momentum,
+                                       running_mean + og, running_var + og, mean + og, invstd + og, scale + og, shift + og, stream);
+        if (rc) return rc;
+    }
+    const int64_t npix = (int64_t)d->N * d->OH * d->OW;
+    if (zmask) return xv2_bn_act_forward_mask(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, ctot, zmask, dtype, stream);
+    return xv2_bn_act_forward(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, ctot, dtype, stream);
+}
+
+extern "C" int xv2_conv2d_backward_data_grouped(const xv2_conv_desc* d, int groups, const void* dy, int lddy,
+                                                const void* const* w_ihwo, void* dx0, int lddx0, int accumulate,
+                                                float* workspace, int dtype, void* stream) {
+    XV2_CHECK_ARG(d && groups >= 1 && w_ihwo && dy && dx0, "conv2d_backward_data_grouped: null argument");
+    xv2::AmaxGuard amax_guard;      // dy's maximum serves every group
+    const size_t es = dtype == XV2_BF16 ? 2 : 4;
+    for (int g = 0; g < groups; ++g) {
+        int rc = xv2_conv2d_backward_data_acc(d, static_cast<const char*>(dy) + (size_t)g * d->Cout * es, lddy, w_ihwo[g],
+                                              static_cast<char*>(dx0) + (size_t)g * d->C0 * es, lddx0, nullptr, 0, accumulate,
+                                              workspace, stream);
+        if (rc) return rc;
+    }
+    return XV2_OK;
+}
+
+extern "C" int xv2_conv2d_backward_weight_async_grouped(const xv2_conv_desc* d, int groups, const void* x0, int ldx0,
+                                                        const void* dy, int lddy, float* dw_oihw, int cin_real,
+                                                        float* workspace, int dtype, void* side_stream, void* stream) {
+    XV2_CHECK_ARG(d && groups >= 1 && x0 && dy && dw_oihw, "conv2d_backward_weight_async_grouped: null argument");
+    xv2::AmaxGuard amax_guard;      // the operands' maxima (whole tensors: upper bounds for a group) serve every group
+    const size_t es = dtype == XV2_BF16 ? 2 : 4;
+    const size_t wper = (size_t)d->Cout * cin_real * d->KH * d->KW;
+    for (int g = 0; g < groups; ++g) {
+        const void* xg = static_cast<const char*>(x0) + (size_t)g * d->C0 * es;
+        const void* dg = static_cast<const char*>(dy) + (size_t)g * d->Cout * es;
+        // (the first group hops to the side stream behind the compute stream's work so far; the side stream runs the rest in order)
+        int rc = (g == 0 && side_stream && side_stream != stream)
+                     ? xv2_conv2d_backward_weight_async(d, xg, ldx0, nullptr, 0, dg, lddy, dw_oihw + g * wper, cin_real, workspace, side_stream, stream)
+                     : xv2_conv2d_backward_weight(d, xg, ldx0, nullptr, 0, dg, lddy, dw_oihw + g * wper, cin_real, workspace,
+                                                  side_stream ? side_stream : stream);
+        if (rc) return rc;
+    }
+    return XV2_OK;
+}
+

@@ -4,6 +4,7 @@ Every Function here owns its backward analytically (no torch op is differentiate
 backward both go through the C ABI.  Activations are NHWC tensors ``[N, H, W, C]`` (contiguous).
 PyTorch is used for device memory, streams and autograd bookkeeping only.
 """
+import ctypes
 import os
 import weakref
 from types import SimpleNamespace
@@ -728,6 +729,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
 
 
 LAYER_CALLS = os.environ.get("XV2_LAYER_CALLS", "1") != "0"      # layer-level ABI calls (include/xv2.h); 0: op by op
+GROUPED_CALLS = os.environ.get("XV2_GROUPED_CALLS", "1") != "0"  # grouped layers: the groups' calls behind one (xv2_*_grouped)
 _persist_bufs = {}
 
 
@@ -757,19 +759,32 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         raise RuntimeError("convolution sources of different element types (%s, %s)" % (x0.dtype, x1.dtype))
     if rgb and STEM_BAND and ihwo_out is None and 5 <= g.kw <= 8 and g.stride == 2 and g.dil == 1 and half:
         return None      # the RGB stem runs as a band convolution (_conv_forward)
-    ohwi, ihwo = _pack(weight.contiguous(), C0t + C1t, True, ihwo_out is not None, half)
-    d = _desc(N, IH, IW, C0t, C1t, Cout, g, OH, OW, half)
+    G = g.groups
+    if G > 1:
+        # grouped layer (ResNeSt's radix convolution): the groups' launches behind ONE call (xv2_conv_bn_act_forward_grouped)
+        if x1 is not None or rgb or not GROUPED_CALLS:
+            return None
+        w = weight.contiguous()
+        C0g, Coutg = C0t // G, Cout // G
+        packs = [_pack(w[gi * Coutg:(gi + 1) * Coutg], C0g, True, ihwo_out is not None, half) for gi in range(G)]
+        d = _desc(N, IH, IW, C0g, 0, Coutg, g, OH, OW, half)
+    else:
+        ohwi, ihwo = _pack(weight.contiguous(), C0t + C1t, True, ihwo_out is not None, half)
+        d = _desc(N, IH, IW, C0t, C1t, Cout, g, OH, OW, half)
     tiles = query("xv2_conv2d_forward_stats_tiles", d)
     if tiles <= 0:
         return None
     if ihwo_out is not None:
-        ihwo_out.append(ihwo)
+        if G > 1:
+            ihwo_out.extend(pk[1] for pk in packs)
+        else:
+            ihwo_out.append(ihwo)
     dev = x0.device
     y = _act((N, OH, OW, Cout), x0, torch.bfloat16 if half else torch.float32)
     z = torch.empty_like(y)
     sums = torch.empty((Cout, 2), dtype=torch.float64, device=dev)
     blob = _f32((4, Cout), x0)                                   # mean, invstd, scale, shift
-    part = _persist("stats", tiles * Cout * 2, dev)
+    part = _persist("stats", tiles * (Cout // G) * 2, dev)
     wsb = query("xv2_conv2d_forward_workspace", d)
     npix = N * OH * OW
     zmask = None
@@ -781,6 +796,14 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         set_amax(amax[0], amax[1], None, amax[2][0] if amax[2] is not None else None)
         if amax[2] is not None:
             z._xv2_amax = amax[2]
+    if G > 1:
+        warr = (ctypes.c_void_p * G)(*[pk[0].data_ptr() for pk in packs])
+        call("xv2_conv_bn_act_forward_grouped", d, G, x0, C0t, ctypes.addressof(warr), y, Cout, part, tiles,
+             _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
+             sums, _stats_scratch(Cout // G, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
+             bn.running_mean, bn.running_var, blob[0], blob[1], blob[2], blob[3], residual, Cout, act, z, Cout, zmask,
+             _dt(y))
+        return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
     call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles,
          _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
          sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
@@ -808,6 +831,17 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
     half = dy.dtype == torch.bfloat16
     dx0 = add_to0 if add_to0 is not None else _act((N, IH, IW, C0t), dy)
     dx1 = add_to1 if add_to1 is not None else (_act((N, IH, IW, C1t), dy) if C1t else None)
+    if G > 1 and LAYER_CALLS and GROUPED_CALLS and C1t == 0 and add_to1 is None:
+        # the groups' backward-data launches behind one call (same launches, same order)
+        packs = ihwo_packs if ihwo_packs else [_pack(w[gi * Coutg:(gi + 1) * Coutg], C0g, False, True, half)[1] for gi in range(G)]
+        d = _desc(N, IH, IW, C0g, 0, Coutg, g, OH, OW, half)
+        wsb = query("xv2_conv2d_backward_data_workspace", d)
+        warr = (ctypes.c_void_p * G)(*[t.data_ptr() for t in packs])
+        if amax_dy is not None:
+            set_amax(None, None, amax_dy, None)
+        call("xv2_conv2d_backward_data_grouped", d, G, dy, Cout_t, ctypes.addressof(warr), dx0, C0t,
+             1 if add_to0 is not None else 0, _ws(wsb, dy) if wsb else None, _dt(dy))
+        return dx0, dx1
     for gi in range(G):
         if ihwo_packs:
             ihwo = ihwo_packs[gi]
@@ -967,6 +1001,18 @@ def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None, amax=None):
         if amax is not None:
             set_amax(*amax)
         call("xv2_conv2d_backward_weight_async", d, x0, C0t, x1, C1t, dy, Cout_t, out, weight.shape[1], ws,
+             side.cuda_stream)
+        dw = out
+    elif LAYER_CALLS and GROUPED_CALLS and x1 is None:
+        # grouped layer: the hop to the side stream and the groups' launches behind one call
+        N, IH, IW, C0t = x0.shape
+        _, OH, OW, Cout_t = dy.shape
+        G = g.groups
+        d = _desc(N, IH, IW, C0t // G, 0, Cout_t // G, g, OH, OW, dy.dtype == torch.bfloat16)
+        ws = _side_workspace(query("xv2_conv2d_backward_weight_workspace", d), side, dy.device)
+        if amax is not None:
+            set_amax(*amax)
+        call("xv2_conv2d_backward_weight_async_grouped", d, G, x0, C0t, dy, Cout_t, out, weight.shape[1], ws, _dt(dy),
              side.cuda_stream)
         dw = out
     else:
@@ -1348,7 +1394,7 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.am_in = am_in
         # (a source that is a transposed convolution's output: its backward wants the maximum of the gradient sent back)
         ctx.want_dx_amax = am_in is not None and bool(getattr(x0_in, "_xv2_convT_out", False))
-        if pre is None and not lazy and LAYER_CALLS and training and g.groups == 1 and ctx.split == 1 and not _sync_group(bn):
+        if pre is None and not lazy and LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn):
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
                                       (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None)
         if fast is not None:
