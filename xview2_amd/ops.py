@@ -1394,7 +1394,8 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.am_in = am_in
         # (a source that is a transposed convolution's output: its backward wants the maximum of the gradient sent back)
         ctx.want_dx_amax = am_in is not None and bool(getattr(x0_in, "_xv2_convT_out", False))
-        if pre is None and not lazy and LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn):
+        if (pre is None and not lazy and LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn) and
+                (g.groups == 1 or not COOP_APPLY)):      # (grouped + gated apply: the per-group gated launches of _conv_forward)
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
                                       (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None)
         if fast is not None:
