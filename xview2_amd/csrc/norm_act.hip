@@ -48,7 +48,9 @@ static ChunkGeom chunk_geom(int64_t npix, int C, int W = 4) {
     }
     if (g.cgw) g.groups = C / g.cgw;
     const int64_t rows_per_pass = g.cgw ? 256 / (g.cgw / W) : 4;
-    int64_t rpb = cdiv(npix * g.groups, bn_blocks(2048));
+    // (bf16 tensors - W = 8 channels per 16-byte lane - are half the bytes: half the blocks; whole-step sweeps of XV2_BN_BLOCKS,
+    //  cfg3 15.75 -> 15.66 ms, cfg2 --precision 16 12.53 -> 12.44 ms; fp32 tensors are indifferent between 1024 and 8192)
+    int64_t rpb = cdiv(npix * g.groups, bn_blocks(W == 8 ? 1024 : 2048));
     rpb = cdiv(rpb, rows_per_pass) * rows_per_pass;
     if (rpb < rows_per_pass * 8) rpb = rows_per_pass * 8;
     g.rpb = (int)rpb;
@@ -1128,7 +1130,7 @@ static int bn_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, int zbi
     const ChunkGeom cg = chunk_geom(npix, C, W);
     if (vecw && cg.cgw) {
         const int rpp = 256 / (cg.cgw / W);
-        int64_t rpb = cdiv(npix * cg.groups, bn_blocks(4096));
+        int64_t rpb = cdiv(npix * cg.groups, bn_blocks(sizeof(T) == 2 ? 2048 : 4096));
         rpb = std::max<int64_t>(cdiv(rpb, rpp) * rpp, rpp * 4);
         hipLaunchKernelGGL(bn_act_bwd_rows_kernel<T>, dim3((unsigned)cdiv(npix, rpb), cg.groups), dim3(256), 0,
                            (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd, gamma, scale, shift, sums2,
