@@ -2045,7 +2045,18 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         const int planned = (p.stats && !p.A1 && p.C1 == 0 && !p.bnb_y) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
         const int R = planned ? planned : (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
         IgemmParams q = p;
-        if ((p.math == XV2_MATH_BF16_STORE || f16x2_ready(q)) && sg_conv_eligible(q, smallc, R)) return sg_conv_launch(q, R, stream);
+        if ((p.math == XV2_MATH_BF16_STORE || f16x2_ready(q)) && sg_conv_eligible(q, smallc, R)) {
+            SgGroupCtx& gc = sg_group_ctx();
+            if (gc.active && gc.w1) {      // a grouped layer: group 1 in the same grid when its operands are ready as well
+                IgemmParams q1 = q;
+                q1.B = static_cast<const float*>(gc.w1);
+                if (p.math == XV2_MATH_BF16_STORE || f16x2_ready(q1)) {
+                    gc.done = 1;
+                    return sg_conv_launch(q, R, stream, &q1);
+                }
+            }
+            return sg_conv_launch(q, R, stream);
+        }
         if (planned) {
             XV2_CHECK_ARG(planned == 64, "igemm: the small-grid plan expects 64-row statistics tiles");
             bm = 64;

@@ -118,7 +118,13 @@ int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, c
 // DMA.  `R` = rows per BatchNorm statistics tile of the plan the caller's buffers were sized for (it writes that geometry).
 bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R);
 int sg_planned_rows(int64_t M, int N, int C, int T, int math);      // rows per statistics tile when the shape is planned for it, else 0
-int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream);
+int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream, const IgemmParams* group1 = nullptr);
+struct SgGroupCtx {
+    int active;            // set by the grouped layer-level entry points around group 0's convolution call
+    const void* w1;        // packed weights of group 1 (the layout of group 0's)
+    int done;              // set by the launcher: both groups went out in one grid
+};
+SgGroupCtx& sg_group_ctx();
 
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them

@@ -9,6 +9,7 @@
 #include "../../include/xv2.h"
 #include "amax_ctx.h"
 #include "xv2_common.h"
+#include "igemm_params.h"
 
 int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream);      // igemm_conv.hip
 
@@ -131,7 +132,31 @@ extern "C" int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int group
     xv2::AmaxGuard amax_guard;      // the context's sources serve every group, its `out` the apply pass
     const size_t es = dtype == XV2_BF16 ? 2 : 4;
     const int ctot = groups * d->Cout;
-    for (int g = 0; g < groups; ++g) {
+    static const int one_grid = [] { const char* e = getenv("XV2_GROUPED_GRID"); return e ? atoi(e) : 1; }();
+    int first = 0;
+    if (groups == 2 && one_grid && !xv2::bn_fold_enabled()) {
+        // Both groups in ONE grid when group 0's convolution takes the small-grid kernel (sg_conv.hip, gridDim.y = 2): the statistics
+        // partials then come out as rows of all 2 * Cout channels and one reduction serves both groups - per channel the same sums
+        // in the same order as the per-group launches.  Otherwise `done` stays 0 and group 0 has run the ordinary way.
+        xv2::SgGroupCtx& gc = xv2::sg_group_ctx();
+        gc.active = 1; gc.w1 = w_ohwi[1]; gc.done = 0;
+        int rc = xv2_conv2d_forward(d, x0, ldx0, nullptr, 0, w_ohwi[0], nullptr, y, ldy, stats_partials, workspace, stream);
+        const int done = gc.done;
+        gc.active = 0; gc.w1 = nullptr; gc.done = 0;
+        if (rc) return rc;
+        if (done) {
+            rc = xv2_bn_reduce_finalize(stats_partials, tiles, ctot, sums, scratch, count, gamma, beta, eps, momentum, running_mean,
+                                        running_var, mean, invstd, scale, shift, stream);
+            if (rc) return rc;
+            first = groups;      // nothing left for the loop below
+        } else {
+            rc = xv2_bn_reduce_finalize(stats_partials, tiles, d->Cout, sums, scratch, count, gamma, beta, eps, momentum, running_mean,
+                                        running_var, mean, invstd, scale, shift, stream);
+            if (rc) return rc;
+            first = 1;
+        }
+    }
+    for (int g = first; g < groups; ++g) {
         const int og = g * d->Cout;
         int rc = xv2_conv2d_forward_bn(d, static_cast<const char*>(x0) + (size_t)g * d->C0 * es, ldx0, nullptr, 0, w_ohwi[g],
                                        static_cast<char*>(y) + (size_t)og * es, ldy, stats_partials, workspace, 1, ctot,
@@ -150,7 +175,17 @@ extern "C" int xv2_conv2d_backward_data_grouped(const xv2_conv_desc* d, int grou
     XV2_CHECK_ARG(d && groups >= 1 && w_ihwo && dy && dx0, "conv2d_backward_data_grouped: null argument");
     xv2::AmaxGuard amax_guard;      // dy's maximum serves every group
     const size_t es = dtype == XV2_BF16 ? 2 : 4;
-    for (int g = 0; g < groups; ++g) {
+    static const int one_grid = [] { const char* e = getenv("XV2_GROUPED_GRID"); return e ? atoi(e) : 1; }();
+    int first = 0;
+    if (groups == 2 && one_grid) {      // (see xv2_conv_bn_act_forward_grouped)
+        xv2::SgGroupCtx& gc = xv2::sg_group_ctx();
+        gc.active = 1; gc.w1 = w_ihwo[1]; gc.done = 0;
+        int rc = xv2_conv2d_backward_data_acc(d, dy, lddy, w_ihwo[0], dx0, lddx0, nullptr, 0, accumulate, workspace, stream);
+        first = gc.done ? groups : 1;
+        gc.active = 0; gc.w1 = nullptr; gc.done = 0;
+        if (rc) return rc;
+    }
+    for (int g = first; g < groups; ++g) {
         int rc = xv2_conv2d_backward_data_acc(d, static_cast<const char*>(dy) + (size_t)g * d->Cout * es, lddy, w_ihwo[g],
                                               static_cast<char*>(dx0) + (size_t)g * d->C0 * es, lddx0, nullptr, 0, accumulate,
                                               workspace, stream);

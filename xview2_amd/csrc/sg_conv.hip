@@ -51,6 +51,12 @@ struct SgParams {
     int IH, IW, OHl, OWl, s_in, osN, osH, osW, os0;
     int mtiles, ntiles, nsl;  // nsl = K stages per tap: C / 16 (fp32 tensors), C / 32 (bf16 storage)
     float rcp_ntiles;
+    // grouped layer as ONE launch (gridDim.y = 2: ResNeSt's radix convolution): group 1 reads channels [C, 2C) of the A rows and
+    // writes channels [N, 2N) of the output rows / statistics rows, with weights (and their maximum) of its own
+    const void* Bx2_g1;
+    const unsigned* amaxB_g1;
+    unsigned a_gbytes, o_gbytes;      // byte offset of group 1 inside a row of A / of the output
+    int stats_ld;                     // channels per statistics row (N, or 2N for a grouped launch)
     Tap taps[9];
 };
 
@@ -155,8 +161,10 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
             decode(row0 + r, dih[u], diw[u], dpix[u], ox);
         }
     }
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.bytesA, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bx2), 0, p.bytesB, 0x00020000);
+    const int grp = blockIdx.y;                // (uniform: 0 unless the launch carries the two groups of a grouped layer)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(p.A)) + (grp ? p.a_gbytes : 0u), 0, p.bytesA - (grp ? p.a_gbytes : 0u), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(grp ? p.Bx2_g1 : p.Bx2), 0, p.bytesB, 0x00020000);
 
     const int nsteps = p.T * p.nsl / G;        // 16-channel K steps of this group
     const int ks0 = g * nsteps;
@@ -288,7 +296,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
     dma(2);
     float inv = 1.f;
     if constexpr (!HS) {
-        const int ea = amax_exponent(p.amaxA), eb = amax_exponent(p.amaxB);
+        const int ea = amax_exponent(p.amaxA), eb = amax_exponent(grp ? p.amaxB_g1 : p.amaxB);
         sA = amax_scale(ea);
         inv = amax_inv(ea) * amax_inv(eb);
     }
@@ -378,7 +386,8 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
                                                                   acc[v / 4][4 * (v % 4) + 3]);
     }
     // rows / columns this lane stores: vector q of the wave <-> column block jq, rows 8 kq + 4 h + (0 .. 3)
-    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.Out, 0, p.bytesO, 0x00020000);
+    // (bytesO is the tight extent of ONE group's output from its first element: the same for both groups)
+    __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.Out) + (grp ? p.o_gbytes : 0u), 0, p.bytesO, 0x00020000);
     const int col0 = nt * BN + l31;
     // byte offset of each owned element, or past the buffer for rows >= M (their values are zeros - zero activation rows - and are
     // dropped by the store; in the sums and the maximum they change nothing)
@@ -501,7 +510,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
                 }
             const int64_t r0 = (int64_t)mt * BM + (int64_t)tl * p.R;
             if (r0 < p.M)
-                *reinterpret_cast<float2*>(p.stats + ((size_t)(r0 / p.R) * p.N + nt * BN + c) * 2) = make_float2(a, b);
+                *reinterpret_cast<float2*>(p.stats + ((size_t)(r0 / p.R) * p.stats_ld + grp * p.N + nt * BN + c) * 2) = make_float2(a, b);
         }
     }
 }
@@ -512,7 +521,7 @@ static int sg_mode() {      // XV2_SG=0: these layers stay on the tiled implicit
 }
 
 template <int WM, int G, int NB, bool PLAIN, bool HS>
-static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStream_t stream) {
+static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStream_t stream, int groups = 1) {
     constexpr size_t ring = (size_t)3 * G * (NB + WM) * 2048;
     constexpr size_t redb = G > 1 ? (size_t)WM * G * NB * 4 * 1024 : 0;
     constexpr size_t smem = (ring > redb ? ring : redb) + 1024;
@@ -528,7 +537,7 @@ static int sg_launch_one(const SgParams& q, double flops, double abytes, hipStre
     }();
     const int total = q.mtiles * q.ntiles, grid = 8 * ((total + 7) / 8);
     prof_begin(kid, flops, abytes, stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * G * 64), smem, stream, q);
+    hipLaunchKernelGGL(kern, dim3(grid, groups), dim3(WM * G * 64), smem, stream, q);
     prof_end(stream);
     XV2_CHECK_LAUNCH();
     return XV2_OK;
@@ -607,10 +616,24 @@ bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     return sg_pick(c.M, p.Nout, p.T * (p.Ctot / kc), p.stats ? R : 0) != 0;
 }
 
-int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
+// Grouped layer as one launch: the layer-level entry points (layer_entry.cpp) announce group 1's weights before they issue group 0's
+// convolution; if that convolution takes this kernel AND group 1's operands are ready too, both groups go out in one grid
+// (gridDim.y = 2) and `done` tells the caller to skip group 1's call.  Thread-local, like the operand-maximum context.
+SgGroupCtx& sg_group_ctx() {
+    static thread_local SgGroupCtx c = {};
+    return c;
+}
+
+int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream, const IgemmParams* p1) {
     const ClassInfo& c = p.cls[0];
     SgParams q;
     const bool hs = p.math == XV2_MATH_BF16_STORE;
+    const int groups = p1 ? 2 : 1;
+    q.Bx2_g1 = p1 ? (hs ? (const void*)p1->B : (const void*)p1->Bx3) : nullptr;
+    q.amaxB_g1 = p1 ? p1->amaxB : nullptr;
+    q.a_gbytes = p1 ? (unsigned)(p.Ctot * (hs ? 2 : 4)) : 0u;
+    q.o_gbytes = p1 ? (unsigned)(p.Nout * (hs ? 2 : 4)) : 0u;
+    q.stats_ld = groups * p.Nout;
     q.A = p.A0; q.Bx2 = hs ? (const void*)p.B : (const void*)p.Bx3; q.Out = p.Out0; q.stats = p.stats;
     q.amaxA = p.amaxA0; q.amaxB = p.amaxB; q.amax_out = p.amax_out;
     q.ep_scale = p.ep_scale; q.ep_shift = p.ep_shift; q.ep_res = p.ep_res; q.ep_act = p.ep_act; q.bias = p.bias;
@@ -628,19 +651,19 @@ int sg_conv_launch(const IgemmParams& p, int R, hipStream_t stream) {
     q.mtiles = (int)cdiv(c.M, 32 * wm);
     q.ntiles = p.Nout / (32 * nb);
     q.rcp_ntiles = 1.0f / (float)q.ntiles;
-    const double flops = 2.0 * (double)c.M * p.Nout * (double)p.T * p.Ctot;
-    const double abytes = (hs ? 2.0 : 4.0) * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
-                                              (double)c.M * p.Nout);
+    const double flops = groups * 2.0 * (double)c.M * p.Nout * (double)p.T * p.Ctot;
+    const double abytes = groups * (hs ? 2.0 : 4.0) * ((double)c.M / std::max(1, c.OHl * c.OWl) * p.IH * p.IW * p.Ctot + (double)p.Nout * p.T * p.Ctot +
+                                                       (double)c.M * p.Nout);
     if (p.amax_out && p.amax_recorded) *p.amax_recorded = 1;
     // PLAIN: 1x1 / stride 1, pixel index = GEMM row on both sides
     const bool plain = p.T == 1 && p.s_in == 1 && p.taps[0].dh == 0 && p.taps[0].dw == 0 && c.os0 == 0 && p.osW == 1 && p.osH == c.OWl &&
                        p.osN == c.OHl * c.OWl && c.OHl == p.IH && c.OWl == p.IW;
 #define XV2_SG_CASE(CFG, WM_, G_, NB_)                                                         \
     case CFG:                                                                                    \
-        return hs ? (plain ? sg_launch_one<WM_, G_, NB_, true, true>(q, flops, abytes, stream)         \
-                           : sg_launch_one<WM_, G_, NB_, false, true>(q, flops, abytes, stream))       \
-                  : (plain ? sg_launch_one<WM_, G_, NB_, true, false>(q, flops, abytes, stream)        \
-                           : sg_launch_one<WM_, G_, NB_, false, false>(q, flops, abytes, stream));
+        return hs ? (plain ? sg_launch_one<WM_, G_, NB_, true, true>(q, flops, abytes, stream, groups)         \
+                           : sg_launch_one<WM_, G_, NB_, false, true>(q, flops, abytes, stream, groups))       \
+                  : (plain ? sg_launch_one<WM_, G_, NB_, true, false>(q, flops, abytes, stream, groups)        \
+                           : sg_launch_one<WM_, G_, NB_, false, false>(q, flops, abytes, stream, groups));
     switch (cfg) {
         XV2_SG_CASE(224, 2, 2, 4)
         XV2_SG_CASE(244, 2, 4, 4)

@@ -784,7 +784,7 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     z = torch.empty_like(y)
     sums = torch.empty((Cout, 2), dtype=torch.float64, device=dev)
     blob = _f32((4, Cout), x0)                                   # mean, invstd, scale, shift
-    part = _persist("stats", tiles * (Cout // G) * 2, dev)
+    part = _persist("stats", tiles * Cout * 2, dev)      # (grouped: both groups' partials in one launch are rows of all Cout channels)
     wsb = query("xv2_conv2d_forward_workspace", d)
     npix = N * OH * OW
     zmask = None
@@ -800,7 +800,7 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         warr = (ctypes.c_void_p * G)(*[pk[0].data_ptr() for pk in packs])
         call("xv2_conv_bn_act_forward_grouped", d, G, x0, C0t, ctypes.addressof(warr), y, Cout, part, tiles,
              _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
-             sums, _stats_scratch(Cout // G, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
+             sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
              bn.running_mean, bn.running_var, blob[0], blob[1], blob[2], blob[3], residual, Cout, act, z, Cout, zmask,
              _dt(y))
         return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
