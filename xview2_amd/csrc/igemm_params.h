@@ -125,6 +125,13 @@ struct SgGroupCtx {
     int done;              // set by the launcher: both groups went out in one grid
 };
 SgGroupCtx& sg_group_ctx();
+// norm_act.hip: split attention's tail, forward, as two launches (fc1 + bn1 + ReLU; fc2 + rSoftMax) - the arithmetic of the four
+// op-level launches they replace (xv2_linear_forward, xv2_bn_rows_forward, xv2_linear_forward, xv2_rsoftmax_forward), bit for bit
+int splat_fc1_bn_launch(const float* gap, const float* w1, const float* b1, int N, int C, int inter, int parts, int train,
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        float* mean, float* invstd, float* scale, float* shift, float* h1, float* a1, hipStream_t stream);
+int splat_fc2_rsoftmax_launch(const float* a1, const float* w2, const float* b2, int N, int inter, int C, float* logits, float* att,
+                              hipStream_t stream);
 
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them

@@ -82,6 +82,16 @@ extern "C" int xv2_splat_tail_forward(const void* x, int N, int64_t hw, int C, i
                                       int dtype, void* stream) {
     int rc = xv2_splat_gap_forward(x, N, hw, C, gap, workspace, dtype, stream);
     if (rc) return rc;
+    static const int fuse = [] { const char* e = getenv("XV2_SPLAT_FUSE"); return e ? atoi(e) : 1; }();
+    if (fuse && parts >= 1 && N % parts == 0 && N / parts <= 64) {
+        // fc1 + bn1 + ReLU and fc2 + rSoftMax as one launch each (norm_act.hip: the same arithmetic, two launches fewer per block)
+        rc = xv2::splat_fc1_bn_launch(gap, w1, b1, N, C, inter, parts, train, gamma1, beta1, eps, momentum, running_mean, running_var,
+                                      mean1, invstd1, scale1, shift1, h1, a1, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = xv2::splat_fc2_rsoftmax_launch(a1, w2, b2, N, inter, C, logits, att, (hipStream_t)stream);
+        if (rc) return rc;
+        return xv2_splat_apply_forward(x, att, N, hw, C, out, dtype, stream);
+    }
     rc = xv2_linear_forward(gap, w1, b1, h1, N, C, inter, stream);
     if (rc) return rc;
     rc = xv2_bn_rows_forward(h1, N / parts, inter, parts, gamma1, beta1, eps, momentum, running_mean, running_var, train,

@@ -787,10 +787,9 @@ __global__ void __launch_bounds__(256) bn_act_bwd_rows_kernel(const T* __restric
 // ONE launch, one thread per channel (two-pass fp64 statistics over its <= 64 rows).  Replaces the five launches of the
 // general path (column partials, fold, un-shift, finalise, apply) - ~4 us each on a [2, 256] tensor, 16 .. 66 times per
 // forward.  S parts = S independent BatchNorm batches back to back (ops.BN_SPLIT), running statistics in part order.
-__global__ void __launch_bounds__(256) bn_rows_fwd_kernel(const float* __restrict__ y, int rows, int C, int S, int act,
-                                                           int train, BnFinalize fin, float* __restrict__ z) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// (the arithmetic of ONE channel, shared with the fused fc1 + bn1 kernel of split attention's tail below: bit-identical by construction)
+__device__ __forceinline__ void bn_rows_channel(const float* __restrict__ y, int rows, int C, int S, int act, int train,
+                                                const BnFinalize& fin, float* __restrict__ z, int c) {
     const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
     for (int s = 0; s < S; ++s) {
         const float* ys = y + (size_t)s * rows * C + c;
@@ -824,6 +823,83 @@ __global__ void __launch_bounds__(256) bn_rows_fwd_kernel(const float* __restric
         for (int r = 0; r < rows; ++r)
             z[((size_t)s * rows + r) * C + c] = apply_act(__fmaf_rn(ys[(size_t)r * C], sc, sh), act);
     }
+}
+__global__ void __launch_bounds__(256) bn_rows_fwd_kernel(const float* __restrict__ y, int rows, int C, int S, int act,
+                                                           int train, BnFinalize fin, float* __restrict__ z) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    bn_rows_channel(y, rows, C, S, act, train, fin, z, c);
+}
+
+// Split attention's tail, forward (ResNeSt SplAtConv2d: fc1 -> bn1 -> ReLU -> fc2 -> rSoftMax on [N, C]-vectors; reference call site
+// model/unet.py:52): two launches instead of four.
+//   splat_fc1_bn_kernel: wave j = output channel j of fc1: h1[n][j] for every sample n - the dot product of linear_fwd_kernel (same
+//   lane assignment, same shuffle tree) - then lane 0 runs bn_rows_fwd_kernel's arithmetic for that channel on the values it has
+//   just stored (a thread reads its own earlier stores).
+//   splat_fc2_rsoftmax_kernel: wave (n, c): the two logits of channel c (rows c and C + c of fc2), then rsoftmax_fwd_kernel's
+//   arithmetic for the pair.
+__global__ void __launch_bounds__(256) splat_fc1_bn_kernel(const float* __restrict__ gap, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, int N, int C, int inter, int S, int train,
+                                                            BnFinalize fin, float* __restrict__ h1, float* __restrict__ a1) {
+    const int lane = threadIdx.x & 63;
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (j >= inter) return;
+    for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += gap[n * C + c] * w1[(size_t)j * C + c];
+        s = wave_sum(s);
+        if (lane == 0) h1[(size_t)n * inter + j] = s + (b1 ? b1[j] : 0.f);
+    }
+    if (lane == 0) bn_rows_channel(h1, N / S, inter, S, XV2_ACT_RELU, train, fin, a1, j);
+}
+__global__ void __launch_bounds__(256) splat_fc2_rsoftmax_kernel(const float* __restrict__ a1, const float* __restrict__ w2,
+                                                                  const float* __restrict__ b2, int N, int inter, int C,
+                                                                  float* __restrict__ logits, float* __restrict__ att) {
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (wid >= N * C) return;
+    const int n = wid / C, c = wid % C;
+    float l[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int o = r * C + c;
+        float s = 0.f;
+        for (int k = lane; k < inter; k += 64) s += a1[n * inter + k] * w2[(size_t)o * inter + k];
+        s = wave_sum(s);
+        l[r] = s + (b2 ? b2[o] : 0.f);
+    }
+    if (lane == 0) {
+        logits[n * 2 * C + c] = l[0];
+        logits[n * 2 * C + C + c] = l[1];
+        const float m = fmaxf(l[0], l[1]);
+        const float e0 = expf(l[0] - m), e1 = expf(l[1] - m);
+        const float inv = 1.f / (e0 + e1);
+        att[n * 2 * C + c] = e0 * inv;
+        att[n * 2 * C + C + c] = e1 * inv;
+    }
+}
+int splat_fc1_bn_launch(const float* gap, const float* w1, const float* b1, int N, int C, int inter, int parts, int train,
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        float* mean, float* invstd, float* scale, float* shift, float* h1, float* a1, hipStream_t stream) {
+    XV2_CHECK_ARG(gap && w1 && h1 && a1 && mean && invstd && scale && shift && N >= 1 && parts >= 1 && N % parts == 0 && N / parts <= 64,
+                  "splat fc1 + bn1: N=%d parts=%d", N, parts);
+    XV2_CHECK_ARG(train || (running_mean && running_var), "splat fc1 + bn1: eval mode needs the running statistics");
+    BnFinalize f;
+    f.count = N / parts; f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
+    f.running_mean = running_mean; f.running_var = running_var;
+    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    hipLaunchKernelGGL(splat_fc1_bn_kernel, dim3((unsigned)cdiv((int64_t)inter * 64, 256)), dim3(256), 0, stream, gap, w1, b1, N, C, inter,
+                       parts, train, f, h1, a1);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+int splat_fc2_rsoftmax_launch(const float* a1, const float* w2, const float* b2, int N, int inter, int C, float* logits, float* att,
+                              hipStream_t stream) {
+    XV2_CHECK_ARG(a1 && w2 && logits && att && N >= 1 && C >= 1 && inter >= 1, "splat fc2 + rsoftmax: null argument");
+    hipLaunchKernelGGL(splat_fc2_rsoftmax_kernel, dim3((unsigned)cdiv((int64_t)N * C * 64, 256)), dim3(256), 0, stream, a1, w2, b2, N, inter,
+                       C, logits, att);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
 }
 
 // backward of the same: dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)), g = dz * act'(z); dgamma / dbeta are the
