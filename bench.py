@@ -269,6 +269,86 @@ def parity_block(ref, hip, precision, size=1024, strict16=False):
     return out
 
 
+COMPACT_LINE_MAX = 6144
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: contract keys + roofline + cpu_baseline + parity + the
+    encoder-forward figures + one short row per other configuration, numbers only.  Everything else (per-kernel tables,
+    notes, the arithmetic's description) is in the detail file."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "steps", "warmup", "ms_per_step",
+                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = out["config"]
+    c["config"] = {"workload": cfg["workload"][:200], "global_batch": cfg["global_batch"],
+                   "parallelism": cfg["parallelism"][:60], "syncbn": cfg["syncbn"][:60], "math": cfg.get("math")}
+    c["loss"] = _r(out.get("loss"), 6)
+    c["model_tflops"] = out.get("model_tflops")
+    c["conv_roofline_frac_whole_step"] = out.get("conv_roofline_frac_whole_step")
+    roof = out.get("roofline")
+    if roof:
+        r = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                         "avg_launch_us", "gflop_per_launch", "launches_timed", "frac_of_fp32_mfma_peak_157.3",
+                         "traffic_commit"))
+        r["kernel"] = r.get("kernel", "")[:96]
+        if roof.get("isolated"):
+            r["isolated"] = _pick(roof["isolated"], ("frac", "avg_launch_us"))
+        if roof.get("all_mfma_kernels"):
+            r["all_mfma_kernels"] = roof["all_mfma_kernels"]
+        c["roofline"] = r
+    else:
+        c["roofline"] = None
+    if out.get("collectives"):
+        c["collectives"] = _pick(out["collectives"], ("allreduce_bytes", "buckets", "allreduce_ms", "bus_gbs",
+                                                      "step_ms_overlapped", "step_ms_collectives_serialised",
+                                                      "overlap_fraction"))
+    if out.get("cpu_baseline"):
+        cb = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu", "seconds", "optimizer_seconds"))
+        cb["value"] = _r(cb.get("value"), 5)
+        cb["seconds"] = _r(cb.get("seconds"), 3)
+        cb["sample"] = out["cpu_baseline"]["sample"][:160]
+        c["cpu_baseline"] = cb
+    par_keys = ("rel", "logits_rel", "argmax_mismatch_px", "argmax_mismatch_px_outside_ties", "pixels", "grad_rel_global",
+                "grad_cosine", "tensors", "gate", "pass")
+    if out.get("parity"):
+        c["parity"] = {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in _pick(out["parity"], par_keys).items()}
+    if out.get("encoder_forward"):
+        c["encoder_forward"] = [
+            dict(_pick(e, ("encoder", "precision", "forward_ms", "mfma_kernels_ms", "gflop_per_pass",
+                           "gflop_counted_by_launches", "peak_tflops", "mfma_util_whole_forward",
+                           "vs_fp32_mfma_peak_157.3")),
+                 eval_forward_ms=e.get("eval_mode", {}).get("forward_ms")) for e in out["encoder_forward"]]
+    if out.get("other_configs"):
+        rows = []
+        for o in out["other_configs"]:
+            row = {"config": o["config"].split(":")[0][:40], "value": o["value"], "unit": o["unit"],
+                   "ms_per_step": o["ms_per_step"], "dtype": o["dtype"],
+                   "roofline": {"mfma": {"frac": o["roofline"]["mfma"]["frac"]},
+                                "hbm": {"frac": o["roofline"]["hbm"]["frac"]}}}
+            chk = o.get("parity") or o.get("cross_check")
+            if chk is not None:
+                row["pass"] = chk.get("pass")
+            if o.get("parity"):
+                row["parity"] = {k: float("%.4g" % v) for k, v in _pick(
+                    o["parity"], ("rel", "logits_rms_rel", "argmax_agreement", "grad_cosine", "bf16_vs_autocast_logits",
+                                  "bf16_vs_autocast_grad")).items() if isinstance(v, float)}
+            rows.append(row)
+        c["other_configs"] = rows
+    sf = out.get("split_form_error_vs_fp64")
+    if sf:
+        c["split_form_error_vs_fp64"] = {k: float("%.3g" % v) for k, v in sf.items() if isinstance(v, float)}
+    c["launch"] = out.get("launch")
+    c["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return c
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -853,12 +933,15 @@ def main():
         tot_ms, tot_gf = sum(r["ms"] for r in rows), sum(r["gflop"] for r in rows)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic_commit = None
         if os.path.exists(tpath):   # HBM bytes per launch from rocprofv3 PMC passes of this same command
-            traffic = json.load(open(tpath)).get(top["kernel"], {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(top["kernel"], {}).get("hbm_bytes_per_launch")
+            traffic_commit = tj.get("_meta", {}).get("commit")
         iso_top = next((r for r in iso if r["kernel"] == top["kernel"]), None)
         peak = kernel_peak(top["kernel"], opt.precision)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_commit": traffic_commit,
                 "math": (F32_SPLIT_TEXT + ".  This kernel: " + ("F16X2, peak = 16-bit dense MFMA peak / 3" if "f16x2" in top["kernel"]
                                                                 else "F32X3, peak = bf16 dense MFMA peak / 6") +
                          " (the instruction stream's own bound); achieved counts ALGORITHMIC fp32 flops (2*M*N*K); peaks are quoted "
@@ -906,8 +989,11 @@ def main():
                                    a.type, "" if a.type == "pre" else " --dmg_model " + a.dmg_model, opt.encoder,
                                    a.loss_str, " --deep_supervision" if a.deep_supervision else "",
                                    " --attention" if a.attention else "", opt.size, opt.size, opt.batch,
-                                   F32_SPLIT_TEXT if x3 else "fp32" if opt.precision == 32 else
-                                   "precision-16 (bf16 activations + bf16 MFMA, fp32 accumulate/statistics/master weights)"),
+                                   "fp32" if opt.precision == 32 else "precision-16 (bf16 storage + bf16 MFMA)"),
+                   "math": ("fp32 tensors/accumulation; products on the 16-bit MFMA from operand splits (%s; detail file)" % (
+                       "F16X2, 3 MFMAs/product" if _xops.F16X2 else "F32X3, 6 MFMAs/product")) if x3 else
+                           "exact fp32 MFMA" if opt.precision == 32 else "bf16 MFMA, fp32 accumulate/statistics/master weights",
+                   "math_detail": F32_SPLIT_TEXT if x3 else None,
                    "global_batch": world * opt.batch,
                    "parallelism": "dp%d" % world + (" (ranks SHARE one GPU over gloo: code-path test, not a scaling "
                                                     "measurement)" if opt.share_gpu else ""),
@@ -974,7 +1060,19 @@ def main():
                 "fp32 CPU oracle step of the headline line)" % (a.type, opt.encoder, a.loss_str, opt.size, opt.size, opt.batch),
                 a, 16, opt.size, opt.batch, dev, steps=10, warmup=3, parity=True, ref=ref, strict16=True))
     if rank == 0:
-        print(json.dumps(out))
+        # the per-kernel tables, notes and prose go to a side file; the LAST stdout line is the compact record (< 6 KB)
+        detail_path = os.environ.get("XV2_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            sys.stderr.write("bench detail not written (%s)\n" % e)
+            detail_path = None
+        line = json.dumps(compact_line(out, detail_path), separators=(",", ":"))
+        assert len(line) < COMPACT_LINE_MAX, len(line)
+        sys.stdout.flush()
+        print(line, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

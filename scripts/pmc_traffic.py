@@ -69,7 +69,9 @@ def pretty(mangled):
 
 f, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 w, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
+import os
+out = {"_meta": {"commit": os.environ.get("XV2_COMMIT", "unknown"),
+                 "note": "tree the PMC passes were taken on (XV2_COMMIT, set by the caller of scripts/profile_bench.sh)"}}
 for k in f:
     name = pretty(k)
     if name:

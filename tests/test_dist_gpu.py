@@ -459,23 +459,47 @@ def test_bench_two_ranks_sharing_the_gpu_run_the_whole_multi_rank_bench_path():
     assert line["value"] > 0 and line["scaling"] == "weak" and "SHARE" in line["config"]["parallelism"]
 
 
-def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size():
+def test_bench_line_carries_parity_roofline_and_encoder_probe_at_reduced_size(tmp_path):
     """the default bench line at a reduced tile (256 x 256 so that the CPU oracle leg takes seconds): contract keys,
-    the first-step parity block against the oracle and the resnest50 encoder-forward utilisation block"""
-    r, line = _run_bench("--steps", "3", "--warmup", "2", "--size", "256", "--no-big-configs")
+    the first-step parity block against the oracle and the resnest50 encoder-forward utilisation block; the line is the
+    LAST stdout line and stays under 6 KB (the driver's parser lost the 25 KB line of round 5), the per-kernel tables
+    and prose are in the detail file"""
+    import json
+    detail_path = str(tmp_path / "bench_detail.json")
+    os.environ["XV2_BENCH_DETAIL"] = detail_path
+    try:
+        r, line = _run_bench("--steps", "3", "--warmup", "2", "--size", "256", "--no-big-configs")
+    finally:
+        os.environ.pop("XV2_BENCH_DETAIL", None)
     assert r.returncode == 0, r.stderr[-2000:]
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "encoder_forward"):
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and json.loads(last) == line
+    assert len(last) < 6144, len(last)
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1
+    for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "encoder_forward",
+              "other_configs"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["cpu_baseline"]["kind"] == "port"
+    assert len(line["config"]["workload"]) <= 200 and "model" not in line["config"]
+    roof = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+              "avg_launch_us", "launches_timed"):
+        assert k in roof, k
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     par = line["parity"]
     assert par["pass"] is True and par["rel"] <= 1e-3 and par["logits_rel"] <= 1e-3
     assert par["argmax_mismatch_px_outside_ties"] == 0 and par["tensors"] > 100
     enc = {e["precision"]: e for e in line["encoder_forward"]}
     assert enc[32]["encoder"] == "resnest50" and 0 < enc[32]["mfma_util_whole_forward"] < 1
     assert abs(enc[32]["gflop_counted_by_launches"] / enc[32]["gflop_per_pass"] - 1) < 0.02
+    assert enc[32]["vs_fp32_mfma_peak_157.3"] > 0
     # cfg3 leg (resnest50, precision 16): its own throughput, MFMA + HBM rooflines and the bf16 parity gate
     cfg3 = line["other_configs"][0]
-    assert cfg3["dtype"] == "bf16" and cfg3["value"] > 0 and "resnest50" in cfg3["config"]
+    assert cfg3["dtype"] == "bf16" and cfg3["value"] > 0 and cfg3["config"] == "cfg3"
     assert 0 < cfg3["roofline"]["mfma"]["frac"] < 1 and 0 < cfg3["roofline"]["hbm"]["frac"] < 1
-    assert cfg3["parity"]["pass"] is True and cfg3["parity"]["rel"] <= 1e-2 and cfg3["parity"]["argmax_agreement"] >= 0.9
+    assert cfg3["pass"] is True and cfg3["parity"]["rel"] <= 1e-2 and cfg3["parity"]["argmax_agreement"] >= 0.9
+    # the detail file: the full record (per-kernel tables, notes)
+    detail = json.load(open(detail_path))
+    assert detail["value"] == line["value"] and len(detail["roofline"]["per_kernel"]) >= 3
+    assert "resnest50" in detail["other_configs"][0]["config"] and detail["other_configs"][0]["parity"]["pass"] is True
