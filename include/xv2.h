@@ -428,7 +428,7 @@ int xv2_splat_tail_forward(const void* x, int N, int64_t hw, int C, int inter, c
                            float* running_mean, float* running_var, int train, int parts, const float* w2,
                            const float* b2, float* gap, float* h1, float* a1, float* mean1, float* invstd1,
                            float* scale1, float* shift1, float* logits, float* att, void* out, float* workspace,
-                           int dtype, void* stream);
+                           int gap_ready, int dtype, void* stream);
 int xv2_splat_tail_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter,
                             const float* gap, const float* h1, const float* a1, const float* mean1,
                             const float* invstd1, const float* gamma1, const float* w1, const float* w2,
@@ -479,6 +479,16 @@ int xv2_linear_backward(const float* x, const float* w, const float* dy, float* 
 int xv2_rsoftmax_forward(const float* logits, float* att, int N, int C, void* stream);
 int xv2_rsoftmax_backward(const float* att, const float* datt, float* dlogits, int N, int C,
                           void* stream);
+/* bn0's apply pass that also takes the global average pool's column sums (ResNeSt SplAtConv2d, oracle/backbones.py:115-171;
+ * reference call site model/unet.py:52): z = act(y * scale + shift) over [N][hw][2C] (the arithmetic of xv2_bn_act_forward) AND the
+ * column-sum partials that xv2_splat_gap_forward would take from z, written to `workspace` (xv2_splat_gap_workspace bytes) -
+ * bit-identical partials, no second pass over z, one launch per block less; xv2_splat_gap_finish folds them into gap.
+ * xv2_conv_bn_act_forward_grouped(gap_part != NULL) runs it as the layer's apply pass; xv2_splat_tail_forward(gap_ready = 1) then
+ * skips the column-sum launch.  XV2_SPLAT_FUSE bit 2 (default on) switches it for A/B runs. */
+int xv2_bn_act_gap_supported(int C);
+int xv2_bn_act_gap_forward(const void* y, const float* scale, const float* shift, int act, void* z, int N, int64_t hw,
+                           int C, float* workspace, int dtype, void* stream);
+int xv2_splat_gap_finish(int N, int64_t hw, int C, float* gap, const float* workspace, void* stream);
 /* out[n,hw,c] = att[n][c]*x[n,hw,c] + att[n][C+c]*x[n,hw,C+c] */
 int xv2_splat_apply_forward(const void* x, const float* att, int N, int64_t hw, int C,
                             void* out, int dtype, void* stream);
@@ -579,7 +589,7 @@ int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int groups, const vo
                                     const float* gamma, const float* beta, float eps, float momentum,
                                     float* running_mean, float* running_var, float* mean, float* invstd,
                                     float* scale, float* shift, const void* residual, int ldr, int act, void* z,
-                                    int ldz, uint8_t* zmask, int dtype, void* stream);
+                                    int ldz, uint8_t* zmask, float* gap_part, int dtype, void* stream);
 /* groups x xv2_conv2d_backward_data_acc */
 int xv2_conv2d_backward_data_grouped(const xv2_conv_desc* d, int groups, const void* dy, int lddy,
                                      const void* const* w_ihwo, void* dx0, int lddx0, int accumulate,

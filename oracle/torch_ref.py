@@ -151,6 +151,26 @@ def compute_loss(loss_fn, preds, label, deep_supervision):
     return loss / (2 - 2 ** (-len(preds)))
 
 
+def precision16_step(model, loss_fn, x, label, deep_supervision, backward=True):
+    """The reference's DEFAULT numerics, `--precision 16` (main.py:36 -> Trainer(precision=16) main.py:99): PyTorch-Lightning's
+    native AMP wraps `training_step` (model/plt.py:50-54: forward AND compute_loss) in autocast.  On the CPU that is
+    torch.autocast("cpu", dtype=torch.bfloat16): convolutions / linear layers take 16-bit operands and give 16-bit results,
+    BatchNorm keeps fp32 parameters and statistics on the 16-bit tensor, the loss's softmax / reductions run in fp32, the
+    parameters and their gradients stay fp32 (master weights).  This is the LIKE-FOR-LIKE comparator of the HIP path's bf16-storage
+    mode: the same network with the same class of rounding, from an independent implementation.
+    -> (loss, preds); parameter gradients are left in .grad when `backward`."""
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        preds = model(x)
+        if isinstance(preds, list):
+            preds32 = [p.float() for p in preds]
+        else:
+            preds32 = preds.float()
+        loss = compute_loss(loss_fn, preds32, label, deep_supervision)
+    if backward:
+        loss.backward()
+    return loss, preds32
+
+
 def convert_to_labels(loss_str, logits):  # utils/f1.py:7-15
     if loss_str == "mse":
         p = torch.round(F.relu(logits[:, 0])) + 1

@@ -79,11 +79,12 @@ extern "C" int xv2_splat_tail_forward(const void* x, int N, int64_t hw, int C, i
                                       float* running_mean, float* running_var, int train, int parts, const float* w2,
                                       const float* b2, float* gap, float* h1, float* a1, float* mean1, float* invstd1,
                                       float* scale1, float* shift1, float* logits, float* att, void* out, float* workspace,
-                                      int dtype, void* stream) {
-    int rc = xv2_splat_gap_forward(x, N, hw, C, gap, workspace, dtype, stream);
+                                      int gap_ready, int dtype, void* stream) {
+    // gap_ready: `workspace` already holds the column-sum partials of x (xv2_bn_act_gap_forward: bn0's apply pass took them)
+    int rc = gap_ready ? xv2_splat_gap_finish(N, hw, C, gap, workspace, stream) : xv2_splat_gap_forward(x, N, hw, C, gap, workspace, dtype, stream);
     if (rc) return rc;
-    static const int fuse = [] { const char* e = getenv("XV2_SPLAT_FUSE"); return e ? atoi(e) : 1; }();
-    if (fuse && parts >= 1 && N % parts == 0 && N / parts <= 64) {
+    const int fuse = xv2::splat_fuse_bits();
+    if ((fuse & 1) && parts >= 1 && N % parts == 0 && N / parts <= 64) {
         // fc1 + bn1 + ReLU and fc2 + rSoftMax as one launch each (norm_act.hip: the same arithmetic, two launches fewer per block)
         rc = xv2::splat_fc1_bn_launch(gap, w1, b1, N, C, inter, parts, train, gamma1, beta1, eps, momentum, running_mean, running_var,
                                       mean1, invstd1, scale1, shift1, h1, a1, (hipStream_t)stream);
@@ -136,7 +137,7 @@ extern "C" int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int group
                                                const float* gamma, const float* beta, float eps, float momentum,
                                                float* running_mean, float* running_var, float* mean, float* invstd,
                                                float* scale, float* shift, const void* residual, int ldr, int act, void* z,
-                                               int ldz, uint8_t* zmask, int dtype, void* stream) {
+                                               int ldz, uint8_t* zmask, float* gap_part, int dtype, void* stream) {
     XV2_CHECK_ARG(d && groups >= 1 && w_ohwi && x0 && y && z && mean && invstd && scale && shift && gamma && beta && running_mean &&
                       running_var && sums && tiles > 0, "conv_bn_act_forward_grouped: null argument / no statistics tiles");
     xv2::AmaxGuard amax_guard;      // the context's sources serve every group, its `out` the apply pass
@@ -175,6 +176,12 @@ extern "C" int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int group
         if (rc) return rc;
     }
     const int64_t npix = (int64_t)d->N * d->OH * d->OW;
+    if (gap_part) {
+        // split attention follows (ResNeSt SplAtConv2d): the apply pass also leaves the global average pool's column-sum partials
+        XV2_CHECK_ARG(groups == 2 && !zmask && !residual && ldy == ctot && ldz == ctot && xv2_bn_act_gap_supported(d->Cout),
+                      "conv_bn_act_forward_grouped: no GAP form for this layer");
+        return xv2_bn_act_gap_forward(y, scale, shift, act, z, d->N, (int64_t)d->OH * d->OW, d->Cout, gap_part, dtype, stream);
+    }
     if (zmask) return xv2_bn_act_forward_mask(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, ctot, zmask, dtype, stream);
     return xv2_bn_act_forward(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, ctot, dtype, stream);
 }

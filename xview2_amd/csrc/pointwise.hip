@@ -6,7 +6,10 @@
 //   * NCHW <-> NHWC conversion at the model boundary (model/plt.py:51 hands NCHW images)
 // All reductions are two-level with a fixed order (deterministic), no atomics.
 #include "xv2_common.h"
+#include "amax_ctx.h"
+#include "../../include/xv2.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace xv2 {
 
@@ -326,6 +329,61 @@ __global__ void __launch_bounds__(256) splat_colsum_kernel(const T* __restrict__
         }
         *reinterpret_cast<float4*>(part + ((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c) = t;
     }
+}
+// bn0 + ReLU of ResNeSt's radix convolution AND the global average pool's column sums in ONE pass over the tensor
+// (oracle/backbones.py SplAtConv2d: bn0 -> ReLU -> split -> sum -> adaptive_avg_pool2d; reference call site model/unet.py:52):
+// the apply pass of the BatchNorm reads y and writes z anyway - with the blocks of splat_colsum_kernel (same grid, same row
+// lanes, same order of additions: part[] carries the bits that kernel would produce from z) the re-read of z and one launch per
+// block disappear.  z = act(y * scale + shift) is bn_act_fwd_kernel's arithmetic (one fma, then the activation); bf16 storage:
+// the sums are taken on the value as stored.  Blocks walk the tensor last chunk first (the convolution that wrote y finished with
+// its last rows: bn_act_fwd_kernel's `rev`).
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_colsum_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, T* __restrict__ z,
+                                                             int64_t hw, int C2, int cgw, int rows_per_chunk,
+                                                             float* __restrict__ part, unsigned* __restrict__ amax) {
+    __shared__ float4 sh[256];
+    __shared__ float amax_red[4];
+    const int n = gridDim.z - 1 - blockIdx.z, chunk = gridDim.x - 1 - blockIdx.x;
+    const int C4 = cgw >> 2, rpp = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    const int c = blockIdx.y * cgw + tx * 4;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk, r1 = min(r0 + (int64_t)rows_per_chunk, hw);
+    const T* py = y + (size_t)n * hw * C2 + c;
+    T* pz = z + (size_t)n * hw * C2 + c;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sf = *reinterpret_cast<const float4*>(shift + c);
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+    float zmax = 0.f;
+    for (int64_t r = r0 + ty; r < r1; r += 8 * (int64_t)rpp) {
+        float4 va[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = ld4(py + min(r + (int64_t)i * rpp, r1 - 1) * C2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r + (int64_t)i * rpp;
+            if (rr < r1) {
+                float4 o;
+                o.x = apply_act(__fmaf_rn(va[i].x, sc.x, sf.x), act); o.y = apply_act(__fmaf_rn(va[i].y, sc.y, sf.y), act);
+                o.z = apply_act(__fmaf_rn(va[i].z, sc.z, sf.z), act); o.w = apply_act(__fmaf_rn(va[i].w, sc.w, sf.w), act);
+                st4(pz + rr * C2, o);
+                zmax = amax_acc(zmax, o);
+                float4& s = (i & 1) ? s1 : s0;       // (the sums of splat_colsum_kernel over the stored z, bit for bit)
+                s.x += Elem<T>::round(o.x); s.y += Elem<T>::round(o.y); s.z += Elem<T>::round(o.z); s.w += Elem<T>::round(o.w);
+            }
+        }
+    }
+    s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
+    sh[threadIdx.x] = s0;
+    __syncthreads();
+    if (ty == 0) {
+        float4 t = sh[tx];
+        for (int q = 1; q < rpp; ++q) {
+            const float4 u = sh[q * C4 + tx];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(part + ((size_t)n * SPLAT_CHUNKS + chunk) * C2 + c) = t;
+    }
+    if (amax) amax_record(amax, zmax, amax_red, blockIdx.x + 61u * blockIdx.y + 17u * blockIdx.z);
 }
 // folds of the chunk partials: block = 16 columns x 16 chunk lanes (grid: column blocks x N), two chains per lane.
 // (64 columns x 4 chunk lanes walked up to 32 dependent-latency loads per lane on a grid of 2 .. 16 blocks: 13.8 us per
@@ -976,6 +1034,42 @@ extern "C" int xv2_splat_gap_forward(const void* x, int N, int64_t hw, int C, fl
                                                  (const T*)x, (const T*)nullptr, hw, 2 * C, 0, cgw, rpc, workspace));
     XV2_CHECK_LAUNCH();
     hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, SF_COLS), N), dim3(256), 0, st, workspace, N, C,
+                       chunks, 1.f / (float)hw, gap);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+// switches for A/B runs (XV2_SPLAT_FUSE, default 5): bit 0 = fc1 + bn1 and fc2 + rSoftMax as one launch each, bit 2 = the GAP's column
+// sums taken by bn0's apply pass.  (Measured and removed, round 6: fc2 + rSoftMax inside the apply launch - every block deriving the
+// attention weights of its own 64 channels first - bit-identical and +0.42 ms per resnest50 encoder forward: a latency-bound
+// prologue in front of 2048 streaming blocks costs more than the 5 us launch it replaces.)
+namespace xv2 {
+int splat_fuse_bits() {
+    static const int v = [] { const char* e = getenv("XV2_SPLAT_FUSE"); return e ? atoi(e) : 5; }();
+    return v;
+}
+}  // namespace xv2
+extern "C" int xv2_bn_act_gap_supported(int C) { return (splat_fuse_bits() & 4) && splat_vec_ok(C) ? 1 : 0; }
+extern "C" int xv2_bn_act_gap_forward(const void* y, const float* scale, const float* shift, int act, void* z, int N, int64_t hw,
+                                      int C, float* workspace, int dtype, void* stream) {
+    XV2_CHECK_ARG(y && scale && shift && z && workspace && N >= 1 && hw >= 1, "bn_act_gap_forward: null argument");
+    XV2_CHECK_ARG(splat_vec_ok(C), "bn_act_gap_forward: unsupported channel count %d", C);
+    XV2_CHECK_ARG(act == XV2_ACT_RELU || act == XV2_ACT_NONE || act == XV2_ACT_LEAKY, "bn_act_gap_forward: activation %d", act);
+    XV2_CHECK_DTYPE(dtype);
+    AmaxGuard amax_guard;
+    unsigned* amax = dtype == XV2_F32 ? amax_ctx().out : nullptr;
+    int chunks, cgw;
+    const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_colsum_kernel<T>), dim3(chunks, 2 * C / cgw, N), dim3(256), 0, (hipStream_t)stream,
+                                                 (const T*)y, scale, shift, act, (T*)z, hw, 2 * C, cgw, rpc, workspace, amax));
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+// gap from partials a preceding xv2_bn_act_gap_forward (or splat_colsum launch) left in `workspace`
+extern "C" int xv2_splat_gap_finish(int N, int64_t hw, int C, float* gap, const float* workspace, void* stream) {
+    XV2_CHECK_ARG(splat_vec_ok(C) && gap && workspace, "splat_gap_finish: unsupported channel count %d / null argument", C);
+    int chunks, cgw;
+    (void)splat_rows(hw, 2 * C, N, chunks, cgw);
+    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, SF_COLS), N), dim3(256), 0, (hipStream_t)stream, workspace, N, C,
                        chunks, 1.f / (float)hw, gap);
     XV2_CHECK_LAUNCH();
     return XV2_OK;

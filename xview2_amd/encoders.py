@@ -115,7 +115,11 @@ class SplAtConv2d(nn.Module):
         self.fc2 = nn.Conv2d(inter, channels * 2, 1)
 
     def forward(self, x):
-        x = xnn.conv_bn_act(self.conv, self.bn0, x, act=ops.ACT_RELU)
+        ops.GAP_REQUEST = True       # bn0's apply pass takes the pool's column sums for the tail below (ops._conv_bn_act_train)
+        try:
+            x = xnn.conv_bn_act(self.conv, self.bn0, x, act=ops.ACT_RELU)
+        finally:
+            ops.GAP_REQUEST = False
         m = self._modules
         bn1, f1, f2 = m["bn1"], m["fc1"]._parameters, m["fc2"]._parameters      # (dict reads: Module.__getattr__ is the slow path)
         xnn.bump_bn_counter(bn1)

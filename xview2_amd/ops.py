@@ -745,7 +745,7 @@ def _persist(tag, nfloats, device):
     return t
 
 
-def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask, amax=None):
+def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask, amax=None, want_gap=False):
     """Training-mode conv + BatchNorm + (residual) + activation of one ungrouped layer as ONE ABI call
     (xv2_conv_bn_act_forward = the three launches of _conv_forward + _bn_forward, same order, same stream).
     Returns y, z, zmask, (mean, invstd, count, scale, shift), or None when the shape has to go op by op."""
@@ -798,11 +798,19 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
             z._xv2_amax = amax[2]
     if G > 1:
         warr = (ctypes.c_void_p * G)(*[pk[0].data_ptr() for pk in packs])
+        gap_part = None
+        if (want_gap and G == 2 and residual is None and zmask is None and act == ACT_RELU and
+                query("xv2_bn_act_gap_supported", Cout // 2) == 1):
+            # split attention consumes z next (SplAtConv2d): the apply pass leaves the global average pool's column-sum partials
+            # in the tail's scratch; the tensor carries the claim to its one consumer (SplitAttentionFn.forward)
+            gap_part = _persist("splat", query("xv2_splat_gap_workspace", N, OH * OW, Cout // 2) // 4 + 16, dev)
         call("xv2_conv_bn_act_forward_grouped", d, G, x0, C0t, ctypes.addressof(warr), y, Cout, part, tiles,
              _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
              sums, _stats_scratch(Cout, dev), float(npix), bn.weight, bn.bias, float(bn.eps), float(bn.momentum),
              bn.running_mean, bn.running_var, blob[0], blob[1], blob[2], blob[3], residual, Cout, act, z, Cout, zmask,
-             _dt(y))
+             gap_part, _dt(y))
+        if gap_part is not None:
+            z._xv2_gap_part = gap_part
         return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
     call("xv2_conv_bn_act_forward", d, x0, C0t, x1, C1t, ohwi, y, Cout, part, tiles,
          _persist("splitk", (wsb + 3) // 4 + 4, dev) if wsb else None,
@@ -1349,6 +1357,11 @@ def conv_bn_act_infer(x0, x1, weight, residual, g, bn, act):
 
 
 # ------------------------------------------------------------------------------------------------
+# set by encoders.SplAtConv2d around its conv + bn0 + ReLU call: the layer's output goes to split attention and nowhere else, so
+# its apply pass may leave the global average pool's partial sums behind (xv2_bn_act_gap_forward)
+GAP_REQUEST = False
+
+
 class ConvBnActFn(torch.autograd.Function):
     """z = act(BN(conv(cat(x0, x1), W)) [+ residual])  (one autograd node per conv layer)"""
 
@@ -1397,7 +1410,8 @@ class ConvBnActFn(torch.autograd.Function):
         if (pre is None and not lazy and LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn) and
                 (g.groups == 1 or not COOP_APPLY)):      # (grouped + gated apply: the per-group gated launches of _conv_forward)
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
-                                      (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None)
+                                      (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None,
+                                      want_gap=GAP_REQUEST)
         if fast is not None:
             y, z, zmask, stats = fast
         elif pre is not None:
@@ -1853,6 +1867,9 @@ class SplitAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, bn1, training):
         _need_cuda(x)
+        gap_part = getattr(x, "_xv2_gap_part", None)
+        if gap_part is not None:
+            x._xv2_gap_part = None          # one consumer, one use
         x = x.contiguous()
         N, H, W, C2 = x.shape
         C, hw = C2 // 2, H * W
@@ -1893,9 +1910,12 @@ class SplitAttentionFn(torch.autograd.Function):
             out = _act((N, H, W, C), x)
             if training:
                 bn_stats_changed()
+            ws = _persist("splat", query("xv2_splat_gap_workspace", N, hw, C) // 4 + 16, x.device)
+            # (the producer's apply pass already took the pool's column sums - _conv_bn_act_train; the scratch is still the one it wrote)
+            gap_ready = 1 if (gap_part is not None and gap_part.data_ptr() == ws.data_ptr()) else 0
             call("xv2_splat_tail_forward", x, N, hw, C, inter, w1m, b1, bn1.weight, bn1.bias, float(bn1.eps),
                  float(bn1.momentum), bn1.running_mean, bn1.running_var, 1 if training else 0, S, w2m, b2, gap, h1, a1,
-                 mean1, invstd1, scale1, shift1, logits, att, out, _persist("splat", query("xv2_splat_gap_workspace", N, hw, C) // 4 + 16, x.device), _dt(x))
+                 mean1, invstd1, scale1, shift1, logits, att, out, ws, gap_ready, _dt(x))
             ctx.save_for_backward(x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att)
             ctx.training, ctx.split = training, S
             ctx.shapes = (w1.shape, w2.shape)
