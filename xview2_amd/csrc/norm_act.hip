@@ -387,6 +387,66 @@ __global__ void __launch_bounds__(256) reduce_stats_kernel(const T* __restrict__
     }
 }
 
+// The same reduction for the layers whose partial count is small (<= RS1_MAX_TILES: every layer of the /4 ... /32 levels at
+// batch 2) in ONE phase: a block of 1024 threads = 32 channels x 32 row lanes reads all rows of its channels with eight 8-byte
+// loads in flight per lane (one or two memory round trips), folds the lanes through LDS in lane order and finalises.  No scratch
+// rows, no ticket, no device-scope hand-off: the two-phase kernel above spends 5 - 8 us per launch on exactly those (a dependent
+// atomic, an acquire fence, a second round of device-scope loads) for a few hundred KB of partials - 126 launches per cfg2 step,
+// ~60 per resnest50 encoder forward, 1200 per cfg5 step, each on the compute stream's critical path.  fp64 sums in a fixed order
+// (lane r adds rows r, r + 32, ... in row order; lanes in lane order), like every reduction here.
+constexpr int64_t RS1_MAX_TILES = 1024;
+template <typename T>
+__global__ void __launch_bounds__(1024) reduce_stats_1phase_kernel(const T* __restrict__ part, int64_t tiles, int C,
+                                                                    double* __restrict__ sums, float* __restrict__ f0,
+                                                                    float* __restrict__ f1, const BnFinalize fin) {
+    __shared__ double sh[1024 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        const T2* p2 = reinterpret_cast<const T2*>(part) + c;
+        for (int64_t t = ty; t < tiles; t += 32 * 8) {
+            T2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t tt = t + 32 * i;
+                v[i] = p2[(size_t)(tt < tiles ? tt : t) * C];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (t + 32 * i < tiles) {
+                    a0 += (double)v[i].x;
+                    a1 += (double)v[i].y;
+                }
+        }
+    }
+    sh[threadIdx.x * 2] = a0;
+    sh[threadIdx.x * 2 + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int t64 = threadIdx.x, ch = blockIdx.x * 32 + (t64 >> 1), which = t64 & 1;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;      // four chains over the 32 row lanes, combined in a fixed order
+#pragma unroll
+    for (int q = 0; q < 32; q += 4) {
+        q0 += sh[((q + 0) * 32 + (t64 >> 1)) * 2 + which];
+        q1 += sh[((q + 1) * 32 + (t64 >> 1)) * 2 + which];
+        q2 += sh[((q + 2) * 32 + (t64 >> 1)) * 2 + which];
+        q3 += sh[((q + 3) * 32 + (t64 >> 1)) * 2 + which];
+    }
+    const double a = (q0 + q1) + (q2 + q3);
+    if (ch < C) {
+        const size_t i = (size_t)ch * 2 + which;
+        sums[i] = a;
+        if (f0 && !which) f0[ch] = (float)a;   // BN backward: dbeta = sum g
+        if (f1 && which) f1[ch] = (float)a;    //              dgamma = sum g*xhat
+    }
+    if (fin.mean) {
+        const double other = __shfl_xor(a, 1, 64);
+        if (ch < C && !which) bn_finalize_channel(fin, ch, a, other);
+    }
+}
+
 // ticket counters for reduce_stats_kernel: a zero-initialised device pool handed out round-robin; every user
 // returns its counters to zero, so concurrent launches on different streams never share a live ticket.
 unsigned* take_tickets(int n) {
@@ -431,6 +491,15 @@ static int reduce_stats(const T* partial, int64_t tiles, int C, double* sums, do
     if (S < 1 || force_s1) S = 1;
     const int groups = (int)cdiv(C, 32);
     XV2_CHECK_ARG(groups <= 4096, "reduce_stats: C=%d too large", C);
+    static const int one_phase = [] { const char* e = getenv("XV2_STATS_1PHASE"); return e ? atoi(e) : 1; }();      // (A/B runs: 0 = always the ticket form)
+    if (one_phase && tiles <= RS1_MAX_TILES && !force_s1) {
+        BnFinalize none1;
+        memset(&none1, 0, sizeof(none1));
+        hipLaunchKernelGGL(reduce_stats_1phase_kernel<T>, dim3((unsigned)groups), dim3(1024), 0, st, partial, tiles, C, sums, f0, f1,
+                           fin ? *fin : none1);
+        XV2_CHECK_LAUNCH();
+        return XV2_OK;
+    }
     unsigned* tickets = S > 1 ? take_tickets(groups) : nullptr;
     XV2_CHECK_ARG(S == 1 || tickets, "reduce_stats: ticket pool allocation failed");
     BnFinalize none;
