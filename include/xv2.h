@@ -161,65 +161,25 @@ int64_t xv2_conv2d_forward_stats_tiles(const xv2_conv_desc* d);
  * (several BatchNorm batches back to back in one launch: the Siamese pre/post passes) needs every range to end on a
  * tile boundary */
 int64_t xv2_conv2d_forward_stats_tile_rows(const xv2_conv_desc* d);
-/* Convolution + training-mode BatchNorm statistics in ONE launch (model/layers.py:92-93 conv -> norm; the encoder
- * blocks): the convolution epilogue writes the per-tile partials and the LAST blocks to arrive (two levels of
- * device-scope tickets, fixed summation order: bit-reproducible) reduce them to sums[parts][part_stride][2] (fp64 sum
- * and sum of squares per channel) and - when `mean` != NULL - derive mean / invstd / scale / shift [parts][part_stride]
- * and update the running statistics, part after part.  Replaces xv2_conv2d_forward + xv2_bn_reduce_stats /
- * xv2_bn_reduce_finalize (two launches).  parts > 1: the batch holds that many independent BatchNorm batches back to back
- * (the Siamese pre / post passes); every part must end on a statistics-tile boundary
- * ((N*OH*OW / parts) % xv2_conv2d_forward_stats_tile_rows(d) == 0).  SyncBatchNorm: pass mean = NULL, all-reduce `sums`,
- * then xv2_bn_finalize.  stats_partials: xv2_conv2d_forward_stats_tiles(d) * Cout * 2 floats; scratch:
- * XV2_BN_SCRATCH_ROWS * Cout * 2 doubles; workspace as for xv2_conv2d_forward. */
+/* Convolution + training-mode BatchNorm statistics behind one call (model/layers.py:92-93 conv -> norm; the encoder blocks):
+ * xv2_conv2d_forward with the per-tile partials, then per part the reduction of the partials (a fixed summation order:
+ * bit-reproducible) to sums[parts][part_stride][2] (fp64 sum and sum of squares per channel) and - when `mean` != NULL - mean /
+ * invstd / scale / shift [parts][part_stride] and the running-statistics update, part after part (xv2_bn_reduce_stats /
+ * xv2_bn_reduce_finalize).  parts > 1: the batch holds that many independent BatchNorm batches back to back (the Siamese pre /
+ * post passes); every part must end on a statistics-tile boundary ((N*OH*OW / parts) % xv2_conv2d_forward_stats_tile_rows(d)
+ * == 0).  SyncBatchNorm: pass mean = NULL, all-reduce `sums`, then xv2_bn_finalize.  stats_partials:
+ * xv2_conv2d_forward_stats_tiles(d) * Cout * 2 floats; scratch: XV2_BN_SCRATCH_ROWS * Cout * 2 doubles; workspace as for
+ * xv2_conv2d_forward.
+ * (Rounds 3 - 5 carried three opt-in variants of this layer that all measured as losses on MI355X and were removed in round 6:
+ * the statistics reduction folded into the convolution launch behind device-scope tickets (+0.65 ms per cfg2 step once fenced
+ * correctly), the BatchNorm apply behind a gate in that same launch (cfg3 18.3 -> 20.3 ms), and the producing layer's BatchNorm
+ * applied in this convolution's operand load (cfg2 27.39 -> 27.63 ms); numbers in DESIGN.md section 4.) */
 int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                           const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
                           int parts, int part_stride, double* sums, double* scratch, double count,
                           const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                           float* shift, void* stream);
-/* xv2_conv2d_forward_bn that also APPLIES the BatchNorm it has just derived - z = act(y * scale + shift [+ residual]),
- * optionally the byte mask of z > 0 - inside the same launch (model/layers.py:89-100 conv -> norm -> activation as ONE
- * launch in training mode; the bottleneck convolutions of the encoders, model/unet.py:45-52).  Every block keeps its output
- * tile in registers, waits at a gate (device-scope flag per column tile) until the last blocks to arrive have folded the
- * statistics and written the coefficients, and then normalises the tile from the registers - y rounded to the storage type
- * first, so z equals xv2_bn_act_forward[_mask] on the stored y bit for bit.  Blocks that wait hold their CU slots: the form
- * is taken only when the whole grid is resident at once (the kernel's occupancy x 256 CUs; split-K plans gate their slab-sum
- * launch instead) - otherwise the call behaves exactly like xv2_conv2d_forward_bn.  *applied (HOST int) tells which: 1 = z
- * (and zmask) were written, 0 = the caller still has to run xv2_bn_act_forward[_mask].  Single-process training-mode
- * BatchNorm only (mean .. shift required).  OPT-IN (XV2_COOP=1 or xv2_set_coop_blocks(n > 0)): exact, and measured SLOWER
- * than the two launches on MI355X - cfg2 fp32 26.66 -> 27.07 ms, cfg3 18.3 -> 20.3 ms per step: the hand-off is ~10 dependent
- * device-scope round trips that every block of the grid sits through (profiles/r04_gated_ab.md).  xv2_set_coop_blocks(n) /
- * XV2_COOP_BLOCKS cap the gated grid (processes SHARING one GPU must keep their combined gated grids within the chip: two
- * partly resident gated launches would wait for each other; a block that waits longer than 4 s traps). */
-int xv2_conv2d_forward_bn_act(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
-                              const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
-                              int parts, int part_stride, double* sums, double* scratch, double count,
-                              const float* gamma, const float* beta, float eps, float momentum,
-                              float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                              float* shift, const void* residual, int ldr, int act, void* z, int ldz,
-                              uint8_t* zmask, int* applied, void* stream);
-/* cap on the grid of gated launches (blocks); n > 0 also switches them on; 0: off; < 0: back to XV2_COOP / XV2_COOP_BLOCKS */
-int xv2_set_coop_blocks(int blocks);
-/* number of gated launches this process has issued (tests assert which form ran) */
-int64_t xv2_coop_count(void);
-/* BatchNorm + activation of the PRODUCING layer applied in this convolution's operand load (model/layers.py:96-100: the
- * BatchNorm + activation between the two convolutions of a bottleneck / decoder block): `y0` is the
- * RAW output of the producing convolution, z0 = act(y0 * pre_scale[c] + pre_shift[c]) (training-mode coefficients, as
- * xv2_bn_act_forward would write it) is formed while the input halo is staged into LDS - zero padding stays zero, z0 is
- * never written to memory.  Results identical bit for bit to xv2_bn_act_forward + xv2_conv2d_forward_bn.  Only for the halo
- * plan of XV2_MATH_F32X3 (3x3, stride 1, pad 1, one source, fp32 tensors): ask xv2_conv2d_forward_pre_supported(d) first;
- * the statistics fold (XV2_BN_FOLD) must be on.  Other arguments as for xv2_conv2d_forward_bn. */
-/* In-launch statistics fold of the convolution kernels (bn_fold.h: the last blocks to arrive reduce the tile partials and derive
- * the BatchNorm coefficients - no separate reduction launch): 1 = on, 0 = off, -1 = back to the environment (XV2_BN_FOLD, default
- * off since round 4; the gated launches imply it).  Both forms give the same statistics up to summation order. */
-int xv2_set_bn_fold(int on);
-int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d);
-int xv2_conv2d_forward_bn_pre(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
-                              const float* pre_shift, int pre_act, const void* w_ohwi, void* y, int ldy,
-                              float* stats_partials, float* workspace, int parts, int part_stride, double* sums,
-                              double* scratch, double count, const float* gamma, const float* beta, float eps,
-                              float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                              float* scale, float* shift, void* stream);
 /* split-K scratch (bytes, may be 0): layers with few output pixels and a deep reduction keep the large
  * tile and fill the chip by splitting K; `workspace` may be NULL, which disables split-K */
 size_t xv2_conv2d_forward_workspace(const xv2_conv_desc* d);
@@ -245,28 +205,6 @@ int xv2_conv2d_backward_data(const xv2_conv_desc* d, const void* dy, int lddy,
 int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* dy, int lddy,
                                  const void* w_ihwo, void* dx0, int lddx0, void* dx1, int lddx1,
                                  int accumulate, float* workspace, void* stream);
-/* Backward-data that ALSO takes the BatchNorm-backward statistics of the layer whose output feeds this convolution
- * (dx IS that layer's dz): with its conv output bn_y and coefficients the epilogue accumulates, per M tile,
- * partials[tile][C0][2] = (sum g, sum g * xhat), g = dx * act'(bn_y * scale + shift), xhat = (bn_y - mean) * invstd -
- * what xv2_bn_act_backward_reduce would compute with a separate pass over dz and y.  Only layers WITHOUT a residual
- * before the activation.  `*_bn_tiles` returns the tile count of the plan, or 0 if the shape has no fused form
- * (stride 2, two sources, split-K plan, the 32-channel direct plan outside XV2_MATH_F32, XV2_MATH_BF16): then use the plain
- * calls.  All storage types since round 4 (bf16: g from the ROUNDED dx, y read as stored).  Fold the partials with
- * xv2_bn_backward_reduce_partials (scratch as for xv2_bn_reduce_stats). */
-int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace);
-int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ihwo,
-                                void* dx0, int lddx0, int accumulate, const void* bn_y, int ld_bn_y,
-                                const float* bn_mean, const float* bn_invstd, const float* bn_scale,
-                                const float* bn_shift, int bn_act, float* partials, float* workspace,
-                                void* stream);
-int64_t xv2_conv_transpose2d_backward_data_bn_tiles(const xv2_conv_desc* d);
-int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy,
-                                          const float* w_ohwi, float* dx, int lddx, const float* bn_y,
-                                          int ld_bn_y, const float* bn_mean, const float* bn_invstd,
-                                          const float* bn_scale, const float* bn_shift, int bn_act,
-                                          float* partials, void* stream);
-int xv2_bn_backward_reduce_partials(const float* partial, int64_t tiles, int C, double* sums2, float* dgamma,
-                                    float* dbeta, double* scratch, void* stream);
 /* dw_oihw (reference layout, Cin = real channel count `cin_real` <= C0+C1) */
 size_t xv2_conv2d_backward_weight_workspace(const xv2_conv_desc* d);
 int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
@@ -279,13 +217,6 @@ int xv2_conv2d_backward_weight(const xv2_conv_desc* d, const void* x0, int ldx0,
 int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                                      const void* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
                                      void* side_stream, void* stream);
-/* the weight gradient of a convolution that ran as xv2_conv2d_forward_bn_pre: its X operand is the producing layer's RAW
- * output y0 and z0 = act(y0 * pre_scale + pre_shift) is formed on load (all-taps XV2_MATH_F32X3 plan, one source: ask
- * xv2_conv2d_backward_weight_pre_supported(d)).  side_stream == NULL or == stream: launched on `stream`. */
-int xv2_conv2d_backward_weight_pre_supported(const xv2_conv_desc* d);
-int xv2_conv2d_backward_weight_pre_async(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
-                                         const float* pre_shift, int pre_act, const void* dy, int lddy,
-                                         float* dw_oihw, float* workspace, void* side_stream, void* stream);
 
 /* nn.ConvTranspose2d(k=2, s=2, bias=False) (model/layers.py:83).  `d` describes the
  * EQUIVALENT convolution (input = the large 2H x 2W tensor with C0 = conv-transpose output
@@ -400,17 +331,6 @@ int xv2_bn_rows_backward(const float* dz, const float* z, const float* y, const 
  *   + xv2_bn_reduce_finalize + xv2_bn_act_forward[_mask] (zmask != NULL selects the mask form).  Single-process
  *   training-mode BatchNorm only (SyncBatchNorm keeps the op-level calls around its all-reduce).
  * xv2_bn_act_backward = xv2_bn_act_backward_reduce[_mask] + xv2_bn_act_backward_apply[_mask] (training mode). */
-/* Statistics reduction + coefficients + running statistics + apply pass of a training-mode BatchNorm in ONE launch (round 5):
- * = xv2_bn_reduce_finalize followed by xv2_bn_act_forward(_mask) - the same sums in the same order, bit-identical results - for
- * layers whose partial count is small (xv2_bn_reduce_finalize_act_forward_supported: C % 32 == 0, tiles <= 128, statistics fold
- * off); every block owns 32 channels and a range of rows and repeats the reduction for its own channels.  Reference:
- * model/layers.py:93-100 (nn.BatchNorm2d in training mode + activation).  zmask NULL: no byte mask. */
-int xv2_bn_reduce_finalize_act_forward_supported(int64_t tiles, int64_t npix, int C);
-int xv2_bn_reduce_finalize_act_forward(const float* partial, int64_t tiles, int C, double* sums, double count,
-                                       const float* gamma, const float* beta, float eps, float momentum,
-                                       float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                       float* shift, const void* y, int ldy, const void* residual, int ldr, int act, void* z,
-                                       int ldz, int64_t npix, uint8_t* zmask, int dtype, void* stream);
 int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                             const void* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
                             float* workspace, double* sums, double* scratch, double count,
@@ -496,26 +416,6 @@ int xv2_splat_apply_forward(const void* x, const float* att, int N, int64_t hw, 
 int xv2_splat_apply_backward(const void* x, const float* att, const void* dout,
                              const float* dgap, int N, int64_t hw, int C, void* dx, float* datt,
                              float* workspace, int dtype, void* stream);
-
-/* The whole [N, C]-vector tail of SplAtConv2d in two calls (three / four launches instead of ~10 / ~12): GAP partial
- * sums + fold, fc1, bn1 (training: batch statistics over the N samples of THIS process + running-statistics update;
- * eval: running statistics) + ReLU, fc2, rSoftMax -> att; and the backward of that chain from dout.  Only without a
- * cross-rank SyncBatchNorm exchange between fc1 and bn1 (otherwise use the op-by-op entry points above).
- * xv2_splat_att_supported: N * inter <= 8192 and the channel constraints of xv2_splat_gap_forward. */
-int xv2_splat_att_supported(int N, int C, int inter);
-size_t xv2_splat_att_workspace(int N, int64_t hw, int C, int inter);
-int xv2_splat_att_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1, const float* b1,
-                          const float* gamma1, const float* beta1, float eps, float momentum, float* running_mean,
-                          float* running_var, int train, const float* w2, const float* b2, float* gap, float* h1,
-                          float* a1, float* mean1, float* invstd1, float* att, float* workspace, int dtype,
-                          void* stream);
-/* dw2 [2C][inter], db2 [2C], dgamma1 / dbeta1 / db1 [inter], dw1 [inter][C], dgap [N][C] (feed dgap to
- * xv2_splat_apply_backward for dx) */
-int xv2_splat_att_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter, const float* gap,
-                           const float* h1, const float* a1, const float* mean1, const float* invstd1,
-                           const float* gamma1, const float* w1, const float* w2, const float* att, int train,
-                           float* dw2, float* db2, float* dgamma1, float* dbeta1, float* dw1, float* db1, float* dgap,
-                           float* workspace, int dtype, void* stream);
 
 /* ---- attention gate glue (model/layers.py:161-166) ---------------------------------------- */
 /* r = relu(a + b) */

@@ -38,7 +38,7 @@ def wrap_calls():
     import importlib
     import pkgutil
     real = _capi.call
-    side_names = ("xv2_conv2d_backward_weight_async", "xv2_conv2d_backward_weight_pre_async")
+    side_names = ("xv2_conv2d_backward_weight_async",)
 
     def recording(name, *args):
         ts = [(i, a.tensor if isinstance(a, _capi.Ptr) else a) for i, a in enumerate(args)

@@ -51,28 +51,11 @@ def pytest_cmdline_main(config):
     if n > 0:
         config.option.numprocesses = n
         os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_threads(n)))
-        # The workers share ONE GPU.  Launches whose blocks wait for each other (include/xv2.h: xv2_conv2d_forward_bn_act
-        # and friends) need their whole grid resident at once; two partly resident ones from different processes would
-        # wait for each other.  256 CUs hold >= 256 blocks of any kernel here: n x 40 stays below that whatever interleaves.
-        # Tests of larger gated grids are marked `gpu_exclusive` and lift the cap under the exclusive lock (tests/gpu_lock.py).
-        os.environ.setdefault("XV2_COOP_BLOCKS", str(max(8, 240 // n)))
     return None
-
-
-@pytest.fixture(autouse=True)
-def _gpu_share(request):
-    """every GPU test of an xdist run holds the GPU lock: shared, or exclusive for `gpu_exclusive` tests (gpu_lock.py)"""
-    if "gpu" not in request.keywords or not os.environ.get("PYTEST_XDIST_WORKER"):
-        yield
-        return
-    from gpu_lock import gpu_lock
-    with gpu_lock("gpu_exclusive" in request.keywords):
-        yield
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_exclusive: alone on the GPU while it runs (large gated launches, tests/gpu_lock.py)")
     if os.environ.get("OMP_NUM_THREADS") is None and (os.cpu_count() or 1) >= 32:
         # single-process runs on a many-core host: same cap (set before torch spins up its thread pool)
         os.environ["OMP_NUM_THREADS"] = str(_cpu_threads(1))

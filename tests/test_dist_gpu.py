@@ -137,7 +137,7 @@ def _two_rank_worker(rank, world, port, outdir, encoder="resnet50", exact_fp32=F
     """one of `world` processes sharing cuda:0 (gloo carries the device tensors): a SyncBatchNorm + bucketed-reducer
     training step of the HIP path on this rank's share of a global batch of `total`"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", XV2_COOP="0")
+                      LOCAL_RANK="0")
     os.environ.setdefault("XV2_SYNCBN", "rccl")      # (the transport tests set it; rccl is also the library default)
     if exact_fp32:
         os.environ["XV2_F32X3"] = "0"        # read when xview2_amd.ops is imported (spawned process: not yet)

@@ -135,7 +135,7 @@ def test_batchnorm_apply_passes_record_the_exact_maximum_of_what_they_write():
     st = ops._bn_forward(y, None, ops.ACT_RELU, ops.BnState(bn, False), None, True)
     dz = torch.randn_like(y) * 1e-5
     tok2 = ops._amax_new(y)
-    dyv = ops._bn_backward(dz, None, y, st[1], bn.weight, ops.ACT_RELU, ops.BnState(bn, False), True, False, None, 1, tok2)[0]
+    dyv = ops._bn_backward(dz, None, y, st[1], bn.weight, ops.ACT_RELU, ops.BnState(bn, False), True, False, 1, tok2)[0]
     torch.cuda.synchronize()
     idx2 = (tok2[0] - tok2[3].base) // ops.AMAX_BYTES
     assert _recorded(tok2[3].buf[idx2]) == dyv.abs().max().item()

@@ -843,46 +843,3 @@ def test_blockwise_teacher_forced_parity(case):
         assert loss_rel <= 1e-2 and agree >= 0.97, (loss_rel, agree)
 
 
-def test_deferred_batchnorm_apply_is_bitwise_identical():
-    """ops.LAZY_BN (opt-in): the BatchNorm + activation between the two convolutions of a bottleneck / decoder block is applied
-    in the consumer's operand load (xv2_conv2d_forward_bn_pre, xv2_conv2d_backward_weight_pre_async) instead of being written
-    to memory.  Same arithmetic, so two training steps must agree bit for bit: loss, logits, the flat gradient, running stats."""
-    from xview2_amd import criterion, networks, ops
-    from xview2_amd.optim import FlatAdamW
-    from xview2_amd.weights import deterministic_init_
-    import bench
-    if ops.MATH_MODE != ops.MATH_F32X3:
-        pytest.skip("the deferred form exists for XV2_MATH_F32X3")
-    dev = torch.device("cuda:0")
-    res = {}
-    old, old_h2 = ops.LAZY_BN, ops.F16X2
-    ops.F16X2 = False      # (the deferred form has no two-plane twin: both legs on the three-plane arithmetic)
-    try:
-        for lazy in (False, True):
-            ops.LAZY_BN = lazy
-            a = bench.make_args("resnet50", "pre", "dice")
-            torch.manual_seed(0)
-            m = networks.UNetLoc(a)
-            deterministic_init_(m, 1)
-            m.to(dev).train()
-            lf = criterion.Loss(a)
-            opt = FlatAdamW(m.parameters(), lr=3e-4)
-            x, y = bench.synthetic_batch(a, 2, 128, 1, dev)
-            out = []
-            for _ in range(2):
-                opt.zero_grad()
-                p = m(x)
-                loss = criterion.compute_loss(lf, p, y, a.deep_supervision)
-                loss.backward()
-                ops.join_wgrad_stream()
-                out.append((float(loss.detach()), p.detach().clone(), opt.flat_g.clone()))
-                opt.step()
-            rs = torch.cat([b.running_var.flatten() for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d)])
-            res[lazy] = (out, rs.clone())
-            del m, opt
-            ops.clear_pack_cache()
-    finally:
-        ops.LAZY_BN, ops.F16X2 = old, old_h2
-    for (l0, p0, g0), (l1, p1, g1) in zip(res[False][0], res[True][0]):
-        assert l0 == l1 and torch.equal(p0, p1) and torch.equal(g0, g1)
-    assert torch.equal(res[False][1], res[True][1])

@@ -596,49 +596,6 @@ def test_f1_device_counts_match_the_reference_bookkeeping(task, loss_str):
     assert torch.equal(torch.as_tensor(d[0]), torch.as_tensor(c[0]))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 3), (1, 64, 64, 32, 32, 3), (2, 16, 16, 128, 256, 1), (2, 32, 32, 256, 128, 3)])
-def test_bn_backward_statistics_taken_in_the_consumer_dgrad_epilogue(shape, dtype):
-    """xv2_conv2d_backward_data_bn (opt-in, ops.FUSE_BN_BWD): conv+BN+ReLU -> conv+BN+ReLU; the first layer's
-    (sum g, sum g*xhat) come out of the second layer's backward-data epilogue.  Gradients must match the default
-    path (separate column-reduction pass) to rounding."""
-    from xview2_amd import ops
-    N, H, W, C0, C1, k = shape
-    torch.manual_seed(7)
-    x = torch.randn(N, H, W, C0, device=dev()).to(dtype)
-    w1 = (torch.randn(C1, C0, k, k, device=dev()) * 0.1)
-    w2 = (torch.randn(C1, C1, k, k, device=dev()) * 0.1)
-    dz = torch.randn(N, H, W, C1, device=dev()).to(dtype)
-    res = {}
-    from xview2_amd import _capi
-    fused_launches = 0
-    for fuse in (False, True):
-        ops.FUSE_BN_BWD = fuse
-        ops.set_storage_dtype(dtype)
-        try:
-            bn1, bn2 = torch.nn.BatchNorm2d(C1).to(dev()), torch.nn.BatchNorm2d(C1).to(dev())
-            a = x.clone().requires_grad_(True)
-            p1, p2 = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
-            g = ops.conv_cfg(k, k, 1, k // 2)
-            h = ops.ConvBnActFn.apply(a, None, p1, bn1.weight, bn1.bias, None, g, ops.BnState(bn1), ops.ACT_RELU, True)
-            z = ops.ConvBnActFn.apply(h, None, p2, bn2.weight, bn2.bias, None, g, ops.BnState(bn2), ops.ACT_LEAKY, True)
-            rec = getattr(h, "_xv2_bnrec", None)
-            z.backward(dz)
-            res[fuse] = (a.grad.clone(), p1.grad.clone(), bn1.weight.grad.clone(), bn1.bias.grad.clone(), p2.grad.clone())
-            if fuse:
-                d = ops._desc(N, H, W, C1, 0, C1, g, H, W, dtype == torch.bfloat16)
-                fused_launches = _capi.query("xv2_conv2d_backward_data_bn_tiles", d, 0, 1)
-                assert rec is not None
-        finally:
-            ops.FUSE_BN_BWD = False
-            ops.set_storage_dtype(None)
-    if shape in ((2, 32, 64, 64, 64, 3), (2, 16, 16, 128, 256, 1)):      # (the others: direct 32-channel plan / split-K plan)
-        assert fused_launches > 0, "the fused form was not planned for this shape: the test compared nothing"
-    for name, u, v in zip(("dx", "dw1", "dgamma1", "dbeta1", "dw2"), res[True], res[False]):
-        close(u, v, 2e-5 if dtype == torch.float32 else 1e-2, name)
-    assert torch.equal(res[True][4], res[False][4])        # the second layer itself is untouched
-
-
 # ---- bf16 STORAGE (XV2_MATH_BF16_STORE, the --precision 16 path): activations, gradients and packed weights are bf16
 # in HBM.  Reference = the same fp32 PyTorch ops evaluated on the bf16-rounded operands; what differs is the rounding
 # of the stored results (2^-9 relative per element) and of the intermediate y before BatchNorm.
@@ -810,52 +767,6 @@ def test_bf16_storage_stem_residual_convt_pool_head():
     close(y.cpu(), yr, 1e-5, "head y bf16-in")
     bf16_close(nchw(ah.grad.float()), xr.grad, 1e-2, "head dx")
     close(wgh.grad, whr.grad, 1e-4, "head dw")
-
-
-@pytest.mark.parametrize("shape", [(2, 12, 12, 64, 32), (8, 6, 6, 128, 64), (2, 4, 4, 512, 256), (3, 8, 8, 256, 128)])
-@pytest.mark.parametrize("training", [True, False])
-def test_fused_split_attention_tail_equals_the_op_by_op_chain(shape, training):
-    """xv2_splat_att_forward / _backward (GAP fold + fc1 + bn1 + ReLU + fc2 + rSoftMax in two launches) against the
-    op-by-op entry points it replaces (which are themselves checked against PyTorch above and stay in use under
-    SyncBatchNorm): same outputs, gradients and running statistics to fp32 rounding."""
-    from xview2_amd import ops
-    N, H, W, C, inter = shape
-    torch.manual_seed(N + C)
-    x = torch.randn(N, H, W, 2 * C, device=dev()).relu_()
-    fc1 = torch.nn.Conv2d(C, inter, 1).to(dev())
-    fc2 = torch.nn.Conv2d(inter, 2 * C, 1).to(dev())
-    dout = torch.randn(N, H, W, C, device=dev())
-    res = {}
-    for fused in (False, True):
-        ops.FUSED_SPLAT = fused
-        try:
-            bn1 = torch.nn.BatchNorm2d(inter).to(dev())
-            with torch.no_grad():
-                bn1.weight.uniform_(0.5, 1.5)
-                bn1.bias.normal_(0, 0.1)
-                bn1.running_mean.normal_(0, 0.1)
-                bn1.running_var.uniform_(0.5, 1.5)
-            torch.manual_seed(7)
-            with torch.no_grad():
-                bn1.weight.copy_(torch.rand(inter) + 0.5)
-                bn1.bias.copy_(torch.randn(inter) * 0.1)
-                bn1.running_mean.copy_(torch.randn(inter) * 0.1)
-                bn1.running_var.copy_(torch.rand(inter) + 0.5)
-            xx = x.clone().requires_grad_(True)
-            ps = [p.detach().clone().requires_grad_(True) for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
-            out = ops.SplitAttentionFn.apply(xx, ps[0], ps[1], bn1.weight, bn1.bias, ps[2], ps[3], ops.BnState(bn1), training)
-            out.backward(dout)
-            res[fused] = [out.detach(), xx.grad] + [p.grad for p in ps] + [bn1.weight.grad, bn1.bias.grad,
-                                                                           bn1.running_mean.clone(), bn1.running_var.clone()]
-        finally:
-            ops.FUSED_SPLAT = False
-    names = ["out", "dx", "dw1", "db1", "dw2", "db2", "dgamma1", "dbeta1", "running_mean", "running_var"]
-    for nm, a, b in zip(names, res[True], res[False]):
-        if nm == "db1" and training:
-            # a bias in front of a training-mode BatchNorm has a mathematically zero gradient: both are round-off
-            assert float(a.abs().max()) <= 1e-4 * float(res[True][2].abs().max()) + 1e-6
-            continue
-        close(a, b, 1e-4, "fused split attention " + nm)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)

@@ -80,7 +80,6 @@ def lib():
             getattr(_lib, name).restype = ctypes.c_size_t
         _lib.xv2_conv2d_forward_stats_tiles.restype = ctypes.c_int64
         _lib.xv2_conv2d_forward_stats_tile_rows.restype = ctypes.c_int64
-        _lib.xv2_coop_count.restype = ctypes.c_int64
     return _lib
 
 

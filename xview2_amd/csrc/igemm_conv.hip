@@ -1587,10 +1587,7 @@ constexpr size_t igemm_smem_bytes() {
 // below the chip's capacity).
 static int g_coop_blocks = -1;      // xv2_set_coop_blocks(): cap on gated grids; > 0 also switches the gated forms on; -1 = env
 long long g_coop_count = 0;         // gated launches issued so far (xv2_coop_count: tests assert WHICH form ran)
-static bool coop_enabled() {
-    static const int v = [] { const char* e = getenv("XV2_COOP"); return e ? atoi(e) : 0; }();
-    return v != 0 || g_coop_blocks > 0;
-}
+static bool coop_enabled() { return false; }      // (round 6: the gated apply's entry points are gone - measured a loss on every configuration)
 bool coop_requested() { return coop_enabled(); }
 int coop_block_cap() {
     static const int envcap = [] { const char* e = getenv("XV2_COOP_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
@@ -2489,110 +2486,24 @@ extern "C" int xv2_conv2d_forward_bn(const xv2_conv_desc* d, const void* x0, int
     XV2_CHECK_ARG(stats_partials && scratch && sums, "conv2d_forward_bn: partials, scratch and sums are required");
     XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn: parts=%d part_stride=%d", parts, part_stride);
     XV2_CHECK_ARG(!mean || (invstd && scale && shift), "conv2d_forward_bn: mean, invstd, scale and shift go together");
-    if (!bn_fold_enabled()) {       // A/B runs (XV2_BN_FOLD=0): the launches this entry point replaces
-        int rc = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
-        if (rc) return rc;
-        const int64_t tiles = xv2_conv2d_forward_stats_tiles(d);
-        XV2_CHECK_ARG(tiles % parts == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, parts);
-        const int64_t tpp = tiles / parts;
-        for (int s = 0; s < parts && !rc; ++s) {
-            const float* ps = stats_partials + (size_t)s * tpp * d->Cout * 2;
-            double* ss = sums + (size_t)s * part_stride * 2;
-            const size_t o = (size_t)s * part_stride;
-            rc = mean ? xv2_bn_reduce_finalize(ps, tpp, d->Cout, ss, scratch, count, gamma, beta, eps, momentum, running_mean,
-                                               running_var, mean + o, invstd + o, scale + o, shift + o, stream)
-                      : xv2_bn_reduce_stats(ps, tpp, d->Cout, ss, scratch, stream);
-        }
-        return rc;
+    // the convolution (with statistics partials per row tile), then per part the reduction of the partials (+ coefficients and
+    // running statistics).  (Round 3 folded the reduction into the convolution launch - the last blocks to arrive summed the
+    // partials behind a device-scope ticket; with the release fences that hand-off needs it cost +0.65 ms per cfg2 step and was
+    // removed in round 6 together with the gated apply that depended on it: a kernel boundary is cheaper)
+    int rc = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
+    if (rc) return rc;
+    const int64_t tiles = xv2_conv2d_forward_stats_tiles(d);
+    XV2_CHECK_ARG(tiles % parts == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, parts);
+    const int64_t tpp = tiles / parts;
+    for (int s = 0; s < parts && !rc; ++s) {
+        const float* ps = stats_partials + (size_t)s * tpp * d->Cout * 2;
+        double* ss = sums + (size_t)s * part_stride * 2;
+        const size_t o = (size_t)s * part_stride;
+        rc = mean ? xv2_bn_reduce_finalize(ps, tpp, d->Cout, ss, scratch, count, gamma, beta, eps, momentum, running_mean,
+                                           running_var, mean + o, invstd + o, scale + o, shift + o, stream)
+                  : xv2_bn_reduce_stats(ps, tpp, d->Cout, ss, scratch, stream);
     }
-    StatsFold f;
-    memset(&f, 0, sizeof(f));
-    f.on = 1;
-    f.S = parts;
-    f.part_stride = part_stride;
-    f.scratch = scratch;
-    f.sums = sums;
-    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
-    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
-    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
-    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
-                             stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f);
-}
-
-extern "C" int xv2_conv2d_forward_bn_act(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
-                                         const void* w_ohwi, void* y, int ldy, float* stats_partials, float* workspace,
-                                         int parts, int part_stride, double* sums, double* scratch, double count,
-                                         const float* gamma, const float* beta, float eps, float momentum,
-                                         float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                         float* shift, const void* residual, int ldr, int act, void* z, int ldz,
-                                         uint8_t* zmask, int* applied, void* stream) {
-    XV2_CHECK_ARG(applied && z && mean && invstd && scale && shift, "conv2d_forward_bn_act: z, the coefficient outputs and `applied` are required");
-    *applied = 0;
-    XV2_CHECK_ARG(stats_partials && scratch && sums, "conv2d_forward_bn_act: partials, scratch and sums are required");
-    XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn_act: parts=%d part_stride=%d", parts, part_stride);
-    XV2_CHECK_ARG(!zmask || (ldz == d->Cout && act != XV2_ACT_SIGMOID), "conv2d_forward_bn_act: the mask form needs dense rows and a ReLU-type activation");
-    if (!bn_fold_enabled())
-        return xv2_conv2d_forward_bn(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, parts, part_stride, sums,
-                                     scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                                     scale, shift, stream);
-    StatsFold f;
-    memset(&f, 0, sizeof(f));
-    f.on = 1;
-    f.S = parts;
-    f.part_stride = part_stride;
-    f.scratch = scratch;
-    f.sums = sums;
-    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
-    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
-    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
-    CoopArgs ca{z, ldz, residual, ldr, act, zmask, applied};
-    return conv_forward_impl(d, (const float*)x0, ldx0, (const float*)x1, ldx1, (const float*)w_ohwi, nullptr, (float*)y, ldy,
-                             stats_partials, workspace, stream, nullptr, nullptr, nullptr, &f, nullptr, nullptr, &ca);
-}
-
-extern "C" int xv2_set_coop_blocks(int blocks) {
-    g_coop_blocks = blocks;
-    return XV2_OK;
-}
-extern "C" int64_t xv2_coop_count(void) { return g_coop_count; }
-
-// 1 if xv2_conv2d_forward_bn_pre() can run this convolution (the halo plan of XV2_MATH_F32X3), else 0
-extern "C" int xv2_conv2d_forward_pre_supported(const xv2_conv_desc* d) {
-    if (d->C1 != 0 || d->math != XV2_MATH_F32X3 || !bn_fold_enabled()) return 0;
-    int flag = 0;
-    float* fake_ws = reinterpret_cast<float*>(16);      // "a workspace is available": the plan may be split-K
-    if (conv_forward_impl(d, nullptr, d->C0, nullptr, 0, nullptr, nullptr, nullptr, d->Cout, nullptr, fake_ws, nullptr, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, &flag) != XV2_OK)
-        return 0;
-    return flag;
-}
-
-// xv2_conv2d_forward_bn whose input is the RAW output y0 of the producing convolution: that layer's training-mode
-// BatchNorm + activation, z0 = act(y0 * pre_scale + pre_shift), is applied while the halo of y0 is staged into LDS (zero
-// padding stays zero) - z0 is never written to memory (model/layers.py:96-100 between the two convolutions of a
-// bottleneck / decoder block).  Same results, bit for bit, as xv2_bn_act_forward followed by xv2_conv2d_forward_bn.
-extern "C" int xv2_conv2d_forward_bn_pre(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
-                                         const float* pre_shift, int pre_act, const void* w_ohwi, void* y, int ldy,
-                                         float* stats_partials, float* workspace, int parts, int part_stride, double* sums,
-                                         double* scratch, double count, const float* gamma, const float* beta, float eps,
-                                         float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                                         float* scale, float* shift, void* stream) {
-    XV2_CHECK_ARG(stats_partials && scratch && sums && bn_fold_enabled(), "conv2d_forward_bn_pre: partials, scratch, sums; statistics fold on");
-    XV2_CHECK_ARG(parts >= 1 && part_stride >= d->Cout, "conv2d_forward_bn_pre: parts=%d part_stride=%d", parts, part_stride);
-    XV2_CHECK_ARG(!mean || (invstd && scale && shift), "conv2d_forward_bn_pre: mean, invstd, scale and shift go together");
-    StatsFold f;
-    memset(&f, 0, sizeof(f));
-    f.on = 1;
-    f.S = parts;
-    f.part_stride = part_stride;
-    f.scratch = scratch;
-    f.sums = sums;
-    f.fin.count = count; f.fin.gamma = gamma; f.fin.beta = beta; f.fin.eps = eps; f.fin.momentum = momentum;
-    f.fin.running_mean = running_mean; f.fin.running_var = running_var;
-    f.fin.mean = mean; f.fin.invstd = invstd; f.fin.scale = scale; f.fin.shift = shift;
-    PreAct pre{pre_scale, pre_shift, pre_act};
-    return conv_forward_impl(d, (const float*)y0, ldy0, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)y, ldy, stats_partials,
-                             workspace, stream, nullptr, nullptr, nullptr, &f, &pre);
+    return rc;
 }
 
 extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1,
@@ -2705,56 +2616,6 @@ extern "C" int xv2_conv2d_backward_data_acc(const xv2_conv_desc* d, const void* 
                                             int lddx1, int accumulate, float* workspace, void* stream) {
     return dgrad_impl(d, (const float*)dy, lddy, (const float*)w_ihwo, (float*)dx0, lddx0, (float*)dx1, lddx1, workspace,
                       (hipStream_t)stream, accumulate);
-}
-
-// ---- backward-data that also takes the BatchNorm-backward statistics of the layer feeding this convolution ------
-static float* const kPlanPtr = reinterpret_cast<float*>(64);   // dry runs never dereference operands
-
-extern "C" int64_t xv2_conv2d_backward_data_bn_tiles(const xv2_conv_desc* d, int accumulate, int has_workspace) {
-    if (d->stride != 1 || d->C1 != 0 || d->math == XV2_MATH_BF16) return 0;
-    long long tiles = 0;
-    if (dgrad_impl(d, kPlanPtr, d->Cout, kPlanPtr, kPlanPtr, d->C0, nullptr, 0, has_workspace ? kPlanPtr : nullptr, nullptr,
-                   accumulate, nullptr, &tiles) != XV2_OK)
-        return 0;
-    return tiles;
-}
-
-extern "C" int xv2_conv2d_backward_data_bn(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ihwo,
-                                           void* dx0, int lddx0, int accumulate, const void* bn_y, int ld_bn_y,
-                                           const float* bn_mean, const float* bn_invstd, const float* bn_scale,
-                                           const float* bn_shift, int bn_act, float* partials, float* workspace,
-                                           void* stream) {
-    XV2_CHECK_ARG(xv2_conv2d_backward_data_bn_tiles(d, accumulate, workspace != nullptr) > 0,
-                  "backward_data_bn: this shape has no fused statistics form (query xv2_conv2d_backward_data_bn_tiles)");
-    XV2_CHECK_ARG(bn_y && bn_mean && bn_invstd && bn_scale && bn_shift && partials && ld_bn_y % 4 == 0 &&
-                      (reinterpret_cast<uintptr_t>(bn_y) & 15) == 0,
-                  "backward_data_bn: BatchNorm operands missing or misaligned");
-    BnbArgs b{(const float*)bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
-    return dgrad_impl(d, (const float*)dy, lddy, (const float*)w_ihwo, (float*)dx0, lddx0, nullptr, 0, workspace,
-                      (hipStream_t)stream, accumulate, &b);
-}
-
-extern "C" int64_t xv2_conv_transpose2d_backward_data_bn_tiles(const xv2_conv_desc* d) {
-    if (d->math != 0) return 0;
-    long long tiles = 0;
-    if (conv_forward_impl(d, kPlanPtr, d->C0, nullptr, 0, kPlanPtr, nullptr, kPlanPtr, d->Cout, nullptr, nullptr, nullptr,
-                          nullptr, nullptr, &tiles) != XV2_OK)
-        return 0;
-    return tiles;
-}
-
-extern "C" int xv2_conv_transpose2d_backward_data_bn(const xv2_conv_desc* d, const float* dy, int lddy,
-                                                     const float* w_ohwi, float* dx, int lddx, const float* bn_y,
-                                                     int ld_bn_y, const float* bn_mean, const float* bn_invstd,
-                                                     const float* bn_scale, const float* bn_shift, int bn_act,
-                                                     float* partials, void* stream) {
-    XV2_CHECK_ARG(xv2_conv_transpose2d_backward_data_bn_tiles(d) > 0,
-                  "conv_transpose2d_backward_data_bn: this shape has no fused statistics form");
-    XV2_CHECK_ARG(bn_y && bn_mean && bn_invstd && bn_scale && bn_shift && partials && ld_bn_y % 4 == 0 &&
-                      (reinterpret_cast<uintptr_t>(bn_y) & 15) == 0,
-                  "conv_transpose2d_backward_data_bn: BatchNorm operands missing or misaligned");
-    BnbArgs b{bn_y, ld_bn_y, bn_mean, bn_invstd, bn_scale, bn_shift, bn_act, partials};
-    return conv_forward_impl(d, dy, lddy, nullptr, 0, w_ohwi, nullptr, dx, lddx, nullptr, nullptr, stream, nullptr, &b);
 }
 
 extern "C" int xv2_conv_transpose2d_forward(const xv2_conv_desc* d, const void* x, int ldx,

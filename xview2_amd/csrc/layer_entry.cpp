@@ -11,8 +11,6 @@
 #include "xv2_common.h"
 #include "igemm_params.h"
 
-int xv2_tensor_amax_into(const float* x, int64_t n, void* slots, void* stream);      // igemm_conv.hip
-
 extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, int ldx0, const void* x1, int ldx1,
                                        const void* w_ohwi, void* y, int ldy, float* stats_partials, int64_t tiles,
                                        float* workspace, double* sums, double* scratch, double count,
@@ -20,26 +18,13 @@ extern "C" int xv2_conv_bn_act_forward(const xv2_conv_desc* d, const void* x0, i
                                        float* running_mean, float* running_var, float* mean, float* invstd,
                                        float* scale, float* shift, const void* residual, int ldr, int act, void* z,
                                        int ldz, uint8_t* zmask, int dtype, void* stream) {
-    // convolution + statistics + coefficients: ONE launch (the last blocks to arrive fold the tile partials, bn_fold.h)
-    // (+ the BatchNorm apply behind a gate in that same launch when its grid is resident at once: xv2_conv2d_forward_bn_act)
+    // convolution (+ statistics partials), statistics reduction + coefficients, apply: three launches behind one call
     xv2::AmaxGuard amax_guard;      // (the convolution reads the context's sources, the apply pass records into its `out`)
-    const int64_t npix_f = (int64_t)d->N * d->OH * d->OW;
-    if (stats_partials && mean && tiles > 0 && xv2_bn_reduce_finalize_act_forward_supported(tiles, npix_f, d->Cout)) {
-        // small layers: convolution, then ONE launch for the statistics reduction, the coefficients and the apply pass
-        int rc0 = xv2_conv2d_forward(d, x0, ldx0, x1, ldx1, w_ohwi, nullptr, y, ldy, stats_partials, workspace, stream);
-        if (rc0) return rc0;
-        return xv2_bn_reduce_finalize_act_forward(stats_partials, tiles, d->Cout, sums, count, gamma, beta, eps, momentum,
-                                                  running_mean, running_var, mean, invstd, scale, shift, y, ldy, residual, ldr,
-                                                  act, z, ldz, npix_f, zmask, dtype, stream);
-    }
-    int applied = 0;
-    int rc = xv2_conv2d_forward_bn_act(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums,
-                                       scratch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                                       scale, shift, residual, ldr, act, z, ldz, zmask, &applied, stream);
+    int rc = xv2_conv2d_forward_bn(d, x0, ldx0, x1, ldx1, w_ohwi, y, ldy, stats_partials, workspace, 1, d->Cout, sums, scratch, count,
+                                   gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, stream);
+    if (rc) return rc;
+    (void)tiles;
     const int64_t npix = (int64_t)d->N * d->OH * d->OW;
-    if (!rc && applied && xv2::amax_ctx().out && dtype == XV2_F32 && ldz == d->Cout)      // (the gated apply does not record)
-        rc = xv2_tensor_amax_into(static_cast<const float*>(z), npix * d->Cout, xv2::amax_ctx().out, stream);
-    if (rc || applied) return rc;
     if (zmask)
         return xv2_bn_act_forward_mask(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, d->Cout, zmask, dtype, stream);
     return xv2_bn_act_forward(y, ldy, scale, shift, residual, ldr, act, z, ldz, npix, d->Cout, dtype, stream);
@@ -145,7 +130,7 @@ extern "C" int xv2_conv_bn_act_forward_grouped(const xv2_conv_desc* d, int group
     const int ctot = groups * d->Cout;
     static const int one_grid = [] { const char* e = getenv("XV2_GROUPED_GRID"); return e ? atoi(e) : 1; }();
     int first = 0;
-    if (groups == 2 && one_grid && !xv2::bn_fold_enabled()) {
+    if (groups == 2 && one_grid) {
         // Both groups in ONE grid when group 0's convolution takes the small-grid kernel (sg_conv.hip, gridDim.y = 2): the statistics
         // partials then come out as rows of all 2 * Cout channels and one reduction serves both groups - per channel the same sums
         // in the same order as the per-group launches.  Otherwise `done` stays 0 and group 0 has run the ordinary way.

@@ -150,15 +150,10 @@ struct ColOp {
 // sums of the BatchNorm backward do the same (default OFF: under that HBM-streaming kernel every device-scope load of
 // the fold is a ~2.5 us round trip and the two-level tail costs +16.7 us per launch where the separate, idle-chip
 // reduction kernel takes 12.5 us - profiles/r03_fold_ab.md)
-static int bn_fold_bits() {
-    static const int v = [] { const char* e = getenv("XV2_BN_FOLD"); return e ? atoi(e) : 0; }();
-    return v;
-}
-static int g_bn_fold_override = -1;      // xv2_set_bn_fold(): 0 / 1 overrides the environment (tests, A/B runs in one process); -1: env
-bool bn_fold_enabled() {
-    if (g_bn_fold_override >= 0) return g_bn_fold_override != 0 || coop_requested();
-    return (bn_fold_bits() & 1) != 0 || coop_requested();
-}
+// (round 6: the in-launch statistics fold - XV2_BN_FOLD, xv2_set_bn_fold - is gone: +0.65 ms per cfg2 step once its hand-off was
+//  fenced correctly; the separate reduction launch, one-phase for small layers, is the only form)
+static int bn_fold_bits() { return 0; }
+bool bn_fold_enabled() { return false; }
 static bool bn_fold_backward() { return (bn_fold_bits() & 2) != 0; }
 
 static int bn_reverse(int bit) {
@@ -585,124 +580,6 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ y
     if (amax) amax_record(amax, zmax, amax_red);
 }
 
-// ---- statistics reduction + coefficients + apply in ONE launch (small layers) ---------------------------------------------
-// A training-mode BatchNorm forward is three launches: the convolution (with statistics partials per row tile), the reduction of
-// the partials (+ coefficients, running statistics) and the apply pass.  For the layers of the /8 ... /32 encoder levels the middle
-// one is 7 - 10 us of ticket and dependent-load latency for a few hundred KB (63 launches, 0.6 ms per cfg2 step; ~70 per resnest50
-// encoder forward).  Here every block of the apply pass owns 32 CHANNELS and a range of rows and first repeats the reduction for its
-// own channels out of L2 - exactly the sums of reduce_stats_kernel, term for term and in its order (S row groups of the tiles, eight
-// lanes with two chains each, quarters of the S rows), so the coefficients carry the same bits as the two-launch form - then
-// normalises its rows with the coefficients in registers.  The blocks of the first row range also write the sums, the coefficients
-// and the running statistics (model/layers.py:93-100 nn.BatchNorm2d in training mode).
-template <typename T, bool MASK>
-__global__ void __launch_bounds__(256) bn_finalize_act_fwd_kernel(const float* __restrict__ part, int64_t tiles, int C, int S,
-                                                                  double* __restrict__ sums, const BnFinalize fin,
-                                                                  const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
-                                                                  int act, T* __restrict__ z, int ldz, int64_t npix,
-                                                                  uint8_t* __restrict__ zmask, unsigned* __restrict__ amax) {
-    __shared__ double sh[256 * 2];
-    __shared__ double rows[8 * 32 * 2];
-    __shared__ float coef[32 * 2];
-    __shared__ float amax_red[4];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 channels x 8 row lanes
-    const int c = blockIdx.x * 32 + tx;
-    const int64_t per = cdiv(tiles, S);
-    // (reduce_stats_kernel, blocks (blockIdx.x, 0 .. S - 1): S <= 8 and per <= 16 here, so lane ty of row group s adds at most the
-    //  tiles t0 + ty and t0 + ty + 8 - chain a, chain e, then a + e.  All loads of all row groups are issued before the first sum:
-    //  one memory round trip per block instead of one per row group)
-    float2 va[8], ve[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int64_t t0 = (int64_t)s * per, t1 = min(t0 + per, tiles), t = t0 + ty;
-        va[s] = (s < S && t < t1) ? *reinterpret_cast<const float2*>(part + ((size_t)t * C + c) * 2) : make_float2(0.f, 0.f);
-        ve[s] = (s < S && t + 8 < t1) ? *reinterpret_cast<const float2*>(part + ((size_t)(t + 8) * C + c) * 2) : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (s >= S) break;
-        double a0 = 0.0, a1 = 0.0, e0 = 0.0, e1 = 0.0;
-        a0 += (double)va[s].x;
-        a1 += (double)va[s].y;
-        e0 += (double)ve[s].x;
-        e1 += (double)ve[s].y;
-        a0 += e0;
-        a1 += e1;
-        sh[threadIdx.x * 2] = a0;
-        sh[threadIdx.x * 2 + 1] = a1;
-        __syncthreads();
-        if (ty == 0) {
-            double b0 = 0.0, b1 = 0.0;
-            for (int q = 0; q < 8; ++q) {
-                b0 += sh[(q * 32 + tx) * 2];
-                b1 += sh[(q * 32 + tx) * 2 + 1];
-            }
-            rows[(s * 32 + tx) * 2] = b0;
-            rows[(s * 32 + tx) * 2 + 1] = b1;
-        }
-        __syncthreads();
-    }
-    {   // (reduce_stats_kernel, last block: 4 row quarters x (32 channels x 2 statistics))
-        const int t64 = threadIdx.x & 63, quarter = threadIdx.x >> 6;
-        const int ch = blockIdx.x * 32 + (t64 >> 1), which = t64 & 1;
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-        auto ld = [&](int row) { return rows[(row * 32 + (t64 >> 1)) * 2 + which]; };
-        const int rq = (S + 3) >> 2;
-        int r = quarter * rq;
-        const int rend = min(r + rq, S);
-        for (; r + 4 <= rend; r += 4) {
-            q0 += ld(r);
-            q1 += ld(r + 1);
-            q2 += ld(r + 2);
-            q3 += ld(r + 3);
-        }
-        for (; r < rend; ++r) q0 += ld(r);
-        double a = (q0 + q1) + (q2 + q3);
-        sh[threadIdx.x] = a;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            a = (sh[t64] + sh[64 + t64]) + (sh[128 + t64] + sh[192 + t64]);
-            const double other = __shfl_xor(a, 1, 64);
-            if (blockIdx.y == 0) {
-                sums[(size_t)ch * 2 + which] = a;
-                if (!which) bn_finalize_channel(fin, ch, a, other);
-            }
-            if (!which) {
-                double m, var, is;
-                float sc, sf;
-                bn_channel_coeffs(fin, ch, a, other, m, var, is, sc, sf);
-                coef[(t64 >> 1) * 2] = sc;
-                coef[(t64 >> 1) * 2 + 1] = sf;
-            }
-        }
-        __syncthreads();
-    }
-    // ---- apply: rows [r0, r1) x this block's 32 channels; a thread = 4 channels (16 / 8 bytes) of every 32nd row
-    const int c4 = (threadIdx.x & 7) * 4, rl = threadIdx.x >> 3;
-    const float4 sc = make_float4(coef[c4 * 2], coef[c4 * 2 + 2], coef[c4 * 2 + 4], coef[c4 * 2 + 6]);
-    const float4 sf = make_float4(coef[c4 * 2 + 1], coef[c4 * 2 + 3], coef[c4 * 2 + 5], coef[c4 * 2 + 7]);
-    const int64_t rper = cdiv(npix, (int64_t)gridDim.y);
-    const int64_t r0 = (int64_t)blockIdx.y * rper, r1 = min(r0 + rper, npix);
-    const int cg = blockIdx.x * 32 + c4;
-    float zmax = 0.f;
-    for (int64_t row = r0 + rl; row < r1; row += 32) {
-        const float4 v = ld4(y + row * ldy + cg);
-        float4 o;
-        o.x = __fmaf_rn(v.x, sc.x, sf.x); o.y = __fmaf_rn(v.y, sc.y, sf.y);
-        o.z = __fmaf_rn(v.z, sc.z, sf.z); o.w = __fmaf_rn(v.w, sc.w, sf.w);
-        if (res) {
-            const float4 r = ld4(res + row * ldr + cg);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        o.x = apply_act(o.x, act); o.y = apply_act(o.y, act);
-        o.z = apply_act(o.z, act); o.w = apply_act(o.w, act);
-        zmax = amax_acc(zmax, o);
-        st4(z + row * ldz + cg, o);
-        if constexpr (MASK)       // one byte per 4 channels, dense rows: byte index = row * C/4 + c/4
-            zmask[row * (C / 4) + (cg >> 2)] = (uint8_t)((o.x > 0.f) | ((o.y > 0.f) << 1) | ((o.z > 0.f) << 2) | ((o.w > 0.f) << 3));
-    }
-    if (amax) amax_record(amax, zmax, amax_red, blockIdx.x + 61 * blockIdx.y);
-}
-
 template <bool VEC, typename T>
 __global__ void __launch_bounds__(256) bn_act_bwd_kernel(const T* __restrict__ dz, int lddz,
                                                           const T* __restrict__ z, int ldz,
@@ -1018,11 +895,6 @@ static inline int ew_grid(int64_t total) {
 
 using namespace xv2;
 
-extern "C" int xv2_set_bn_fold(int on) {
-    g_bn_fold_override = on < 0 ? -1 : (on != 0);
-    return XV2_OK;
-}
-
 extern "C" int xv2_bn_reduce_stats(const float* partial, int64_t tiles, int C, double* sums, double* scratch,
                                    void* stream) {
     XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_reduce_stats: empty");
@@ -1040,12 +912,6 @@ extern "C" int xv2_bn_reduce_finalize(const float* partial, int64_t tiles, int C
     f.running_mean = running_mean; f.running_var = running_var;
     f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
     return reduce_stats<float>(partial, tiles, C, sums, scratch, (hipStream_t)stream, nullptr, nullptr, &f);
-}
-
-extern "C" int xv2_bn_backward_reduce_partials(const float* partial, int64_t tiles, int C, double* sums2, float* dgamma,
-                                               float* dbeta, double* scratch, void* stream) {
-    XV2_CHECK_ARG(tiles > 0 && C > 0, "bn_backward_reduce_partials: empty");
-    return reduce_stats<float>(partial, tiles, C, sums2, scratch, (hipStream_t)stream, dbeta, dgamma);
 }
 
 extern "C" size_t xv2_bn_tensor_stats_workspace(int64_t npix, int C) {
@@ -1166,56 +1032,6 @@ extern "C" int xv2_bn_act_forward_mask(const void* y, int ldy, const float* scal
     XV2_CHECK_DTYPE(dtype);
     XV2_DISPATCH_DTYPE(dtype, return bn_act_forward_impl<T>((const T*)y, ldy, scale, shift, (const T*)residual, ldr, act,
                                                            (T*)z, ldz, npix, C, zmask, stream));
-}
-
-// shapes the one-launch form takes: whole 32-channel groups, 4-element vector rows, a partial count whose repeated reduction per
-// block stays small next to the apply work; XV2_BN_FUSED_FWD=0 keeps the two launches (A/B runs)
-extern "C" int xv2_bn_reduce_finalize_act_forward_supported(int64_t tiles, int64_t npix, int C) {
-    // (measured neutral on the cfg2 step - 21.63 vs 21.61 ms, two same-box pairs - and +0.65 ms when it also took the layers with
-    //  256 .. 1024 partial rows: once more a kernel boundary costs less than what replaces it.  Opt-in: XV2_BN_FUSED_FWD=1)
-    static const int on = [] { const char* e = getenv("XV2_BN_FUSED_FWD"); return e ? atoi(e) : 0; }();
-    if (!on || bn_fold_enabled()) return 0;
-    return (C % 32 == 0 && tiles >= 1 && tiles <= 128 && npix >= 1) ? 1 : 0;      // (<= 8 row groups of <= 16 tiles: the kernel's unrolled sums)
-}
-
-extern "C" int xv2_bn_reduce_finalize_act_forward(const float* partial, int64_t tiles, int C, double* sums, double count,
-                                                  const float* gamma, const float* beta, float eps, float momentum,
-                                                  float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
-                                                  float* shift, const void* y, int ldy, const void* residual, int ldr, int act, void* z,
-                                                  int ldz, int64_t npix, uint8_t* zmask, int dtype, void* stream) {
-    XV2_CHECK_DTYPE(dtype);
-    XV2_CHECK_ARG(xv2_bn_reduce_finalize_act_forward_supported(tiles, npix, C), "bn_reduce_finalize_act_forward: unsupported shape");
-    XV2_CHECK_ARG(partial && sums && mean && invstd && scale && shift && y && z, "bn_reduce_finalize_act_forward: null operand");
-    XV2_CHECK_ARG(!zmask || act != XV2_ACT_SIGMOID, "bn_reduce_finalize_act_forward: the mask form needs a ReLU-type activation");
-    const size_t es = dtype == XV2_BF16 ? 2 : 4;
-    XV2_CHECK_ARG(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && ((uintptr_t)y % (4 * es)) == 0 && ((uintptr_t)z % (4 * es)) == 0 &&
-                      (!residual || ((uintptr_t)residual % (4 * es)) == 0),
-                  "bn_reduce_finalize_act_forward: rows must be aligned to 4 elements");
-    AmaxGuard amax_guard;
-    unsigned* amax = dtype == XV2_F32 ? amax_ctx().out : nullptr;
-    BnFinalize f;
-    f.count = count; f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
-    f.running_mean = running_mean; f.running_var = running_var;
-    f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
-    int S = (int)std::min<int64_t>(XV2_BN_SCRATCH_ROWS, cdiv(tiles, 16));       // (the row groups of reduce_stats: same sums, same order)
-    if (S < 1) S = 1;
-    const int groups = C / 32;
-    // row ranges: enough blocks for the chip (~4 per CU), at least 64 rows each
-    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(npix, 64), cdiv(1024, groups)));
-    const dim3 grid((unsigned)groups, (unsigned)chunks);
-#define XV2_BNF_LAUNCH(TT, MM)                                                                                                   \
-    hipLaunchKernelGGL((bn_finalize_act_fwd_kernel<TT, MM>), grid, dim3(256), 0, (hipStream_t)stream, partial, tiles, C, S, sums, f, \
-                       (const TT*)y, ldy, (const TT*)residual, ldr, act, (TT*)z, ldz, npix, zmask, amax)
-    if (dtype == XV2_BF16) {
-        if (zmask) XV2_BNF_LAUNCH(bf16_t, true);
-        else XV2_BNF_LAUNCH(bf16_t, false);
-    } else {
-        if (zmask) XV2_BNF_LAUNCH(float, true);
-        else XV2_BNF_LAUNCH(float, false);
-    }
-#undef XV2_BNF_LAUNCH
-    XV2_CHECK_LAUNCH();
-    return XV2_OK;
 }
 
 template <typename T>

@@ -550,243 +550,6 @@ __global__ void rsoftmax_bwd_kernel(const float* __restrict__ a, const float* __
     dl[n * 2 * C + C + c] = a1 * (d1 - dot);
 }
 
-// ------------------------------------------------------------------ fused split-attention tail
-// The [N, C]-vector part of SplAtConv2d - GAP fold, fc1, bn1 (+ReLU), fc2, rSoftMax - is ~10 tiny launches when
-// written op by op (4-5 us of GPU time and ~13 us of host time each, 16/33/66 blocks per resnest50/101/200 pass, once
-// more in backward).  Without a cross-rank statistics exchange between fc1 and bn1 the whole chain is two launches.
-//   (splat_colsum_kernel + splat_gap_finish_kernel: the GAP itself, chip-wide)
-//   splat_fc1_kernel   grid (ceil(inter/64), N): 64 outputs of h1[n] = fc1(gap[n]) per block.
-//   splat_att_kernel   grid (C/64): every block rebuilds bn1 for ALL `inter` channels from h1 [N][inter] (two-pass
-//                      fp64 statistics over the N samples; block 0 stores them and updates the running statistics),
-//                      a1 = relu(bn1(h1)) in LDS, then fc2 + rSoftMax for its 64 channel pairs (c, C + c).
-constexpr int SPLAT_MAX_NI = 8192;      // N * inter floats of LDS per matrix (h1 / a1)
-
-__global__ void __launch_bounds__(256) splat_fc1_kernel(const float* __restrict__ gap, int N, int C, int inter,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         float* __restrict__ h1) {
-    extern __shared__ float sg[];       // [C] gap of sample n
-    const int n = blockIdx.y, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) sg[c] = gap[(size_t)n * C + c];
-    __syncthreads();
-    // 4 lanes per output, 64 outputs per block
-    const int j = blockIdx.x * 64 + (tid >> 2), q = tid & 3;
-    float s = 0.f;
-    if (j < inter) {
-        const float* w = w1 + (size_t)j * C;
-        for (int c = q; c < C; c += 4) s += sg[c] * w[c];
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (j < inter && q == 0) h1[(size_t)n * inter + j] = s + (b1 ? b1[j] : 0.f);
-}
-
-struct SplatBn {
-    const float* gamma;
-    const float* beta;
-    float* running_mean;
-    float* running_var;
-    float eps, momentum;
-    int train;
-};
-
-__global__ void __launch_bounds__(256) splat_att_kernel(const float* __restrict__ h1, int N, int C, int inter,
-                                                         SplatBn bn, const float* __restrict__ w2,
-                                                         const float* __restrict__ b2, float* __restrict__ a1,
-                                                         float* __restrict__ mean1, float* __restrict__ invstd1,
-                                                         float* __restrict__ att) {
-    extern __shared__ float sm[];
-    float* sa = sm;                     // [N][inter]  h1, then a1
-    float* sl = sm + N * inter;         // [N][128]    logits of this block's channel pairs
-    const int tid = threadIdx.x, c0 = blockIdx.x * 64;
-    for (int i = tid; i < N * inter; i += 256) sa[i] = h1[i];
-    __syncthreads();
-    for (int j = tid; j < inter; j += 256) {
-        double m, var;
-        if (bn.train) {
-            double s = 0.0;
-            for (int n = 0; n < N; ++n) s += (double)sa[n * inter + j];
-            m = s / N;
-            double v = 0.0;
-            for (int n = 0; n < N; ++n) {
-                const double d = (double)sa[n * inter + j] - m;
-                v += d * d;
-            }
-            var = v / N;
-        } else {
-            m = (double)bn.running_mean[j];
-            var = (double)bn.running_var[j];
-        }
-        const float is = (float)(1.0 / sqrt(var + (double)bn.eps));
-        const float sc = (bn.gamma ? bn.gamma[j] : 1.f) * is;
-        const float sh = (bn.beta ? bn.beta[j] : 0.f) - (float)m * sc;
-        for (int n = 0; n < N; ++n) {
-            const float v = __fmaf_rn(sa[n * inter + j], sc, sh);
-            sa[n * inter + j] = v > 0.f ? v : 0.f;
-        }
-        if (blockIdx.x == 0) {
-            mean1[j] = (float)m;
-            invstd1[j] = is;
-            if (bn.train && bn.running_mean) {
-                const double unb = N > 1 ? var * N / (N - 1.0) : var;
-                bn.running_mean[j] = (1.f - bn.momentum) * bn.running_mean[j] + bn.momentum * (float)m;
-                bn.running_var[j] = (1.f - bn.momentum) * bn.running_var[j] + bn.momentum * (float)unb;
-            }
-        }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int i = tid; i < N * inter; i += 256) a1[i] = sa[i];
-    // fc2 for the 128 outputs k = c0 + [0,64) and C + c0 + [0,64): 2 lanes per output
-    const int ko = tid >> 1, q = tid & 1;                       // ko in [0,128)
-    const int k = ko < 64 ? c0 + ko : C + c0 + (ko - 64);
-    const bool kok = (ko < 64 ? c0 + ko : c0 + ko - 64) < C;
-    const float* w = w2 + (size_t)(kok ? k : 0) * inter;
-    for (int n = 0; n < N; ++n) {
-        float s = 0.f;
-        if (kok)
-            for (int j = q; j < inter; j += 2) s += sa[n * inter + j] * w[j];
-        s += __shfl_xor(s, 1, 64);
-        if (q == 0) sl[n * 128 + ko] = s + ((kok && b2) ? b2[k] : 0.f);
-    }
-    __syncthreads();
-    for (int i = tid; i < N * 64; i += 256) {
-        const int n = i >> 6, cc = i & 63;
-        if (c0 + cc >= C) continue;
-        const float l0 = sl[n * 128 + cc], l1 = sl[n * 128 + 64 + cc];
-        const float mx = fmaxf(l0, l1);
-        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
-        const float inv = 1.f / (e0 + e1);
-        att[(size_t)n * 2 * C + c0 + cc] = e0 * inv;
-        att[(size_t)n * 2 * C + C + c0 + cc] = e1 * inv;
-    }
-}
-
-// backward, first half (after splat_colsum_kernel + splat_datt_finish_kernel produced datt).  grid (C/64): block = the
-// channel pairs (c, C + c), c in [c0, c0 + 64): rSoftMax backward -> dlogits [N][128] (LDS), dw2 / db2 rows of its 128 outputs, and its
-// contribution to da1: pda1[block][N][inter] = sum_{k in block} dlogits[n][k] * w2[k][j].
-__global__ void __launch_bounds__(256) splat_att_bwd1_kernel(const float* __restrict__ datt, int N, int C,
-                                                              int inter, const float* __restrict__ att,
-                                                              const float* __restrict__ a1,
-                                                              const float* __restrict__ w2, float* __restrict__ dw2,
-                                                              float* __restrict__ db2, float* __restrict__ pda1) {
-    extern __shared__ float sm[];
-    float* sa = sm;                      // [N][inter] a1
-    float* sd = sm + N * inter;          // [N][128]   dlogits
-    const int tid = threadIdx.x, c0 = blockIdx.x * 64;
-    for (int i = tid; i < N * inter; i += 256) sa[i] = a1[i];
-    for (int i = tid; i < N * 64; i += 256) {
-        const int n = i >> 6, cc = i & 63;
-        float dl0 = 0.f, dl1 = 0.f;
-        if (c0 + cc < C) {
-            const float d0 = datt[(size_t)n * 2 * C + c0 + cc], d1 = datt[(size_t)n * 2 * C + C + c0 + cc];
-            const float a0 = att[(size_t)n * 2 * C + c0 + cc], a1v = att[(size_t)n * 2 * C + C + c0 + cc];
-            const float dot = a0 * d0 + a1v * d1;
-            dl0 = a0 * (d0 - dot);
-            dl1 = a1v * (d1 - dot);
-        }
-        sd[n * 128 + cc] = dl0;
-        sd[n * 128 + 64 + cc] = dl1;
-    }
-    __syncthreads();
-    // dw2[k][j] = sum_n dlogits[n][k] * a1[n][j]; db2[k] = sum_n dlogits[n][k]
-    for (int e = tid; e < 128 * inter; e += 256) {
-        const int ko = e / inter, j = e - ko * inter;
-        const int cc = ko < 64 ? ko : ko - 64;
-        if (c0 + cc >= C) continue;
-        const int k = ko < 64 ? c0 + cc : C + c0 + cc;
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += sd[n * 128 + ko] * sa[n * inter + j];
-        dw2[(size_t)k * inter + j] = s;
-    }
-    if (tid < 128) {
-        const int cc = tid < 64 ? tid : tid - 64;
-        if (c0 + cc < C) {
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) s += sd[n * 128 + tid];
-            db2[tid < 64 ? c0 + cc : C + c0 + cc] = s;
-        }
-    }
-    // partial da1 over this block's 128 outputs
-    for (int e = tid; e < N * inter; e += 256) {
-        const int n = e / inter, j = e - n * inter;
-        float s = 0.f;
-        for (int ko = 0; ko < 128; ++ko) {
-            const int cc = ko < 64 ? ko : ko - 64;
-            if (c0 + cc >= C) continue;
-            const int k = ko < 64 ? c0 + cc : C + c0 + cc;
-            s += sd[n * 128 + ko] * w2[(size_t)k * inter + j];
-        }
-        pda1[((size_t)blockIdx.x * N + n) * inter + j] = s;
-    }
-}
-
-// backward, second half.  grid (ceil(C/64)): every block folds da1 from the `nb` partials, runs the bn1 backward over
-// the N samples for all `inter` channels (block 0 stores dgamma / dbeta / db1), then dgap and dw1 for its 64 columns.
-__global__ void __launch_bounds__(256) splat_att_bwd2_kernel(const float* __restrict__ pda1, int nb, int N, int C,
-                                                              int inter, const float* __restrict__ gap,
-                                                              const float* __restrict__ h1,
-                                                              const float* __restrict__ a1,
-                                                              const float* __restrict__ mean1,
-                                                              const float* __restrict__ invstd1,
-                                                              const float* __restrict__ gamma1, int train,
-                                                              const float* __restrict__ w1, float* __restrict__ dgamma1,
-                                                              float* __restrict__ dbeta1, float* __restrict__ dw1,
-                                                              float* __restrict__ db1, float* __restrict__ dgap) {
-    extern __shared__ float sm[];
-    float* sh1 = sm;                    // [N][inter] dh1
-    float* sgp = sm + N * inter;        // [N][64]    gap columns of this block
-    const int tid = threadIdx.x, c0 = blockIdx.x * 64;
-    for (int j = tid; j < inter; j += 256) {
-        const float mu = mean1[j], is = invstd1[j], gm = gamma1 ? gamma1[j] : 1.f;
-        float sg = 0.f, sgx = 0.f;
-        for (int n = 0; n < N; ++n) {
-            float d = 0.f;
-            for (int b = 0; b < nb; ++b) d += pda1[((size_t)b * N + n) * inter + j];
-            const float g = a1[n * inter + j] > 0.f ? d : 0.f;
-            sh1[n * inter + j] = g;
-            sg += g;
-            sgx += g * ((h1[n * inter + j] - mu) * is);
-        }
-        const float invn = 1.f / (float)N;
-        for (int n = 0; n < N; ++n) {
-            const float g = sh1[n * inter + j];
-            const float xh = (h1[n * inter + j] - mu) * is;
-            sh1[n * inter + j] = train ? gm * is * (g - sg * invn - xh * sgx * invn) : gm * is * g;
-        }
-        if (blockIdx.x == 0) {
-            dgamma1[j] = sgx;
-            dbeta1[j] = sg;
-        }
-    }
-    for (int i = tid; i < N * 64; i += 256) {
-        const int n = i >> 6, cc = i & 63;
-        sgp[i] = c0 + cc < C ? gap[(size_t)n * C + c0 + cc] : 0.f;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0)
-        for (int j = tid; j < inter; j += 256) {
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) s += sh1[n * inter + j];
-            db1[j] = s;
-        }
-    // dgap[n][c] = sum_j dh1[n][j] * w1[j][c]   (64 columns x N rows per block)
-    for (int i = tid; i < N * 64; i += 256) {
-        const int n = i >> 6, cc = i & 63;
-        if (c0 + cc >= C) continue;
-        float s = 0.f;
-        for (int j = 0; j < inter; ++j) s += sh1[n * inter + j] * w1[(size_t)j * C + c0 + cc];
-        dgap[(size_t)n * C + c0 + cc] = s;
-    }
-    // dw1[j][c] = sum_n dh1[n][j] * gap[n][c]
-    for (int e = tid; e < inter * 64; e += 256) {
-        const int j = e >> 6, cc = e & 63;
-        if (c0 + cc >= C) continue;
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += sh1[n * inter + j] * sgp[n * 64 + cc];
-        dw1[(size_t)j * C + c0 + cc] = s;
-    }
-}
-
 static int pick_L(int Cin) {
     int L = 1;
     while (L * 2 <= 64 && L * 2 * 4 <= Cin) L *= 2;
@@ -1143,68 +906,3 @@ extern "C" int xv2_rsoftmax_backward(const float* att, const float* datt, float*
     return XV2_OK;
 }
 
-// ---- fused split-attention tail (see splat_fc1_kernel) --------------------------------------------------------
-extern "C" int xv2_splat_att_supported(int N, int C, int inter) {
-    return (N >= 1 && N <= 32 && N * inter <= SPLAT_MAX_NI && splat_vec_ok(C) && inter >= 1 && C % 4 == 0) ? 1 : 0;
-}
-extern "C" size_t xv2_splat_att_workspace(int N, int64_t hw, int C, int inter) {
-    (void)hw;
-    return (size_t)N * SPLAT_CHUNKS * 2 * C * sizeof(float) + (size_t)cdiv(C, 64) * N * inter * sizeof(float) +
-           (size_t)N * 2 * C * sizeof(float);
-}
-extern "C" int xv2_splat_att_forward(const void* x, int N, int64_t hw, int C, int inter, const float* w1,
-                                     const float* b1, const float* gamma1, const float* beta1, float eps,
-                                     float momentum, float* running_mean, float* running_var, int train,
-                                     const float* w2, const float* b2, float* gap, float* h1, float* a1,
-                                     float* mean1, float* invstd1, float* att, float* workspace, int dtype,
-                                     void* stream) {
-    XV2_CHECK_ARG(xv2_splat_att_supported(N, C, inter), "splat_att: unsupported shape N=%d C=%d inter=%d", N, C, inter);
-    XV2_CHECK_ARG(train || (running_mean && running_var), "splat_att: eval mode needs the running statistics");
-    XV2_CHECK_DTYPE(dtype);
-    int chunks, cgw;
-    const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
-    hipStream_t st = (hipStream_t)stream;
-    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((splat_colsum_kernel<T, false>), dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
-                                                 (const T*)x, (const T*)nullptr, hw, 2 * C, 0, cgw, rpc, workspace));
-    XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splat_gap_finish_kernel, dim3((unsigned)cdiv(C, SF_COLS), N), dim3(256), 0, st, workspace, N, C,
-                       chunks, 1.f / (float)hw, gap);
-    XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splat_fc1_kernel, dim3((unsigned)cdiv(inter, 64), N), dim3(256), (size_t)C * sizeof(float), st,
-                       gap, N, C, inter, w1, b1, h1);
-    XV2_CHECK_LAUNCH();
-    SplatBn bn{gamma1, beta1, running_mean, running_var, eps, momentum, train};
-    hipLaunchKernelGGL(splat_att_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), (size_t)(N * inter + N * 128) * sizeof(float),
-                       st, h1, N, C, inter, bn, w2, b2, a1, mean1, invstd1, att);
-    XV2_CHECK_LAUNCH();
-    return XV2_OK;
-}
-extern "C" int xv2_splat_att_backward(const void* x, const void* dout, int N, int64_t hw, int C, int inter,
-                                      const float* gap, const float* h1, const float* a1, const float* mean1,
-                                      const float* invstd1, const float* gamma1, const float* w1, const float* w2,
-                                      const float* att, int train, float* dw2, float* db2, float* dgamma1,
-                                      float* dbeta1, float* dw1, float* db1, float* dgap, float* workspace, int dtype,
-                                      void* stream) {
-    XV2_CHECK_ARG(xv2_splat_att_supported(N, C, inter), "splat_att: unsupported shape N=%d C=%d inter=%d", N, C, inter);
-    XV2_CHECK_DTYPE(dtype);
-    int chunks, cgw;
-    const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
-    hipStream_t st = (hipStream_t)stream;
-    // datt partials: column sums of x * dout (dout broadcast over the two radix groups)
-    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((splat_colsum_kernel<T, true>), dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
-                                                 (const T*)x, (const T*)dout, hw, 2 * C, C, cgw, rpc, workspace));
-    XV2_CHECK_LAUNCH();
-    float* pda1 = workspace + (size_t)N * SPLAT_CHUNKS * 2 * C;
-    const int nb = (int)cdiv(C, 64);
-    float* datt = pda1 + (size_t)nb * N * inter;
-    hipLaunchKernelGGL(splat_datt_finish_kernel, dim3((unsigned)cdiv(2 * C, SF_COLS), N), dim3(256), 0, st, workspace, N, 2 * C,
-                       chunks, datt);
-    XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splat_att_bwd1_kernel, dim3(nb), dim3(256), (size_t)(N * inter + N * 128) * sizeof(float), st,
-                       datt, N, C, inter, att, a1, w2, dw2, db2, pda1);
-    XV2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(splat_att_bwd2_kernel, dim3(nb), dim3(256), (size_t)(N * inter + N * 64) * sizeof(float), st, pda1,
-                       nb, N, C, inter, gap, h1, a1, mean1, invstd1, gamma1, train, w1, dgamma1, dbeta1, dw1, db1, dgap);
-    XV2_CHECK_LAUNCH();
-    return XV2_OK;
-}

@@ -1882,33 +1882,6 @@ extern "C" int xv2_conv2d_backward_weight_async(const xv2_conv_desc* d, const vo
                       (hipStream_t)side_stream);
 }
 
-// 1 if xv2_conv2d_backward_weight_pre_async() can run this layer (all-taps F32X3 plan, one source), else 0
-extern "C" int xv2_conv2d_backward_weight_pre_supported(const xv2_conv_desc* d) {
-    int flag = 0;
-    if (wgrad_impl(d, nullptr, d->C0, nullptr, 0, nullptr, d->Cout, nullptr, d->C0, nullptr, nullptr, nullptr, &flag) != XV2_OK) return 0;
-    return flag;
-}
-// xv2_conv2d_backward_weight_async whose X operand is the RAW output y0 of the producing convolution: z0 = act(y0 *
-// pre_scale + pre_shift) is formed on load (see xv2_conv2d_forward_bn_pre); same results bit for bit as with z0 in memory
-extern "C" int xv2_conv2d_backward_weight_pre_async(const xv2_conv_desc* d, const void* y0, int ldy0, const float* pre_scale,
-                                                    const float* pre_shift, int pre_act, const void* dy, int lddy,
-                                                    float* dw_oihw, float* workspace, void* side_stream, void* stream) {
-    hipStream_t launch = (hipStream_t)stream;
-    if (side_stream && side_stream != stream) {
-        static thread_local hipEvent_t evs[64] = {};
-        int dev = 0;
-        XV2_CHECK_HIP(hipGetDevice(&dev));
-        XV2_CHECK_ARG(dev >= 0 && dev < 64, "backward_weight_pre_async: device index %d out of range", dev);
-        hipEvent_t& ev = evs[dev];
-        if (!ev) XV2_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        XV2_CHECK_HIP(hipEventRecord(ev, (hipStream_t)stream));
-        XV2_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, ev, 0));
-        launch = (hipStream_t)side_stream;
-    }
-    WgradPre pre{pre_scale, pre_shift, pre_act};
-    return wgrad_impl(d, (const float*)y0, ldy0, nullptr, 0, (const float*)dy, lddy, dw_oihw, d->C0, workspace, launch, &pre);
-}
-
 // conv_transpose: the equivalent conv `d` has input = the transposed conv's OUTPUT gradient (large
 // tensor, C0 channels) and output-gradient = the transposed conv's INPUT x (Cout channels).
 extern "C" int xv2_conv_transpose2d_backward_weight(const xv2_conv_desc* d, const void* x, int ldx,

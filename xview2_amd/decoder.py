@@ -20,9 +20,8 @@ class ConvLayer(nn.Module):  # layers.py:89-100
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False)
         self.batch_norm = nn.BatchNorm2d(out_channels, affine=True)
 
-    def forward(self, x0, x1=None, lazy_out=False, passthrough=0):
-        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY, lazy_out=lazy_out,
-                               passthrough=passthrough)
+    def forward(self, x0, x1=None, passthrough=0):
+        return xnn.conv_bn_act(self.conv, self.batch_norm, x0, x1, act=ops.ACT_LEAKY, passthrough=passthrough)
 
 
 class ConvBlock(nn.Module):  # layers.py:119-128
@@ -32,8 +31,7 @@ class ConvBlock(nn.Module):  # layers.py:119-128
         self.conv2 = ConvLayer(out_channels, out_channels)
 
     def forward(self, x0, x1=None):
-        # conv1's BatchNorm + LeakyReLU is applied in conv2's operand load (its output has no other consumer)
-        return self.conv2(self.conv1(x0, x1, lazy_out=True))
+        return self.conv2(self.conv1(x0, x1))
 
 
 class AttentionLayer(nn.Module):  # layers.py:68-77

@@ -36,12 +36,10 @@ class Bottleneck(nn.Module):
         # the block input has two consumers (conv1 and the shortcut): the shortcut reads conv1's pass-through alias,
         # so its gradient is added inside conv1's backward-data kernel rather than by a separate elementwise pass
         fuse = x.is_cuda and torch.is_grad_enabled() and x.requires_grad
-        # bn1 + ReLU is applied in conv2's operand load when conv2 is a stride-1 3x3 (its output has no other consumer)
-        lazy = self.conv2.stride == (1, 1) and self.conv2.groups == 1
         if fuse:
-            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True, lazy_out=lazy)
+            out, x = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, passthrough=True)
         else:
-            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU, lazy_out=lazy)
+            out = xnn.conv_bn_act(self.conv1, self.bn1, x, act=ops.ACT_RELU)
         out = xnn.conv_bn_act(self.conv2, self.bn2, out, act=ops.ACT_RELU)
         if self.downsample is None:
             idt = x

@@ -62,25 +62,19 @@ class bn_split:
 FUSED_INFERENCE = True     # eval + no_grad: one launch per conv layer (tests switch it off to compare both forms)
 
 
-def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False, lazy_out=False):
+def conv_bn_act(conv, bn, x0, x1=None, act=ops.ACT_NONE, residual=None, passthrough=False):
     """act(BN(conv(cat(x0, x1))) [+ residual]) - one fused autograd node.  passthrough=True (or 1) returns (out, x0 alias):
     hand the alias to x0's other consumer and the two gradients are summed inside the backward-data kernel; 2 = alias of x1,
     3 = (out, x0 alias, x1 alias)."""
     passthrough = int(passthrough) & (3 if x1 is not None else 1)
     if not bn.training and not torch.is_grad_enabled() and x0.is_cuda and FUSED_INFERENCE:
         # inference: BatchNorm folded into the convolution epilogue (xv2_conv2d_forward_fused), no autograd node
-        tag = getattr(x0, "_xv2_lazy", None)
-        if tag is not None:
-            # XV2_LAZY_BN with a partially frozen network: the producer (BatchNorm in train mode) handed out its RAW
-            # convolution output tagged with its coefficients - materialise its BatchNorm + activation before convolving
-            x0 = ops._apply_pre(x0, tag)
         z = ops.conv_bn_act_infer(x0, x1, conv.weight, residual, _cfg(conv), ops.BnState(bn, False), act)
         return _with_aliases(z, x0, x1, passthrough)
     bump_bn_counter(bn)
-    # lazy_out: the result feeds exactly ONE further conv_bn_act call and nothing else (see ops.ConvBnActFn.forward)
     bs = ops.BnState(bn, SYNC_BN)
     out = ops.ConvBnActFn.apply(x0, x1, conv._parameters["weight"], bs.weight, bs.bias, residual, _cfg(conv),
-                                bs, act, bn.training, passthrough, lazy_out)
+                                bs, act, bn.training, passthrough)
     if passthrough == 3:
         ops.carry_amax(x0, out[1])
         ops.carry_amax(x1, out[2])

@@ -107,11 +107,9 @@ def fp32_math():
     products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped terms < 2^-23 of |a||b| per product, i.e. the
     rounding class of an fp32 multiply) - 1.5-1.7x the exact-fp32 MFMA's throughput.  XV2_F32X3=0 selects the exact
     fp32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain) everywhere.
-    Two differences to keep in mind: (1) non-finite operands - the split forms inf - bf16(inf) = NaN in its residual terms,
+    One difference to keep in mind: non-finite operands - the split forms inf - bf16(inf) = NaN in its residual terms,
     so an operand that is +-Inf yields NaN where the fp32 MFMA would propagate Inf (both are already-diverged training
-    states; finite inputs are unaffected); (2) the producer-layer BatchNorm-backward statistics in the backward-data
-    epilogue (XV2_FUSE_BN_BWD, off by default) exist in the exact-fp32 kernels only: the *_bn_tiles queries return 0 in
-    this mode and the caller takes the separate column-sum pass."""
+    states; finite inputs are unaffected)."""
     return MATH_F32 if os.environ.get("XV2_F32X3", "1") == "0" else MATH_F32X3
 
 
@@ -547,52 +545,16 @@ def _stats_scratch(C, device):
     return t
 
 
-# Deferred BatchNorm apply: built, bit-identical (logits, every gradient, running statistics at 128^2 and
-# 1024^2; tests/test_model_gpu.py) and measured SLOWER on the cfg2 fp32 step - 27.39 -> 27.63 ms with 17 of the 63 apply launches
-# gone: the apply kernel it removes is HBM-bound and cheap (0.3 ms), the fused-multiply-add + activation it adds sit in the
-# operand loaders of the power-limited MFMA kernels (halo form, all-taps weight gradient), and the two layers of a pair
-# leave the one-call layer entry points.  Off by default; XV2_LAZY_BN=1 saves 0.75 GB of activations at 2 x 1024^2.
-LAZY_BN = os.environ.get("XV2_LAZY_BN", "0") != "0"
 STEM_BAND = os.environ.get("XV2_STEM_BAND", "1") != "0"      # --precision 16: RGB stem on the 32-channel bf16 kernel (xv2_pad_band)
 
 
-def _apply_pre(y0, pre):
-    """materialise z0 = act(y0 * scale + shift) (the deferred BatchNorm apply of a lazy producer, see ConvBnActFn)"""
-    scale, shift, act = pre
-    C = y0.shape[-1]
-    z = torch.empty_like(y0)
-    call("xv2_bn_act_forward", y0, C, scale, shift, None, C, act, z, C, y0.numel() // C, C, _dt(y0))
-    return z
-
-
-# BatchNorm apply inside the convolution launch (xv2_conv2d_forward_bn_act: blocks wait at a gate for the coefficients): exact,
-# tested, and measured SLOWER than the two-launch form on every configuration (cfg3 18.3 -> 20.3 ms; include/xv2.h) - opt-in
-COOP_APPLY = os.environ.get("XV2_COOP", "0") != "0"
-_applied_flag = None
-
-
-def _applied():
-    global _applied_flag
-    if _applied_flag is None:
-        import ctypes
-        _applied_flag = ctypes.c_int(0)
-    return _applied_flag
-
-
-def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, pre=None, apply=None,
-                  amax_in=None, amax_out=None):
+def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None, bn=None, fused=None, amax_in=None, amax_out=None):
     """-> y [N,OH,OW,Cout], sums (double [Cout,2]) or None.
-    `pre` = (scale, shift, act): x0 is the RAW output of the producing convolution and that layer's BatchNorm + activation
-    is applied in this convolution's operand load (xv2_conv2d_forward_bn_pre) when the plan allows it - two more values are
-    returned then: the tensor that stands for the input in the backward pass (x0 itself, or the materialised z0) and whether
-    the deferred form ran.  If `ihwo_out` is a list, the backward-data weight
-    packs are produced by the same repack launch and appended to it (one per group).  With `bn` (a BnState that
-    does not synchronise across ranks) the statistics reduction also derives the BatchNorm coefficients in the
-    same launch and the third return value is (mean, invstd, scale, shift).  `fused` = (scale, shift, residual, act):
-    inference form, the folded BatchNorm / residual / activation run in the convolution epilogue and y IS the
-    activated output (xv2_conv2d_forward_fused).  `apply` = {"residual", "act", "want_mask"}: training mode, the
-    BatchNorm this launch derives is also APPLIED by it when its grid is resident at once (xv2_conv2d_forward_bn_act);
-    on success apply["z"] (and apply["zmask"]) hold the activated output - the caller skips its apply pass."""
+    If `ihwo_out` is a list, the backward-data weight packs are produced by the same repack launch and appended to it (one
+    per group).  With `bn` (a BnState that does not synchronise across ranks) the statistics reduction also derives the
+    BatchNorm coefficients in the same launch and the third return value is (mean, invstd, scale, shift).  `fused` = (scale,
+    shift, residual, act): inference form, the folded BatchNorm / residual / activation run in the convolution epilogue and y
+    IS the activated output (xv2_conv2d_forward_fused)."""
     N, IH, IW, C0t = x0.shape
     C1t = x1.shape[3] if x1 is not None else 0
     Cout_t = weight.shape[0]
@@ -612,7 +574,7 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         bn_stats_changed()
     stats_ok = True        # False: the M tiles do not split evenly over the S parts -> statistics taken from y afterwards
     band_w = None
-    if (rgb and STEM_BAND and G == 1 and ihwo_out is None and pre is None and 5 <= g.kw <= 8 and
+    if (rgb and STEM_BAND and G == 1 and ihwo_out is None and 5 <= g.kw <= 8 and
             g.stride == 2 and g.dil == 1 and half):
         # RGB stem as a band convolution (xv2_pad_band): KH taps x 32 "channels" (8 pixels x 4) on the 32-channel bf16 kernel
         # instead of the exact-fp32 gather kernel - under --precision 16 only: for fp32 tensors the split-bf16 form of the
@@ -629,15 +591,6 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
         call("xv2_pack_stem_band", weight.contiguous(), Cout_t, Cin_w, KH, g.kw, band_w, XV2_BF16 if half else XV2_F32)
         x0, IH, IW, C0t = xb, IHp, IWp, 32
         g = conv_cfg(KH, 1, 2, 0, 1, 1, g.math)
-    pre_used = False
-    if pre is not None:
-        d0 = _desc(N, IH, IW, C0t, C1t, Cout_t, g, OH, OW, half)
-        ok = (want_stats and fused is None and G == 1 and x1 is None and S == 1 and not half and
-              query("xv2_conv2d_forward_pre_supported", d0) == 1 and query("xv2_conv2d_forward_stats_tiles", d0) > 0)
-        if ok:
-            pre_used = True
-        else:
-            x0 = _apply_pre(x0, pre)
     w = weight.contiguous()
     if G > 1 and x1 is not None:
         raise RuntimeError("grouped convolution over a virtual concat is not supported")
@@ -674,34 +627,6 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             # convolution + statistics (+ coefficients) in one launch: the last blocks to arrive fold the tile partials
             og = gi * Coutg
             fin = [None] * 4 if coeffs is None else [Ptr(t, og) for t in coeffs]
-            if pre_used:
-                call("xv2_conv2d_forward_bn_pre", d, x0, C0t, pre[0], pre[1], pre[2], ohwi, Ptr(y, og), Cout_t,
-                     _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
-                     S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
-                     _off(bn.weight, og) if bn is not None else None, _off(bn.bias, og) if bn is not None else None,
-                     float(bn.eps) if bn is not None else 0.0, float(bn.momentum) if bn is not None else 0.0,
-                     _off(bn.running_mean, og) if coeffs is not None else None,
-                     _off(bn.running_var, og) if coeffs is not None else None, *fin)
-                continue
-            if apply is not None and coeffs is not None and COOP_APPLY and (gi == 0 or apply.get("n") == gi):
-                # ... and the apply behind the gate of the same launch (every group must take it, else the caller applies)
-                if gi == 0:
-                    apply["z"] = torch.empty_like(y)
-                    apply["zmask"] = None
-                    if apply["want_mask"] and G == 1 and _mask_ok(Cout_t, apply["act"], half):
-                        apply["zmask"] = torch.empty((N * OH * OW * (Cout_t // 4),), dtype=torch.uint8, device=x0.device)
-                    apply["residual"] = _same(apply["residual"], y)
-                    apply["n"] = 0
-                res, flag = apply["residual"], _applied()
-                call("xv2_conv2d_forward_bn_act", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
-                     _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
-                     S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
-                     _off(bn.weight, og), _off(bn.bias, og), float(bn.eps), float(bn.momentum),
-                     _off(bn.running_mean, og), _off(bn.running_var, og), *fin,
-                     None if res is None else Ptr(res, og), Cout_t, apply["act"], Ptr(apply["z"], og), Cout_t, apply["zmask"],
-                     ctypes_addr(flag))
-                apply["n"] += flag.value
-                continue
             call("xv2_conv2d_forward_bn", d, Ptr(x0, gi * C0g), 4 if band_w is not None else C0t, x1, C1t, ohwi, Ptr(y, og), Cout_t,
                  _persist("stats", tiles * Coutg * 2, x0.device), _persist("splitk", (wsb + 3) // 4 + 4, x0.device) if wsb else None,
                  S, Cout_t, Ptr(sums, og * 2), _stats_scratch(Coutg, x0.device), float(N * OH * OW // S),
@@ -716,13 +641,8 @@ def _conv_forward(x0, x1, weight, g, bias=None, want_stats=False, ihwo_out=None,
             if want_stats:
                 stats_ok = False
     assert cin_w <= C0g + C1t
-    if apply is not None and not (apply.get("n") == G and stats_ok):
-        apply.pop("z", None)
-        apply.pop("zmask", None)
     if want_stats and not stats_ok:
         sums, coeffs = None, None           # _bn_forward takes the statistics of each part from y
-    if pre is not None:
-        return y, sums, coeffs, x0, pre_used
     if bn is not None:
         return y, sums, coeffs
     return y, sums
@@ -820,11 +740,10 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
     return y, z, zmask, (blob[0], blob[1], float(npix), blob[2], blob[3])
 
 
-def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, bnrec=None, add_to1=None, amax_dy=None,
+def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_to0=None, add_to1=None, amax_dy=None,
                         amax_out=None):
     """`add_to0`: a gradient already held for source 0 (its other consumer's contribution); the kernel epilogue adds
-    the convolution's contribution INTO that tensor, which is returned as dx0.  `bnrec`: the _BnRec of the layer
-    that produced source 0 - its BatchNorm-backward statistics are taken in the same epilogue when the plan allows."""
+    the convolution's contribution INTO that tensor, which is returned as dx0."""
     N, IH, IW = in_shape
     _, OH, OW, Cout_t = dy.shape
     G = g.groups
@@ -860,15 +779,6 @@ def _conv_backward_data(dy, weight, g, in_shape, C0t, C1t, ihwo_packs=None, add_
         acc = (1 if add_to0 is not None else 0) | (2 if add_to1 is not None else 0)
         if amax_dy is not None:      # F16X2: dy's maximum; amax_out: a token - the launch records max |dx0| into it
             set_amax(None, None, amax_dy, amax_out[0] if (amax_out is not None and G == 1) else None)
-        if (bnrec is not None and G == 1 and C1t == 0 and add_to1 is None and bnrec.y.dtype == dy.dtype and
-                dy.numel() // Cout_t * C0t <= FUSE_BN_BWD_MAX):
-            tiles = query("xv2_conv2d_backward_data_bn_tiles", d, acc, 1 if wsb else 0)
-            if tiles > 0:
-                part = _f32((tiles, C0t, 2), dy)
-                call("xv2_conv2d_backward_data_bn", d, dy, Cout_t, ihwo, dx0, C0t, acc, bnrec.y, C0t, bnrec.mean,
-                     bnrec.invstd, bnrec.scale, bnrec.shift, bnrec.act, part, _ws(wsb, dy) if wsb else None)
-                bnrec.part, bnrec.tiles, bnrec.token = part, tiles, (dx0.data_ptr(), dx0._version)
-                continue
         call("xv2_conv2d_backward_data_acc", d, Ptr(dy, gi * Coutg), Cout_t, ihwo, Ptr(dx0, gi * C0g), C0t, dx1, C1t,
              acc, _ws(wsb, dy) if wsb else None)
     if amax_out is not None and amax_dy is not None and G == 1:
@@ -938,40 +848,6 @@ def join_wgrad_stream():
         torch.cuda.current_stream().wait_stream(_wgrad_stream)
     # (allocations that re-use these blocks are made on the compute stream, behind the wait above)
     _side_keep.clear()
-
-
-def _conv_backward_weight_pre(y0, pre, dy, weight, g, wparam=None):
-    """weight gradient of a convolution whose input was the deferred BatchNorm + activation of y0 (xv2_conv2d_forward_bn_pre):
-    the X operand is formed on load when the plan allows it, else z0 is materialised for this call"""
-    global _join_queued
-    N, IH, IW, C0t = y0.shape
-    _, OH, OW, Cout_t = dy.shape
-    d = _desc(N, IH, IW, C0t, 0, Cout_t, g, OH, OW, False)
-    if g.groups != 1 or y0.dtype != torch.float32 or query("xv2_conv2d_backward_weight_pre_supported", d) != 1:
-        return _conv_backward_weight(_apply_pre(y0, pre), None, dy, weight, g, wparam)
-    side_ok = ASYNC_WGRAD and (WGRAD_SIDE == "all" or (WGRAD_SIDE == "3x3") == (g.kh * g.kw > 1))
-    out = grad_slot(weight if wparam is None else wparam) if side_ok else None
-    side = None
-    if out is not None:
-        if not _join_queued:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
-                _join_queued = True
-                side = _side_stream()
-            except RuntimeError:      # not inside a backward pass (direct call): stay synchronous
-                side = None
-        else:
-            side = _side_stream()
-    elif ASYNC_WGRAD and _wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(_wgrad_stream)      # a shared weight's earlier contribution (see below)
-    dw = out if out is not None else _grad_like(weight if wparam is None else wparam)
-    nbytes = query("xv2_conv2d_backward_weight_workspace", d)
-    ws = _side_workspace(nbytes, side, dy.device) if side is not None else _ws(nbytes, dy)
-    call("xv2_conv2d_backward_weight_pre_async", d, y0, C0t, pre[0], pre[1], pre[2], dy, Cout_t, dw, ws,
-         side.cuda_stream if side is not None else None)
-    if side is not None:
-        _keep_for_side((y0, dy, pre[0], pre[1]), side)
-    return dw
 
 
 def _conv_backward_weight(x0, x1, dy, weight, g, wparam=None, amax=None):
@@ -1146,31 +1022,6 @@ def _off(t, o):
 
 
 ZMASK = os.environ.get("XV2_ZMASK", "1") != "0"
-# Producer-layer BatchNorm-backward statistics inside the consumer's backward-data epilogue: implemented and exact,
-# but measured 0.3 ms/step SLOWER on cfg2 (the extra read of y lengthens the serial epilogue of big-activation
-# layers by about what the separate HBM-speed pass cost, and there are 8x more partial rows to fold): off by default.
-FUSE_BN_BWD = os.environ.get("XV2_FUSE_BN_BWD", "0") != "0"
-FUSE_BN_BWD_MAX = int(float(os.environ.get("XV2_FUSE_BN_BWD_MAX", "1e12")))      # only tensors of at most this many elements
-
-
-class _BnRec:
-    """What a conv+BN layer leaves on its output tensor so that the ONE convolution consuming it can take this
-    layer's BatchNorm-backward statistics in its backward-data epilogue (xv2_conv2d_backward_data_bn).  The consumer
-    stores the per-tile partials here together with a token identifying the gradient tensor they were computed on;
-    the producer's backward uses them only if it is handed exactly that tensor, unmodified."""
-    __slots__ = ("y", "mean", "invstd", "scale", "shift", "act", "C", "part", "tiles", "token")
-
-    def __init__(self, y, mean, invstd, scale, shift, act):
-        self.y, self.mean, self.invstd, self.scale, self.shift, self.act = y, mean, invstd, scale, shift, act
-        self.C = y.shape[-1]
-        self.part, self.tiles, self.token = None, 0, None
-
-
-def _bn_rec_of(x, C):
-    rec = getattr(x, "_xv2_bnrec", None) if FUSE_BN_BWD else None
-    return rec if rec is not None and rec.C == C else None
-
-
 def _mask_ok(C, act, half=False):
     """layers whose activation follows a residual add can hand the backward pass a byte mask instead of z
     (W = channels per 16-byte lane of the BatchNorm kernels: 4 in fp32, 8 in bf16)"""
@@ -1243,7 +1094,7 @@ def _bn_forward(y, residual, act, bn, sums, training, coeffs=None, want_mask=Fal
     return z, (mean, invstd, count, scale, shift)
 
 
-def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, split=1, amax_tok=None):
+def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, split=1, amax_tok=None):
     """z may be None (layers without a residual input): the activation mask is then recomputed from y; a uint8 `z` is
     the byte mask written by xv2_bn_act_forward_mask.  split: see _bn_forward (the per-part coefficients are [S, C])."""
     mean, invstd, count, scale, shift = stats
@@ -1253,7 +1104,7 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
     rows = npix // S
     dz = _same(dz, y).contiguous()
     dt = _dt(y)
-    if (_bn_rows_ok(y, rows, bn, training) and z is not None and z.dtype == torch.float32 and not want_res and rec is None
+    if (_bn_rows_ok(y, rows, bn, training) and z is not None and z.dtype == torch.float32 and not want_res
             and mean.numel() == S * C):
         dy = torch.empty_like(y)
         dgamma, dbeta = _grad_like(bn.weight), _grad_like(bn.bias)
@@ -1264,13 +1115,7 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
     wsn = query("xv2_bn_backward_workspace", rows, C)
     ws = _persist("bnbwd", (wsn + 3) // 4 + 4, y.device) if (LAYER_CALLS and S == 1) else _ws(wsn, y)
     masked = z is not None and z.dtype == torch.uint8
-    pre = None
-    if rec is not None and rec.part is not None:
-        # statistics already taken by the consumer's backward-data epilogue - valid only for that very tensor
-        if z is None and S == 1 and rec.token == (dz.data_ptr(), dz._version):
-            pre = (rec.part, rec.tiles)
-        rec.part, rec.token = None, None
-    if LAYER_CALLS and training and S == 1 and pre is None and not _sync_group(bn):
+    if LAYER_CALLS and training and S == 1 and not _sync_group(bn):
         # column sums + apply as one ABI call (xv2_bn_act_backward: the same two launches)
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if want_res else None
@@ -1285,9 +1130,7 @@ def _bn_backward(dz, z, y, stats, gamma, act, bn, training, want_res, rec=None, 
         o, oc = h * rows * C, h * C
         dg, db = (dgamma, dbeta) if h == 0 else tmp      # the parameter gradients are the LOCAL sums over all parts
         s2 = Ptr(sums2, oc * 2)
-        if pre is not None:
-            call("xv2_bn_backward_reduce_partials", pre[0], pre[1], C, sums2, dgamma, dbeta, _stats_scratch(C, y.device))
-        elif masked:
+        if masked:
             call("xv2_bn_act_backward_reduce_mask", Ptr(dz, o), C, Ptr(z, h * rows * (C // 4)), Ptr(y, o), C,
                  Ptr(mean, oc), Ptr(invstd, oc), act, rows, C, s2, dg, db, ws, dt)
         else:
@@ -1366,7 +1209,7 @@ class ConvBnActFn(torch.autograd.Function):
     """z = act(BN(conv(cat(x0, x1), W)) [+ residual])  (one autograd node per conv layer)"""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training, passthrough=False, lazy_out=False):
+    def forward(ctx, x0, x1, weight, gamma, beta, residual, g, bn, act, training, passthrough=False):
         """passthrough: also return x0 itself as a second output.  A caller whose x0 has a SECOND consumer (the
         residual shortcut of a bottleneck) feeds that consumer from this alias: its gradient then arrives here and
         the backward-data kernel adds onto it in its epilogue, instead of autograd summing two tensors afterwards.
@@ -1378,12 +1221,6 @@ class ConvBnActFn(torch.autograd.Function):
             passthrough &= 1
         ctx.passthrough = passthrough
         x0_in, x1_in = x0, x1
-        # Deferred BatchNorm apply (model/layers.py:96-100 between two convolutions): a producer called
-        # with lazy_out=True returns its RAW convolution output y tagged with (scale, shift, act) instead of z; its one
-        # consumer - this function - applies them in the operand load of the halo kernel and of the weight gradient
-        # (or materialises z here when its plan has no such form).  The tag never leaves a pair of conv_bn_act calls.
-        pre = getattr(x0, "_xv2_lazy", None)
-        ctx.src_rec = _bn_rec_of(x0, x0.shape[-1]) if (x1 is None and g.groups == 1) else None
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         residual = residual.contiguous() if residual is not None else None
@@ -1391,70 +1228,39 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.ihwo = [] if need_dx else None
         ctx.split = BN_SPLIT if (training and x0.shape[0] % BN_SPLIT == 0) else 1
         ctx.has_res = residual is not None
-        fast = ap = None
-        lazy = (lazy_out and LAZY_BN and training and not ctx.has_res and ctx.split == 1 and not _sync_group(bn) and
-                x0.dtype == torch.float32 and MATH_MODE == MATH_F32X3)
-        ctx.pre = None
-        if pre is not None and (not training or x1 is not None):
-            x0, pre = _apply_pre(x0, pre), None
+        fast = None
         # F16X2: the maxima of the sources (recorded by their producers) and a slot for this layer's output
         am_in = am_out = None
         # (eval mode too: the fused inference launches record the same maxima in their epilogues - conv_bn_act_infer - so the
         #  two inference paths stay bit-identical)
-        if _amax_active(x0) and pre is None and not lazy and not COOP_APPLY:
+        if _amax_active(x0):
             am_in = (getattr(x0_in, "_xv2_amax", None), getattr(x1_in, "_xv2_amax", None) if x1_in is not None else None)
             am_out = _amax_new(x0)
         ctx.am_in = am_in
         # (a source that is a transposed convolution's output: its backward wants the maximum of the gradient sent back)
         ctx.want_dx_amax = am_in is not None and bool(getattr(x0_in, "_xv2_convT_out", False))
-        if (pre is None and not lazy and LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn) and
-                (g.groups == 1 or not COOP_APPLY)):      # (grouped + gated apply: the per-group gated launches of _conv_forward)
+        if LAYER_CALLS and training and ctx.split == 1 and not _sync_group(bn):
             fast = _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ctx.ihwo, ctx.has_res,
                                       (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_out) if am_in is not None else None,
                                       want_gap=GAP_REQUEST)
         if fast is not None:
             y, z, zmask, stats = fast
-        elif pre is not None:
-            y, sums, coeffs, x0, used = _conv_forward(x0, None, weight, g, None, want_stats=True, ihwo_out=ctx.ihwo, bn=bn,
-                                                      pre=pre)
-            ctx.pre = pre if used else None
         else:
-            if training and COOP_APPLY and not lazy and not _sync_group(bn):
-                ap = {"residual": residual, "act": act, "want_mask": ctx.has_res}
-            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn, apply=ap,
+            y, sums, coeffs = _conv_forward(x0, x1, weight, g, None, want_stats=training, ihwo_out=ctx.ihwo, bn=bn,
                                             amax_in=(_tok_ptr(am_in[0]), _tok_ptr(am_in[1])) if am_in is not None else None)
-        if ap is not None and "z" in ap and coeffs is not None:
-            # the convolution launch(es) applied the BatchNorm they derived (grouped / split-batch layers: xv2_conv2d_forward_bn_act)
-            z, zmask = ap["z"], ap["zmask"]
-            stats = (coeffs[0], coeffs[1], float(y.numel() // y.shape[-1] // ctx.split), coeffs[2], coeffs[3])
-        elif fast is None and lazy and coeffs is not None:
-            # this layer's own apply is deferred to ITS consumer: hand out y with the coefficients attached
-            rows = y.numel() // y.shape[-1]
-            stats = (coeffs[0], coeffs[1], float(rows), coeffs[2], coeffs[3])
-            z, zmask = y, None
-            z._xv2_lazy = (coeffs[2], coeffs[3], act)
-        elif fast is not None:
-            pass
-        elif ctx.has_res:
-            z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split,
-                                          amax_tok=am_out)
-        else:
-            z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split, amax_tok=am_out)
-            zmask = None
+            if ctx.has_res:
+                z, stats, zmask = _bn_forward(y, residual, act, bn, sums, training, coeffs, want_mask=True, split=ctx.split,
+                                              amax_tok=am_out)
+            else:
+                z, stats = _bn_forward(y, residual, act, bn, sums, training, coeffs, split=ctx.split, amax_tok=am_out)
+                zmask = None
         # the activation mask of the backward pass is recomputed from y unless a residual entered before it; then it
         # comes from the byte mask written next to z (or from z itself for shapes without a mask form)
         ctx.save_for_backward(x0, x1, weight, gamma, y, (zmask if zmask is not None else z) if ctx.has_res else None,
-                              stats[0], stats[1], stats[3], stats[4], *(ctx.pre[:2] if ctx.pre is not None else ()))
-        ctx.pre_act = ctx.pre[2] if ctx.pre is not None else 0
-        ctx.has_pre = ctx.pre is not None
-        ctx.pre = None
+                              stats[0], stats[1], stats[3], stats[4])
         ctx.count = stats[2]
         ctx.g, ctx.bn, ctx.act, ctx.training = g, bn, act, training
         ctx.wparam = weight
-        ctx.rec = None
-        if FUSE_BN_BWD and not ctx.has_res:
-            ctx.rec = _BnRec(y, stats[0], stats[1], stats[3], stats[4], act)
-            z._xv2_bnrec = ctx.rec
         if passthrough == 3:
             return z, x0_in, x1_in
         if passthrough == 2:
@@ -1467,20 +1273,16 @@ class ConvBnActFn(torch.autograd.Function):
     def backward(ctx, dz, *dps):
         dpass = dps[0] if ctx.passthrough & 1 else None
         dpass1 = (dps[1] if ctx.passthrough == 3 else dps[0]) if ctx.passthrough & 2 else None
-        if ctx.has_pre:
-            x0, x1, weight, gamma, y, z, mean, invstd, scale, shift, psc, psf = ctx.saved_tensors
-        else:
-            x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
+        x0, x1, weight, gamma, y, z, mean, invstd, scale, shift = ctx.saved_tensors
         g = ctx.g
         if dz is None:
             dz = torch.zeros_like(y)
         dpass, dpass1 = _same(dpass, y), _same(dpass1, y)
         am_in = ctx.am_in
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
-                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5], ctx.rec,
+                                               ctx.bn, ctx.training, ctx.has_res and ctx.needs_input_grad[5],
                                                ctx.split, _amax_new(y) if am_in is not None else None)
         am_dy = _amax_ptr(dy)
-        ctx.rec = None
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             acc = acc1 = None
@@ -1490,10 +1292,8 @@ class ConvBnActFn(torch.autograd.Function):
                     and tuple(dpass1.shape) == tuple(x1.shape)):
                 acc1, dpass1 = dpass1, None
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc,
-                                           ctx.src_rec if (dpass is None and acc1 is None) else None, acc1, am_dy,
+                                           x1.shape[3] if x1 is not None else 0, ctx.ihwo, acc, acc1, am_dy,
                                            _amax_new(y) if (ctx.want_dx_amax and am_dy is not None and dpass is None) else None)
-            ctx.src_rec = None
             if dpass is not None:
                 dx0 = dx0 + dpass
             if dpass1 is not None:
@@ -1506,14 +1306,12 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.ihwo = None
         if not ctx.needs_input_grad[2]:
             dw = None
-        elif ctx.has_pre:
-            dw = _conv_backward_weight_pre(x0, (psc, psf, ctx.pre_act), dy, weight, g, ctx.wparam)
         else:
             wam = (_tok_ptr(am_in[0]), _tok_ptr(am_in[1]), am_dy) if (am_dy is not None and am_in is not None) else None
             dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam, wam)
         ctx.wparam = None
         return (dx0, dx1, dw, dgamma if ctx.needs_input_grad[3] else None,
-                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None, None)
+                dbeta if ctx.needs_input_grad[4] else None, dres, None, None, None, None, None)
 
 
 class ConvFn(torch.autograd.Function):
@@ -1522,7 +1320,6 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, g):
         _need_cuda(x0)
-        ctx.src_rec = _bn_rec_of(x0, x0.shape[-1]) if (x1 is None and g.groups == 1) else None
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         y, _ = _conv_forward(x0, x1, weight, g, bias, want_stats=False)
@@ -1539,8 +1336,7 @@ class ConvFn(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             dx0, dx1 = _conv_backward_data(dy, weight, g, x0.shape[:3], x0.shape[3],
-                                           x1.shape[3] if x1 is not None else 0, None, None, ctx.src_rec)
-        ctx.src_rec = None
+                                           x1.shape[3] if x1 is not None else 0, None, None)
         dw = _conv_backward_weight(x0, x1, dy, weight, g, ctx.wparam) if ctx.needs_input_grad[2] else None
         ctx.wparam = None
         db = None
@@ -1563,7 +1359,6 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         the alias and its gradient is summed in this layer's backward-data epilogue"""
         _need_cuda(x)
         ctx.set_materialize_grads(False)
-        ctx.src_rec = _bn_rec_of(x, x.shape[-1])
         x_in = x
         x = x.contiguous()
         N, H, W, Cin = x.shape
@@ -1600,7 +1395,6 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ohwi, _ = _pack(weight.contiguous(), Cout, True, False, x.dtype == torch.bfloat16)
             acc = _acc_target(_same(dpass, x), x.shape, x)
-            rec, ctx.src_rec = ctx.src_rec, None
             if acc is not None:      # summed onto the other consumer's gradient in the epilogue
                 dx = acc
                 wsb = query("xv2_conv2d_forward_workspace", d)
@@ -1614,15 +1408,8 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
                     call("xv2_conv_transpose2d_backward_weight", d, x, Cin, dy, Cout, dw, ws)
                 return dx, dw, None
             dx = torch.empty_like(x)
-            tiles = query("xv2_conv_transpose2d_backward_data_bn_tiles", d) if (rec is not None and x.dtype == torch.float32) else 0
-            if tiles > 0:      # the producer layer's BatchNorm-backward statistics ride along in the epilogue
-                part = _f32((tiles, Cin, 2), x)
-                call("xv2_conv_transpose2d_backward_data_bn", d, dy, Cout, ohwi, dx, Cin, rec.y, Cin, rec.mean,
-                     rec.invstd, rec.scale, rec.shift, rec.act, part)
-                rec.part, rec.tiles, rec.token = part, tiles, (dx.data_ptr(), dx._version)
-            else:
-                set_amax(am_dy)
-                call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
+            set_amax(am_dy)
+            call("xv2_conv_transpose2d_backward_data", d, dy, Cout, ohwi, dx, Cin)
         if ctx.needs_input_grad[1]:
             dw = _grad_like(ctx.wparam)
             ws = _ws(query("xv2_conv2d_backward_weight_workspace", d), dy)
@@ -1686,7 +1473,7 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, dz):
         y, z, gamma, mean, invstd, scale, shift = ctx.saved_tensors
         dy, dres, dgamma, dbeta = _bn_backward(dz, z, y, (mean, invstd, ctx.count, scale, shift), gamma, ctx.act,
-                                               ctx.bn, ctx.training, ctx.has_res, None, ctx.split)
+                                               ctx.bn, ctx.training, ctx.has_res, ctx.split)
         return dy, dgamma, dbeta, dres, None, None, None
 
 
@@ -1850,19 +1637,14 @@ class GateMulFn(torch.autograd.Function):
         return dskip, dgate
 
 
-# Fused [N, C]-vector tail of split attention (xv2_splat_att_forward / _backward: 4 + 5 launches instead of 11 + 12):
-# exact, tested, but measured SLOWER on MI355X (resnest50 step 43.7 -> 44.5 ms fp32, 19.9 -> 20.8 ms bf16) - its few
-# fat blocks walk 128..256-long dependent load chains where the op-by-op kernels spread the same work over the chip -
-# so it stays opt-in (XV2_FUSED_SPLAT=1).
-FUSED_SPLAT = os.environ.get("XV2_FUSED_SPLAT", "0") != "0"
 SPLAT_TAIL = os.environ.get("XV2_SPLAT_TAIL", "1") != "0"      # the op-level tail behind one ABI call each way (xv2_splat_tail_*)
 
 
 class SplitAttentionFn(torch.autograd.Function):
     """ResNeSt radix-2 split attention on top of the (already BN+ReLU'd) grouped-conv output x
     [N,H,W,2C]: gap -> fc1 -> BN1 -> ReLU -> fc2 -> rSoftMax -> sum_r att_r * x_r.
-    Without a SyncBatchNorm exchange the [N, C]-vector chain runs as xv2_splat_att_forward / _backward (3 + 4 launches
-    instead of ~10 + ~12 tiny ones); with it, op by op around the all-reduce of bn1's statistics."""
+    Without a SyncBatchNorm exchange the [N, C]-vector chain runs behind one ABI call each way (xv2_splat_tail_forward /
+    _backward); with it, op by op around the all-reduce of bn1's statistics."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, bn1, training):
@@ -1876,25 +1658,6 @@ class SplitAttentionFn(torch.autograd.Function):
         inter = w1.shape[0]
         w1m, w2m = w1.reshape(inter, C).contiguous(), w2.reshape(C2, inter).contiguous()
         gap, att = _f32((N, C), x), _f32((N, C2), x)
-        ctx.fused = (FUSED_SPLAT and not (training and (_sync_group(bn1) or BN_SPLIT > 1)) and b1 is not None and
-                     query("xv2_splat_att_supported", N, C, inter) == 1)
-        ctx.tail = False
-        if ctx.fused:
-            h1, a1 = _f32((N, inter), x), _f32((N, inter), x)
-            mean1, invstd1 = _f32((inter,), x), _f32((inter,), x)
-            ws = _ws(query("xv2_splat_att_workspace", N, hw, C, inter), x)
-            if training:
-                bn_stats_changed()
-            call("xv2_splat_att_forward", x, N, hw, C, inter, w1m, b1, bn1.weight, bn1.bias, float(bn1.eps),
-                 float(bn1.momentum), bn1.running_mean, bn1.running_var, 1 if training else 0, w2m, b2, gap, h1, a1,
-                 mean1, invstd1, att, ws, _dt(x))
-            out = _act((N, H, W, C), x)
-            call("xv2_splat_apply_forward", x, att, N, hw, C, out, _dt(x))
-            ctx.save_for_backward(x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att)
-            ctx.training = training
-            ctx.shapes = (w1.shape, w2.shape)
-            ctx.params = (w1, b1, w2, b2, bn1.weight, bn1.bias)
-            return out
         S = BN_SPLIT if (training and N % BN_SPLIT == 0) else 1
         ctx.tail = (LAYER_CALLS and SPLAT_TAIL and BN_ROWS and N // S <= 64 and not (training and _sync_group(bn1)))
         if ctx.tail:
@@ -1939,24 +1702,6 @@ class SplitAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        if ctx.fused:
-            x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
-            dout = _same(dout, x).contiguous()
-            N, H, W, C2 = x.shape
-            C, hw = C2 // 2, H * W
-            inter = w1m.shape[0]
-            pw1, pb1, pw2, pb2, pg1, pbe1 = ctx.params
-            ctx.params = None
-            dw1, db1, dw2, db2 = _grad_like(pw1), _grad_like(pb1), _grad_like(pw2), _grad_like(pb2)
-            dg1, dbe1 = _grad_like(pg1), _grad_like(pbe1)
-            dgap = _f32((N, C), x)
-            ws = _ws(query("xv2_splat_att_workspace", N, hw, C, inter), x)
-            call("xv2_splat_att_backward", x, dout, N, hw, C, inter, gap, h1, a1, mean1, invstd1, g1, w1m, w2m, att,
-                 1 if ctx.training else 0, dw2, db2, dg1, dbe1, dw1, db1, dgap, ws, _dt(x))
-            dx = torch.empty_like(x)
-            call("xv2_splat_apply_backward", x, att, dout, dgap, N, hw, C, dx, None, ws, _dt(x))
-            s1, s2 = ctx.shapes
-            return dx, dw1.reshape(s1), db1, dg1, dbe1, dw2.reshape(s2), db2, None, None
         if ctx.tail:
             x, gap, w1m, h1, a1, g1, mean1, invstd1, w2m, att = ctx.saved_tensors
             dout = _same(dout, x).contiguous()
@@ -1999,7 +1744,7 @@ class SplitAttentionFn(torch.autograd.Function):
         db2 = _grad_like(pb2) if pb2 is not None else _f32((C2,), x)
         call("xv2_linear_backward", a1, w2m, dlogits, da1, dw2, db2, N, inter, C2)
         dh1, _, dg1, dbe1 = _bn_backward(da1, a1, h1, (mean1, invstd1, ctx.count, scale1, shift1), g1, ACT_RELU,
-                                         ctx.bn1, ctx.training, False, None, ctx.split)
+                                         ctx.bn1, ctx.training, False, ctx.split)
         dgap, dw1 = _f32((N, C), x), _grad_like(pw1)
         db1 = _grad_like(pb1) if pb1 is not None else _f32((inter,), x)
         call("xv2_linear_backward", gap, w1m, dh1, dgap, dw1, db1, N, C, inter)
