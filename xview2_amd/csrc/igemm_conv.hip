@@ -41,9 +41,11 @@
 #ifndef XV2_HABL
 #define XV2_HABL 0      // halo-form ablations (debug): 1 no halo stores, 2 unshifted fragment rows
 #endif
-#ifndef XV2_HB3
-#define XV2_HB3 0      // halo form, 64-column tiles: force 3 blocks per CU (168 VGPRs)
-#endif
+// Halo form, 64-column tiles, two fp16 planes (F16X2): three blocks per CU.  The launches of this instantiation (64-channel 3x3
+// layers: resnet50 layer1, ResNeSt's radix convolutions of layer1, the 512^2 decoder level, the ResNeSt stem) are latency-bound -
+// 4 to 18 K slices per block, each behind a global-load round trip - and the kernel needed 171 VGPRs, three over the 168 that admit
+// a third block.  With the bound the compiler fits 168 without scratch (the three-plane instantiations spill: they keep two).
+// Same box: cfg2 step 20.75 -> 20.68 ms, resnest50 encoder forward 4.82 -> 4.80 ms (profiles/r06_*_ab6_halo_3blocks.txt).
 #ifndef XV2_PF
 #define XV2_PF 3      // three-plane per-tap main loop: stages between a global load and its split (3: two raw register sets,
                       // 4: three - measured identical on every cfg2 layer and on the step, and the 128 x 128 tile spills: the
@@ -116,7 +118,7 @@ constexpr int LDS_LD_H = BK + 8;   // bf16 row stride in elements (80 bytes: con
 // PMC had shown the plane stores as the most expensive producer step in clock; emulated first (garbage data): -12 %.
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
           bool HALO = false, bool BX3 = false, int NPL = 3>
-__global__ void __launch_bounds__(256, (HALO && BN == 64 && XV2_HB3) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
+__global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 : X3 ? 2 : 1) igemm_kernel(const IgemmParams p) {
     static_assert(!BX3 || HALO, "pre-split weights: halo form only");
     static_assert(NPL == 3 || (NPL == 2 && X3 && (BX3 || !HALO)), "two fp16 planes (F16X2): halo form with pre-split weights, or the per-tap form");
     static_assert(!X3 || (!SMALLC && !HS && BF16), "split-bf16 mode: fp32 tensors, bf16 MFMA");

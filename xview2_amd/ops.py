@@ -367,10 +367,12 @@ def _wamax_take(device):
 
 
 def _forget_entry(e, keep_amax=False):
-    if e.x3:
-        for key in e.x3:
-            query("xv2_presplit_forget", key)
-        e.x3 = None
+    # every layout that has planes registered in the library (three bf16 planes and / or two fp16 planes: the fp16 planes of 1x1
+    # layouts, and of 3x3 layouts while F16X2 is on, have no three-plane twin) is forgotten BEFORE the planes are dropped - a
+    # registration that outlives its planes would hand a freed pointer to the kernels that stream them
+    for key in set(e.x3 or ()) | set(e.x2 or ()):
+        query("xv2_presplit_forget", key)
+    e.x3 = None
     e.x2 = None
     if keep_amax:
         if e.amax is not None:      # (xv2_presplit_forget dropped the registration of those layouts as well)
@@ -839,6 +841,13 @@ def _keep_for_side(tensors, side):
     for t in tensors:
         if t is not None:
             t.record_stream(side)
+
+
+def begin_step():
+    """start of a training step (FlatAdamW.zero_grad): if the previous backward pass ended in an exception its end-of-backward
+    join never ran - the operand references held for the side stream and the 'join queued' mark must not leak into this step"""
+    if _join_queued or _side_keep:
+        join_wgrad_stream()
 
 
 def join_wgrad_stream():

@@ -51,6 +51,7 @@ class FlatAdamW:
         self._lr_on_dev = lr
 
     def zero_grad(self):
+        ops.begin_step()               # (a backward pass that raised leaves its side-stream bookkeeping behind)
         self.flat_g.zero_()            # one memset; parameters that get no gradient this step stay at zero
         self.epoch += 1
         for p in self.params:
