@@ -1,17 +1,7 @@
-// In-launch fold of per-tile BatchNorm statistics partials: the kernel that PRODUCES the partials (convolution epilogue,
-// split-K slab sum, column sums of the BatchNorm backward) also reduces them and, for a single-process training-mode
-// nn.BatchNorm2d (model/layers.py:93, the encoder blocks), derives the coefficients and running statistics - no
-// separate reduction launch.  Two levels of device-scope tickets:
-//   * every block publishes its row of partials with write-through (sc1) stores and draws a ticket of its GROUP of G
-//     consecutive tiles; the group's last arriver adds the G rows in tile order into scratch[group] (fp64);
-//   * it then draws the TOP ticket of its column tile; the last group's block adds the group rows in group order, writes
-//     the sums and finalises.
-// Which block does the adding is timing dependent, WHAT it adds and in which order is not: results are bit-reproducible.
-// Hand-off form (MI355X guide, Guideline 16): payload = 8-byte agent-scope relaxed atomic stores (write-through), every
-// storing wave drains with an asm s_waitcnt before the block barrier, one lane draws the ticket, the consumer reads with
-// agent-scope relaxed atomic loads; tickets return to zero inside the launch (the pool is shared by later launches).
-// S > 1: the tiles hold S independent BatchNorm batches back to back (ops.BN_SPLIT: the Siamese pre / post passes);
-// groups never straddle a part, sums / coefficients are per part and the running statistics see the parts in order.
+// BatchNorm coefficients from the per-channel sums: THE arithmetic of every training-mode BatchNorm forward here (the reduction
+// kernels of norm_act.hip, BatchNorm over a handful of rows, split attention's bn1), and the ticket pool of the two-phase
+// statistics reduction.  (Rounds 3 - 5 also kept the in-launch fold of the statistics partials and the gate of the in-launch apply
+// in this header; both were removed in round 6 - DESIGN.md section 4.)
 #pragma once
 #include "xv2_common.h"
 
@@ -52,9 +42,8 @@ __device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1
     bn_channel_coeffs(f, c, s1, s2, m, var, is, sc, sf);
     f.mean[out_off + c] = (float)m;
     f.invstd[out_off + c] = (float)is;
-    // (write-through: with a gate - see StatsFold::gate - the other blocks of this launch read them right away)
-    __hip_atomic_store(f.scale + out_off + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(f.shift + out_off + c, sf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f.scale[out_off + c] = sc;
+    f.shift[out_off + c] = sf;
     if (f.running_mean) {
         const double vc = var * f.count;
         const double unb = f.count > 1.0 ? vc / (f.count - 1.0) : var;
@@ -66,202 +55,7 @@ __device__ inline void bn_finalize_channel(const BnFinalize& f, int c, double s1
     }
 }
 
-struct StatsFold {
-    double* scratch;      // [S * ngroups][C][2]
-    unsigned* tickets;    // [S * ngroups * ntn] group tickets, then [ntn] top tickets; zero between launches
-    double* sums;         // [S][C][2] out (may be nullptr)
-    float* f0;            // optional fp32 copies of the two sums (BatchNorm backward: dbeta, dgamma); S == 1 only
-    float* f1;
-    int S, tiles_per_part, G, ngroups, ntn, C;
-    int part_stride;      // channels between the outputs (sums, coefficients) of consecutive parts (>= C: channel groups)
-    int on;               // 0: no in-launch fold (partials only)
-    BnFinalize fin;       // outputs of part s at offset s * part_stride
-    // Gate (optional): EVERY block of the launch waits, after its tile's fold duties, until the column tile's sums /
-    // coefficients are final, and then goes on to USE them (BatchNorm apply out of the accumulators: no second launch,
-    // no re-read of the convolution output).  The whole grid must be resident at once - the launcher checks the grid
-    // against the kernel's occupancy (coop_capacity) and falls back to the two-launch form otherwise.
-    unsigned* gate;       // [ntn][2]: flag (0 -> 1 when column tile tn is final), departures; zero between launches
-    int gate_n;           // blocks waiting per column tile
-};
-
-// host: group size so that level 1 and level 2 are balanced and S * ngroups rows fit the scratch (XV2_BN_SCRATCH_ROWS)
-static inline bool stats_fold_plan(StatsFold& f, int64_t tiles, int S, int ntn, int C) {
-    f.on = 0;
-    if (S < 1 || tiles <= 0 || tiles % S != 0 || S > XV2_BN_SCRATCH_ROWS) return false;
-    const int64_t tpp = tiles / S;
-    int64_t G = 1;
-    while (G * G < tpp) ++G;                                         // ceil(sqrt(tpp))
-    const int64_t maxg = XV2_BN_SCRATCH_ROWS / S;
-    if (cdiv(tpp, G) > maxg) G = cdiv(tpp, maxg);
-    f.S = S;
-    f.tiles_per_part = (int)tpp;
-    f.G = (int)G;
-    f.ngroups = (int)cdiv(tpp, G);
-    f.ntn = ntn;
-    f.C = C;
-    f.on = 1;
-    return true;
-}
-static inline int stats_fold_tickets(const StatsFold& f) { return f.S * f.ngroups * f.ntn + f.ntn; }
-
 unsigned* take_tickets(int n);      // norm_act.hip: zero-initialised device pool, handed out round-robin
-int coop_capacity(const void* kern, int threads, size_t smem);   // igemm_conv.hip: blocks of `kern` the chip holds at once
-int coop_block_cap();               // igemm_conv.hip: XV2_COOP_BLOCKS / xv2_set_coop_blocks cap on gated grids
-bool bn_fold_enabled();             // norm_act.hip: XV2_BN_FOLD=1 (or gated launches requested) folds the statistics in-launch
-bool coop_requested();              // igemm_conv.hip: XV2_COOP=1 or xv2_set_coop_blocks(n > 0)
-
-// ---- gate: a launch-wide "the reduction is final" hand-off between blocks that are all resident -------------------------
-// coop_open: called by ONE thread of the finishing block after that block's result stores were issued write-through and
-// drained (s_waitcnt vmcnt(0) + barrier).  coop_wait: called by ONE thread of every waiting block (the finisher included);
-// returns once the flag is up, having executed an agent-scope acquire; the last block to leave re-arms the gate (both
-// words back to zero: the pool they come from is shared by later launches).  A block that waits longer than ~4 s (the
-// grid was not resident at once: a planning bug, or several processes crowding one GPU) traps instead of hanging the box.
-__device__ __forceinline__ void coop_open(unsigned* gate) {
-    __hip_atomic_store(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void coop_wait(unsigned* gate, int nblocks) {
-    if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        const unsigned long long t0 = wall_clock64();          // 100 MHz
-        while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 400000000ull) __builtin_trap();
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const unsigned prev = __hip_atomic_fetch_add(gate + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == (unsigned)(nblocks - 1)) {       // everybody has seen the flag
-        __hip_atomic_store(gate + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ float coop_load(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// write-through store of one (s1, s2) partial
-__device__ __forceinline__ void fold_store(float* p, float s1, float s2) {
-    const unsigned long long v = ((unsigned long long)__float_as_uint(s2) << 32) | __float_as_uint(s1);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fold_store(double* p, double s1, double s2) {
-    __hip_atomic_store(p, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double fold_load(const float* p) {
-    return (double)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double fold_load(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// sum of `n` rows of one column, `stride` elements apart: SIXTEEN device-scope loads in flight (each is a memory round
-// trip - the producers stored write-through), fixed association: ((q0+q1)+(q2+q3)) + ... independent of who adds
-template <typename PT>
-__device__ __forceinline__ double fold_rows(const PT* p, size_t stride, int n) {
-    double q[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) q[j] = 0.0;
-    int r = 0;
-    for (; r + 16 <= n; r += 16) {
-        double t[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = fold_load(p + (size_t)(r + j) * stride);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) q[j] += t[j];
-    }
-    {
-        double t[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t[j] = r + j < n ? fold_load(p + (size_t)(r + j) * stride) : 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) q[j] += t[j];
-    }
-#pragma unroll
-    for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-        for (int j = 0; j < w; ++j) q[j] += q[j + w];
-    return q[0];
-}
-
-// Called by ALL threads of a block (blockDim.x == 256) after the block's threads stored its row of partials
-// part[tile][C][2] for columns [col0, col0 + ncols) with fold_store().  `flag`: one int of LDS.
-// DRAIN = false: the storing waves already drained their partial stores (asm s_waitcnt vmcnt(0)) before this call.
-template <typename PT, bool DRAIN = true>
-__device__ __forceinline__ void stats_fold_tile(const StatsFold& f, const PT* part, int tile, int tn, int col0, int ncols,
-                                                volatile int* flag) {
-    const int tid = threadIdx.x;
-    const int s = tile / f.tiles_per_part, tl = tile - s * f.tiles_per_part;
-    const int g = tl / f.G;
-    const int gfirst = g * f.G, gcount = min(f.G, f.tiles_per_part - gfirst);
-    // ---- level 1: the group's last arriver folds the group's rows
-    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its rows are at the coherence point
-    __syncthreads();
-    if (tid == 0) {
-        unsigned* t = f.tickets + ((size_t)(s * f.ngroups + g) * f.ntn + tn);
-        // (round 4: an agent-scope RELEASE ahead of the ticket - L2 write-back of this XCD before the arrival becomes visible.
-        //  The rows were stored write-through and drained, which passed every stress run of round 3; comparisons of the model
-        //  tests still failed about one run in five with six processes crowding the GPU and this fold on, never with it off -
-        //  DESIGN.md section 7.  The fold is opt-in now and follows the memory model to the letter.)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (unsigned)(gcount - 1);
-        if (last) {
-            __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // partial and scratch rows live in buffers that are re-used launch after launch: one agent-scope acquire
-            // drops whatever this CU / XCD still caches of them before the rows are read
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    const int grow = s * f.ngroups + g;
-    for (int v = tid; v < ncols * 2; v += 256) {
-        const size_t i = (size_t)(col0 + (v >> 1)) * 2 + (v & 1), stride = (size_t)f.C * 2;
-        const PT* p = part + (size_t)(s * f.tiles_per_part + gfirst) * stride + i;
-        __hip_atomic_store(f.scratch + (size_t)grow * stride + i, fold_rows(p, stride, gcount), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- level 2: the column tile's last group folds the group rows of every part, in order
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        unsigned* t = f.tickets + (size_t)f.S * f.ngroups * f.ntn + tn;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned prev = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (unsigned)(f.S * f.ngroups - 1);
-        if (last) {
-            __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    for (int v0 = 0; v0 < ncols * 2; v0 += 256) {       // uniform trip count: the shuffle below needs whole lane pairs
-        const int v = v0 + tid;
-        const bool ok = v < ncols * 2;
-        const int c = col0 + (v >> 1), which = v & 1;
-        const size_t i = (size_t)c * 2 + which, stride = (size_t)f.C * 2;
-        for (int sp = 0; sp < f.S; ++sp) {
-            const double a = ok ? fold_rows(f.scratch + (size_t)sp * f.ngroups * stride + i, stride, f.ngroups) : 0.0;
-            const double other = __shfl_xor(a, 1, 64);
-            if (!ok) continue;
-            if (f.sums) __hip_atomic_store(f.sums + (size_t)sp * f.part_stride * 2 + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (f.f0 && !which) f.f0[c] = (float)a;
-            if (f.f1 && which) f.f1[c] = (float)a;
-            if (f.fin.mean && !which) bn_finalize_channel(f.fin, c, a, other, sp * f.part_stride);
-        }
-    }
-    if (f.gate) {         // the column tile is final: let the waiting blocks of this launch go on
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            coop_open(f.gate + 2 * tn);
-        }
-    }
-}
 
 }  // namespace xv2
 

@@ -79,23 +79,10 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A0), 0, p.bytesA0, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.bytesB, 0x00020000);
 
-    // contiguous range of patches per block (neighbouring patches share halo columns in L2).  With the in-launch
-    // statistics fold (bn_fold.h) the grid is a multiple of the S BatchNorm parts and a block's run stays inside one part:
-    // the block is the fold's "tile" (it sums its own patches in patch order), fold.tiles_per_part = blocks per part.
-    int p0, p1;
-    if (p.fold.on) {
-        const int bpp = p.fold.tiles_per_part, ppp = npatches / p.fold.S;
-        const int sp = blockIdx.x / bpp, bl = blockIdx.x - sp * bpp;
-        const int per = (ppp + bpp - 1) / bpp;
-        p0 = sp * ppp + min(bl * per, ppp);
-        p1 = sp * ppp + min(bl * per + per, ppp);
-    } else {
-        const int per = (npatches + gridDim.x - 1) / gridDim.x;
-        p0 = blockIdx.x * per;
-        p1 = min(p0 + per, npatches);
-        if (p0 >= p1) return;
-    }
-    double fsum1 = 0.0, fsum2 = 0.0;            // fold: this block's statistics (threads 0..31 = channel)
+    // contiguous range of patches per block (neighbouring patches share halo columns in L2)
+    const int per = (npatches + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = min(p0 + per, npatches);
+    if (p0 >= p1) return;
 
     // weights, once: [tap][n][32 channels]
     if constexpr (X3) {
@@ -190,9 +177,6 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
     // per-lane channel constants of the epilogue (lane & 31 = output channel), loaded once
     const float bv = p.bias ? p.bias[l31] : 0.f;
     const float esc = p.ep_scale ? p.ep_scale[l31] : 0.f, esf = p.ep_scale ? p.ep_shift[l31] : 0.f;
-    const bool bnb = p.bnb_y != nullptr;     // BN-backward statistics of the producer layer (IgemmParams::bnb_*)
-    const float bmu = bnb ? p.bnb_mean[l31] : 0.f, bis = bnb ? p.bnb_invstd[l31] : 0.f;
-    const float bsc = bnb ? p.bnb_scale[l31] : 0.f, bsf = bnb ? p.bnb_shift[l31] : 0.f;
 
     if (p0 < p1) {
         hload(p0);
@@ -301,16 +285,9 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
                 v = apply_act(v, p.ep_act);
             }
             st1(reinterpret_cast<OT*>(p.Out0) + (rowpix + col) * p.ldo0 + l31, v);
-            if (bnb) {
-                const float yv = p.bnb_y[(rowpix + col) * p.bnb_ldy + l31];
-                const float g = v * act_grad_from_pre(__fmaf_rn(yv, bsc, bsf), p.bnb_act);
-                s1 += g;
-                s2 += g * ((yv - bmu) * bis);
-            } else {
-                const float sv = HS ? bf16_round(acc[r]) : acc[r];
-                s1 += sv;
-                s2 += sv * sv;
-            }
+            const float sv = HS ? bf16_round(acc[r]) : acc[r];
+            s1 += sv;
+            s2 += sv * sv;
         }
         if (p.stats) {
             s1 += __shfl_xor(s1, 32, 64);
@@ -330,29 +307,12 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
                 a1 += red[((half * 4 + w) * 32 + ch) * 2 + 0];
                 a2 += red[((half * 4 + w) * 32 + ch) * 2 + 1];
             }
-            if (p.fold.on) {
-                if (NW > 4) {      // both halves onto the channel's thread (fixed order: rows 0-3, then 4-7)
-                    const float b1 = __shfl_down(a1, 32, 64), b2 = __shfl_down(a2, 32, 64);
-                    a1 += b1;
-                    a2 += b2;
-                }
-                if (tid < 32) {
-                    fsum1 += (double)a1;
-                    fsum2 += (double)a2;
-                }
-            } else {
-                float* st = p.stats + (((size_t)patch * (NW / 4) + half) * 32 + ch) * 2;
-                st[0] = a1;
-                st[1] = a2;
-            }
+            float* st = p.stats + (((size_t)patch * (NW / 4) + half) * 32 + ch) * 2;
+            st[0] = a1;
+            st[1] = a2;
         }
         if (patch + 1 < p1) hstore();
         __syncthreads();
-    }
-    if (p.fold.on) {
-        // (an empty run - more blocks than patches of a part - still takes part with a zero row: the ticket counts blocks)
-        if (tid < 32) fold_store(p.stats + ((size_t)blockIdx.x * 32 + tid) * 2, (float)fsum1, (float)fsum2);
-        stats_fold_tile<float>(p.fold, p.stats, blockIdx.x, 0, 0, 32, reinterpret_cast<int*>(red));
     }
 }
 
@@ -399,17 +359,6 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
     IgemmParams q = p;
     const bool h2 = x3 && f16x2_ready_pertap(q);      // F16X2: maxima of the source and of the weights known
-    if (p.fold.on) {
-        const int S = p.fold.S;
-        XV2_CHECK_ARG(p.stats && S >= 1 && npatches % S == 0, "direct3x3: %d patches do not split into %d BatchNorm parts",
-                      npatches, S);
-        grid = std::max(S, grid / S * S);
-        StatsFold f = p.fold;
-        XV2_CHECK_ARG(stats_fold_plan(f, grid, S, 1, 32), "direct3x3: statistics fold plan failed");
-        f.tickets = take_tickets(stats_fold_tickets(f));
-        XV2_CHECK_ARG(f.tickets, "direct3x3: ticket pool allocation failed");
-        q.fold = f;
-    }
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);

@@ -520,7 +520,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
 #pragma unroll
         for (int i = 0; i < MR; ++i) abase[i] = ((wm * WTM + i * 32) / PW + 1) * HWD + l31 + 1;
         float4 hraw[HL], rbb[BROWS], rbb1[BROWS];
-        float4 hsc = make_float4(1.f, 1.f, 1.f, 1.f), hsf = make_float4(0.f, 0.f, 0.f, 0.f);      // pre_scale / pre_shift of hraw's slice
         uint2 pkb[BROWS][NPL], pkh[HL][NPL];
         bf16x8 fa0[MR][NPL], fb0[NR][NPL], fa1[MR][NPL], fb1[NR][NPL];
         auto hload = [&](int cs) {
@@ -528,10 +527,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             const bool first = cc < p.C0;
             const int ld = first ? p.ldA0 : p.ldA1;
             const int ch = (first ? cc : cc - p.C0) + (tid & 3) * 4;
-            if (p.pre_scale) {      // single source (checked on the host): this thread's four channels of the slice
-                hsc = *reinterpret_cast<const float4*>(p.pre_scale + ch);
-                hsf = *reinterpret_cast<const float4*>(p.pre_shift + ch);
-            }
 #pragma unroll
             for (int j = 0; j < HL; ++j) {
                 const int off = hpix[j] >= 0 ? ((hpix[j] * ld + ch) << 2) : (int)0x80000000;
@@ -543,13 +538,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
         auto hsplit = [&]() {
 #pragma unroll
             for (int j = 0; j < HL; ++j) {
-                float4 v = hraw[j];
-                if (p.pre_scale && hpix[j] >= 0) {      // same arithmetic as bn_act_fwd_kernel; the padding stays zero
-                    v.x = apply_act(__fmaf_rn(v.x, hsc.x, hsf.x), p.pre_act);
-                    v.y = apply_act(__fmaf_rn(v.y, hsc.y, hsf.y), p.pre_act);
-                    v.z = apply_act(__fmaf_rn(v.z, hsc.z, hsf.z), p.pre_act);
-                    v.w = apply_act(__fmaf_rn(v.w, hsc.w, hsf.w), p.pre_act);
-                }
+                const float4 v = hraw[j];
                 if constexpr (NPL == 2) split2hx4(v, sA, pkh[j][0], pkh[j][1]);
                 else split3x4(v, pkh[j][0], pkh[j][1], pkh[j][NPL - 1]);
             }
@@ -1082,7 +1071,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
     }
     float omax = 0.f;                                     // F16X2: max |value stored to Out0| (IgemmParams::amax_out)
     float4 ss1 = make_float4(0, 0, 0, 0), ss2 = ss1;      // reducer: statistics of the summed tile (this thread's 4 channels)
-    const bool do_stats = p.stats && p.ksplit == 1 && !p.bnb_y;
+    const bool do_stats = p.stats && p.ksplit == 1;
     if (do_stats) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
@@ -1105,17 +1094,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             }
         }
     }
-    // BN-backward statistics of the producer layer (see IgemmParams::bnb_*): a thread keeps ONE group of 4 channels through
-    // every staging pass (256 % (BN / 4) == 0), so its coefficients are loaded once and its sums run over the whole tile
-    const bool bnb = p.bnb_y && !(p.ksplit > 1);
-    float4 bmu = make_float4(0, 0, 0, 0), bis = bmu, bsc = bmu, bsf = bmu, bs1 = bmu, bs2 = bmu;
-    if (bnb) {
-        const int bc = n0 + (tid % (BN / 4)) * 4;
-        bmu = *reinterpret_cast<const float4*>(p.bnb_mean + bc);
-        bis = *reinterpret_cast<const float4*>(p.bnb_invstd + bc);
-        bsc = *reinterpret_cast<const float4*>(p.bnb_scale + bc);
-        bsf = *reinterpret_cast<const float4*>(p.bnb_shift + bc);
-    }
 #pragma unroll
   for (int hh = 0; hh < NH; ++hh) {
     if (NH == 1 || (wm * WTM) / HROWS == hh) {
@@ -1134,9 +1112,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
     }
     __syncthreads();
     if (hh == 0 && do_stats && tid < BN) {
-        // this tile's row of statistics partials (red[] is complete behind the barrier above).  With the in-launch fold the
-        // row is published write-through and drained HERE, ahead of the output stores: a drain at the end of the kernel
-        // would wait for the whole tile's stores
+        // this tile's row of statistics partials (red[] is complete behind the barrier above)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WGM; ++w) {
@@ -1144,13 +1120,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             s2 += red[(w * BN + tid) * 2 + 1];
         }
         float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-        if (p.fold.on) {
-            fold_store(st, s1, s2);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            st[0] = s1;
-            st[1] = s2;
-        }
+        st[0] = s1;
+        st[1] = s2;
     }
     if (skf && sk_reducer && hh == 0) {
         // every other K-split block of this tile has arrived, i.e. is past its main loop: wait for their slabs
@@ -1233,37 +1204,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             }
             st4(o, v);
             if (p.amax_out && col < p.N0) omax = amax_acc(omax, v);
-            if (bnb) {      // y in the storage type; g = the value as STORED (what the BatchNorm backward will read)
-                const float4 yv = ld4(reinterpret_cast<const OT*>(p.bnb_y) + (size_t)off * p.bnb_ldy + col);
-                v = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));
-                const float gx = v.x * act_grad_from_pre(__fmaf_rn(yv.x, bsc.x, bsf.x), p.bnb_act);
-                const float gy = v.y * act_grad_from_pre(__fmaf_rn(yv.y, bsc.y, bsf.y), p.bnb_act);
-                const float gz = v.z * act_grad_from_pre(__fmaf_rn(yv.z, bsc.z, bsf.z), p.bnb_act);
-                const float gw = v.w * act_grad_from_pre(__fmaf_rn(yv.w, bsc.w, bsf.w), p.bnb_act);
-                bs1.x += gx; bs1.y += gy; bs1.z += gz; bs1.w += gw;
-                bs2.x += gx * ((yv.x - bmu.x) * bis.x); bs2.y += gy * ((yv.y - bmu.y) * bis.y);
-                bs2.z += gz * ((yv.z - bmu.z) * bis.z); bs2.w += gw * ((yv.w - bmu.w) * bis.w);
-            }
-        }
-        if (bnb && hh == NH - 1) {
-            __syncthreads();                       // every thread is done reading Cs: reuse it for the fold
-            float* sb = smem + tid * 8;
-            sb[0] = bs1.x; sb[1] = bs1.y; sb[2] = bs1.z; sb[3] = bs1.w;
-            sb[4] = bs2.x; sb[5] = bs2.y; sb[6] = bs2.z; sb[7] = bs2.w;
-            __syncthreads();
-            if (tid < BN) {
-                constexpr int RL = 256 / F4R;      // row lanes holding the same channel group
-                const int grp = tid >> 2, comp = tid & 3;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < RL; ++q) {
-                    s1 += smem[(grp + F4R * q) * 8 + comp];
-                    s2 += smem[(grp + F4R * q) * 8 + 4 + comp];
-                }
-                float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-                st[0] = s1;
-                st[1] = s2;
-            }
         }
     }
     if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
@@ -1293,72 +1233,10 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 s2 += smem[(grp + F4R * q) * 8 + 4 + comp];
             }
             float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-            if (p.fold.on) {
-                fold_store(st, s1, s2);
-            } else {
-                st[0] = s1;
-                st[1] = s2;
-            }
+            st[0] = s1;
+            st[1] = s2;
         }
-        if (p.fold.on) stats_fold_tile<float, true>(p.fold, p.stats, tm, tn, n0, BN, rowoff);
         return;
-    }
-    // the tile rows are reduced (and the BatchNorm coefficients derived) by the last blocks to arrive: bn_fold.h
-    if (do_stats && p.fold.on) stats_fold_tile<float, false>(p.fold, p.stats, tm, tn, n0, BN, reinterpret_cast<int*>(red));
-    // ---- BatchNorm apply in the same launch (IgemmParams::cz): wait at the gate until this column tile's coefficients are
-    // final, then normalise + (residual) + activate the tile out of the accumulators.  The grid is resident at once
-    // (launcher: coop_capacity), so every block arrives.
-    if (do_stats && p.fold.on && p.fold.gate && p.cz) {
-        if (tid == 0) coop_wait(p.fold.gate + 2 * tn, p.fold.gate_n);
-        __syncthreads();
-        // (everything below is derived from a laundered copy of the thread index: nothing of this pass may be computed ahead
-        // of - and kept live across - the fold, whose 64 registers of loads in flight set the kernel's register count)
-        int t2 = threadIdx.x;
-        asm volatile("" : "+v"(t2));
-        constexpr int F4R = BN / 4;
-        const int part_off = (tm / p.fold.tiles_per_part) * p.fold.part_stride;
-        const int ccol = n0 + (t2 % F4R) * 4;             // this thread's 4 columns (256 % F4R == 0: the same in every pass)
-        float4 sc, sf;
-        {
-            const float* ps = p.fold.fin.scale + part_off + ccol;
-            const float* pf = p.fold.fin.shift + part_off + ccol;
-            sc = make_float4(coop_load(ps), coop_load(ps + 1), coop_load(ps + 2), coop_load(ps + 3));
-            sf = make_float4(coop_load(pf), coop_load(pf + 1), coop_load(pf + 2), coop_load(pf + 3));
-        }
-        const int c4n = p.Nout >> 2;
-        // The tile is NOT kept in the accumulators across the wait (64 live registers under the fold's 64 would cost the
-        // bf16 kernels their third block per CU): one staging pass (NH == 1) leaves the whole tile in LDS, where it still is;
-        // with two passes (bf16 storage) a thread re-reads the 8 bytes per element it has just stored (L2-hot, and exactly
-        // "y as stored").
-#pragma unroll 1
-        for (int hh = 0; hh < NH; ++hh) {
-#pragma unroll 2
-            for (int e = t2; e < HROWS * F4R; e += 256) {
-                const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
-                const int off = rowoff[row];
-                if (off < 0) continue;
-                const int col = n0 + c;
-                float4 v;
-                if constexpr (NH == 1) {
-                    v = *reinterpret_cast<const float4*>(Cs + row * CLD + c);
-                    v = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));   // y as stored
-                } else {
-                    v = ld4(reinterpret_cast<const OT*>(p.Out0) + (size_t)off * p.ldo0 + col);
-                }
-                v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
-                v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
-                if (p.cres) {
-                    const float4 r = ld4(reinterpret_cast<const OT*>(p.cres) + (size_t)off * p.cldres + col);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                v.x = apply_act(v.x, p.cact); v.y = apply_act(v.y, p.cact);
-                v.z = apply_act(v.z, p.cact); v.w = apply_act(v.w, p.cact);
-                st4(reinterpret_cast<OT*>(p.cz) + (size_t)off * p.cldz + col, v);
-                if (p.cmask)
-                    p.cmask[(size_t)off * c4n + (col >> 2)] =
-                        (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
-            }
-        }
     }
 }
 
@@ -1366,12 +1244,6 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
 // for 32-row tiles: stats[tile][Nout][2].  256 threads = 64 column lanes (float4) x 4 row lanes.  (32 rows, all slabs
 // of a row in flight: 64-row tiles left a 128-block grid latency-bound - cfg3 bf16 20.5 -> 19.2 ms; 16 rows: slower)
 constexpr int SPLITK_ROWS = 32;
-struct CoopApply {        // IgemmParams::cz .. cact for the slab-sum kernel
-    void* z;
-    const void* res;
-    unsigned char* mask;
-    int ldz, ldres, act;
-};
 template <typename OT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int M,
                                                              int Nout, const float* __restrict__ bias,
@@ -1381,10 +1253,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                                                              const float* __restrict__ ep_scale,
                                                              const float* __restrict__ ep_shift,
                                                              const OT* __restrict__ ep_res, int ep_ldres, int ep_act,
-                                                             const StatsFold fold, const CoopApply ca, unsigned* __restrict__ amax_out) {
+                                                             unsigned* __restrict__ amax_out) {
     __shared__ float sh[256 * 8];
     float omax = 0.f;      // F16X2: max |value stored to out0| (IgemmParams::amax_out)
-    __shared__ int fold_flag;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int r0 = blockIdx.x * SPLITK_ROWS;
     const size_t slab = (size_t)M * Nout;
@@ -1516,56 +1387,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
                         a2 += sh[(w * 64 + tx) * 8 + 4 + k];
                     }
                     float* st = stats + ((size_t)blockIdx.x * Nout + c + k) * 2;
-                    if (fold.on) {
-                        fold_store(st, a1, a2);
-                    } else {
-                        st[0] = a1;
-                        st[1] = a2;
-                    }
+                    st[0] = a1;
+                    st[1] = a2;
                 }
             }
             __syncthreads();
-            // (the grid covers the columns exactly once: gridDim.y = ceil(Nout / 256), one pass of this loop per block)
-            if (fold.on) stats_fold_tile<float>(fold, stats, blockIdx.x, blockIdx.y, cb, min(256, Nout - cb), &fold_flag);
-            // BatchNorm apply in the same launch (IgemmParams::cz): every block waits until its column tile's coefficients
-            // are final and normalises the 32 rows it has just written (a thread re-reads its own stores: y as stored)
-            if (fold.on && fold.gate && ca.z) {
-                if (threadIdx.x == 0) coop_wait(fold.gate + 2 * blockIdx.y, fold.gate_n);
-                __syncthreads();
-                if (c < Nout) {
-                    const int part_off = ((int)blockIdx.x / fold.tiles_per_part) * fold.part_stride;
-                    const float* ps = fold.fin.scale + part_off + c;
-                    const float* pf = fold.fin.shift + part_off + c;
-                    const float4 sc = make_float4(coop_load(ps), coop_load(ps + 1), coop_load(ps + 2), coop_load(ps + 3));
-                    const float4 sf = make_float4(coop_load(pf), coop_load(pf + 1), coop_load(pf + 2), coop_load(pf + 3));
-                    constexpr int NRW = SPLITK_ROWS / 4;
-                    float4 yv[NRW], rv[NRW];
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i) {
-                        const int rr = min(r0 + ty + 4 * i, M - 1);
-                        yv[i] = ld4(out0 + (size_t)rr * ldo0 + c);
-                        rv[i] = ca.res ? ld4(reinterpret_cast<const OT*>(ca.res) + (size_t)rr * ca.ldres + c) : make_float4(0, 0, 0, 0);
-                    }
-                    const int c4n = Nout >> 2;
-#pragma unroll
-                    for (int i = 0; i < NRW; ++i) {
-                        const int r = r0 + ty + 4 * i;
-                        if (r >= M) continue;
-                        float4 v = yv[i];
-                        v.x = __fmaf_rn(v.x, sc.x, sf.x); v.y = __fmaf_rn(v.y, sc.y, sf.y);
-                        v.z = __fmaf_rn(v.z, sc.z, sf.z); v.w = __fmaf_rn(v.w, sc.w, sf.w);
-                        if (ca.res) {
-                            v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
-                        }
-                        v.x = apply_act(v.x, ca.act); v.y = apply_act(v.y, ca.act);
-                        v.z = apply_act(v.z, ca.act); v.w = apply_act(v.w, ca.act);
-                        st4(reinterpret_cast<OT*>(ca.z) + (size_t)r * ca.ldz + c, v);
-                        if (ca.mask)
-                            ca.mask[(size_t)r * c4n + (c >> 2)] =
-                                (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
-                    }
-                }
-            }
         }
     }    if (amax_out) amax_record(amax_out, omax, sh, blockIdx.x + 13 * blockIdx.y);
 }
@@ -1573,34 +1399,6 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, bool HIN, int WGM, bool HALO = false, int NPL = 3>
 constexpr size_t igemm_smem_bytes() {
     return (size_t)igemm_main_floats<BM, BN, HIN, (HIN && WGM >= 2) ? 2 : 1, HALO, NPL>() * 4 + BM * 4 + 4 * BN * 2 * 4;
-}
-
-// ---- launches whose blocks wait for each other (StatsFold::gate) --------------------------------------------------------
-// Such a grid must be RESIDENT at once: blocks that wait at the gate hold their CU slots, a block that was never dispatched
-// would never arrive.  coop_capacity = what the chip holds of this kernel when it has the chip to itself (other kernels only
-// delay a launch - they finish without waiting for us - as long as no second gated launch is in flight: the library gates
-// launches of the COMPUTE stream only).
-// MEASURED A LOSS, hence OPT-IN (XV2_COOP=1, or xv2_set_coop_blocks(n > 0)): same box, gated vs two launches - cfg2 fp32 26.66 ->
-// 27.07 ms, cfg2 --precision 16 14.09 -> 14.58, cfg3 18.3 -> 20.3 ms, resnest50 encoder forward 6.42 -> 6.76 (fp32) / 4.95 -> 5.58
-// ms (bf16): the hand-off chain (partials -> group ticket -> group fold -> top ticket -> fold + coefficients -> gate -> acquire ->
-// coefficient loads) is ~10 dependent device-scope round trips of 1 - 2.5 us each, paid by EVERY block of the grid while it
-// holds its CU; a kernel boundary plus the streaming apply kernel costs less than that on MI355X (profiles/r04_gated_ab.md).
-// XV2_COOP_BLOCKS caps the grid (processes that share one GPU - the test suite's workers - must keep their combined gated grids
-// below the chip's capacity).
-static int g_coop_blocks = -1;      // xv2_set_coop_blocks(): cap on gated grids; > 0 also switches the gated forms on; -1 = env
-long long g_coop_count = 0;         // gated launches issued so far (xv2_coop_count: tests assert WHICH form ran)
-static bool coop_enabled() { return false; }      // (round 6: the gated apply's entry points are gone - measured a loss on every configuration)
-bool coop_requested() { return coop_enabled(); }
-int coop_block_cap() {
-    static const int envcap = [] { const char* e = getenv("XV2_COOP_BLOCKS"); return e ? atoi(e) : (1 << 30); }();
-    return g_coop_blocks >= 0 ? g_coop_blocks : envcap;
-}
-int coop_capacity(const void* kern, int threads, size_t smem) {
-    int nb = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, smem) != hipSuccess) return 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    // blocks go to the 8 XCDs round-robin: whole blocks per CU, whole CUs per XCD
-    return nb * (cus / 8) * 8;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool SMALLC, bool BF16 = false, bool HS = false, bool X3 = false,
@@ -1629,17 +1427,6 @@ static int launch_one(const IgemmParams& p, hipStream_t stream) {
         flops += 2.0 * (double)q.cls[c].M * q.Nout * kreal;
     }
     const int grid = maxtiles * (q.Nout / BN);
-    if (q.cz && q.ksplit == 1) {
-        // BatchNorm apply behind the gate: only if the whole grid is resident at once
-        static const int cap = coop_capacity(reinterpret_cast<const void*>(kern), 256, smem);
-        if (coop_enabled() && q.fold.on && q.fold.gate && q.ncls == 1 && grid <= std::min(cap, coop_block_cap())) {
-            if (q.coop_applied) *q.coop_applied = 1;
-            ++g_coop_count;
-        } else {
-            q.cz = nullptr;
-            q.fold.gate = nullptr;
-        }
-    }
     // algorithmic bytes: input pixels x channels + weights + output, each once
     const double ein = (HS && !SMALLC) ? 2.0 : 4.0, eout = HS ? 2.0 : 4.0;
     double abytes = ein * ((double)q.cls[0].M / std::max(1, q.cls[0].OHl * q.cls[0].OWl) * q.IH * q.IW *
@@ -1776,24 +1563,6 @@ size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
     return ks > 1 ? (size_t)ks * M * Nout * sizeof(float) : 0;
-}
-
-// complete the in-launch statistics fold for the tiling that was picked (bn_fold.h)
-static int complete_fold(IgemmParams& p, int64_t tiles, int ntn) {
-    if (!p.fold.on) return XV2_OK;
-    StatsFold f = p.fold;
-    XV2_CHECK_ARG(p.stats && p.ncls == 1 && stats_fold_plan(f, tiles, p.fold.S, ntn, p.Nout),
-                  "conv2d_forward_bn: %lld statistics tiles do not split into %d parts", (long long)tiles, p.fold.S);
-    f.tickets = take_tickets(stats_fold_tickets(f));
-    XV2_CHECK_ARG(f.tickets, "conv2d_forward_bn: ticket pool allocation failed");
-    f.gate = nullptr;
-    f.gate_n = (int)tiles;
-    if (p.cz && f.fin.mean && coop_enabled()) {       // BatchNorm apply in the same launch: the launcher of the kernel decides
-        f.gate = take_tickets(2 * ntn);
-        XV2_CHECK_ARG(f.gate, "conv2d_forward_bn: ticket pool allocation failed");
-    }
-    p.fold = f;
-    return XV2_OK;
 }
 
 // ---- weights pre-split into bf16 planes (igemm_kernel<..., BX3>) ------------------------------------------------------
@@ -1948,7 +1717,7 @@ static bool presplit_lookup(const void* b, int nrows, int T, int ctot, const voi
 }
 // F16X2 for this launch: the operand maxima of both sides are known and the weights exist as two scaled fp16 planes
 static bool f16x2_ready(IgemmParams& p) {
-    if (!f16x2_enabled() || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1) || p.pre_scale) return false;
+    if (!f16x2_enabled() || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1)) return false;
     std::lock_guard<std::mutex> lk(g_presplit_mu);
     auto it = g_presplit2.find(p.B);
     if (it == g_presplit2.end() || it->second.nrows != p.Nout || it->second.T != p.T || it->second.ctot != p.Ctot) return false;
@@ -1960,7 +1729,7 @@ static bool f16x2_ready(IgemmParams& p) {
 }
 // ... of the per-tap form (both operands split in the kernel): the maxima of the sources and of the packed weights
 bool f16x2_ready_pertap(IgemmParams& p) {
-    if (!f16x2_enabled(2) || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1) || p.pre_scale) return false;
+    if (!f16x2_enabled(2) || p.math != XV2_MATH_F32X3 || !p.amaxA0 || (p.A1 && !p.amaxA1)) return false;
     std::lock_guard<std::mutex> lk(g_presplit_mu);
     auto it = g_wamax.find(p.B);
     if (it == g_wamax.end()) return false;
@@ -2011,37 +1780,18 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     int bm, bn, ks;
     int64_t maxM = 0;
     for (int c = 0; c < p.ncls; ++c) maxM = std::max<int64_t>(maxM, p.cls[c].M);
-    if (p.plan_tiles) {      // dry run for the fused BN-backward statistics: which tiling would this launch use?
-        *p.plan_tiles = 0;
-        if (p.ncls != 1 || smallc || p.Out1) return XV2_OK;
-        if (direct3x3_eligible(p, smallc)) {      // (the direct kernel takes them in its exact-fp32 form only)
-            *p.plan_tiles = p.math == XV2_MATH_F32 ? p.cls[0].M / 128 : 0;
-            return XV2_OK;
-        }
-        pick_tile(maxM, p.Nout, smallc, splitk_ws ? p.cls[0].nkt : 0, p.math, bm, bn, ks);
-        if (ks == 1 && bn >= 64) *p.plan_tiles = cdiv(maxM, bm);
-        return XV2_OK;
-    }
-    if (direct3x3_eligible(p, smallc)) {
-        if (p.plan_halo) {
-            *p.plan_halo = 0;
-            return XV2_OK;
-        }
-        XV2_CHECK_ARG(!p.pre_scale, "conv2d_forward_bn_pre: the direct 3x3 plan has no pre-activation form");
-        p.cz = nullptr;
-        return direct3x3_launch(p, stream);
-    }
+    if (direct3x3_eligible(p, smallc)) return direct3x3_launch(p, stream);
     if (smallc && p.math == XV2_MATH_F32X3) p.math = XV2_MATH_F32; // RGB stem: exact fp32
     pick_tile(maxM * (p.ncls > 1 ? p.ncls : 1), p.Nout, smallc, (p.ncls == 1 && splitk_ws) ? p.cls[0].nkt : 0, p.math, bm, bn, ks);
     if (getenv("XV2_DEBUG_TILE"))
         fprintf(stderr, "igemm M=%lld N=%d nkt=%d ws=%d -> %dx%d ks=%d\n", (long long)maxM, p.Nout, p.cls[0].nkt,
                 splitk_ws != nullptr, bm, bn, ks);
-    if (!p.plan_halo && !smallc && p.ncls == 1 && (p.math == XV2_MATH_F32X3 || p.math == XV2_MATH_BF16_STORE)) {
+    if (!smallc && p.ncls == 1 && (p.math == XV2_MATH_F32X3 || p.math == XV2_MATH_BF16_STORE)) {
         // small grids (the /8 ... /32 encoder levels): sg_conv.hip instead of a 64-row / split-K plan of the tiled kernel.
         // Forward launches with statistics: the descriptor queries (xv2_conv2d_forward_stats_tiles / _tile_rows / _workspace)
         // already answered with sg_planned_rows() for this shape, so the partials have that geometry whichever kernel runs -
         // if the operands are not ready for it (no recorded maxima, no fp16 planes) the tiled kernel takes 64-row tiles, unsplit.
-        const int planned = (p.stats && !p.A1 && p.C1 == 0 && !p.bnb_y) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
+        const int planned = (p.stats && !p.A1 && p.C1 == 0) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
         const int R = planned ? planned : (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
         IgemmParams q = p;
         if ((p.math == XV2_MATH_BF16_STORE || f16x2_ready(q)) && sg_conv_eligible(q, smallc, R)) {
@@ -2065,46 +1815,20 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     p.ksplit = ks;
     p.part = splitk_ws;
     p.kt_per_split = (int)cdiv(p.cls[0].nkt, ks);
-    const bool stem7 = ks == 1 && !p.plan_halo && stem7x7_eligible(p, smallc);
-    if (stem7 || (ks == 1 && (bm == 128 || !p.stats) && !p.plan_halo && thin1x1_eligible(p, smallc))) {
-        // HBM-bound 1x1 layers: the streaming kernel (thin_conv.hip).  It writes the 128-row statistics partials of the
-        // BM = 128 plan and leaves their reduction to the separate launch (one device-scope hand-off per 128 rows would
-        // stall its barrier-free waves).  The 7x7 RGB stem (stem_conv.hip) does the same with its two rows per patch.
-        const StatsFold fold = p.fold;
-        p.fold.on = 0;
-        p.cz = nullptr;
-        int rc = stem7 ? stem7x7_launch(p, stream) : thin1x1_launch(p, stream);
-        if (rc || !fold.on) return rc;
-        const int64_t tiles = cdiv(maxM, 128);
-        XV2_CHECK_ARG(fold.S >= 1 && tiles % fold.S == 0, "conv2d_forward_bn: %lld statistics tiles do not split into %d parts",
-                      (long long)tiles, fold.S);
-        const int64_t tpp = tiles / fold.S;
-        for (int s = 0; s < fold.S && !rc; ++s) {
-            const float* ps = p.stats + (size_t)s * tpp * p.Nout * 2;
-            double* ss = fold.sums + (size_t)s * fold.part_stride * 2;
-            const size_t o = (size_t)s * fold.part_stride;
-            const BnFinalize& f = fold.fin;
-            rc = f.mean ? xv2_bn_reduce_finalize(ps, tpp, p.Nout, ss, fold.scratch, f.count, f.gamma, f.beta, f.eps, f.momentum,
-                                                 f.running_mean, f.running_var, f.mean + o, f.invstd + o, f.scale + o,
-                                                 f.shift + o, stream)
-                        : xv2_bn_reduce_stats(ps, tpp, p.Nout, ss, fold.scratch, stream);
-        }
-        return rc;
+    const bool stem7 = ks == 1 && stem7x7_eligible(p, smallc);
+    if (stem7 || (ks == 1 && (bm == 128 || !p.stats) && thin1x1_eligible(p, smallc))) {
+        // HBM-bound 1x1 layers: the streaming kernel (thin_conv.hip), and the 7x7 RGB stem (stem_conv.hip); both write the
+        // 128-row statistics partials of the BM = 128 plan
+        return stem7 ? stem7x7_launch(p, stream) : thin1x1_launch(p, stream);
     }
     if (ks == 1) {
         int mk = 0;
         for (int c = 0; c < p.ncls; ++c) mk = std::max(mk, p.cls[c].nkt);
         p.kt_per_split = mk;
-        if (int rc = complete_fold(p, cdiv(maxM, bm), p.Nout / bn)) return rc;
-        if (!p.plan_halo && bm == 128 && bn >= 64 && halo_eligible(p, smallc, XV2_MATH_BF16_STORE))
+        if (bm == 128 && bn >= 64 && halo_eligible(p, smallc, XV2_MATH_BF16_STORE))
             return bn == 128 ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
                              : launch_one<128, 64, 2, 2, false, true, true, false, true>(p, stream);
         const bool halo1 = bm == 128 && bn >= 64 && halo_eligible(p, smallc);
-        if (p.plan_halo) {
-            *p.plan_halo = halo1 ? 1 : 0;
-            return XV2_OK;
-        }
-        XV2_CHECK_ARG(!p.pre_scale || halo1, "conv2d_forward_bn_pre: this shape is not planned as the halo form (query _pre_supported)");
         if (halo1) {
             if (f16x2_ready(p))
                 return bn == 128 ? launch_one<128, 128, 2, 2, false, true, false, true, true, true, 2>(p, stream)
@@ -2138,45 +1862,20 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
                 halo = false;
             }
         }
-        if (p.plan_halo) {
-            *p.plan_halo = (halo && !halo16) ? 1 : 0;
-            return XV2_OK;
-        }
-        XV2_CHECK_ARG(!p.pre_scale || (halo && !halo16), "conv2d_forward_bn_pre: this shape is not planned as the halo form");
         if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8 &&
             2 * cdiv(maxM, 128) * (p.Nout / 128) <= (1 << 16)) {      // (two tickets per tile from a pool of 65536)
-            p.cz = nullptr;       // (no gated apply behind the in-launch slab sum)
             // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
             // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
             const int64_t ntiles = cdiv(maxM, 128) * (p.Nout / 128);
             p.sk_tickets = take_tickets((int)(2 * ntiles));
             XV2_CHECK_ARG(p.sk_tickets, "igemm: ticket pool allocation failed");
-            if (int rc = complete_fold(p, cdiv(maxM, 128), p.Nout / 128)) return rc;
             return p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
                    : f16x2_ready_pertap(p)       ? launch_one<128, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream)
                    : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
                    : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
                                                  : launch_one<128, 128, 2, 2, false>(p, stream);
         }
-        // split-K: the slab-sum kernel takes the statistics (64-row tiles, 256-column tiles) and folds them
-        if (int rc = complete_fold(p, cdiv(maxM, SPLITK_ROWS), (int)cdiv(p.Nout, 256))) return rc;
-        StatsFold fold = p.fold;
-        p.fold.on = 0;
-        CoopApply ca{p.cz, p.cres, p.cmask, p.cldz, p.cldres, p.cact};
-        p.cz = nullptr;           // (the GEMM launch writes slabs; the slab-sum launch below is the one that applies)
-        {
-            const long long rblocks = (long long)cdiv(p.cls[0].M, SPLITK_ROWS) * cdiv(p.Nout, 256);
-            static const int cap_f = coop_capacity(reinterpret_cast<const void*>(splitk_reduce_kernel<float>), 256, 0);
-            static const int cap_h = coop_capacity(reinterpret_cast<const void*>(splitk_reduce_kernel<bf16_t>), 256, 0);
-            const int cap = std::min(p.math == XV2_MATH_BF16_STORE ? cap_h : cap_f, coop_block_cap());
-            if (coop_enabled() && ca.z && fold.on && fold.gate && !p.Out1 && rblocks <= cap) {
-                if (p.coop_applied) *p.coop_applied = 1;
-                ++g_coop_count;
-            } else {
-                ca.z = nullptr;
-                fold.gate = nullptr;
-            }
-        }
+        // split-K: the slab-sum kernel takes the statistics (32-row tiles)
         int rc = (halo && halo16)              ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
                  : p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
                  : (halo && p.npl == 2)        ? launch_one<128, 128, 2, 2, false, true, false, true, true, true, 2>(p, stream)
@@ -2193,11 +1892,11 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         if (p.math == XV2_MATH_BF16_STORE)
             hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, (bf16_t*)p.Out0, p.ldo0, p.N0, (bf16_t*)p.Out1, p.ldo1, p.stats, p.accum | rolled,
-                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, fold, ca, (unsigned*)nullptr);
+                               p.ep_scale, p.ep_shift, (const bf16_t*)p.ep_res, p.ep_ldres, p.ep_act, (unsigned*)nullptr);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, stream, splitk_ws, p.ksplit, M, p.Nout,
                                p.bias, p.Out0, p.ldo0, p.N0, p.Out1, p.ldo1, p.stats, p.accum | rolled, p.ep_scale, p.ep_shift,
-                               p.ep_res, p.ep_ldres, p.ep_act, fold, ca, p.amax_out);
+                               p.ep_res, p.ep_ldres, p.ep_act, p.amax_out);
         XV2_CHECK_LAUNCH();
         return XV2_OK;
     }
@@ -2294,14 +1993,6 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.accum = 0;
     p.ep_scale = p.ep_shift = p.ep_res = nullptr;
     p.ep_ldres = p.ep_act = 0;
-    p.bnb_y = p.bnb_mean = p.bnb_invstd = p.bnb_scale = p.bnb_shift = nullptr;
-    p.bnb_ldy = p.bnb_act = 0;
-    p.plan_tiles = nullptr;
-    p.plan_halo = nullptr;
-    p.cz = nullptr; p.cres = nullptr; p.cmask = nullptr; p.cldz = p.cldres = p.cact = 0; p.coop_applied = nullptr;
-    p.pre_scale = p.pre_shift = nullptr;
-    p.pre_act = 0;
-    memset(&p.fold, 0, sizeof(p.fold));
     XV2_CHECK_ARG(d->math >= 0 && d->math <= XV2_MATH_F32X3, "conv: unknown math mode %d", d->math);
     p.A1 = nullptr;
     p.Out1 = nullptr;
@@ -2347,71 +2038,21 @@ extern "C" size_t xv2_conv2d_backward_data_workspace(const xv2_conv_desc* d) {
     return igemm_splitk_bytes((int64_t)d->N * d->IH * d->IW, d->C0 + d->C1, false, d->KH * d->KW * (d->Cout / BK), d->math);
 }
 
-struct BnbArgs {          // producer-layer BatchNorm backward statistics (IgemmParams::bnb_*)
-    const float* y;
-    int ldy;
-    const float* mean;
-    const float* invstd;
-    const float* scale;
-    const float* shift;
-    int act;
-    float* partials;
-};
-static void set_bnb(IgemmParams& p, const BnbArgs* b) {
-    if (!b) return;
-    p.bnb_y = b->y; p.bnb_ldy = b->ldy; p.bnb_mean = b->mean; p.bnb_invstd = b->invstd;
-    p.bnb_scale = b->scale; p.bnb_shift = b->shift; p.bnb_act = b->act;
-    p.stats = b->partials;
-}
-
 struct FwdEpilogue {
     const float* scale;
     const float* shift;
     const float* res;
     int ldres, act;
 };
-struct PreAct {           // IgemmParams::pre_*
-    const float* scale;
-    const float* shift;
-    int act;
-};
-struct CoopArgs {         // IgemmParams::cz ..: BatchNorm apply in the same launch
-    void* z;
-    int ldz;
-    const void* res;
-    int ldres, act;
-    unsigned char* mask;
-    int* applied;
-};
-
 static int amax_rows_into(const float* x, int64_t rows, int C, int64_t ld, unsigned* slots, hipStream_t stream);      // below
 static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, const float* x1, int ldx1,
                              const float* w_ohwi, const float* bias, float* y, int ldy, float* stats,
-                             float* workspace, void* stream, const FwdEpilogue* ep, const BnbArgs* bnb = nullptr,
-                             long long* plan = nullptr, const StatsFold* fold = nullptr, const PreAct* pre = nullptr,
-                             int* plan_halo = nullptr, const CoopArgs* coop = nullptr, int accumulate = 0) {
+                             float* workspace, void* stream, const FwdEpilogue* ep, int accumulate = 0) {
     AmaxGuard amax_guard;
     IgemmParams p;
     int rc = fill_common(p, d);
     if (rc) return rc;
     p.accum = accumulate & 1;      // ADD the result onto what y holds (the gradient of the tensor's other consumer)
-    if (coop && coop->z) {
-        XV2_CHECK_ARG(fold && fold->fin.mean && out_aligned(d, coop->z, coop->ldz) &&
-                          (!coop->res || out_aligned(d, coop->res, coop->ldres)) && coop->applied,
-                      "conv2d_forward_bn_act: coefficients, aligned z / residual rows and the `applied` flag are required");
-        p.cz = coop->z; p.cldz = coop->ldz; p.cres = coop->res; p.cldres = coop->ldres; p.cact = coop->act;
-        p.cmask = coop->mask; p.coop_applied = coop->applied;
-    }
-    p.plan_tiles = plan;
-    p.plan_halo = plan_halo;
-    const bool dry = plan_halo != nullptr;
-    if (pre) {
-        XV2_CHECK_ARG(pre->scale && pre->shift && !x1 && d->C1 == 0 && (reinterpret_cast<uintptr_t>(pre->scale) & 15) == 0 &&
-                          (reinterpret_cast<uintptr_t>(pre->shift) & 15) == 0,
-                      "conv2d_forward_bn_pre: one source, 16-byte aligned scale / shift");
-        p.pre_scale = pre->scale; p.pre_shift = pre->shift; p.pre_act = pre->act;
-    }
-    if (fold) p.fold = *fold;
     if (ep) {
         XV2_CHECK_ARG(ep->scale && ep->shift && !stats, "conv2d_forward_fused: scale and shift are required, stats excluded");
         XV2_CHECK_ARG((reinterpret_cast<uintptr_t>(ep->scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(ep->shift) & 15) == 0 &&
@@ -2423,16 +2064,15 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     XV2_CHECK_ARG(smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "conv2d_forward: C0=%d C1=%d must be multiples of 32 (or a single 4-channel source)", d->C0, d->C1);
     XV2_CHECK_ARG(!(stats && bias), "conv2d_forward: stats and bias are mutually exclusive");
-    XV2_CHECK_ARG(dry || out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
+    XV2_CHECK_ARG(out_aligned(d, y, ldy), "conv2d_forward: output rows must be aligned to 4 elements");
     // (band form of an RGB stem, xv2_pad_band: pixel stride 4 with an even pixel index on every access keeps 16-byte alignment)
     const bool band = d->C0 == 32 && d->C1 == 0 && ldx0 == 4 && d->KW == 1 && d->stride == 2 && d->pad == 0 && d->IW % 2 == 0;
-    XV2_CHECK_ARG(dry || esz_in(d) == 4 || band || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
+    XV2_CHECK_ARG(esz_in(d) == 4 || band || (ldx0 % 8 == 0 && (!x1 || ldx1 % 8 == 0) && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 &&
                                      (reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ohwi) & 15) == 0),
                   "conv2d_forward: bf16 operands must be 16-byte aligned with row strides that are multiples of 8");
-    XV2_CHECK_ARG(dry || !(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
+    XV2_CHECK_ARG(!(stats && !workspace && xv2_conv2d_forward_workspace(d) > 0),
                   "conv2d_forward: this shape is planned as split-K; pass the workspace when stats are requested");
     p.A0 = x0; p.A1 = x1; p.B = w_ohwi; p.bias = bias; p.Out0 = y; p.Out1 = nullptr; p.stats = stats;
-    set_bnb(p, bnb);
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
     p.ldA0 = ldx0; p.ldA1 = ldx1;
     p.IH = d->IH; p.IW = d->IW; p.s_in = d->stride;
@@ -2462,7 +2102,7 @@ static int conv_forward_impl(const xv2_conv_desc* d, const float* x0, int ldx0, 
     // F16X2, inference (fused epilogue): record max |z| for the next layer - in the epilogue of the tiled kernels, by a pass
     // of its own behind the direct / streaming / stem kernels
     int amax_recorded = 0;
-    if (ep && !dry && !plan && p.math != XV2_MATH_BF16_STORE && p.math != XV2_MATH_BF16) {
+    if (ep && p.math != XV2_MATH_BF16_STORE && p.math != XV2_MATH_BF16) {
         p.amax_out = amax_ctx().out;
         p.amax_recorded = &amax_recorded;
     }
@@ -2520,7 +2160,7 @@ extern "C" int xv2_conv2d_forward_fused(const xv2_conv_desc* d, const void* x0, 
 // backward-data of conv `d`: A = dy [N][OH][OW][Cout], output = dx [N][IH][IW][C0|C1]
 static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const float* w_ihwo,
                       float* dx0, int lddx0, float* dx1, int lddx1, float* workspace, hipStream_t stream,
-                      int accumulate = 0, const BnbArgs* bnb = nullptr, long long* plan = nullptr) {
+                      int accumulate = 0) {
     AmaxGuard amax_guard;
     IgemmParams p;
     int rc = fill_common(p, d);
@@ -2528,13 +2168,11 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
     p.amaxA0 = amax_ctx().dy;      // the A operand of a backward-data launch is the output gradient
     p.amaxA1 = nullptr;
     int amax_recorded = 0;
-    if (!plan && d->math == XV2_MATH_F32X3) {      // F16X2: the maximum of dx0 for ITS consumers (a transposed convolution's backward)
+    if (d->math == XV2_MATH_F32X3) {      // F16X2: the maximum of dx0 for ITS consumers (a transposed convolution's backward)
         p.amax_out = amax_ctx().out;
         p.amax_recorded = &amax_recorded;
     }
-    p.plan_tiles = plan;
     p.accum = accumulate & (dx1 ? 3 : 1);
-    set_bnb(p, bnb);
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_data: Cout=%d must be a multiple of 32", d->Cout);
     XV2_CHECK_ARG(d->C0 % 32 == 0 && d->C1 % 32 == 0, "backward_data: C0=%d/C1=%d must be multiples of 32", d->C0, d->C1);
     const int s = d->stride;
@@ -2588,7 +2226,7 @@ static int dgrad_impl(const xv2_conv_desc* d, const float* dy, int lddy, const f
             c.nkt = c.ntaps * p.cpt;
             p.cls[ncls++] = c;
         }
-    if (need_zero && !plan) {
+    if (need_zero) {
         XV2_CHECK_ARG(lddx0 == d->C0 && (d->C1 == 0 || lddx1 == d->C1),
                       "backward_data: strided outputs unsupported when parity classes are empty");
         // pixels no tap reaches get a zero gradient - or, when accumulating, keep what they hold
@@ -2646,7 +2284,7 @@ extern "C" int xv2_conv_transpose2d_backward_data_acc(const xv2_conv_desc* d, co
     AmaxGuard amax_guard;
     if (const int rc = thin_convT_backward_data(d, dy, lddy, w_ohwi, dx, lddx, accumulate, (hipStream_t)stream); rc >= 0) return rc;
     return conv_forward_impl(d, (const float*)dy, lddy, nullptr, 0, (const float*)w_ohwi, nullptr, (float*)dx, lddx, nullptr,
-                             workspace, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, accumulate);
+                             workspace, stream, nullptr, accumulate);
 }
 
 // ---- pre-split weights (see PresplitEntry) ---------------------------------------------------------------------------

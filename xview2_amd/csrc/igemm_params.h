@@ -59,35 +59,6 @@ struct IgemmParams {
     const float* ep_shift;
     const float* ep_res;
     int ep_ldres, ep_act;
-    // BatchNorm-backward statistics of the layer that PRODUCED this convolution's input, taken in the backward-data
-    // epilogue: the result v is that layer's dz; with its conv output y and coefficients the epilogue accumulates
-    // g = v * act'(y*scale+shift) and g * xhat per channel into stats[tile][Nout][2] (no separate pass over dz, y)
-    const float* bnb_y;
-    const float* bnb_mean;
-    const float* bnb_invstd;
-    const float* bnb_scale;
-    const float* bnb_shift;
-    int bnb_ldy, bnb_act;
-    // halo form only: the A operand is the RAW convolution output of the producing layer and that layer's training-mode
-    // BatchNorm + activation is applied while the halo is staged: a = act(y * pre_scale[c] + pre_shift[c]) inside the image,
-    // 0 in the padding (model/layers.py:96-100 BatchNorm + activation between two convolutions, never materialised)
-    const float* pre_scale;
-    const float* pre_shift;
-    int pre_act;
-    int* plan_halo;          // dry run: report whether the plan is the halo form (the only one with pre_*) and launch nothing
-    long long* plan_tiles;   // dry run: report the M-tile count of the plan (0 = no fused BN-backward form) and launch nothing
-    // in-launch fold of the BatchNorm statistics partials (bn_fold.h); the caller fills scratch / sums / S / part_stride /
-    // fin and sets fold.on = 1, the launcher completes the plan (group size, tickets) for the tiling it picks
-    StatsFold fold;
-    // Training-mode BatchNorm APPLY in the same launch (fold.on, fold.fin and fold.gate set, ksplit == 1 in the GEMM kernel or
-    // the slab-sum kernel of a split-K plan): once the coefficients are final every block forms
-    // z = act(y * scale + shift [+ res]) from the tile it still holds - y rounded to the storage type first, so the result
-    // equals xv2_bn_act_forward on the stored y bit for bit (model/layers.py:93-100).  cz == nullptr: off.
-    void* cz;
-    const void* cres;
-    unsigned char* cmask;    // optional byte mask of z > 0 (xv2_bn_act_forward_mask), dense rows of Nout / 4 bytes
-    int cldz, cldres, cact;
-    int* coop_applied;       // host: set to 1 by the launcher when the plan took the in-launch apply
     int ncls;
     ClassInfo cls[4];
     Tap taps[52];

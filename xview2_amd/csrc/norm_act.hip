@@ -139,23 +139,8 @@ struct ColOp {
 
 // XV2_BN_REVERSE (A/B runs): bit 0 = the backward apply, bit 1 = the forward apply, bit 2 = the backward column sums walk
 // their tensors last-to-first
-// XV2_BN_FOLD: bit 0 = the convolution kernels fold their statistics tiles in-launch.  Round 3 measured it -0.2 ms per cfg2
-// fp32 step and -1.7 ms per resnest50 bf16 step against the separate reduction launch and made it the default.  Round 4 turned
-// it OFF by default: (a) with this round's planner and kernels the separate launch measures 0.4 - 0.6 % FASTER on cfg2 fp32,
-// cfg2 bf16 and cfg3 and 0.4 % slower on cfg4 (same-box pairs); (b) with six test processes crowding one
-// GPU, siamese / reproducibility comparisons of the model tests failed intermittently (about one run in five) with the fold on -
-// also with F16X2 off - and not once in six repetitions with it off: an inter-block hand-off that is not proven race-free under
-// that load has no place on the default path.  It stays available (XV2_BN_FOLD=1) and is implied by the gated launches
-// (XV2_COOP / xv2_set_coop_blocks), which need it.  bit 1 = the column
-// sums of the BatchNorm backward do the same (default OFF: under that HBM-streaming kernel every device-scope load of
-// the fold is a ~2.5 us round trip and the two-level tail costs +16.7 us per launch where the separate, idle-chip
-// reduction kernel takes 12.5 us - profiles/r03_fold_ab.md)
-// (round 6: the in-launch statistics fold - XV2_BN_FOLD, xv2_set_bn_fold - is gone: +0.65 ms per cfg2 step once its hand-off was
-//  fenced correctly; the separate reduction launch, one-phase for small layers, is the only form)
-static int bn_fold_bits() { return 0; }
-bool bn_fold_enabled() { return false; }
-static bool bn_fold_backward() { return (bn_fold_bits() & 2) != 0; }
-
+// (rounds 3 - 5 could fold the chunk / tile partials inside the producing launch - XV2_BN_FOLD, device-scope tickets; removed in
+//  round 6: +0.65 ms per cfg2 step once fenced correctly)
 static int bn_reverse(int bit) {
     static const int v = [] { const char* e = getenv("XV2_BN_REVERSE"); return e ? atoi(e) : 3; }();
     return (v >> bit) & 1;
@@ -163,9 +148,8 @@ static int bn_reverse(int bit) {
 
 template <int MODE, typename T>
 __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op, int64_t npix, int C, int rpb, int cgw,
-                                                              double* __restrict__ part, int rev, const StatsFold fold) {
+                                                              double* __restrict__ part, int rev) {
     __shared__ float sh[256 * 8 * Vec16<T>::NV];
-    __shared__ int fold_flag;
     const int tid = threadIdx.x;
     // rev: the row chunks are dispatched last-to-first (same chunk -> rows -> partial-row mapping, same sums): the
     // kernel that produced the tensors finished with their last rows
@@ -225,16 +209,10 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op,
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 double* o = out + (blockIdx.y * cgw + tid * 4 + k) * 2;
-                if (fold.on) {
-                    fold_store(o, a0[k], a1[k]);
-                } else {
-                    o[0] = a0[k];
-                    o[1] = a1[k];
-                }
+                o[0] = a0[k];
+                o[1] = a1[k];
             }
         }
-        // in-launch fold of the chunk rows (bn_fold.h): the chunk is the "tile", the channel group the column tile
-        if (fold.on) stats_fold_tile<double>(fold, part, chunk, blockIdx.y, blockIdx.y * cgw, cgw, &fold_flag);
     } else {
         // generic fallback: 64 channel lanes x 4 row lanes
         const int tx = tid & 63, ty = tid >> 6;
@@ -266,16 +244,11 @@ __global__ void __launch_bounds__(256) column_partials_kernel(ColOp<MODE, T> op,
                     a0 += shd[(q * 64 + tx) * 2];
                     a1 += shd[(q * 64 + tx) * 2 + 1];
                 }
-                if (fold.on) {
-                    fold_store(out + c * 2, a0, a1);
-                } else {
-                    out[c * 2] = a0;
-                    out[c * 2 + 1] = a1;
-                }
+                out[c * 2] = a0;
+                out[c * 2 + 1] = a1;
             }
             __syncthreads();
         }
-        if (fold.on) stats_fold_tile<double>(fold, part, chunk, 0, 0, C, &fold_flag);
     }
 }
 
@@ -930,22 +903,9 @@ static int column_sums(const ColOp<MODE, T>& op, int64_t npix, int C, double* su
     part = (part + 15) & ~(size_t)15;
     double* dpart = reinterpret_cast<double*>(workspace);
     double* scratch = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + part);
-    // XV2_BN_FOLD bit 1: the chunk rows are folded inside the launch (bn_fold.h); default: the separate reduction launch
-    StatsFold fold;
-    memset(&fold, 0, sizeof(fold));
-    if (bn_fold_backward() && stats_fold_plan(fold, g.chunks, 1, g.cgw ? g.groups : 1, C)) {
-        fold.scratch = scratch;
-        fold.sums = sums;
-        fold.f0 = f0;
-        fold.f1 = f1;
-        fold.part_stride = C;
-        fold.tickets = take_tickets(stats_fold_tickets(fold));
-        XV2_CHECK_ARG(fold.tickets, "column_sums: ticket pool allocation failed");
-    }
     hipLaunchKernelGGL((column_partials_kernel<MODE, T>), dim3((unsigned)g.chunks, g.groups), dim3(256), 0, st, op, npix,
-                       C, g.rpb, g.cgw, dpart, MODE == 1 ? bn_reverse(2) : 0, fold);
+                       C, g.rpb, g.cgw, dpart, MODE == 1 ? bn_reverse(2) : 0);
     XV2_CHECK_LAUNCH();
-    if (fold.on) return XV2_OK;
     return reduce_stats<double>(dpart, g.chunks, C, sums, scratch, st, f0, f1);
 }
 

@@ -603,7 +603,6 @@ bool sg_conv_eligible(const IgemmParams& p, bool smallc, int R) {
     if (sg_mode() == 0 || smallc) return false;
     if (hs ? (!sg_bf16_enabled() || p.ep_scale || p.amax_out) : (p.math != XV2_MATH_F32X3 || p.npl != 2 || !p.Bx3 || !p.amaxA0 || !p.amaxB)) return false;
     if (p.ncls != 1 || p.A1 || p.C1 != 0 || p.Out1 || p.N0 != p.Nout || p.T > 9) return false;
-    if (p.bnb_y || p.pre_scale || p.cz || p.fold.on || p.plan_halo || p.plan_tiles) return false;
     if (p.ep_scale && ((p.ep_res && p.ep_ldres != p.ldo0) || p.stats || (p.accum & 1))) return false;
     if (p.bias && p.stats) return false;
     const ClassInfo& c = p.cls[0];

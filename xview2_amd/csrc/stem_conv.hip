@@ -302,7 +302,7 @@ static bool stem_enabled() {      // XV2_STEM7=0: the implicit-GEMM kernel (A/B 
 
 bool stem7x7_eligible(const IgemmParams& p, bool smallc) {
     if (!stem_enabled() || !smallc || p.ncls != 1 || p.Nout != 64 || p.N0 != 64 || p.T != 49 || p.s_in != 2) return false;
-    if (p.math == XV2_MATH_BF16 || p.accum || p.ep_res || (p.ep_scale && p.stats) || p.bnb_y || p.pre_scale || p.Out1 || p.A1 || p.ldA0 != 4) return false;
+    if (p.math == XV2_MATH_BF16 || p.accum || p.ep_res || (p.ep_scale && p.stats) || p.Out1 || p.A1 || p.ldA0 != 4) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 49 || c.tap0 != 0 || c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl) return false;
     if (c.OHl % S_PH != 0 || c.OWl % S_PW != 0 || c.OHl * 2 != p.IH || c.OWl * 2 != p.IW) return false;

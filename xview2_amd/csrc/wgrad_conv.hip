@@ -34,11 +34,6 @@ struct WgradParams {
     int tiles_n;  // column tiles per tap (Ctot / BN), or column tiles overall for SMALLC
     int fast;     // OW % 32 == 0 and operands < 2 GiB: scalar pixel decode + buffer loads
     unsigned bytesX0, bytesX1, bytesDY;
-    // all-taps F32X3 kernel only: X0 is the RAW output of the producing convolution and that layer's training-mode BatchNorm
-    // + activation is applied on load: x = act(X0 * pre_scale[c] + pre_shift[c]) inside the image, 0 in the padding
-    const float* pre_scale;
-    const float* pre_shift;
-    int pre_act;
     // F16X2 (xv2_common.h): the maxima of the X sources and of dY, all three known -> the NPL = 2 kernels (two scaled fp16 planes)
     const unsigned* amaxX0;
     const unsigned* amaxX1;
@@ -980,28 +975,13 @@ __global__ void __launch_bounds__(256, 3) wgrad_alltaps_x3_kernel(const WgradPar
     const bool x_ok = iw >= 0, x2 = tid < 16, x2_ok = x2 && iw2 < p.IW;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rd = zero, rx = zero, rx2 = zero;
-    // producer layer's BatchNorm + activation on the X operand (WgradParams::pre_*): this thread's four channels
-    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.pre_scale) {
-        psc = *reinterpret_cast<const float4*>(p.pre_scale + xch + c4 * 4);
-        psf = *reinterpret_cast<const float4*>(p.pre_shift + xch + c4 * 4);
-    }
-    auto pre = [&](float4 v) {
-        if (p.pre_scale) {      // same arithmetic as bn_act_fwd_kernel
-            v.x = apply_act(__fmaf_rn(v.x, psc.x, psf.x), p.pre_act);
-            v.y = apply_act(__fmaf_rn(v.y, psc.y, psf.y), p.pre_act);
-            v.z = apply_act(__fmaf_rn(v.z, psc.z, psf.z), p.pre_act);
-            v.w = apply_act(__fmaf_rn(v.w, psc.w, psf.w), p.pre_act);
-        }
-        return v;
-    };
     auto load_dy = [&](int r) { rd = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch); };
     auto load_x = [&](int ih) {
         rx = zero;
         rx2 = zero;
         if ((unsigned)ih < (unsigned)p.IH) {
-            if (x_ok) rx = pre(*reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch));
-            if (x2_ok) rx2 = pre(*reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx));
+            if (x_ok) rx = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch);
+            if (x2_ok) rx2 = *reinterpret_cast<const float4*>(xa0 + (size_t)ih * x_pitch + (size_t)32 * ldx);
         }
     };
     float sX = 1.f, sD = 1.f;      // F16X2 operand scales
@@ -1232,20 +1212,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
     const size_t x_pitch = (size_t)p.IW * ldx;
     const bool xok0 = iw >= 0, xok1 = true, x2 = tid < 32, xok2 = x2 && iw + 32 < p.IW;      // iw + 16 is always inside
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psf = zero;
-    if (p.pre_scale) {
-        psc = *reinterpret_cast<const float4*>(p.pre_scale + xch + c4 * 4);
-        psf = *reinterpret_cast<const float4*>(p.pre_shift + xch + c4 * 4);
-    }
-    auto pre = [&](float4 v) {
-        if (p.pre_scale) {
-            v.x = apply_act(__fmaf_rn(v.x, psc.x, psf.x), p.pre_act);
-            v.y = apply_act(__fmaf_rn(v.y, psc.y, psf.y), p.pre_act);
-            v.z = apply_act(__fmaf_rn(v.z, psc.z, psf.z), p.pre_act);
-            v.w = apply_act(__fmaf_rn(v.w, psc.w, psf.w), p.pre_act);
-        }
-        return v;
-    };
     float4 rd0 = zero, rd1 = zero, rx0 = zero, rx1 = zero, rx2 = zero;
     auto load_dy = [&](int r) {
         rd0 = *reinterpret_cast<const float4*>(dy0 + (size_t)r * dy_pitch);
@@ -1255,9 +1221,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
         rx0 = rx1 = rx2 = zero;
         if ((unsigned)ih < (unsigned)p.IH) {
             const float* xr = xa0 + (size_t)ih * x_pitch;
-            if (xok0) rx0 = pre(*reinterpret_cast<const float4*>(xr));
-            if (xok1) rx1 = pre(*reinterpret_cast<const float4*>(xr + (size_t)16 * ldx));
-            if (xok2) rx2 = pre(*reinterpret_cast<const float4*>(xr + (size_t)32 * ldx));
+            if (xok0) rx0 = *reinterpret_cast<const float4*>(xr);
+            if (xok1) rx1 = *reinterpret_cast<const float4*>(xr + (size_t)16 * ldx);
+            if (xok2) rx2 = *reinterpret_cast<const float4*>(xr + (size_t)32 * ldx);
         }
     };
     float sX = 1.f, sD = 1.f;      // F16X2 operand scales
@@ -1664,14 +1630,9 @@ static int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t s
     return XV2_OK;
 }
 
-struct WgradPre {
-    const float* scale;
-    const float* shift;
-    int act;
-};
 static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, const float* x1, int ldx1,
                       const float* dy, int lddy, float* dw_oihw, int cin_real, float* workspace,
-                      hipStream_t stream, const WgradPre* pre = nullptr, int* plan_pre = nullptr) {
+                      hipStream_t stream) {
     AmaxGuard amax_guard;
     xv2_conv_desc dcopy = *d_in;            // XV2_MATH_F32X3: the all-taps kernel has a split-bf16 variant; the other
     const bool x3 = dcopy.math == XV2_MATH_F32X3;      // weight-gradient kernels run the exact fp32 MFMA
@@ -1681,21 +1642,14 @@ static int wgrad_impl(const xv2_conv_desc* d_in, const float* x0, int ldx0, cons
     XV2_CHECK_ARG(d->Cout % 32 == 0, "backward_weight: Cout=%d must be a multiple of 32", d->Cout);
     const WgradPlan pl = make_plan(d, x3);
     const bool hs = d->math == XV2_MATH_BF16_STORE;
-    if (plan_pre) {          // dry run: is this the all-taps F32X3 plan (the only one with a pre-activation form)?
-        *plan_pre = (pl.alltaps && x3 && d_in->C1 == 0) ? 1 : 0;
-        return XV2_OK;
-    }
-    XV2_CHECK_ARG(!pre || (pl.alltaps && x3 && !x1 && pre->scale && pre->shift),
-                  "backward_weight_pre: not the all-taps F32X3 plan (query _pre_supported), or two sources");
     XV2_CHECK_ARG(pl.smallc || (d->C0 % 32 == 0 && d->C1 % 32 == 0 && d->C0 > 0),
                   "backward_weight: C0=%d C1=%d must be multiples of 32", d->C0, d->C1);
     WgradParams p;
     p.X0 = x0; p.X1 = x1; p.DY = dy; p.part = workspace;
-    p.pre_scale = pre ? pre->scale : nullptr; p.pre_shift = pre ? pre->shift : nullptr; p.pre_act = pre ? pre->act : 0;
     p.amaxX0 = amax_ctx().a0; p.amaxX1 = amax_ctx().a1; p.amaxDY = amax_ctx().dy;
     static const int f16x2_on = [] { const char* e = getenv("XV2_F16X2"); return (e ? atoi(e) : 7) & 4; }();
     // F16X2: all operand maxima known (xv2_amax_ctx) - two scaled fp16 planes, three MFMAs per product
-    const bool h2 = x3 && f16x2_on && !pre && p.amaxX0 && p.amaxDY && (!x1 || p.amaxX1);
+    const bool h2 = x3 && f16x2_on && p.amaxX0 && p.amaxDY && (!x1 || p.amaxX1);
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1; p.ldX0 = ldx0; p.ldX1 = ldx1; p.ldDY = lddy;
     p.Cout = d->Cout;
     p.IH = d->IH; p.IW = d->IW; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride;
