@@ -80,22 +80,6 @@ constexpr int igemm_main_floats() {
     return loop > epi ? loop : epi;
 }
 
-// 16-byte device-scope (write-through / L1-bypassing) accesses of the in-launch split-K sum
-__device__ __forceinline__ void sk_store(float* p, const float4& v) {
-    typedef unsigned long long u64;
-    const u64 lo = ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-    const u64 hi = ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
-    __hip_atomic_store(reinterpret_cast<u64*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 sk_load(const float* p) {
-    typedef unsigned long long u64;
-    const u64 lo = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 hi = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
-                       __uint_as_float((unsigned)(hi >> 32)));
-}
-
 // bf16-compute variant ("--precision 16"): operands stay fp32 in HBM, are rounded to bf16 (RNE) while being staged
 // into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate); everything outside the MFMA is unchanged.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -229,7 +213,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
         h_ow0 = tw * PW;
         if (tid < BM) {
             const int oh = h_oh0 + tid / PW, ow = h_ow0 + tid % PW;
-            rowoff[tid] = (p.ksplit > 1 && !p.sk_tickets) ? (h_n * ci.OHl + oh) * ci.OWl + ow      // slab row = GEMM row
+            rowoff[tid] = p.ksplit > 1 ? (h_n * ci.OHl + oh) * ci.OWl + ow      // slab row = GEMM row
                                                           : h_n * p.osN + oh * p.osH + ow * p.osW + ci.os0;
         }
     } else
@@ -237,7 +221,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
         const int m = m0 + tid;
         int off = -1;
         if (m < ci.M) {
-            if (p.ksplit > 1 && !p.sk_tickets) {
+            if (p.ksplit > 1) {
                 off = m;   // slab rows are plain GEMM rows (summed by splitk_reduce_kernel)
             } else {
                 const int n = m / ohw;
@@ -1049,28 +1033,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
     constexpr int CLD = BN + 4;
     constexpr int HROWS = BM / NH;          // rows staged per pass
     float* Cs = smem;
-    // Split-K summed IN the launch (p.sk_tickets): the K-split blocks of an output tile draw an arrival ticket; the LAST
-    // to arrive is the tile's reducer - it keeps its partial tile in LDS, waits until the others (all of them already in
-    // their epilogues) have published their slabs write-through, adds the slabs in slab order (its own share taken from
-    // LDS: the same bits it would have written) and runs the ordinary epilogue.  One slab write and one slab read per
-    // tile saved against the separate slab-sum kernel, and that launch with them; bit-reproducible (fixed slab order).
-    // (not for bf16 storage: the reducer needs its slab loads in flight - 28 registers - and that kernel lives on three
-    // blocks per CU at 152 of 168 registers; its slabs keep going to splitk_reduce_kernel)
-    const bool skf = !HS && p.ksplit > 1 && p.sk_tickets != nullptr;
-    bool sk_reducer = false;
-    unsigned* skt = nullptr;
-    if (skf) {
-        skt = p.sk_tickets + 2 * ((size_t)tm * ntn + tn);
-        int* flag = reinterpret_cast<int*>(red);
-        if (tid == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(skt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = prev == (unsigned)(gridDim.z - 1);
-        }
-        __syncthreads();
-        sk_reducer = *flag != 0;
-    }
     float omax = 0.f;                                     // F16X2: max |value stored to Out0| (IgemmParams::amax_out)
-    float4 ss1 = make_float4(0, 0, 0, 0), ss2 = ss1;      // reducer: statistics of the summed tile (this thread's 4 channels)
     const bool do_stats = p.stats && p.ksplit == 1;
     if (do_stats) {
 #pragma unroll
@@ -1123,24 +1086,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
         st[0] = s1;
         st[1] = s2;
     }
-    if (skf && sk_reducer && hh == 0) {
-        // every other K-split block of this tile has arrived, i.e. is past its main loop: wait for their slabs
-        if (tid == 0) {
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-                if (__hip_atomic_load(skt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            __hip_atomic_store(skt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(skt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the slab workspace is re-used launch after launch: drop whatever this CU / XCD still caches of it
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
     {
         constexpr int F4R = BN / 4;
-        float* slab = (p.ksplit > 1 && !(skf && sk_reducer)) ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
-        const size_t slab_elems = (size_t)ci.M * p.Nout;
+        float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
 #pragma unroll 4
         for (int e = tid; e < HROWS * F4R; e += 256) {
             const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
@@ -1148,37 +1096,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             if (off < 0) continue;
             float4 v = *reinterpret_cast<const float4*>(Cs + (row - hh * HROWS) * CLD + c);
             const int col = n0 + c;
-            if (slab) {
-                float* dst = slab + (size_t)(skf ? m0 + row : off) * p.Nout + col;
-                if (skf) {        // write-through (sc1): the reducer on another XCD reads it in this launch
-                    sk_store(dst, v);
-                } else {
-                    *reinterpret_cast<float4*>(dst) = v;
-                }
+            if (slab) {      // split-K: this block's partial tile goes to its slab (summed by splitk_reduce_kernel)
+                *reinterpret_cast<float4*>(slab + (size_t)off * p.Nout + col) = v;
                 continue;
-            }
-            if (skf) {            // reducer: slabs in slab order, own share from LDS
-                const float* src = p.part + (size_t)(m0 + row) * p.Nout + col;
-                float4 t[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    t[z] = make_float4(0, 0, 0, 0);
-                    if (z < (int)gridDim.z && z != (int)blockIdx.z) t[z] = sk_load(src + (size_t)z * slab_elems);
-                }
-                float4 a = make_float4(0, 0, 0, 0);
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    if (z < (int)gridDim.z) {
-                        const float4 u = z == (int)blockIdx.z ? v : t[z];
-                        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-                    }
-                }
-                v = a;
-                if (p.stats) {    // statistics on the values as they will be stored
-                    const float4 q = make_float4(Elem<OT>::round(v.x), Elem<OT>::round(v.y), Elem<OT>::round(v.z), Elem<OT>::round(v.w));
-                    ss1.x += q.x; ss1.y += q.y; ss1.z += q.z; ss1.w += q.w;
-                    ss2.x += q.x * q.x; ss2.y += q.y * q.y; ss2.z += q.z * q.z; ss2.w += q.w * q.w;
-                }
             }
             if (p.bias) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
@@ -1208,36 +1128,8 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
     }
     if (NH > 1 && hh + 1 < NH) __syncthreads();      // the staging tile is rewritten by the next pass
   }
-    // (blocks that stored FINAL values: unsplit launches and the in-launch reducers; slab writers leave it to the slab sum)
-    if (!HS && p.amax_out && (p.ksplit == 1 || (skf && sk_reducer))) amax_record(p.amax_out, omax, red, blockIdx.x + 13 * blockIdx.y);
-    if (skf && !sk_reducer) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its slab stores are at the coherence point
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(skt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (skf && p.stats) {
-        constexpr int F4R = BN / 4;
-        __syncthreads();                           // every thread is done reading Cs: reuse it for the fold
-        float* sb = smem + tid * 8;
-        sb[0] = ss1.x; sb[1] = ss1.y; sb[2] = ss1.z; sb[3] = ss1.w;
-        sb[4] = ss2.x; sb[5] = ss2.y; sb[6] = ss2.z; sb[7] = ss2.w;
-        __syncthreads();
-        if (tid < BN) {
-            constexpr int RL = 256 / F4R;          // row lanes holding the same channel group
-            const int grp = tid >> 2, comp = tid & 3;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < RL; ++q) {
-                s1 += smem[(grp + F4R * q) * 8 + comp];
-                s2 += smem[(grp + F4R * q) * 8 + 4 + comp];
-            }
-            float* st = p.stats + ((size_t)tm * p.Nout + n0 + tid) * 2;
-            st[0] = s1;
-            st[1] = s2;
-        }
-        return;
-    }
+    // (blocks that stored FINAL values: unsplit launches; slab writers leave it to the slab sum)
+    if (!HS && p.amax_out && p.ksplit == 1) amax_record(p.amax_out, omax, red, blockIdx.x + 13 * blockIdx.y);
 }
 
 // Sum the split-K slabs, add the bias, scatter to the NHWC output(s) and emit the BatchNorm partial sums
@@ -1535,28 +1427,18 @@ static void pick_tile(int64_t M, int Nout, bool smallc, int nkt, int math, int& 
     }
 }
 
-// XV2_SPLITK_FOLD=1 (A/B runs): the split-K slabs of the fp32 kernels are summed INSIDE the launch by the last K-split
-// block of every output tile (epilogue of igemm_kernel) instead of by splitk_reduce_kernel.  Built, bit-reproducible and
-// measured (profiles/r03_fold_ab.md): against the 64-row slab-sum kernel of round 2 it won 0.4 ms per cfg2 step, against
-// this round's 32-row / all-slabs-in-flight slab-sum kernel it LOSES (isolated l3.conv1 0.035 -> 0.061 ms, l4.conv2 0.063 ->
-// 0.090 ms; cfg2 step 28.57 -> 28.74 ms): the sums run at the tail of each tile's last block, when only 1/ksplit of the
-// blocks is still resident, with a device-scope round trip per dependent step - the separate kernel uses the whole chip.
-// Default off.
-static bool splitk_fold_enabled() {
-    static const int v = [] { const char* e = getenv("XV2_SPLITK_FOLD"); return e ? atoi(e) : 0; }();
-    return v != 0;
-}
-
+// (round 3 could sum the split-K slabs inside the GEMM launch - XV2_SPLITK_FOLD: measured slower than the 32-row slab-sum kernel
+//  and removed in round 6 with the other in-launch hand-offs)
 int64_t igemm_stats_tiles(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
-    return (ks > 1 && !(splitk_fold_enabled() && math != XV2_MATH_BF16_STORE)) ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
+    return ks > 1 ? cdiv(M, SPLITK_ROWS) : cdiv(M, bm);
 }
 
 int igemm_stats_tile_rows(int64_t M, int Nout, bool smallc, int nkt, int math) {
     int bm, bn, ks;
     pick_tile(M, Nout, smallc, nkt, math, bm, bn, ks);
-    return (ks > 1 && !(splitk_fold_enabled() && math != XV2_MATH_BF16_STORE)) ? SPLITK_ROWS : bm;
+    return ks > 1 ? SPLITK_ROWS : bm;
 }
 
 size_t igemm_splitk_bytes(int64_t M, int Nout, bool smallc, int nkt, int math) {
@@ -1792,7 +1674,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
         // already answered with sg_planned_rows() for this shape, so the partials have that geometry whichever kernel runs -
         // if the operands are not ready for it (no recorded maxima, no fp16 planes) the tiled kernel takes 64-row tiles, unsplit.
         const int planned = (p.stats && !p.A1 && p.C1 == 0) ? sg_planned_rows(maxM, p.Nout, p.Ctot, p.T, p.math) : 0;
-        const int R = planned ? planned : (ks > 1 && !splitk_fold_enabled()) ? SPLITK_ROWS : bm;
+        const int R = planned ? planned : ks > 1 ? SPLITK_ROWS : bm;
         IgemmParams q = p;
         if ((p.math == XV2_MATH_BF16_STORE || f16x2_ready(q)) && sg_conv_eligible(q, smallc, R)) {
             SgGroupCtx& gc = sg_group_ctx();
@@ -1846,7 +1728,7 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
     } else {
         p.ksplit = (int)cdiv(p.cls[0].nkt, p.kt_per_split);
         const bool halo16 = halo_eligible(p, smallc, XV2_MATH_BF16_STORE);
-        bool halo = (!splitk_fold_enabled() && halo_eligible(p, smallc)) || halo16;
+        bool halo = halo_eligible(p, smallc) || halo16;
         if (halo) {      // K ranges of whole 32-channel chunks (all nine taps of a halo slice stay in one block)
             const int nch = p.cls[0].nkt / 9, cps = (int)cdiv(nch, p.ksplit), nks = (int)cdiv(nch, cps);
             if (nks > 1) {
@@ -1861,19 +1743,6 @@ int igemm_launch(IgemmParams& p, bool smallc, float* splitk_ws, hipStream_t stre
             } else {
                 halo = false;
             }
-        }
-        if (splitk_fold_enabled() && p.math != XV2_MATH_BF16_STORE && p.ksplit <= 8 &&
-            2 * cdiv(maxM, 128) * (p.Nout / 128) <= (1 << 16)) {      // (two tickets per tile from a pool of 65536)
-            // the slabs are summed inside the launch by the last K-split block of every output tile (epilogue of
-            // igemm_kernel): no slab-sum launch, statistics per 128-row tile like the unsplit form
-            const int64_t ntiles = cdiv(maxM, 128) * (p.Nout / 128);
-            p.sk_tickets = take_tickets((int)(2 * ntiles));
-            XV2_CHECK_ARG(p.sk_tickets, "igemm: ticket pool allocation failed");
-            return p.math == XV2_MATH_BF16_STORE ? launch_one<128, 128, 2, 2, false, true, true>(p, stream)
-                   : f16x2_ready_pertap(p)       ? launch_one<128, 128, 2, 2, false, true, false, true, false, false, 2>(p, stream)
-                   : p.math == XV2_MATH_F32X3    ? launch_one<128, 128, 2, 2, false, true, false, true>(p, stream)
-                   : p.math                      ? launch_one<128, 128, 2, 2, false, true>(p, stream)
-                                                 : launch_one<128, 128, 2, 2, false>(p, stream);
         }
         // split-K: the slab-sum kernel takes the statistics (32-row tiles)
         int rc = (halo && halo16)              ? launch_one<128, 128, 2, 2, false, true, true, false, true>(p, stream)
@@ -1978,7 +1847,6 @@ static int fill_common(IgemmParams& p, const xv2_conv_desc* d) {
     p.bias = nullptr;
     p.stats = nullptr;
     p.part = nullptr;
-    p.sk_tickets = nullptr;
     p.Bx3 = nullptr;
     p.bytesBx3 = 0;
     p.npl = 3;

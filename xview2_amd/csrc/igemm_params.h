@@ -28,8 +28,6 @@ struct IgemmParams {
     float* Out1;
     float* stats;
     float* part;       // split-K slabs [ksplit][M][Nout] (ksplit > 1 only)
-    unsigned* sk_tickets;   // != NULL: the slabs are summed in-launch by the last K-split block of each output tile
-                            // (two zero-initialised counters per tile: arrivals, published slabs)
     unsigned bytesA0, bytesA1, bytesB;  // buffer extents for the hardware bounds check (< 2 GiB each)
     const float* Bx3;                   // halo form: B pre-split into three bf16 planes (xv2_presplit_weights), or nullptr
     unsigned bytesBx3;

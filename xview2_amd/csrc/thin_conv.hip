@@ -373,7 +373,7 @@ static bool thin_shape(int K, int N, int math) {
 bool thin1x1_eligible(const IgemmParams& p, bool smallc) {
     if (!thin_enabled() || smallc || (p.math != XV2_MATH_F32X3 && p.math != XV2_MATH_BF16_STORE)) return false;
     if (p.ncls != 1 || p.T != 1 || p.s_in != 1 || p.C1 != 0 || p.A1 || p.Out1 || p.N0 != p.Nout) return false;
-    if (p.bias || p.ep_scale || p.ksplit != 1 || p.sk_tickets) return false;
+    if (p.bias || p.ep_scale || p.ksplit != 1) return false;
     const ClassInfo& c = p.cls[0];
     if (c.ntaps != 1 || c.tap0 != 0 || p.taps[0].dh != 0 || p.taps[0].dw != 0 || p.taps[0].slot != 0) return false;
     if (c.os0 != 0 || p.osW != 1 || p.osH != c.OWl || p.osN != c.OHl * c.OWl || c.OHl != p.IH || c.OWl != p.IW) return false;
