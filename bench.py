@@ -499,13 +499,18 @@ def encoder_forward_probe(encoder, precision, size, batch, dev, iters=10):
             for _ in range(3):
                 fwd()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                fwd()
-            e1.record()
-            torch.cuda.synchronize()
-            wall = e0.elapsed_time(e1) / iters
+            # three timed repetitions of `iters` passes, the fastest counts: the pass is 245 dependent launches of 5 - 130 us
+            # and a host hiccup (the enqueueing thread descheduled for a few ms) shows up as GPU idle time inside the events
+            walls = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    fwd()
+                e1.record()
+                torch.cuda.synchronize()
+                walls.append(e0.elapsed_time(e1) / iters)
+            wall = min(walls)
             _capi.query("xv2_prof_enable", 1)
             for _ in range(iters):
                 fwd()
@@ -946,17 +951,16 @@ def main():
                 rows = timed
         # second leg: the same step with the weight-gradient kernels serialised on the compute stream (no
         # co-scheduling), i.e. every kernel alone on the chip - the per-kernel roofline without contention
-        _xops.ASYNC_WGRAD = False
-        isteps = min(opt.steps, 4)
-        step()
-        torch.cuda.synchronize()
-        _capi.query("xv2_prof_enable", 1)
-        for _ in range(isteps):
+        with _xops.wgrad_on_compute_stream():
+            isteps = min(opt.steps, 4)
             step()
-        torch.cuda.synchronize()
-        iso = collect_prof(_capi)
-        _capi.query("xv2_prof_enable", 0)
-        _xops.ASYNC_WGRAD = True
+            torch.cuda.synchronize()
+            _capi.query("xv2_prof_enable", 1)
+            for _ in range(isteps):
+                step()
+            torch.cuda.synchronize()
+            iso = collect_prof(_capi)
+            _capi.query("xv2_prof_enable", 0)
         if not rows:
             rows, psteps = iso, isteps
     if world > 1:

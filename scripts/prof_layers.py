@@ -16,7 +16,7 @@ def step():
     opt.zero_grad(); l = lf(m(x), y); l.backward(); opt.step()
 if os.environ.get("XV2_PROF_ISOLATED") == "1":      # weight gradients on the compute stream: every kernel alone on the chip
     from xview2_amd import ops as _ops
-    _ops.ASYNC_WGRAD = False
+    _ops.wgrad_on_compute_stream().__enter__()
 for _ in range(2): step()
 torch.cuda.synchronize()
 _capi.query("xv2_prof_enable", 1)

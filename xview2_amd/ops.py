@@ -798,6 +798,22 @@ WGRAD_SIDE = os.environ.get("XV2_WGRAD_SIDE", "all")
 _wgrad_stream = None
 
 
+class wgrad_on_compute_stream:
+    """`with ops.wgrad_on_compute_stream():` - weight gradients are launched on the compute stream (every kernel alone on the
+    chip: the isolated leg of bench.py's roofline, scripts/prof_layers.py); the side stream is joined on both sides"""
+
+    def __enter__(self):
+        global ASYNC_WGRAD
+        join_wgrad_stream()
+        self.old, ASYNC_WGRAD = ASYNC_WGRAD, False
+        return self
+
+    def __exit__(self, *exc):
+        global ASYNC_WGRAD
+        ASYNC_WGRAD = self.old
+        return False
+
+
 def _priority_stream(prio):
     """experiment hook (XV2_WGRAD_PRIORITY): a HIP stream at an explicit queue priority (1 = lowest, -1 = highest).
     Measured: no gain on one GPU, and at the LOWEST priority the step with RCCL collectives in it (SyncBatchNorm,
