@@ -20,6 +20,12 @@
 // Epilogue: optional bias, scattered NHWC store through a per-row pixel-offset table, and
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
 #include "igemm_params.h"
+#ifndef XV2_HU
+#define XV2_HU 1       // 0: the run-time (tap, slice, ring) loop of rounds 3 - 5 for the F16X2 halo form (A/B builds)
+#endif
+#ifndef XV2_HBAR
+#define XV2_HBAR 1     // old loop (XV2_HU=0 / three planes): 1 bare barrier, 2 relaxed wait at tap 0, 4 scheduling pipeline (no effect: branches)
+#endif
 #include "amax_ctx.h"
 #include <stdlib.h>
 #include <string.h>
@@ -39,7 +45,7 @@
 #endif
 
 #ifndef XV2_HABL
-#define XV2_HABL 0      // halo-form ablations (debug): 1 no halo stores, 2 unshifted fragment rows
+#define XV2_HABL 0      // halo-form ablations (debug): 1 no halo stores, 2 unshifted fragment rows, 16 no MFMA, 32 no DMA inside the K loop (F16X2 form)
 #endif
 // Halo form, 64-column tiles, two fp16 planes (F16X2): three blocks per CU.  The launches of this instantiation (64-channel 3x3
 // layers: resnet50 layer1, ResNeSt's radix convolutions of layer1, the 512^2 decoder level, the ResNeSt stem) are latency-bound -
@@ -57,6 +63,7 @@
 namespace xv2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int N> struct IC { static constexpr int value = N; };
 
 constexpr int LDS_LD = BK + 4;
 constexpr int LDS_LD_H_ = BK + 8;
@@ -592,6 +599,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 for (int j = 0; j < NR; ++j) fb[j][q] = *reinterpret_cast<const bf16x8*>(b + q * PLB + j * 32 * LDK);
         };
         auto mfma_stage = [&](const bf16x8 (&fa)[MR][NPL], const bf16x8 (&fb)[NR][NPL]) {
+#if XV2_HABL & 16
+            return;
+#endif
             if constexpr (NPL == 2) {        // fp16 planes: m*h, h*m, h*h
                 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
@@ -693,11 +703,32 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 const bool pf = st + 3 < s_end;
                 if (pf) dma(st + 3, bc);
                 mfma_stage(fa, fb);
+#if XV2_HBAR & 4
+                {   // the next stage's fragment reads and the DMA issue go BETWEEN this stage's MFMAs (operands already in registers)
+                    constexpr int NMF = 3 * MR * NR, NRD = NPL * (MR + NR);
+#pragma unroll
+                    for (int g = 0; g < NMF; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+                        if (g >= NMF / 2 && g < NMF / 2 + CPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+#endif
                 const bool swap = last && more;
                 if (swap) {
                     hsplit();
                     hstore();
                 }
+#if XV2_HBAR & 2
+                // (the halo loads of the next slice were issued behind the previous barrier, i.e. between the DMA of st+2 and
+                //  of st+3: at the first tap they may stay in flight together with st+3)
+                if (pf && tp == 0 && cs + 1 < cs_end && st > s_begin) {
+                    if constexpr (CPW == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                    else if constexpr (CPW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else
+#endif
                 if (pf) {
                     if constexpr (CPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else if constexpr (CPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -705,12 +736,193 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+#if XV2_HBAR & 1
+                // a bare barrier: __syncthreads() carries a workgroup fence, and with LDS-DMA in flight the fence is
+                // `s_waitcnt vmcnt(0)` - the DMA of st+3 issued in THIS iteration had to land before its barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#else
                 __syncthreads();
+#endif
                 if (swap) {
                     read_a(0, na);
                     if (cs + 2 < cs_end) hload(cs + 2);
                 }
             };
+#if XV2_HU
+            if constexpr (NPL == 2) {
+            // ---- F16X2: the K loop as straight-line code.  Two 16-channel slices = 18 stages (slice half, spatial tap u) per trip:
+            // ring slot, fragment set, fragment offsets and LDS destinations are instruction immediates; per stage a wave issues
+            // its MFMAs, the fragment reads of the next stage between them, and two to four DMA instructions whose only
+            // run-time input is one scalar offset.  (The loop it replaces carried tap / slice / ring state at run time: ~170
+            // instructions per stage around 12 MFMAs, the matrix pipe waiting for both waves of a SIMD to get through them.)
+            //   * spatial order: stage tap u multiplies the halo shifted by (u / 3 - 1, u % 3 - 1) with weight tap u (forward)
+            //     or 8 - u (backward-data: the flipped kernel) - the fragment offsets do not depend on the direction;
+            //   * BOTH operands arrive by DMA and the two kinds have their own waves, because vmcnt counts in order: waves 0, 1
+            //     stream the weight stages (confirmed two stages after issue), waves 2, 3 fetch the fp32 halo of the NEXT slice
+            //     into a staging area at tap 0 and confirm it at tap 7 - seven stages of cover instead of the one a shared
+            //     queue leaves; at tap 8 every thread takes its four 16-byte pieces from staging, splits, stores the planes;
+            //   * every DMA is unconditional: past the end of the K range it lands in a slot nobody reads (or past the buffer:
+            //     the hardware writes zeros); bare s_barrier + explicit counts (__syncthreads() is vmcnt(0) with LDS-DMA in flight).
+            constexpr int NCHW = STBX * 2 / 1024 / 2;                // 1 KB weight pieces per weight wave and stage: 4 / 2
+            constexpr int HCH = 7;                                   // 1 KB halo pieces per halo wave and slice (13 of 14 carry rows)
+            constexpr int STG_B = (NPL * PLA + 3 * STBX) * 2;        // byte offset of the staging area
+            static_assert((size_t)STG_B + 2 * HCH * 1024 <= (size_t)MAIN_FLOATS * 4, "planes + weight ring + halo staging fit");
+            static_assert(NCHW == 4 || NCHW == 2, "weight pieces per wave");
+            char* lds = reinterpret_cast<char*>(smem);
+            const int nsl = p.Ctot / 16;
+            __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Bx3), 0, p.bytesBx3, 0x00020000);
+            const bool wwave = __builtin_amdgcn_readfirstlane(wave) < 2;
+            // weight waves: unit / first piece of this wave inside a stage image (BN = 128: one 64-row unit each; 64: half a unit)
+            const int w_unit = BN == 128 ? (wave & 1) : 0, w_cq0 = BN == 128 ? 0 : (wave & 1) * 2;
+            const int w_voff = ((tn * (BN / 64) + w_unit) * p.T * nsl) * (2048 * NPL) + w_cq0 * 1024 + lane * 16;
+            const int w_lds = NPL * PLA * 2 + w_unit * 4096 + w_cq0 * 1024;      // + slot * STBX * 2
+            // weight tap of spatial tap u, as a byte offset: u * tstep + t0 (forward: u, backward-data: 8 - u)
+            const int tstep = sgn * nsl * (2048 * NPL), t0 = sgn > 0 ? 0 : 8 * nsl * (2048 * NPL);
+            auto dma_w = [&](auto SLOT, auto U, int cs) {
+                constexpr int slot = decltype(SLOT)::value, u = decltype(U)::value;
+                const int so = __builtin_amdgcn_readfirstlane(t0 + u * tstep + cs * (2048 * NPL));
+                auto dst = (__attribute__((address_space(3))) void*)(lds + w_lds + slot * STBX * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 1024, 0);
+                if constexpr (NCHW == 4) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 2048, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 3072, 0);
+                }
+            };
+            // halo waves: pixel of this lane's 16-byte piece e = (hw * 7 + i) * 64 + lane  (row slot e >> 2, channel quad e & 3)
+            int hvp[HCH];
+            {
+                const int hw = wave & 1;
+#pragma unroll
+                for (int i = 0; i < HCH; ++i) {
+                    const int e = (hw * HCH + i) * 64 + lane, hq = e >> 2;
+                    const int hp = (hq & ~7) | ((hq & 3) << 1) | ((hq >> 2) & 1);
+                    const int hr = hp / HWD, hc = hp - hr * HWD;
+                    const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
+                    const bool ok = hq < NHP && hr < PH + 2 && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+                    hvp[i] = ok ? (h_n * p.IH + ih) * p.IW + iw : -1;
+                }
+            }
+            auto dma_h = [&](int cs) {
+                const int cc = (cs >> 1) * BK + (cs & 1) * 16;
+                const bool first = cc < p.C0;
+                const int ld = first ? p.ldA0 : p.ldA1;
+                const int so = __builtin_amdgcn_readfirstlane((first ? cc : cc - p.C0) * 4);
+                const int hw = wave & 1;
+#pragma unroll
+                for (int i = 0; i < HCH; ++i) {
+                    const int vo = hvp[i] >= 0 ? ((hvp[i] * ld + (lane & 3) * 4) << 2) : (int)0x80000000;
+                    auto dst = (__attribute__((address_space(3))) void*)(lds + STG_B + (hw * HCH + i) * 1024);
+                    if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, dst, 16, vo, so, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, dst, 16, vo, so, 0, 0);
+                }
+            };
+            // staging -> planes: this thread's pieces e = tid + 256 j (the mapping of hpix / hrow above)
+            unsigned stg_a[HL];
+#pragma unroll
+            for (int j = 0; j < HL; ++j) {
+                const int e = tid + j * 256;
+                stg_a[j] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + STG_B) + (e < NHP * 4 ? e : 0) * 16;
+            }
+            auto stage_to_planes = [&]() {
+#pragma unroll
+                for (int j = 0; j < HL; j += 2) {
+                    i32x4 r0_, r1_;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0_), "=&v"(r1_) : "v"(stg_a[j]), "v"(stg_a[j + 1]) : "memory");
+                    hraw[j] = __builtin_bit_cast(float4, r0_);
+                    hraw[j + 1] = __builtin_bit_cast(float4, r1_);
+                }
+                hsplit();
+                hstore();
+            };
+            // fragment addresses: A = halo row of (pixel, tap (-1, -1)) of this lane, B = its row of a weight stage image
+            const __bf16* a_ptr[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i) a_ptr[i] = sa + (abase[i] - HWD - 1) * LDK + 8 * h;
+            const __bf16* b_ptr[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int row = wn * WTN + j * 32 + l31, unit = row >> 6, r = row & 63;
+                b_ptr[j] = sbw + unit * (1024 * NPL) + r * 16 + ((h ^ ((r >> 2) & 1)) * 8);
+            }
+            bf16x8 fa[2][MR][NPL], fb[2][NR][NPL];
+            auto rd_a = [&](auto U, bf16x8 (&f)[MR][NPL]) {
+                constexpr int u = decltype(U)::value, off = ((u / 3) * HWD + (u % 3)) * LDK;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q)
+#pragma unroll
+                    for (int i = 0; i < MR; ++i) f[i][q] = *reinterpret_cast<const bf16x8*>(a_ptr[i] + q * PLA + off);
+            };
+            auto rd_b = [&](auto SLOT, bf16x8 (&f)[NR][NPL]) {
+                constexpr int slot = decltype(SLOT)::value;
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) f[j][q] = *reinterpret_cast<const bf16x8*>(b_ptr[j] + slot * STBX + q * 1024);
+            };
+            // stage J of a trip (slices cs, cs + 1): see above
+            auto stage = [&](auto JJ, int cs) {
+                constexpr int J = decltype(JJ)::value, u = J % 9, shf = J / 9, slot = J % 3, par = J & 1;
+                constexpr int J3 = J + 3, u3 = J3 % 9, sh3 = J3 / 9;               // the stage whose weights are issued here
+#if !(XV2_HABL & 32)
+                if (wwave) {
+                    dma_w(IC<slot>{}, IC<u3>{}, cs + sh3);
+                } else if (u == 0) {
+                    dma_h(cs + shf + 1);
+                }
+#endif
+                rd_b(IC<(J + 1) % 3>{}, fb[par ^ 1]);
+                if constexpr (u != 8) rd_a(IC<(u + 1) % 9>{}, fa[par ^ 1]);
+                mfma_stage(fa[par], fb[par]);
+                {
+                    constexpr int NMF = 3 * MR * NR, NRD = NPL * NR + (u != 8 ? NPL * MR : 0);
+#pragma unroll
+                    for (int g = 0; g < NMF; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if constexpr (u == 8) stage_to_planes();
+                if (wwave) {
+                    if constexpr (NCHW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (u == 7) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if constexpr (u == 8) rd_a(IC<0>{}, fa[par ^ 1]);
+            };
+            // prologue: halo of the first slice (staging -> planes), weight stages 0, 1, 2
+            if (wwave) {
+                dma_w(IC<0>{}, IC<0>{}, cs_begin);
+                dma_w(IC<1>{}, IC<1>{}, cs_begin);
+                dma_w(IC<2>{}, IC<2>{}, cs_begin);
+                if constexpr (NCHW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                dma_h(cs_begin);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            stage_to_planes();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            rd_a(IC<0>{}, fa[0]);
+            rd_b(IC<0>{}, fb[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // (every wave holds its first fragments before slot 0 is re-filled: r05_race_halo_prologue.md)
+            for (int cs = cs_begin; cs < cs_end; cs += 2) {
+                stage(IC<0>{}, cs); stage(IC<1>{}, cs); stage(IC<2>{}, cs); stage(IC<3>{}, cs); stage(IC<4>{}, cs); stage(IC<5>{}, cs);
+                stage(IC<6>{}, cs); stage(IC<7>{}, cs); stage(IC<8>{}, cs); stage(IC<9>{}, cs); stage(IC<10>{}, cs); stage(IC<11>{}, cs);
+                stage(IC<12>{}, cs); stage(IC<13>{}, cs); stage(IC<14>{}, cs); stage(IC<15>{}, cs); stage(IC<16>{}, cs); stage(IC<17>{}, cs);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA issued past the end: before the epilogue re-uses LDS)
+            __syncthreads();
+            } else {
+#endif
             hload(cs_begin);
             dma(s_begin, 0);
             dma(s_begin + 1, 1);
@@ -743,6 +955,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 }
                 bc = bc == 2 ? 0 : bc + 1;
             }
+#if XV2_HU
+            }
+#endif
         } else {
         hload(cs_begin);
         bload(s_begin, rbb);
@@ -1014,8 +1229,17 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
 
     }      // !X3
 #if XV2_ABL & 8
-    if (acc[0][0][0] == 123.456f) p.Out0[0] = 1.f;
-    return;
+    {      // (every accumulator stays live: a test of acc[0][0][0] alone let the compiler drop three quarters of the MFMAs)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) p.Out0[0] = t;
+        return;
+    }
 #endif
     if constexpr (NPL == 2) {      // F16X2: undo the operand scales (powers of two: exact)
         const float ia = amax_inv(amax_exponent(p.amaxA0, p.amaxA1)), ib = amax_inv(amax_exponent(p.amaxB));
