@@ -10,6 +10,7 @@ SHAPES = [
     ("dec1.c1  1536->512 @64", 2, 64, 64, 512, 1024, 512, 3, 1, 1),
     ("dec2.c1   768->256 @128", 2, 128, 128, 256, 512, 256, 3, 1, 1),
     ("dec3.c1   384->128 @256", 2, 256, 256, 128, 256, 128, 3, 1, 1),
+    ("dec3.c2   128->128 @256", 2, 256, 256, 128, 0, 128, 3, 1, 1),
     ("dec4.c1   128->64  @512", 2, 512, 512, 64, 64, 64, 3, 1, 1),
     ("dec5.c1    32->32  @1024", 2, 1024, 1024, 32, 0, 32, 3, 1, 1),
     ("l3.conv2  256->256 @64", 2, 64, 64, 256, 0, 256, 3, 1, 1),

@@ -863,7 +863,7 @@ def test_presplit_weight_planes_are_the_exact_three_way_split():
     for packed, rows, ch in ((ohwi, Cout, Cin), (ihwo, Cin, Cout)):
         planes = e.x3[packed.data_ptr()].view(rows // 64, 9, ch // 16, 3, 64, 2, 8).float()
         r = torch.arange(64, device=planes.device)
-        swap = ((r >> 2) & 1).bool()
+        swap = ((r >> 3) & 1).bool()
         planes = torch.where(swap.view(1, 1, 1, 1, 64, 1, 1), planes.flip(5), planes)       # undo the half swap
         total = planes[:, :, :, 0] + planes[:, :, :, 1] + planes[:, :, :, 2]                   # [unit][tap][slice][64][2][8]
         back = total.reshape(rows // 64, 9, ch // 16, 64, 16).permute(0, 3, 1, 2, 4).reshape(rows, 9, ch)
@@ -895,7 +895,7 @@ def test_f16x2_weight_planes_hold_the_scaled_weights_to_22_bits():
     for packed, rows, ch in ((ohwi, Cout, Cin), (ihwo, Cin, Cout)):
         planes = e.x2[packed.data_ptr()][0].view(rows // 64, 9, ch // 16, 2, 64, 2, 8).float()
         r = torch.arange(64, device=planes.device)
-        swap = ((r >> 2) & 1).bool()
+        swap = ((r >> 3) & 1).bool()
         planes = torch.where(swap.view(1, 1, 1, 1, 64, 1, 1), planes.flip(5), planes)
         total = (planes[:, :, :, 0].double() + planes[:, :, :, 1].double()) / s
         back = total.reshape(rows // 64, 9, ch // 16, 64, 16).permute(0, 3, 1, 2, 4).reshape(rows, 9, ch)

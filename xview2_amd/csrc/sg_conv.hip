@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(WM * G * 64, 2) sg_conv_kernel(const SgParams 
         }
     };
     f16x8 bfrag[2][NB][2];      // [double buffer][column block][fp32 tensors: plane h / m; bf16 storage: MFMA step 0 / 1] (bit patterns)
-    const unsigned boff = HS ? (unsigned)(l31 * 64) : (unsigned)(l31 * 32 + ((h ^ ((l31 >> 2) & 1)) * 16));
+    const unsigned boff = HS ? (unsigned)(l31 * 64) : (unsigned)(l31 * 32 + ((h ^ ((l31 >> 3) & 1)) * 16));
     auto read_b = [&](int slot, f16x8 (&fb)[NB][2]) {
         const char* base = smem + slot * STAGE + g * GSL + boff;
 #pragma unroll

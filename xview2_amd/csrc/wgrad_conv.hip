@@ -19,7 +19,7 @@
 #define XV2_WABL 0      // timing ablations of wgrad_alltaps64_x3_kernel (results are garbage): 1 no MFMA, 2 no split + plane stores, 4 no global loads, 8 no fragment reads
 #endif
 #ifndef XV2_WPF
-#define XV2_WPF 1      // all-taps 64 x 64 F16X2 kernel: 1 fragment reads one product ahead, 2 + producer between the MFMAs (no gain), 0 neither
+#define XV2_WPF 1      // all-taps 64 x 64 F16X2 kernel: fragment reads one product ahead of the MFMAs (0: read, wait, multiply per product)
 #endif
 namespace xv2 {
 
@@ -1279,87 +1279,17 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
     store_x(r0 + 1);
     load_dy(r0);
     store_dy(0);
-#if XV2_WPF == 2
-    if constexpr (NPL == 2) {
-        if (r0 + 1 < r1) {       // the raw registers run ONE row step ahead of the LDS stores (below)
-            load_dy(r0 + 1);
-            load_x(r0 + 2);
-        }
-    }
-#endif
     __syncthreads();
     for (int r = r0; r < r1; ++r) {
         const int buf = (r - r0) & 1;
         const bool more = r + 1 < r1;
 #if !(XV2_WABL & 4)
-        if (more && !(XV2_WPF == 2 && NPL == 2)) {
+        if (more) {
             load_dy(r + 1);
             load_x(r + 2);
         }
 #endif
         const bf16_t* ab = planes + buf * 32 * 64;
-#if XV2_WPF == 2
-        if constexpr (NPL == 2) {
-            // One row step = 18 (k-step, tap) products = 54 MFMAs per wave.  The row step's producer work - split of the dY row
-            // r + 1 / input row r + 2 (fetched during the PREVIOUS row step) into the two fp16 planes and their LDS stores - sits
-            // BETWEEN those MFMAs (products 1, 3, 5, 7: one 16-byte piece each), the fetch of the next pieces behind product 8;
-            // the transpose reads of product i + 1 are issued before the MFMAs of product i.  Before: loads at the top, all splits
-            // and stores behind the last MFMA - and the two blocks of a CU ran those phases in step: the matrix pipe idled while
-            // both waves of a SIMD split, 24 % of the kernel (ablation, profiles/r06_wgrad_ablation.txt).
-            // (the stores are unconditional: behind the last row step they go to buffers nobody reads any more)
-            const int ca = wa * 32 + fcol, cb = wb * 32 + fcol;
-            bf16x8 a_h[2], a_m[2], b_h[2], b_m[2];
-            auto rowp = [&](int kh) { return planes + 2 * 32 * 64 + ((r - 1 + kh + 4) & 3) * 34 * 64; };
-            const int dyo = (buf ^ 1) * 32 * 64, ring = 2 * 32 * 64 + ((r + 2 + 4) & 3) * 34 * 64;
-            a_h[0] = frag(ab, frow, ca);
-            a_m[0] = frag(ab + PL, frow, ca);
-            b_h[0] = frag(rowp(0), frow, cb);
-            b_m[0] = frag(rowp(0) + PL, frow, cb);
-#pragma unroll
-            for (int i = 0; i < 18; ++i) {
-                const int ks = i / 9, t = i % 9, cur = i & 1;
-                if (i + 1 < 18) {
-                    const int ks1 = (i + 1) / 9, t1 = (i + 1) % 9, kh1 = t1 / 3, kw1 = t1 % 3;
-                    b_h[cur ^ 1] = frag(rowp(kh1), 16 * ks1 + frow + kw1, cb);
-                    b_m[cur ^ 1] = frag(rowp(kh1) + PL, 16 * ks1 + frow + kw1, cb);
-                    if (t1 == 0) {
-                        a_h[1] = frag(ab, 16 + frow, ca);
-                        a_m[1] = frag(ab + PL, 16 + frow, ca);
-                    }
-                }
-                if (i == 1) put(dyo + w64_off(pxa, c4 * 4), rd0, sD);
-                if (i == 3) put(dyo + w64_off(pxa + 16, c4 * 4), rd1, sD);
-                if (i == 5) put(ring + w64_off(pxa, c4 * 4), rx0, sX);
-                if (i == 7) put(ring + w64_off(pxa + 16, c4 * 4), rx1, sX);
-                f32x16 c = acc[t];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_m[ks]), __builtin_bit_cast(f16x8, b_h[cur]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h[ks]), __builtin_bit_cast(f16x8, b_m[cur]), c, 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h[ks]), __builtin_bit_cast(f16x8, b_h[cur]), c, 0, 0, 0);
-                if (i == 8) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                else if (i + 1 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                if (i == 1 || i == 3 || i == 5 || i == 7) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (i == 8) {
-                    if (x2) put(ring + w64_off(pxa + 32, c4 * 4), rx2, sX);
-                    if (r + 2 < r1) {
-                        load_dy(r + 2);
-                        load_x(r + 3);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __syncthreads();
-            continue;
-        }
-#endif
 #if XV2_WPF
         if constexpr (NPL == 2) {
             // software pipeline over the 18 (k-step, tap) products of a row step: the transpose reads of product i + 1 are
@@ -1376,12 +1306,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_alltaps64_x3_kernel(const WgradP
                 const int ks = i / 9, t = i % 9, cur = i & 1;
                 if (i + 1 < 18 && !(XV2_WABL & 8)) {
                     const int ks1 = (i + 1) / 9, t1 = (i + 1) % 9, kh1 = t1 / 3, kw1 = t1 % 3;
-                    b_h[cur ^ 1] = frag(rowp(kh1), 16 * ks1 + frow + kw1, cb);
-                    b_m[cur ^ 1] = frag(rowp(kh1) + PL, 16 * ks1 + frow + kw1, cb);
+                    // (read order: what the FIRST MFMA of the next product takes comes last - one wait in front of the three
+                    //  MFMAs covers them all and nothing stands between MFMAs on one accumulator: ~43 cycles each, MI355X_MICROARCH)
                     if (t1 == 0) {
                         a_h[1] = frag(ab, 16 + frow, ca);
                         a_m[1] = frag(ab + PL, 16 + frow, ca);
                     }
+                    b_m[cur ^ 1] = frag(rowp(kh1) + PL, 16 * ks1 + frow + kw1, cb);
+                    b_h[cur ^ 1] = frag(rowp(kh1), 16 * ks1 + frow + kw1, cb);
                 }
                 f32x16 c = acc[t];
 #if XV2_WABL & 1
