@@ -905,8 +905,8 @@ def test_f16x2_weight_planes_hold_the_scaled_weights_to_22_bits():
 
 
 def test_halo_form_of_the_bf16_storage_kernel_in_a_subprocess():
-    """igemm_kernel<..., bf16hbm, HALO> (XV2_HALO_BF16=1, opt-in after measurement): halo and weight tiles global -> LDS by
-    direct-to-LDS loads, swizzled 64-byte rows.  3x3 forward and backward-data against fp32 PyTorch on the bf16-rounded
+    """igemm_kernel<..., bf16hbm, HALO> (default; XV2_HALO_BF16=0: the per-tap form): halo and weight tiles global -> LDS by
+    direct-to-LDS loads (80-byte halo rows, swizzled 64-byte weight rows), the K loop as straight-line code.  3x3 forward and backward-data against fp32 PyTorch on the bf16-rounded
     operands (gate 3e-2 of the tensor maximum, the bf16 rounding of the stored result)."""
     import subprocess
     import sys
@@ -938,9 +938,10 @@ for (N, H, W, C0, C1, Co) in [(2, 32, 64, 64, 0, 128), (1, 64, 64, 32, 0, 64), (
     assert e1 <= 3e-2 and e2 <= 3e-2, (N, H, W, C0, C1, Co, e1, e2)
 print("halo ok %%.2e" %% worst)
 """ % root
-    env = dict(os.environ, XV2_HALO_BF16="1")
-    r = subprocess.run([sys.executable, "-c", snippet], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "halo ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for flag in ("1", "0"):      # the halo form (default since round 6) and the per-tap form it replaced on these layers
+        env = dict(os.environ, XV2_HALO_BF16=flag)
+        r = subprocess.run([sys.executable, "-c", snippet], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "halo ok" in r.stdout, flag + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_halo_form_of_the_f32x3_kernel_in_a_subprocess():

@@ -74,8 +74,8 @@ constexpr int igemm_main_floats() {
         const int loop = 2 * 2 * (BM + BN) * 24 / 2, epi = BM * (BN + 4);      // (64 x 128: 37 KB instead of 55 - three blocks per CU)
         return loop > epi ? loop : epi;
     }
-    if (HALO && HIN) {      // bf16 storage: two halo buffers [208][32] bf16 + three weight stages [BN][32] bf16, or half the tile
-        const int loop = (2 * 208 * 32 + 3 * BN * 32) / 2, epi = (BM / NH) * (BN + 4);
+    if (HALO && HIN) {      // bf16 storage: two halo buffers (17 KB each: 208 rows of 80 bytes in 1 KB DMA pieces) + three weight stages [BN][32] bf16, or half the tile
+        const int loop = (2 * 17 * 1024 + 3 * BN * 64) / 4, epi = (BM / NH) * (BN + 4);
         return loop > epi ? loop : epi;
     }
     if (HALO) {      // three halo planes [208][24] bf16 + two weight stages of three planes [BN][24] bf16, or the epilogue tile
@@ -355,14 +355,167 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
         // read shifted rows of the same halo.  LDS rows are 64 B, the four 16-byte chunks of row r stored at position
         // chunk ^ ((r >> 1) & 3): 8 consecutive rows x one chunk = 8 different 16-byte bank groups.
         constexpr int HWD = PW + 2, NHR = ((PH + 2) * HWD + 7) / 8 * 8;          // 204 -> 208 halo rows
+        const int ntp = ci.ntaps;
+        const int sl_begin = kt_begin / ntp, sl_end = kt_end / ntp;              // 32-channel slices
+        const int sgn = __builtin_amdgcn_readfirstlane(taps[0].dh < 0 ? 1 : -1);
+#if XV2_HU
+        {
+        // ---- the K loop as straight-line code (the F16X2 form below, without its split): two 32-channel slices = 18 stages per
+        // trip, ring slot / halo buffer / fragment set / fragment offsets as immediates, spatial tap order (weight tap u or 8 - u),
+        // waves 0, 1 gather the weight stages (16 rows x 64 B per 1 KB piece, the LDS swizzle is the lane's choice of chunk),
+        // waves 2, 3 fetch the next slice's halo straight into the other halo buffer at tap 0 and confirm it at tap 7, fragments
+        // of stage j + 1 are read between the MFMAs of stage j, bare barriers.  Halo rows are 80 bytes (64 + a pad chunk the DMA
+        // fills with zeros): no row-dependent swizzle, so the nine taps are nine immediates, and consecutive rows are
+        // conflict-free for ds_read_b128's lane groups; weight rows are 64 bytes with chunk c of row r at c ^ ((r >> 3) & 3).
+        constexpr int HPC = 17, HBB = HPC * 1024, WBB = BN * 64;                 // halo buffer: 17 pieces of 1 KB (1040 of 1088 granules are rows)
+        constexpr int NWP = BN / 16 / 2;                                         // weight pieces per weight wave and stage: 4 / 2
+        constexpr int NHW = (HPC + 1) / 2;                                       // halo pieces per halo wave: 9 (the second one's last is idle)
+        static_assert((size_t)2 * HBB + 3 * WBB <= (size_t)MAIN_FLOATS * 4, "halo buffers + weight ring fit");
+        char* lds = reinterpret_cast<char*>(smem);
+        const bool wwave = __builtin_amdgcn_readfirstlane(wave) < 2;
+        const int nsl = p.Ctot / BK;
+        // weight waves: lane -> (row, chunk) of its pieces; voff[j] carries MINUS the piece's immediate (the immediate applies to
+        // the global AND the LDS address; the range check sees their sum)
+        // (four scalars, not an array: a captured int[] in these lambdas makes this clang drop the HOST stub of the instantiation)
+        auto w_off = [&](int j) {
+            const int row = ((wave & 1) * NWP + j) * 16 + (lane >> 2), pos = lane & 3;
+            return (((n0 + row) * p.T * p.Ctot) << 1) + ((pos ^ ((row >> 3) & 3)) << 4) - j * 1024;
+        };
+        const int w_voff0 = w_off(0), w_voff1 = w_off(1), w_voff2 = w_off(NWP == 4 ? 2 : 0), w_voff3 = w_off(NWP == 4 ? 3 : 0);
+        const int w_lds = 2 * HBB + (wave & 1) * NWP * 1024;
+        const int tstep = sgn * (p.Ctot << 1), t0 = sgn > 0 ? 0 : 8 * (p.Ctot << 1);
+        auto dma_w = [&](auto SLOT, auto U, int sl, bool live = true) {
+            constexpr int slot = decltype(SLOT)::value, u = decltype(U)::value;
+            const int so = __builtin_amdgcn_readfirstlane(t0 + u * tstep + sl * (BK * 2));
+            auto dst = (__attribute__((address_space(3))) void*)(lds + w_lds + slot * WBB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, live ? w_voff0 : (int)0x80000000, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, live ? w_voff1 : (int)0x80000000, so, 1024, 0);
+            if constexpr (NWP == 4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, live ? w_voff2 : (int)0x80000000, so, 2048, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, live ? w_voff3 : (int)0x80000000, so, 3072, 0);
+            }
+        };
+        // halo waves: granule g = (hw * 9 + i) * 64 + lane = (row g / 5, position g % 5); position 4 is the pad
+        int hpx[NHW];
+#pragma unroll
+        for (int i = 0; i < NHW; ++i) {
+            const int g = ((wave & 1) * NHW + i) * 64 + lane, row = g / 5, pos = g - row * 5;
+            const int hr = row / HWD, hc = row - hr * HWD;
+            const int ih = h_oh0 - 1 + hr, iw = h_ow0 - 1 + hc;
+            const bool ok = pos < 4 && row < (PH + 2) * HWD && (unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW;
+            hpx[i] = ok ? (((h_n * p.IH + ih) * p.IW + iw) << 2) + pos : -1;     // pixel * 4 + chunk
+        }
+        auto dma_h = [&](int sl, auto HBUF) {
+            constexpr int hbuf = decltype(HBUF)::value;
+            const int cc = sl * BK;
+            const bool first = cc < p.C0;
+            const int ld = first ? p.ldA0 : p.ldA1;
+            const int so = __builtin_amdgcn_readfirstlane((first ? cc : cc - p.C0) << 1);
+#pragma unroll
+            for (int i = 0; i < NHW; ++i) {
+                if ((wave & 1) * NHW + i < HPC) {                                 // wave-uniform
+                    const int vo = hpx[i] >= 0 ? (((hpx[i] >> 2) * ld) << 1) + ((hpx[i] & 3) << 4) : (int)0x80000000;
+                    auto dst = (__attribute__((address_space(3))) void*)(lds + hbuf * HBB + ((wave & 1) * NHW + i) * 1024);
+                    if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, dst, 16, vo, so, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, dst, 16, vo, so, 0, 0);
+                }
+            }
+        };
+        // fragment addresses: A = halo row of (pixel, tap (-1, -1)), 8 channels at 16 * (2 ks + h); B = the lane's row of a stage
+        const char* a_ptr[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a_ptr[i] = lds + (((wm * WTM + i * 32) / PW) * HWD + l31) * 80 + h * 16;
+        const char* b_ptr[NR][2];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int row = wn * WTN + j * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b_ptr[j][ks] = lds + 2 * HBB + row * 64 + (((ks * 2 + h) ^ ((row >> 3) & 3)) << 4);
+        }
+        bf16x8 fa[2][2][MR], fb[2][2][NR];
+        auto rd_a = [&](auto U, auto HBUF, bf16x8 (&f)[2][MR]) {
+            constexpr int off = decltype(HBUF)::value * HBB + ((decltype(U)::value / 3) * HWD + (decltype(U)::value % 3)) * 80;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MR; ++i) f[ks][i] = *reinterpret_cast<const bf16x8*>(a_ptr[i] + off + ks * 32);
+        };
+        auto rd_b = [&](auto SLOT, bf16x8 (&f)[2][NR]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) f[ks][j] = *reinterpret_cast<const bf16x8*>(b_ptr[j][ks] + decltype(SLOT)::value * WBB);
+        };
+        auto stage = [&](auto JJ, int sl) {
+            constexpr int J = decltype(JJ)::value, u = J % 9, shf = J / 9, slot = J % 3, par = J & 1;
+            constexpr int J3 = J + 3, u3 = J3 % 9, sh3 = J3 / 9;
+            if (wwave) {
+                if constexpr (sh3 == 0) dma_w(IC<slot>{}, IC<u3>{}, sl + sh3);
+                else dma_w(IC<slot>{}, IC<u3>{}, sl + sh3, sl + sh3 < nsl);
+            } else if (u == 0) {
+                if (sl + shf + 1 < sl_end) dma_h(sl + shf + 1, IC<(shf ^ 1)>{});
+            }
+            rd_b(IC<(J + 1) % 3>{}, fb[par ^ 1]);
+            if constexpr (u != 8) rd_a(IC<u + 1>{}, IC<shf>{}, fa[par ^ 1]);
+            else rd_a(IC<0>{}, IC<(shf ^ 1)>{}, fa[par ^ 1]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NR; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[par][ks][i], fb[par][ks][j], acc[i][j], 0, 0, 0);
+            {
+                constexpr int NMF = 2 * MR * NR, NRD = 2 * (MR + NR);
+#pragma unroll
+                for (int g = 0; g < NMF; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (NRD + NMF - 1) / NMF, 0);
+                }
+            }
+            if (wwave) {
+                if constexpr (NWP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else if (u == 7) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        if (wwave) {
+            dma_w(IC<0>{}, IC<0>{}, sl_begin);
+            dma_w(IC<1>{}, IC<1>{}, sl_begin);
+            dma_w(IC<2>{}, IC<2>{}, sl_begin);
+            if constexpr (NWP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            dma_h(sl_begin, IC<0>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        rd_a(IC<0>{}, IC<0>{}, fa[0]);
+        rd_b(IC<0>{}, fb[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (every wave holds its first fragments before slot 0 is re-filled)
+        int sl = sl_begin;
+        for (; sl + 1 < sl_end; sl += 2) {
+            stage(IC<0>{}, sl); stage(IC<1>{}, sl); stage(IC<2>{}, sl); stage(IC<3>{}, sl); stage(IC<4>{}, sl); stage(IC<5>{}, sl);
+            stage(IC<6>{}, sl); stage(IC<7>{}, sl); stage(IC<8>{}, sl); stage(IC<9>{}, sl); stage(IC<10>{}, sl); stage(IC<11>{}, sl);
+            stage(IC<12>{}, sl); stage(IC<13>{}, sl); stage(IC<14>{}, sl); stage(IC<15>{}, sl); stage(IC<16>{}, sl); stage(IC<17>{}, sl);
+        }
+        if (sl < sl_end) {      // an odd number of slices: the first half of a trip
+            stage(IC<0>{}, sl); stage(IC<1>{}, sl); stage(IC<2>{}, sl); stage(IC<3>{}, sl); stage(IC<4>{}, sl); stage(IC<5>{}, sl);
+            stage(IC<6>{}, sl); stage(IC<7>{}, sl); stage(IC<8>{}, sl);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA issued past the end: before the epilogue re-uses LDS)
+        __syncthreads();
+        }
+#else
         constexpr int HB = NHR * 32, WB = BN * 32;                               // elements per halo buffer / weight stage
         static_assert((size_t)(2 * HB + 3 * WB) * 2 <= (size_t)MAIN_FLOATS * 4, "halo buffers + weight ring fit");
         __bf16* sh = reinterpret_cast<__bf16*>(smem);                            // [2][NHR][32]
         __bf16* sw = sh + 2 * HB;                                                // [3][BN][32]
-        const int ntp = ci.ntaps;
-        const int sl_begin = kt_begin / ntp, sl_end = kt_end / ntp;              // 32-channel slices
         const int s_begin = sl_begin * ntp, s_end = sl_end * ntp;                // stage = (slice, tap)
-        const int sgn = __builtin_amdgcn_readfirstlane(taps[0].dh < 0 ? 1 : -1);
         // halo DMA: granule g = 16 B of LDS = (row g / 4, position g % 4) <- chunk position ^ ((row >> 1) & 3) of that pixel;
         // instruction j of this wave covers granules (4 * j + wave) * 64 + lane  (13 instructions per buffer: wave 0 issues 4)
         constexpr int HNI = NHR * 4 / 64;                                        // 13
@@ -463,7 +616,12 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             };
             const int nhalo = nh ? (wave == 0 ? 4 : 3) : 0;      // wave-uniform
             wait_n((pf ? WNI : 0) + nhalo);
+#if XV2_HBAR & 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (bare barrier: see the F16X2 form below)
+            __builtin_amdgcn_s_barrier();
+#else
             __syncthreads();
+#endif
             slot = slot == 2 ? 0 : slot + 1;
             if (++tp == ntp) {
                 tp = 0;
@@ -471,6 +629,7 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 hbuf ^= 1;
             }
         }
+#endif
     } else if constexpr (X3 && HALO) {
         // 6 x 34 halo pixels.  The patch is 4 x 32 so that the 32 lanes of an MFMA row tile read 32 CONSECUTIVE LDS rows
         // whatever the tap: with 8 x 16 patches (two patch rows per tile, a jump of 18 or 24 LDS rows between lanes 15 and
@@ -781,15 +940,18 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
             const int w_lds = NPL * PLA * 2 + w_unit * 4096 + w_cq0 * 1024;      // + slot * STBX * 2
             // weight tap of spatial tap u, as a byte offset: u * tstep + t0 (forward: u, backward-data: 8 - u)
             const int tstep = sgn * nsl * (2048 * NPL), t0 = sgn > 0 ? 0 : 8 * nsl * (2048 * NPL);
-            auto dma_w = [&](auto SLOT, auto U, int cs) {
+            // (the scalar offset takes no part in the buffer's range check: a stage past the END of the weight tensor is sent out
+            //  of range through the lane offset - zeros into a slot nobody reads, no memory access)
+            auto dma_w = [&](auto SLOT, auto U, int cs, bool live = true) {
                 constexpr int slot = decltype(SLOT)::value, u = decltype(U)::value;
                 const int so = __builtin_amdgcn_readfirstlane(t0 + u * tstep + cs * (2048 * NPL));
+                const int vo = live ? w_voff : (int)0x80000000;
                 auto dst = (__attribute__((address_space(3))) void*)(lds + w_lds + slot * STBX * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 1024, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, vo, so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, vo, so, 1024, 0);
                 if constexpr (NCHW == 4) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 2048, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, w_voff, so, 3072, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, vo, so, 2048, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, dst, 16, vo, so, 3072, 0);
                 }
             };
             // halo waves: pixel of this lane's 16-byte piece e = (hw * 7 + i) * 64 + lane  (row slot e >> 2, channel quad e & 3)
@@ -870,9 +1032,10 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                 constexpr int J3 = J + 3, u3 = J3 % 9, sh3 = J3 / 9;               // the stage whose weights are issued here
 #if !(XV2_HABL & 32)
                 if (wwave) {
-                    dma_w(IC<slot>{}, IC<u3>{}, cs + sh3);
+                    if constexpr (sh3 == 2) dma_w(IC<slot>{}, IC<u3>{}, cs + sh3, cs + sh3 < nsl);
+                    else dma_w(IC<slot>{}, IC<u3>{}, cs + sh3);
                 } else if (u == 0) {
-                    dma_h(cs + shf + 1);
+                    if (shf == 0 || cs + 2 < cs_end) dma_h(cs + shf + 1);
                 }
 #endif
                 rd_b(IC<(J + 1) % 3>{}, fb[par ^ 1]);
@@ -894,6 +1057,9 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if XV2_HABL & 64
+                if constexpr ((J & 1) == 0 || u >= 7)      // (timing only: every second barrier dropped - wrong results)
+#endif
                 __builtin_amdgcn_s_barrier();
                 if constexpr (u == 8) rd_a(IC<0>{}, fa[par ^ 1]);
             };
@@ -1865,9 +2031,10 @@ static bool presplit_enabled() {      // XV2_PRESPLIT=0: weights split in the ke
 // halo form of the bf16-storage kernel (both operands global -> LDS by DMA, no register path): exact, and measured NOT
 // faster than the per-tap form - cfg2 3x3 layers forward 550 -> 526, backward-data 598 -> 559 TFLOP/s (dec1 0.164 -> 0.203 ms,
 // dec2 / dec3 equal, l4.conv2 0.029 -> 0.026): that kernel has no split and no conversion to save, its producer is already
-// one 16-byte load + one 16-byte LDS store per 8 channels.  Opt-in (XV2_HALO_BF16=1).
+// one 16-byte load + one 16-byte LDS store per 8 channels.  Default since the K loop is straight-line code (round 6:
+// cfg2 --precision 16 12.06 -> 11.61 ms, cfg3 15.0 -> 14.4 ms, profiles/r06_halo_bf16_straight_line_ab.txt); XV2_HALO_BF16=0: per-tap form.
 static bool halo_bf16_enabled() {
-    static const int v = [] { const char* e = getenv("XV2_HALO_BF16"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("XV2_HALO_BF16"); return e ? atoi(e) : 1; }();
     return v != 0;
 }
 static bool halo_eligible(const IgemmParams& p, bool smallc, int math = XV2_MATH_F32X3) {

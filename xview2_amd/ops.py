@@ -686,6 +686,9 @@ def _conv_bn_act_train(x0, x1, weight, g, bn, residual, act, ihwo_out, want_mask
         # grouped layer (ResNeSt's radix convolution): the groups' launches behind ONE call (xv2_conv_bn_act_forward_grouped)
         if x1 is not None or rgb or not GROUPED_CALLS:
             return None
+        if bn.weight is None or bn.bias is None or bn.running_mean is None or bn.running_var is None:
+            return None      # affine=False / track_running_stats=False: the grouped entry point takes none of them as NULL - op by op
+
         w = weight.contiguous()
         C0g, Coutg = C0t // G, Cout // G
         packs = [_pack(w[gi * Coutg:(gi + 1) * Coutg], C0g, True, ihwo_out is not None, half) for gi in range(G)]
