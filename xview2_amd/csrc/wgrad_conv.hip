@@ -18,6 +18,9 @@
 #ifndef XV2_WABL
 #define XV2_WABL 0      // timing ablations of wgrad_alltaps64_x3_kernel (results are garbage): 1 no MFMA, 2 no split + plane stores, 4 no global loads, 8 no fragment reads
 #endif
+#ifndef XV2_WTI
+#define XV2_WTI 1      // transpose-read weight gradients: running (image, row, column) of the next tile instead of two divisions per tile
+#endif
 #ifndef XV2_WPF
 #define XV2_WPF 1      // all-taps 64 x 64 F16X2 kernel: fragment reads one product ahead of the MFMAs (0: read, wait, multiply per product)
 #endif
@@ -366,12 +369,23 @@ __global__ void __launch_bounds__(256) wgrad_tr_kernel(const WgradParams p) {
         b_const[j] = b_k[j] * ldx + xch + b_c8 * 8;
     }
     i32x4 ra[APASS], rb[BPASS];
+    // (image, output row, first column) of the NEXT tile to fetch - the tiles are fetched in order: no division per tile
+    int t_n = (kt0 * 32) / ohw, t_oh = ((kt0 * 32) - t_n * ohw) / p.OW, t_ow0 = (kt0 * 32) - t_n * ohw - t_oh * p.OW;
     auto gload = [&](int kt) {      // a 32-pixel reduction tile lies inside one output row (OW % 32 == 0)
         const int mb = kt * 32;
-        const int n = mb / ohw;
-        const int rem = mb - n * ohw;
-        const int oh = rem / p.OW;
-        const int ow0 = rem - oh * p.OW;
+#if XV2_WTI
+        const int n = t_n, oh = t_oh, ow0 = t_ow0;
+#else
+        const int n = mb / ohw, oh = (mb - n * ohw) / p.OW, ow0 = mb - n * ohw - oh * p.OW;
+#endif
+        t_ow0 += 32;
+        if (t_ow0 >= p.OW) {
+            t_ow0 = 0;
+            if (++t_oh == p.OH) {
+                t_oh = 0;
+                ++t_n;
+            }
+        }
         const int ih = oh * p.stride + dh;
         const bool rowok = (unsigned)ih < (unsigned)p.IH;
         const int iw0 = ow0 * p.stride;
@@ -511,12 +525,24 @@ __global__ void __launch_bounds__(256) wgrad_tr_x3_kernel(const WgradParams p) {
         b_const[j] = b_k[j] * ldx + xch + b_c4 * 4;
     }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+    // (image, output row, first column) of the NEXT tile to fetch: the tiles are fetched in order kt0, kt0 + 1, ..., so the two
+    // integer divisions per tile of the first version (~40 scalar instructions each) happen once per block
+    int t_n = (kt0 * 32) / ohw, t_oh = ((kt0 * 32) - t_n * ohw) / p.OW, t_ow0 = (kt0 * 32) - t_n * ohw - t_oh * p.OW;
     auto gload_into = [&](int kt, i32x4 (&ra)[APASS], i32x4 (&rb)[BPASS]) {   // a 32-pixel tile lies inside one output row
         const int mb = kt * 32;
-        const int n = mb / ohw;
-        const int rem = mb - n * ohw;
-        const int oh = rem / p.OW;
-        const int ow0 = rem - oh * p.OW;
+#if XV2_WTI
+        const int n = t_n, oh = t_oh, ow0 = t_ow0;
+#else
+        const int n = mb / ohw, oh = (mb - n * ohw) / p.OW, ow0 = mb - n * ohw - oh * p.OW;
+#endif
+        t_ow0 += 32;
+        if (t_ow0 >= p.OW) {
+            t_ow0 = 0;
+            if (++t_oh == p.OH) {
+                t_oh = 0;
+                ++t_n;
+            }
+        }
         const int ih = oh * p.stride + dh;
         const bool rowok = (unsigned)ih < (unsigned)p.IH;
         const int iw0 = ow0 * p.stride;
