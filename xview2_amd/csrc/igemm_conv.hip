@@ -20,6 +20,9 @@
 // Epilogue: optional bias, scattered NHWC store through a per-row pixel-offset table, and
 // (training) per-channel partial sums / sums of squares for the following BatchNorm.
 #include "igemm_params.h"
+#ifndef XV2_EPF
+#define XV2_EPF 1      // epilogue: the training path's store loop without the general loop's per-row tests (0: general loop only)
+#endif
 #ifndef XV2_HU
 #define XV2_HU 1       // 0: the run-time (tap, slice, ring) loop of rounds 3 - 5 for the F16X2 halo form (A/B builds)
 #endif
@@ -1481,6 +1484,21 @@ __global__ void __launch_bounds__(256, (HALO && BN == 64 && X3 && NPL == 2) ? 3 
     {
         constexpr int F4R = BN / 4;
         float* slab = p.ksplit > 1 ? p.part + (size_t)blockIdx.z * ci.M * p.Nout : nullptr;
+        // the training step's launch (one output, no bias, no inference epilogue, no accumulation, unsplit): the loop without
+        // the general one's six kernel-uniform tests per row (every instruction of a power-limited kernel is paid in clock)
+        if (XV2_EPF && !slab && !p.bias && !p.ep_scale && !p.accum && p.N0 == p.Nout) {
+            OT* const o0 = reinterpret_cast<OT*>(p.Out0) + n0;
+            const bool rec = p.amax_out != nullptr;
+#pragma unroll 4
+            for (int e = tid; e < HROWS * F4R; e += 256) {
+                const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
+                const int off = rowoff[row];
+                if (off < 0) continue;
+                const float4 v = *reinterpret_cast<const float4*>(Cs + (row - hh * HROWS) * CLD + c);
+                st4(o0 + (size_t)off * p.ldo0 + c, v);
+                if (rec) omax = amax_acc(omax, v);
+            }
+        } else
 #pragma unroll 4
         for (int e = tid; e < HROWS * F4R; e += 256) {
             const int row = hh * HROWS + e / F4R, c = (e % F4R) * 4;
