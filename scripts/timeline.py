@@ -43,6 +43,13 @@ def main(db, which=6):
     print("  largest gaps on the compute queue (us, after -> before):")
     for g, i in holes:
         print("     %8.1f  %-44s -> %s" % (g / 1e3, short(q0[i][2])[:44], short(q0[i + 1][2])[:44]))
+    # what the OTHER queues ran inside the largest hole (the step's tail: the compute stream waits for the last weight gradients)
+    g0, i0 = holes[0]
+    lo, hi = q0[i0][1], q0[i0 + 1][0]
+    print("  inside the largest gap (%.1f us), other queues:" % (g0 / 1e3))
+    for n, s_, e_, q in step:
+        if e_ > lo and s_ < hi and (s_, e_, n) not in (q0[i0], q0[i0 + 1]) and not (s_ == q0[i0][0]):
+            print("     %+8.1f .. %+8.1f us  %s" % ((s_ - lo) / 1e3, (e_ - lo) / 1e3, short(n)[:70]))
     big = sum(g for g, _ in holes if g >= 20000)
     print("  gaps >= 20 us among them: %.3f ms" % (big / 1e6))
     # union busy / overlap
