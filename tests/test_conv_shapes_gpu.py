@@ -148,6 +148,11 @@ def test_cfg2_conv_layer_at_true_size(case):
         conv_names = [n for n in runs[True]["names"] if not n.startswith("wgrad_reduce")]
         assert len(conv_names) >= 3 and all("f16x2" in n for n in conv_names), runs[True]["names"]
         assert not any("f16x2" in n for n in runs[False]["names"]), runs[False]["names"]
+        if k == 3 and s == 1 and Cout % 64 == 0 and (C1 or B * H * H > 40000):
+            # 3x3 / stride 1 above the small-grid kernel's range (or with two sources): forward AND backward-data take the halo
+            # form with pre-split weights - since round 6 its K loop is the straight-line code of igemm_conv.hip (XV2_HU)
+            halo = [n for n in conv_names if n.startswith("igemm_kernel") and "halo,wx2" in n]
+            assert len(halo) >= 2, conv_names
     # host reference
     xr = (torch.cat([x0, x1], 1) if C1 else x0).clone().requires_grad_(True)
     wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
