@@ -1,7 +1,7 @@
 """Bitwise reproducibility of full-size training steps while OTHER processes load the same GPU (uneven load is what
 exposes inter-workgroup hand-off races - MI355X guide, Guideline 16): run N steps from the same state R times and
 report every parameter whose gradient differs between repetitions.
-usage: python scripts/stress_determinism.py [encoder] [reps] [load_procs]"""
+usage: [XV2_STRESS_P16=1] [XV2_STRESS_POST=1] [XV2_STRESS_POISON=GiB] python scripts/stress_determinism.py [encoder] [reps] [load_procs]"""
 import os
 import subprocess
 import sys
@@ -40,6 +40,8 @@ def run_once(a, x, y, steps=2):
 
 def main():
     import bench
+    if os.environ.get("XV2_STRESS_P16"):      # --precision 16: bf16 storage (the load processes inherit it)
+        bench.set_precision(16)
     enc = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     nload = int(sys.argv[3]) if len(sys.argv) > 3 else 2
