@@ -50,6 +50,14 @@ def main(db, which=6):
     for n, s_, e_, q in step:
         if e_ > lo and s_ < hi and (s_, e_, n) not in (q0[i0], q0[i0 + 1]) and not (s_ == q0[i0][0]):
             print("     %+8.1f .. %+8.1f us  %s" % ((s_ - lo) / 1e3, (e_ - lo) / 1e3, short(n)[:70]))
+    import os
+    flt = os.environ.get("XV2_TIMELINE_FILTER")
+    if flt:      # every launch of the step whose name contains the filter: offset from the step's start, duration, what ran before it on its queue
+        print("  launches matching %r:" % flt)
+        for q, L in byq.items():
+            for i, (s_, e_, n) in enumerate(L):
+                if flt in n:
+                    print("     %+9.1f us  %7.1f us  after %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, short(L[i - 1][2])[:60] if i else "-"))
     big = sum(g for g, _ in holes if g >= 20000)
     print("  gaps >= 20 us among them: %.3f ms" % (big / 1e6))
     # union busy / overlap

@@ -12,6 +12,7 @@
 // Same contract as igemm_kernel for this shape class (tap list with |dh|,|dw| <= 1, bias, BatchNorm partial sums
 // per 128-pixel tile, deterministic).  model/layers.py:92 (ConvLayer 3x3) at decoder level 5 and its backward-data.
 #include "igemm_params.h"
+#include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
         hstore();
     }
     __syncthreads();
+    float omax = 0.f;
     for (int patch = p0; patch < p1; ++patch) {
         if (patch + 1 < p1) hload(patch + 1);
         // TWO accumulators, alternating: a wave owns ONE 32 x 32 output tile, so with a single accumulator every MFMA
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
                 v = apply_act(v, p.ep_act);
             }
             st1(reinterpret_cast<OT*>(p.Out0) + (rowpix + col) * p.ldo0 + l31, v);
+            omax = fmaxf(omax, fabsf(v));
             const float sv = HS ? bf16_round(acc[r]) : acc[r];
             s1 += sv;
             s2 += sv * sv;
@@ -314,6 +317,10 @@ __global__ void __launch_bounds__(X3 ? 512 : 256) direct3x3_n32_kernel(const Ige
         if (patch + 1 < p1) hstore();
         __syncthreads();
     }
+    // F16X2: max |value stored| (IgemmParams::amax_out; the backward-data launch of the 1024^2 level: a pass of its own over dx
+    // took 55 us per step)
+    if constexpr (!HS)
+        if (p.amax_out) amax_record(p.amax_out, omax, red);
 }
 
 bool direct3x3_eligible(const IgemmParams& p, bool smallc) {
@@ -359,6 +366,9 @@ int direct3x3_launch(const IgemmParams& p, hipStream_t stream) {
     int grid = std::min(npatches, x3 ? 256 : p.math == XV2_MATH_BF16_STORE ? 1024 : 512);
     IgemmParams q = p;
     const bool h2 = x3 && f16x2_ready_pertap(q);      // F16X2: maxima of the source and of the weights known
+    static const bool own_pass = [] { const char* e = getenv("XV2_AMAX_PASS"); return e && atoi(e) == 1; }();      // A/B runs: the round-5 form
+    if (own_pass) q.amax_out = nullptr;
+    else if (p.amax_out && p.amax_recorded && p.math != XV2_MATH_BF16_STORE) *p.amax_recorded = 1;      // (the kernel's epilogue records)
     const double flops = 2.0 * (double)c.M * 32.0 * 9.0 * p.Ctot;
     const double abytes = (p.math == XV2_MATH_BF16_STORE ? 2.0 : 4.0) *
                           ((double)c.M * p.Ctot + 32.0 * 9.0 * p.Ctot + (double)c.M * 32.0);

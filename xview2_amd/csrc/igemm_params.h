@@ -78,7 +78,8 @@ bool thin1x1_eligible(const IgemmParams& p, bool smallc);
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream);
 // the same streaming kernel for nn.ConvTranspose2d(64 -> 32, 2, 2) at >= 65536 small-grid pixels (the 1024^2 decoder level):
 // forward = four 32-column blocks scattered to the four big-grid pixels, backward-data = K gathered from them.  -1: other shape
-int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, hipStream_t stream);
+int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, unsigned* amax_out,
+                       hipStream_t stream);
 int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, const void* w_ohwi, void* dx, int lddx,
                              int accumulate, hipStream_t stream);
 

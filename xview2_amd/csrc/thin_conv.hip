@@ -33,6 +33,7 @@ struct ThinParams {
     int W;                // MODE 1 / 2: width of the SMALL grid of the 2x2 / stride-2 transposed convolution (W % 32 == 0)
     const unsigned* amaxA;    // F16X2 (PF = 2): the recorded maxima of the activations and of the weights (xv2_common.h)
     const unsigned* amaxB;
+    unsigned* amax_out;       // != nullptr (fp32 tensors): the store loop records max |value stored| into these 64 slots (xv2_common.h)
 };
 
 // MODE 1 / 2: nn.ConvTranspose2d(k = 2, s = 2) (model/layers.py:80-86) of the 1024^2 decoder level, forward and backward-data.
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(WAVES * 64, (HS || PF == 2) ? 2 : 1) thin1x1_k
     __syncthreads();
 
     const __bf16* wl = sw + l31 * KP + 8 * h;              // this lane's B-operand row (column l31 of a 32-column block)
+    float omax = 0.f;                                      // F16X2: max |value stored| of this wave (ThinParams::amax_out)
     for (; tile < p.tiles; tile += nw) {
         float s1[NB], s2[NB];
 #pragma unroll
@@ -303,6 +305,7 @@ __global__ void __launch_bounds__(WAVES * 64, (HS || PF == 2) ? 2 : 1) thin1x1_k
                                         o[(size_t)dr * ostep] = v;
                                         s1[j] += v;
                                         s2[j] += v * v;
+                                        omax = fmaxf(omax, fabsf(v));
                                     }
                                 }
                             }
@@ -340,6 +343,8 @@ __global__ void __launch_bounds__(WAVES * 64, (HS || PF == 2) ? 2 : 1) thin1x1_k
             }
         }
     }
+    if constexpr (!HS)
+        if (p.amax_out) amax_record_wave(p.amax_out, omax, blockIdx.x * WAVES + wave);
 }
 
 static bool thin_enabled() {      // XV2_THIN=0: these layers stay on the tiled implicit-GEMM kernel (A/B runs)
@@ -387,11 +392,13 @@ bool thin1x1_eligible(const IgemmParams& p, bool smallc) {
 int thin1x1_launch(const IgemmParams& p, hipStream_t stream) {
     ThinParams q;
     q.amaxA = q.amaxB = nullptr;
+    q.amax_out = nullptr;
     q.A = p.A0; q.B = p.B; q.Out = p.Out0; q.stats = p.stats;
     q.M = p.cls[0].M; q.ldA = p.ldA0; q.ldo = p.ldo0; q.accum = p.accum & 1; q.W = 0;
     q.tiles = (int)cdiv(q.M, 128);
     q.bytesA = p.bytesA0;
     q.amaxA = q.amaxB = nullptr;
+    q.amax_out = nullptr;
     IgemmParams pc = p;
     const bool h2 = !q.accum && f16x2_ready_pertap(pc);      // F16X2: the maxima of the source and of the weights are known
     if (h2) {
@@ -434,10 +441,12 @@ static bool thin_ct_shape(const xv2_conv_desc* d, int ld_small, int ld_big, cons
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
-int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, hipStream_t stream) {
+int thin_convT_forward(const xv2_conv_desc* d, const void* x, int ldx, const void* w_ihwo, void* y, int ldy, unsigned* amax_out,
+                       hipStream_t stream) {
     if (!thin_ct_shape(d, ldx, ldy, x, w_ihwo, y)) return -1;
     ThinParams q;
     q.amaxA = q.amaxB = nullptr;
+    q.amax_out = d->math == XV2_MATH_BF16_STORE ? nullptr : amax_out;      // (recorded by the store loop: no pass of its own over y)
     q.A = x; q.B = w_ihwo; q.Out = y; q.stats = nullptr;
     q.M = d->N * d->OH * d->OW; q.ldA = ldx; q.ldo = ldy; q.accum = 0; q.W = d->OW;
     q.tiles = (int)cdiv(q.M, 128);
@@ -458,6 +467,7 @@ int thin_convT_backward_data(const xv2_conv_desc* d, const void* dy, int lddy, c
     if (d->math != XV2_MATH_BF16_STORE && !force) return -1;
     ThinParams q;
     q.amaxA = q.amaxB = nullptr;
+    q.amax_out = nullptr;
     q.A = dy; q.B = w_ohwi; q.Out = dx; q.stats = nullptr;
     q.M = d->N * d->OH * d->OW; q.ldA = lddy; q.ldo = lddx; q.accum = accumulate & 1; q.W = d->OW;
     q.tiles = (int)cdiv(q.M, 128);

@@ -196,6 +196,13 @@ __device__ __forceinline__ void amax_record(unsigned* slots, float local_abs_max
     }
 }
 
+// wave-level record (kernels whose waves never meet: no LDS scratch, no barrier): one fire-and-forget atomic per wave
+__device__ __forceinline__ void amax_record_wave(unsigned* slots, float local_abs_max, unsigned slot_hint) {
+    const unsigned v = wave_max_u(__float_as_uint(local_abs_max) & 0x7fffffffu);
+    if ((threadIdx.x & 63) == 0 && v)
+        __hip_atomic_fetch_max(slots + (slot_hint & (AMAX_SLOTS - 1)) * AMAX_STRIDE, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifndef XV2_T0
 #define XV2_T0 0   // emulation switch: 3 drops the three smallest product terms of the F32X3 kernels
 #endif
