@@ -75,6 +75,14 @@ def main(db, which=6):
         depth += d
         last = t
     print("  any kernel running %.3f ms (idle %.3f ms), >=2 kernels running %.3f ms" % (union / 1e6, (t1 - t0 - union) / 1e6, multi / 1e6))
+    if os.environ.get("XV2_TIMELINE_ALL"):      # every kernel name of the step: launches, total and average time
+        agg = defaultdict(lambda: [0, 0])
+        for n, s_, e_, q in step:
+            agg[short(n)][0] += e_ - s_
+            agg[short(n)][1] += 1
+        print("  all kernels of the step:")
+        for n, (t, k) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            print("     %-64s %4d %8.3f ms  %7.1f us" % (n, k, t / 1e6, t / k / 1e3))
     # phases: forward ends at the loss kernel
     loss_i = next((i for i, r in enumerate(step) if "loss_fwd" in r[0]), None)
     if loss_i is not None:
