@@ -1106,7 +1106,7 @@ def main():
             out.setdefault("other_configs", []).append(config_leg(
                 "cfg2 at --precision 16: --type %s --encoder %s --loss_str %s, %dx%d, batch %d (bf16 storage against the "
                 "fp32 CPU oracle step of the headline line)" % (a.type, opt.encoder, a.loss_str, opt.size, opt.size, opt.batch),
-                a, 16, opt.size, opt.batch, dev, steps=10, warmup=3, parity=True, ref=ref, strict16=True))
+                a, 16, opt.size, opt.batch, dev, steps=12, warmup=8, parity=True, ref=ref, strict16=True))      # (the GPU sat idle for the ~2 minutes of the CPU oracle: 3 warm-up steps left the timed ones in its clock ramp, 13.5 vs 11.8 ms)
     if rank == 0:
         # the per-kernel tables, notes and prose go to a side file; the LAST stdout line is the compact record (< 6 KB)
         detail_path = os.environ.get("XV2_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")

@@ -1,3 +1,6 @@
-python -m pytest tests/test_conv_shapes_gpu.py tests/test_f16x2_gpu.py tests/test_ops_gpu.py -q -x 2>&1 | tail -2
-python -m pytest tests/test_model_gpu.py -q -x -k "pre_resnet50" 2>&1 | tail -2
-scripts/ab_multi.sh "XV2_AMAX_PASS=1" "XV2_AMAX_PASS=0" -- --steps 30 --warmup 8
+for args in "--no-cpu-baseline" "--no-cpu-baseline --no-big-configs" "--no-cpu-baseline"; do
+python bench.py $args 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$args', '|', d['ms_per_step'], [(o['config'][:12], o['ms_per_step']) for o in d['other_configs']])"
+done
