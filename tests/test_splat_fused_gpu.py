@@ -91,3 +91,57 @@ def test_splat_conv_block_of_the_model_path_against_pytorch(shape, training):
             continue      # mathematically zero in front of a training-mode BatchNorm: both sides are round-off
         e = float((p.grad.cpu() - q.grad).abs().max()) / max(float(q.grad.abs().max()), 1e-12)
         assert e <= 2e-3, (k, e)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 32), (2, 8, 8, 256, 128), (3, 12, 20, 128, 64), (8, 4, 4, 512, 256)])
+def test_tail_backward_with_two_launches_less_is_bitwise_the_op_by_op_chain(shape):
+    """xv2_splat_tail_backward since round 6 - datt's fold + rSoftMax's backward in one launch, both products of each dense layer's
+    backward in one problem-indexed launch (XV2_SPLAT_FUSE bits 3 and 4) - against the public op-level entry points: the fold
+    launch followed by xv2_rsoftmax_backward (bit for bit), the dense layer's weight / bias gradient from the separate kernel
+    (dx = NULL call: bit for bit) and its input gradient against an fp64 product."""
+    from xview2_amd._capi import call, query
+    N, H, W, C, inter = shape
+    hw, C2 = H * W, 2 * C
+    g = torch.Generator().manual_seed(C + inter + N)
+    x = torch.randn(N, H, W, C2, generator=g).to(DEV)
+    dout = torch.randn(N, H, W, C, generator=g).to(DEV)
+    att = torch.softmax(torch.randn(N, 2, C, generator=g), dim=1).reshape(N, C2).contiguous().to(DEV)
+    ws = torch.zeros(query("xv2_splat_gap_workspace", N, hw, C) // 4 + 16, device=DEV)
+    # op by op (public entry points: three launches)
+    datt_ref = torch.empty(N, C2, device=DEV)
+    call("xv2_splat_apply_backward", x, att, dout, None, N, hw, C, None, datt_ref, ws, 0)
+    dl_ref = torch.empty(N, C2, device=DEV)
+    call("xv2_rsoftmax_backward", att, datt_ref, dl_ref, N, C)
+    # the dense layer's backward: dw / db alone (dx = NULL: the separate weight-gradient kernel), then both products in one launch
+    a1 = torch.randn(N, inter, generator=g).to(DEV)
+    w2 = (torch.randn(C2, inter, generator=g) * 0.1).to(DEV)
+    dw_ref, db_ref = torch.empty(C2, inter, device=DEV), torch.empty(C2, device=DEV)
+    call("xv2_linear_backward", a1, w2, dl_ref, None, dw_ref, db_ref, N, inter, C2)
+    da, dw, db = torch.empty(N, inter, device=DEV), torch.empty(C2, inter, device=DEV), torch.empty(C2, device=DEV)
+    call("xv2_linear_backward", a1, w2, dl_ref, da, dw, db, N, inter, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    da64 = dl_ref.double() @ w2.double()
+    assert float((da.double() - da64).abs().max()) <= 1e-5 * float(da64.abs().max())
+    # the whole tail: datt and dlogits of the fused launch are outputs of the call
+    gap = torch.randn(N, C, generator=g).to(DEV)
+    h1 = torch.randn(N, inter, generator=g).to(DEV)
+    mean1, invstd1 = h1.mean(0).contiguous(), (1.0 / (h1.var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    g1 = (torch.rand(inter, generator=g) + 0.5).to(DEV)
+    a1 = torch.relu((h1 - mean1) * invstd1 * g1).contiguous()
+    w1 = (torch.randn(inter, C, generator=g) * 0.1).to(DEV)
+    outs = {k: torch.empty(s, device=DEV) for k, s in dict(datt=(N, C2), dl=(N, C2), da1=(N, inter), dh1=(N, inter), dgap=(N, C),
+                                                          dw2=(C2, inter), db2=(C2,), dg1=(inter,), dbe1=(inter,), dw1=(inter, C),
+                                                          db1=(inter,)).items()}
+    dx = torch.empty_like(x)
+    call("xv2_splat_tail_backward", x, dout, N, hw, C, inter, gap, h1, a1, mean1, invstd1, g1, w1, w2, att, 1, 1, outs["datt"],
+         outs["dl"], outs["da1"], outs["dh1"], outs["dgap"], outs["dw2"], outs["db2"], outs["dg1"], outs["dbe1"], outs["dw1"],
+         outs["db1"], dx, ws, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["datt"], datt_ref)
+    assert torch.equal(outs["dl"], dl_ref)
+    da1_ref = torch.empty(N, inter, device=DEV)
+    dw2_ref, db2_ref = torch.empty(C2, inter, device=DEV), torch.empty(C2, device=DEV)
+    call("xv2_linear_backward", a1, w2, dl_ref, None, dw2_ref, db2_ref, N, inter, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["dw2"], dw2_ref) and torch.equal(outs["db2"], db2_ref)

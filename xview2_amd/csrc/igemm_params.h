@@ -102,7 +102,9 @@ int splat_fc1_bn_launch(const float* gap, const float* w1, const float* b1, int 
                         float* mean, float* invstd, float* scale, float* shift, float* h1, float* a1, hipStream_t stream);
 int splat_fc2_rsoftmax_launch(const float* a1, const float* w2, const float* b2, int N, int inter, int C, float* logits, float* att,
                               hipStream_t stream);
-int splat_fuse_bits();      // pointwise.hip: XV2_SPLAT_FUSE (A/B switch of the fused split-attention launches)
+int splat_fuse_bits();
+int splat_datt_rsoftmax_backward(const void* x, const float* att, const void* dout, int N, int64_t hw, int C, float* datt,
+                                 float* dlogits, float* workspace, int dtype, void* stream);      // pointwise.hip      // pointwise.hip: XV2_SPLAT_FUSE (A/B switch of the fused split-attention launches)
 
 // stem_conv.hip: the 7x7 / stride-2 RGB stem of the ResNet encoders (4-channel image -> 64 channels) from an LDS-resident input
 // patch and weight tensor; writes the 128-pixel statistics partials of the BM = 128 plan, never folds them

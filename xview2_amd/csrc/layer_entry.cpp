@@ -96,10 +96,16 @@ extern "C" int xv2_splat_tail_backward(const void* x, const void* dout, int N, i
                                        const float* att, int train, int parts, float* datt, float* dlogits, float* da1,
                                        float* dh1, float* dgap, float* dw2, float* db2, float* dgamma1, float* dbeta1,
                                        float* dw1, float* db1, void* dx, float* workspace, int dtype, void* stream) {
-    int rc = xv2_splat_apply_backward(x, att, dout, nullptr, N, hw, C, nullptr, datt, workspace, dtype, stream);
-    if (rc) return rc;
-    rc = xv2_rsoftmax_backward(att, datt, dlogits, N, C, stream);
-    if (rc) return rc;
+    int rc;
+    if (xv2::splat_fuse_bits() & 16) {      // datt's fold and rSoftMax's backward in one launch (bit-identical)
+        rc = xv2::splat_datt_rsoftmax_backward(x, att, dout, N, hw, C, datt, dlogits, workspace, dtype, stream);
+        if (rc) return rc;
+    } else {
+        rc = xv2_splat_apply_backward(x, att, dout, nullptr, N, hw, C, nullptr, datt, workspace, dtype, stream);
+        if (rc) return rc;
+        rc = xv2_rsoftmax_backward(att, datt, dlogits, N, C, stream);
+        if (rc) return rc;
+    }
     rc = xv2_linear_backward(a1, w2, dlogits, da1, dw2, db2, N, inter, 2 * C, stream);
     if (rc) return rc;
     rc = xv2_bn_rows_backward(da1, a1, h1, mean1, invstd1, gamma1, N / parts, inter, parts, XV2_ACT_RELU, train, dh1, dgamma1,

@@ -425,6 +425,28 @@ __global__ void __launch_bounds__(256) splat_datt_finish_kernel(const float* __r
     const float a = splat_fold(part + (size_t)n * SPLAT_CHUNKS * C2 + cc, (size_t)C2, chunks, sh);
     if (threadIdx.x < SF_COLS && c < C2) datt[(size_t)n * C2 + c] = a;
 }
+// ... and rSoftMax's backward in the same launch (the split-attention tail, backward: the fold of the two radix columns of a
+// channel - the arithmetic of splat_datt_finish_kernel, column by column - then rsoftmax_bwd_kernel's two lines; datt is still
+// written: it is an output of the ABI call)
+__global__ void __launch_bounds__(256) splat_datt_rsoftmax_bwd_kernel(const float* __restrict__ part, const float* __restrict__ att,
+                                                                       int N, int C, int chunks, float* __restrict__ datt,
+                                                                       float* __restrict__ dl) {
+    __shared__ float sh[256], sh2[256];
+    const int c = blockIdx.x * SF_COLS + (threadIdx.x % SF_COLS), n = blockIdx.y;
+    const int cc = min(c, C - 1);
+    const float* p = part + (size_t)n * SPLAT_CHUNKS * 2 * C;
+    const float d0 = splat_fold(p + cc, (size_t)2 * C, chunks, sh);          // radix 0
+    const float d1 = splat_fold(p + C + cc, (size_t)2 * C, chunks, sh2);     // radix 1
+    if (threadIdx.x < SF_COLS && c < C) {
+        const size_t i0 = (size_t)n * 2 * C + c, i1 = i0 + C;
+        datt[i0] = d0;
+        datt[i1] = d1;
+        const float a0 = att[i0], a1 = att[i1];
+        const float dot = a0 * d0 + a1 * d1;
+        dl[i0] = a0 * (d0 - dot);
+        dl[i1] = a1 * (d1 - dot);
+    }
+}
 template <typename T>
 __global__ void splat_apply_fwd_kernel(const T* __restrict__ x, const float* __restrict__ att, int64_t hw,
                                        int C, T* __restrict__ out, int64_t total4) {
@@ -481,11 +503,10 @@ __global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict
 // x 4 chains still walked Cout / 16 = 32 .. 128 dependent rounds on a grid of 4 - 8 blocks: 10.5 us per launch, 32 launches per
 // resnest50 step, 264 per resnest200 step.  Now Cout / 128 rounds on 4x the blocks)
 constexpr int LB_COLS = 16, LB_LANES = 16;
-__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                                             float* __restrict__ dx, int N, int Cin, int Cout) {
-    __shared__ float sh[256];
+__device__ __forceinline__ void linear_bwd_dx_block(const float* __restrict__ w, const float* __restrict__ dy,
+                                                    float* __restrict__ dx, int Cin, int Cout, int bx, int n, float* sh) {
     const int tx = threadIdx.x % LB_COLS, ty = threadIdx.x / LB_COLS;
-    const int c = blockIdx.x * LB_COLS + tx, n = blockIdx.y;
+    const int c = bx * LB_COLS + tx;
     float s[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = 0.f;
@@ -513,9 +534,14 @@ __global__ void __launch_bounds__(256) linear_bwd_dx_kernel(const float* __restr
         dx[(size_t)n * Cin + c] = a;
     }
 }
-__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                     float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int N, int Cin, int Cout) {
+    __shared__ float sh[256];
+    linear_bwd_dx_block(w, dy, dx, Cin, Cout, blockIdx.x, blockIdx.y, sh);
+}
+__device__ __forceinline__ void linear_bwd_dw_block(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout, int bx) {
+    const int i = bx * blockDim.x + threadIdx.x;
     if (i >= Cout * (Cin + 1)) return;
     const int o = i / (Cin + 1), c = i % (Cin + 1);
     float s = 0.f;
@@ -526,6 +552,22 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* _
         for (int n = 0; n < N; ++n) s += dy[n * Cout + o];
         db[o] = s;
     }
+}
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                     float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout) {
+    linear_bwd_dw_block(x, dy, dw, db, N, Cin, Cout, blockIdx.x);
+}
+// both products of a dense layer's backward as ONE launch (problem-indexed grid: the first nbx * N blocks are the blocks of
+// linear_bwd_dx_kernel, the rest those of linear_bwd_dw_kernel - the same block code, bit-identical results, one launch less per
+// dense layer: 264 per resnest200 step)
+__global__ void __launch_bounds__(256) linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ dw, float* __restrict__ db, int N, int Cin, int Cout,
+                                                          int nbx) {
+    __shared__ float sh[256];
+    const int b = blockIdx.x;
+    if (b < nbx * N) linear_bwd_dx_block(w, dy, dx, Cin, Cout, b % nbx, b / nbx, sh);      // (block-uniform branch)
+    else linear_bwd_dw_block(x, dy, dw, db, N, Cin, Cout, b - nbx * N);
 }
 __global__ void rsoftmax_fwd_kernel(const float* __restrict__ l, float* __restrict__ a, int N, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -807,7 +849,7 @@ extern "C" int xv2_splat_gap_forward(const void* x, int N, int64_t hw, int C, fl
 // prologue in front of 2048 streaming blocks costs more than the 5 us launch it replaces.)
 namespace xv2 {
 int splat_fuse_bits() {
-    static const int v = [] { const char* e = getenv("XV2_SPLAT_FUSE"); return e ? atoi(e) : 5; }();
+    static const int v = [] { const char* e = getenv("XV2_SPLAT_FUSE"); return e ? atoi(e) : 29; }();
     return v;
 }
 }  // namespace xv2
@@ -872,6 +914,25 @@ extern "C" int xv2_splat_apply_backward(const void* x, const float* att, const v
     }
     return XV2_OK;
 }
+namespace xv2 {
+// the first two steps of the split-attention tail's backward as two launches instead of three: datt (column sums of dout * x,
+// folded) AND rSoftMax's backward in the fold launch (XV2_SPLAT_FUSE bit 4; layer_entry.cpp xv2_splat_tail_backward)
+int splat_datt_rsoftmax_backward(const void* x, const float* att, const void* dout, int N, int64_t hw, int C, float* datt,
+                                 float* dlogits, float* workspace, int dtype, void* stream) {
+    XV2_CHECK_ARG(C % 4 == 0 && splat_vec_ok(C), "splat_apply: unsupported channel count %d", C);
+    XV2_CHECK_DTYPE(dtype);
+    hipStream_t st = (hipStream_t)stream;
+    int chunks, cgw;
+    const int rpc = splat_rows(hw, 2 * C, N, chunks, cgw);
+    XV2_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((splat_colsum_kernel<T, true>), dim3(chunks, 2 * C / cgw, N), dim3(256), 0, st,
+                                                 (const T*)x, (const T*)dout, hw, 2 * C, C, cgw, rpc, workspace));
+    XV2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(splat_datt_rsoftmax_bwd_kernel, dim3((unsigned)cdiv(C, SF_COLS), N), dim3(256), 0, st, workspace, att, N, C,
+                       chunks, datt, dlogits);
+    XV2_CHECK_LAUNCH();
+    return XV2_OK;
+}
+}  // namespace xv2
 extern "C" int xv2_linear_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int Cout,
                                   void* stream) {
     hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)cdiv((int64_t)N * Cout * 64, 256)), dim3(256), 0,
@@ -882,6 +943,12 @@ extern "C" int xv2_linear_forward(const float* x, const float* w, const float* b
 extern "C" int xv2_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                                    int N, int Cin, int Cout, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (dx && (splat_fuse_bits() & 8)) {      // both products in one launch (XV2_SPLAT_FUSE bit 3)
+        const int nbx = (int)cdiv(Cin, LB_COLS), nbw = (int)cdiv(Cout * (Cin + 1), 256);
+        hipLaunchKernelGGL(linear_bwd_kernel, dim3((unsigned)(nbx * N + nbw)), dim3(256), 0, st, x, w, dy, dx, dw, db, N, Cin, Cout, nbx);
+        XV2_CHECK_LAUNCH();
+        return XV2_OK;
+    }
     if (dx) {
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)cdiv(Cin, LB_COLS), N), dim3(256), 0, st, w, dy, dx, N, Cin,
                            Cout);
